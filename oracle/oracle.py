@@ -1,0 +1,397 @@
+"""
+oracle/oracle.py — NumPy/C CPU restatement of the Fibers.jl hot path (TEST INFRASTRUCTURE).
+
+PARITY UNPINNED: the reference is Julia (not runnable here) and has no tests or golden
+vectors (test/runtests.jl:4-6), so this restatement is checked only against analytic
+known answers (tests/test_oracle_*.py).  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module; the product (fibers.jl_amd) never does.
+
+The work-struct constructors (DTIwork, GQIwork, DSIwork, StreamWork) are restated here in
+float32 NumPy following the Julia sources line by line; the per-voxel loops and the
+streamline integrator live in fibers_oracle.c (OpenMP, the reference's z-slice / seed-chunk
+decomposition).  Arrays are Fortran-ordered [nx,ny,nz,nframes] like `MRI.vol` (mri.jl:81).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+f32 = np.float32
+_pf = np.ctypeslib.ndpointer(dtype=np.float32, flags="F_CONTIGUOUS")
+_pfc = np.ctypeslib.ndpointer(dtype=np.float32)
+_pu8 = np.ctypeslib.ndpointer(dtype=np.uint8)
+_pi32 = np.ctypeslib.ndpointer(dtype=np.int32)
+_pi64 = np.ctypeslib.ndpointer(dtype=np.int64)
+
+
+def build():
+    """Compile the C restatement (gcc); idempotent."""
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libfibers_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.orc_gqi_rec.restype = C.c_float
+        _LIB.orc_dsi_rec.restype = C.c_float
+        _LIB.orc_stream.restype = C.c_int64
+        _LIB.orc_find_peaks.restype = C.c_int
+        _LIB.orc_max_threads.restype = C.c_int
+    return _LIB
+
+
+def max_threads():
+    return int(lib().orc_max_threads())
+
+
+def _fvol(a):
+    return np.asfortranarray(a, dtype=np.float32)
+
+
+def _mask_u8(mask):
+    """`mask.vol[ix,iy,iz] == 0 && continue` (dti.jl:261): any non-zero value is in-mask."""
+    m = np.asarray(mask)
+    if m.ndim == 4:
+        m = m[..., 0]
+    return np.asfortranarray((m != 0).astype(np.uint8))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ----------------------------------------------------------------------------------------
+# pinv (LinearAlgebra.pinv on a Float32 matrix: LAPACK SVD, rtol = eps(Float32)*min(m,n))
+# ----------------------------------------------------------------------------------------
+def pinv32(A):
+    A = np.asarray(A, dtype=np.float32)
+    if A.size == 0:
+        return np.zeros(A.shape[::-1], np.float32)
+    U, S, Vt = np.linalg.svd(A, full_matrices=False)         # float32 LAPACK, like Julia
+    tol = f32(np.finfo(np.float32).eps * min(A.shape)) * S.max()
+    Sinv = np.zeros_like(S)
+    keep = S > tol
+    Sinv[keep] = f32(1) / S[keep]
+    return ((Vt.T * Sinv) @ U.T).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------
+# DTI / ADC   (dti.jl:39-84, 101-155, 164-213, 243-335)
+# ----------------------------------------------------------------------------------------
+def dti_work(bval, bvec):
+    bval = np.asarray(bval, np.float32)
+    bvec = np.asarray(bvec, np.float32)
+    nvol = bval.shape[0]
+    A = np.empty((nvol, 7), np.float32)
+    A[:, 0] = bvec[:, 0] ** 2                                  # dti.jl:131-136
+    A[:, 1] = f32(2) * bvec[:, 0] * bvec[:, 1]
+    A[:, 2] = f32(2) * bvec[:, 0] * bvec[:, 2]
+    A[:, 3] = bvec[:, 1] ** 2
+    A[:, 4] = f32(2) * bvec[:, 1] * bvec[:, 2]
+    A[:, 5] = bvec[:, 2] ** 2
+    A[:, :6] *= -bval[:, None]                                 # dti.jl:138
+    A[:, 6] = 1                                                # dti.jl:140
+    return dict(nvol=nvol, A=A, pA=pinv32(A), ib0=(bval == bval.min()))   # dti.jl:117,143
+
+
+def adc_work(bval):
+    bval = np.asarray(bval, np.float32)
+    A = np.stack([-bval, np.ones_like(bval)], axis=1).astype(np.float32)   # dti.jl:68-69
+    return dict(nvol=bval.shape[0], A=A, pA=pinv32(A), ib0=(bval == bval.min()))
+
+
+_DTI_FIELDS = ("s0", "eigval1", "eigval2", "eigval3", "eigvec1", "eigvec2", "eigvec3", "rd", "md", "fa")
+
+
+def dti_from_d(d):
+    out = np.zeros(16, np.float32)
+    lib().orc_dti_from_d(_p(np.ascontiguousarray(d, np.float32)), _p(out))
+    return out
+
+
+def sym3_eigen(a11, a12, a13, a22, a23, a33):
+    w = np.zeros(3, np.float32)
+    v = np.zeros((3, 3), np.float32)
+    L = lib()
+    L.orc_sym3_eigen.argtypes = [C.c_float] * 6 + [C.c_void_p, C.c_void_p]
+    L.orc_sym3_eigen(a11, a12, a13, a22, a23, a33, _p(w), _p(v))
+    return w, v.T.copy()      # columns = eigenvectors, ascending eigenvalues
+
+
+def dti_fit(dwi, mask, bval, bvec, nthreads=1):
+    """dti_fit(dwi::MRI, mask::MRI) (dti.jl:221) -> dict of the 10 DTI volumes."""
+    if bval is None or len(bval) == 0:
+        raise ValueError("Missing b-value table from input DWI structure")       # dti.jl:224
+    if bvec is None or len(bvec) == 0:
+        raise ValueError("Missing gradient table from input DWI structure")      # dti.jl:228
+    dwi = _fvol(dwi)
+    nx, ny, nz, nvol = dwi.shape
+    W = dti_work(bval, bvec)
+    m = _mask_u8(mask)
+    nvox = nx * ny * nz
+    out = {k: np.zeros((nx, ny, nz, 3) if "vec" in k else (nx, ny, nz), np.float32, order="F") for k in _DTI_FIELDS}
+    partial = np.zeros(nvox, np.int64)
+    npart = C.c_int64(0)
+    pA = np.asfortranarray(W["pA"])
+    ib0 = W["ib0"].astype(np.uint8)
+    lib().orc_dti_fit(_p(dwi), _p(m), nx, ny, nz, nvol, _p(pA), _p(ib0),
+                      *[_p(out[k]) for k in _DTI_FIELDS], _p(partial), C.byref(npart), int(nthreads))
+    # per-voxel pinv branch (dti.jl:297-298)
+    flat = {k: out[k].reshape((nvox, -1) if "vec" in k else (nvox,), order="F") for k in _DTI_FIELDS}
+    dflat = dwi.reshape((nvox, nvol), order="F")
+    for vox in np.sort(partial[: npart.value]):
+        s = dflat[vox]
+        ipos = s > 0
+        d = pinv32(W["A"][ipos]) @ np.log(s[ipos]).astype(np.float32)
+        o = dti_from_d(d.astype(np.float32))
+        flat["s0"][vox], flat["eigval1"][vox], flat["eigval2"][vox], flat["eigval3"][vox] = o[0:4]
+        flat["eigvec1"][vox], flat["eigvec2"][vox], flat["eigvec3"][vox] = o[4:7], o[7:10], o[10:13]
+        flat["rd"][vox], flat["md"][vox], flat["fa"][vox] = o[13:16]
+    out["_npartial"] = int(npart.value)
+    return out
+
+
+def adc_fit(dwi, mask, bval, nthreads=1):
+    """adc_fit(dwi::MRI, mask::MRI) (dti.jl:164) -> (adc, s0)."""
+    if bval is None or len(bval) == 0:
+        raise ValueError("Missing b-value table from input DWI structure")
+    dwi = _fvol(dwi)
+    nx, ny, nz, nvol = dwi.shape
+    W = adc_work(bval)
+    m = _mask_u8(mask)
+    nvox = nx * ny * nz
+    adc = np.zeros((nx, ny, nz), np.float32, order="F")
+    s0 = np.zeros((nx, ny, nz), np.float32, order="F")
+    partial = np.zeros(nvox, np.int64)
+    npart = C.c_int64(0)
+    lib().orc_adc_fit(_p(dwi), _p(m), nx, ny, nz, nvol, _p(np.asfortranarray(W["pA"])),
+                      _p(W["ib0"].astype(np.uint8)), _p(adc), _p(s0), _p(partial), C.byref(npart), int(nthreads))
+    dflat = dwi.reshape((nvox, nvol), order="F")
+    a_flat, s_flat = adc.reshape(nvox, order="F"), s0.reshape(nvox, order="F")
+    for vox in partial[: npart.value]:
+        s = dflat[vox]
+        ipos = s > 0
+        d = pinv32(W["A"][ipos]) @ np.log(s[ipos]).astype(np.float32)
+        a_flat[vox] = d[0]
+        s_flat[vox] = np.exp(f32(d[1]))
+    return adc, s0
+
+
+# ----------------------------------------------------------------------------------------
+# GQI   (gqi.jl:32-82, 109-201)
+# ----------------------------------------------------------------------------------------
+def fold_faces(faces, nvert):
+    """faces[faces .> nvert] .-= nvert (gqi.jl:63-64); returns 0-based int32 [nfaces,3] F-order."""
+    f = np.array(faces, dtype=np.int64, copy=True)
+    f[f > nvert] -= nvert
+    return np.asfortranarray((f - 1).astype(np.int32))
+
+
+def _sinc32(x):
+    """Base.sinc on Float32: sinpi(x)/(pi*x), sinc(0)=1; evaluated in float64, rounded once."""
+    xd = x.astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        y = np.where(xd == 0, 1.0, np.sin(np.pi * xd) / (np.pi * xd))
+    return y.astype(np.float32)
+
+
+def gqi_work(bval, bvec, vertices, faces, sigma=1.25):
+    bval = np.asarray(bval, np.float32)
+    bvec = np.asarray(bvec, np.float32)
+    V = np.asarray(vertices, np.float32)
+    nvert = V.shape[0] // 2                                     # gqi.jl:48
+    scale = np.sqrt(bval * f32(0.01506)) * (f32(sigma) / f32(np.pi))       # gqi.jl:68
+    bq = bvec * scale[:, None]
+    X = (V[nvert:, :] @ bq.T).astype(np.float32)                # gqi.jl:69
+    return dict(nvol=bval.shape[0], nvert=nvert, A=np.asfortranarray(_sinc32(X)),
+                faces=fold_faces(faces, nvert), vertices=np.asfortranarray(V))
+
+
+def find_peaks(o, faces0):
+    """find_peaks!(W) for one ODF (gqi.jl:180-201) -> (isort 0-based, nvalid, odf_peak)."""
+    o = np.ascontiguousarray(o, np.float32)
+    n = o.shape[0]
+    pk = np.zeros(n, np.float32)
+    isort = np.zeros(n, np.int32)
+    tmp = np.zeros(n, np.int32)
+    f = np.asfortranarray(faces0, dtype=np.int32)
+    nv = lib().orc_find_peaks(_p(o), n, _p(f), f.shape[0], _p(pk), _p(isort), _p(tmp))
+    return isort, int(nv), pk
+
+
+def gqi_rec(dwi, mask, bval, bvec, vertices, faces, sigma=1.25, nthreads=1):
+    """gqi_rec (gqi.jl:109) -> dict(odf, peak[3], qa[3], odfmax)."""
+    if bval is None or len(bval) == 0:
+        raise ValueError("Missing b-value table from input DWI structure")
+    if bvec is None or len(bvec) == 0:
+        raise ValueError("Missing gradient table from input DWI structure")
+    dwi = _fvol(dwi)
+    nx, ny, nz, nvol = dwi.shape
+    W = gqi_work(bval, bvec, vertices, faces, sigma)
+    m = _mask_u8(mask)
+    odf = np.zeros((nx, ny, nz, W["nvert"]), np.float32, order="F")
+    peak = [np.zeros((nx, ny, nz, 3), np.float32, order="F") for _ in range(3)]
+    qa = [np.zeros((nx, ny, nz), np.float32, order="F") for _ in range(3)]
+    with np.errstate(all="ignore"):
+        odfmax = lib().orc_gqi_rec(_p(dwi), _p(m), nx, ny, nz, nvol, _p(W["A"]), W["nvert"],
+                                   _p(W["faces"]), W["faces"].shape[0], _p(W["vertices"]), W["vertices"].shape[0],
+                                   _p(odf), *[_p(x) for x in peak], *[_p(x) for x in qa], int(nthreads))
+    return dict(odf=odf, peak=peak, qa=qa, odfmax=float(odfmax))
+
+
+# ----------------------------------------------------------------------------------------
+# DSI   (dsi.jl:41-143, 171-270)
+# ----------------------------------------------------------------------------------------
+def dsi_work(bval, bvec, vertices, faces, hann_width=32):
+    bval = np.asarray(bval, np.float32)
+    bvec = np.asarray(bvec, np.float32)
+    V = np.asarray(vertices, np.float32)
+    q = bvec * np.sqrt(bval)[:, None]                           # dsi.jl:62
+    bmin = bval.min()
+    dq = np.sqrt(bval[bval > bmin].min())                       # dsi.jl:66
+    iq = np.rint(q / dq).astype(np.int32)                       # dsi.jl:67 (ties to even)
+    nfft = int(iq.max() - iq.min() + 1)
+    nfft = 2 ** int(np.ceil(np.log2(nfft)))                     # dsi.jl:70-71
+    if nfft != 16:
+        raise NotImplementedError("oracle supports the 16^3 q-grid only (nfft=%d)" % nfft)
+    shift = nfft // 2 + 1                                       # dsi.jl:73 (1-based centre)
+    sub = iq + shift                                            # 1-based subscripts
+    iq_ind = (sub[:, 0] - 1) + nfft * (sub[:, 1] - 1) + nfft * nfft * (sub[:, 2] - 1)   # 0-based linear
+    H = np.zeros(nfft ** 3, np.float32)
+    if hann_width == 0:
+        H[:] = 1
+    else:                                                       # dsi.jl:83-84 (computed in Float64)
+        r = np.sqrt((iq.astype(np.int64) ** 2).sum(axis=1).astype(np.float64))
+        H[iq_ind] = ((1.0 + np.cos(r * (2 * np.pi / hann_width))) * 0.5).astype(np.float32)
+    nvert = V.shape[0] // 2
+    qr = f32(nfft / 2 - 1) * np.linspace(0.3, 0.9, 21).astype(np.float32)       # dsi.jl:104
+    dqr = f32(qr[1] - qr[0])
+    # iq_sub_interp[3, nrad, nvert] = v * qr' .+ iq_shift   (dsi.jl:106-109)
+    interp = (V[nvert:, :].T[:, None, :] * qr[None, :, None] + f32(shift)).astype(np.float32)
+    return dict(nvol=bval.shape[0], nfft=nfft, nvert=nvert, dqr=dqr, iq=iq, iq_ind=iq_ind.astype(np.int32),
+                H=H, qr=qr, qr2=(qr ** 2).astype(np.float32), interp=np.asfortranarray(interp),
+                faces=fold_faces(faces, nvert), vertices=np.asfortranarray(V), shift=shift)
+
+
+def dsi_rec(dwi, mask, bval, bvec, vertices, faces, hann_width=32, nthreads=1):
+    """dsi_rec (dsi.jl:171) -> dict(pdf, odf, peak[3], qa[3], odfmax)."""
+    if bval is None or len(bval) == 0:
+        raise ValueError("Missing b-value table from input DWI structure")
+    if bvec is None or len(bvec) == 0:
+        raise ValueError("Missing gradient table from input DWI structure")
+    dwi = _fvol(dwi)
+    nx, ny, nz, nvol = dwi.shape
+    W = dsi_work(bval, bvec, vertices, faces, hann_width)
+    m = _mask_u8(mask)
+    pdf = np.zeros((nx, ny, nz, nvol), np.float32, order="F")
+    odf = np.zeros((nx, ny, nz, W["nvert"]), np.float32, order="F")
+    peak = [np.zeros((nx, ny, nz, 3), np.float32, order="F") for _ in range(3)]
+    qa = [np.zeros((nx, ny, nz), np.float32, order="F") for _ in range(3)]
+    L = lib()
+    L.orc_dsi_rec.argtypes = None
+    odfmax = L.orc_dsi_rec(_p(dwi), _p(m), nx, ny, nz, nvol, _p(W["iq_ind"]), _p(W["H"]), _p(W["interp"]),
+                           W["qr"].shape[0], _p(W["qr2"]), C.c_float(float(W["dqr"])),
+                           W["nvert"], _p(W["faces"]), W["faces"].shape[0], _p(W["vertices"]), W["vertices"].shape[0],
+                           _p(pdf), _p(odf), *[_p(x) for x in peak], *[_p(x) for x in qa], int(nthreads))
+    return dict(pdf=pdf, odf=odf, peak=peak, qa=qa, odfmax=float(odfmax))
+
+
+# ----------------------------------------------------------------------------------------
+# Streamlines   (stream.jl:74-193 non-LCM/non-micro, 340-374, 501-541, 625-690, 730-790)
+# ----------------------------------------------------------------------------------------
+def cosd32(deg):
+    """cosd(Float32(deg)): exact-degree cosine, rounded to Float32."""
+    deg = float(f32(deg))
+    exact = {0.0: 1.0, 60.0: 0.5, 90.0: 0.0, 120.0: -0.5, 180.0: -1.0}
+    if deg in exact:
+        return f32(exact[deg])
+    return f32(np.cos(np.deg2rad(np.float64(deg))))
+
+
+def stream_work(ovec, f=None, f_thresh=0.03, fa=None, fa_thresh=0.1, mask=None):
+    """StreamWork mask / vector repack (stream.jl:76-145). ovec: list of [nx,ny,nz,3]."""
+    ovecs = [ovec] if isinstance(ovec, np.ndarray) else list(ovec)
+    fs = None if f is None else ([f] if isinstance(f, np.ndarray) else list(f))
+    nvec = len(ovecs)
+    nx, ny, nz = ovecs[0].shape[:3]
+    if mask is None:                                            # stream.jl:95-100
+        mk = np.zeros((nx, ny, nz), bool)
+        for v in ovecs:
+            mk |= np.any(np.asarray(v) != 0, axis=3)
+    else:                                                       # stream.jl:102
+        m = np.asarray(mask)
+        mk = (m[..., 0] if m.ndim == 4 else m) > 0
+    if fa is not None:                                          # stream.jl:116
+        a = np.asarray(fa, np.float32)
+        mk = mk & ((a[..., 0] if a.ndim == 4 else a) >= f32(fa_thresh))
+    arr = np.zeros((3, nvec, nx, ny, nz), np.float32, order="F")
+    for k, v in enumerate(ovecs):
+        om = mk
+        if fs is not None:                                      # stream.jl:138
+            fk = np.asarray(fs[k], np.float32)
+            om = mk & ((fk[..., 0] if fk.ndim == 4 else fk) >= f32(f_thresh))
+        v = np.asarray(v, np.float32)
+        for c in range(3):                                      # stream.jl:141-145 (Bool is a strong zero)
+            arr[c, k] = np.where(om, v[..., c], f32(0))
+    return np.asfortranarray(mk), arr
+
+
+def seeds_from_mask(maskbool):
+    """findall(mask) in column-major order -> [n,3] int32 1-based (stream.jl:744,754)."""
+    lin = np.flatnonzero(np.asarray(maskbool).ravel(order="F"))
+    nx, ny, nz = maskbool.shape
+    return np.stack([lin % nx + 1, (lin // nx) % ny + 1, lin // (nx * ny) + 1], axis=1).astype(np.int32)
+
+
+def stream(ovec, sublist, f=None, f_thresh=0.03, fa=None, fa_thresh=0.1, mask=None, seed=None,
+           len_min=3, len_max=None, ang_thresh=45, step_size=0.5, smooth_coeff=0.2, nthreads=1,
+           return_all_npts=False):
+    """stream (stream.jl:730) with an explicit `sublist` [nsub,3] instead of the global RNG
+    (stream.jl:176-181).  Returns list of [npts,3] float32 arrays (1-based voxel coords) in
+    reference order, plus seed_index (seed*nsub+sub) per kept line."""
+    mk, arr = stream_work(ovec, f, f_thresh, fa, fa_thresh, mask)
+    nx, ny, nz = mk.shape
+    if len_max is None:
+        len_max = max(nx, ny, nz)                               # stream.jl:74 default
+    if seed is None:
+        seeds = seeds_from_mask(mk)
+    else:
+        sd = np.asarray(seed)
+        if mask is not None and sd.shape != np.asarray(mask).shape:
+            raise ValueError("Dimension mismatch between seed mask %s and brain mask %s"
+                             % (sd.shape, np.asarray(mask).shape))   # stream.jl:746-749
+        seeds = seeds_from_mask((sd[..., 0] if sd.ndim == 4 else sd) > 0)
+    sub = np.ascontiguousarray(sublist, np.float32).reshape(-1, 3)
+    seeds = np.ascontiguousarray(seeds)
+    p_npts, p_seed, p_xyz = C.POINTER(C.c_int32)(), C.POINTER(C.c_int64)(), C.POINTER(C.c_float)()
+    total = C.c_int64(0)
+    all_npts = np.zeros(max(1, seeds.shape[0] * sub.shape[0]), np.int32)
+    L = lib()
+    nl = L.orc_stream(_p(arr), _p(mk.astype(np.uint8, order="F")), nx, ny, nz, arr.shape[1],
+                      _p(seeds), C.c_int64(seeds.shape[0]), _p(sub), sub.shape[0],
+                      int(len_min), int(len_max), C.c_float(float(cosd32(ang_thresh))),
+                      C.c_float(float(f32(step_size))), C.c_float(float(f32(smooth_coeff))),
+                      C.byref(p_npts), C.byref(p_seed), C.byref(p_xyz), C.byref(total),
+                      _p(all_npts), int(nthreads))
+    npts = np.ctypeslib.as_array(p_npts, shape=(max(nl, 1),))[:nl].copy()
+    sidx = np.ctypeslib.as_array(p_seed, shape=(max(nl, 1),))[:nl].copy()
+    xyz = np.ctypeslib.as_array(p_xyz, shape=(max(total.value, 1) * 3,))[: total.value * 3].copy().reshape(-1, 3)
+    for ptr in (p_npts, p_seed, p_xyz):
+        L.orc_free(C.cast(ptr, C.c_void_p))
+    res = dict(npts=npts, seed_index=sidx, xyz=xyz, nseeds=seeds.shape[0], nsub=sub.shape[0], seeds=seeds)
+    if return_all_npts:
+        res["all_npts"] = all_npts[: seeds.shape[0] * sub.shape[0]]
+    return res
+
+
+def split_lines(res):
+    off = np.concatenate([[0], np.cumsum(res["npts"])])
+    return [res["xyz"][off[i]:off[i + 1]] for i in range(len(res["npts"]))]
