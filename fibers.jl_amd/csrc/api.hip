@@ -1,0 +1,272 @@
+// api.hip — host-buffer ("drop-in") entry points: stage caller-owned host arrays through HBM,
+// run the device-resident path (fibd_*), copy results back.  These are the functions the Julia
+// wrapper ccalls in place of the bodies of dti_fit / adc_fit / gqi_rec / dsi_rec / stream.
+#include <memory>
+
+#include "common.h"
+
+namespace {
+
+// mask.vol[...] == 0 && continue (dti.jl:261, gqi.jl:135, dsi.jl:200)  -> nonzero test
+// mask.vol .> 0 (stream.jl:102), seed.vol .> 0 (stream.jl:751)         -> positive test
+template <typename T>
+void mask_convert_t(const T *m, int64_t n, bool positive, uint8_t *out) {
+    if (positive) for (int64_t i = 0; i < n; i++) out[i] = m[i] > (T)0 ? 1 : 0;
+    else          for (int64_t i = 0; i < n; i++) out[i] = m[i] != (T)0 ? 1 : 0;
+}
+
+int mask_convert(const void *m, int dtype, int64_t n, bool positive, std::vector<uint8_t> &out) {
+    out.resize((size_t)n);
+    switch (dtype) {
+        case FIB_U8: case FIB_BOOL: mask_convert_t((const uint8_t *)m, n, positive, out.data()); break;
+        case FIB_I8:  mask_convert_t((const int8_t *)m, n, positive, out.data()); break;
+        case FIB_I16: mask_convert_t((const int16_t *)m, n, positive, out.data()); break;
+        case FIB_U16: mask_convert_t((const uint16_t *)m, n, positive, out.data()); break;
+        case FIB_I32: mask_convert_t((const int32_t *)m, n, positive, out.data()); break;
+        case FIB_U32: mask_convert_t((const uint32_t *)m, n, positive, out.data()); break;
+        case FIB_I64: mask_convert_t((const int64_t *)m, n, positive, out.data()); break;
+        case FIB_F32: mask_convert_t((const float *)m, n, positive, out.data()); break;
+        case FIB_F64: mask_convert_t((const double *)m, n, positive, out.data()); break;
+        default: return fib::fail(FIB_ERR_INVALID, "unknown mask dtype %d", dtype);
+    }
+    return FIB_OK;
+}
+
+struct PlanDeleter { void operator()(fib_dti_plan *p) const { fib_dti_plan_destroy(p); } };
+
+#define RC(x) do { int _rc = (x); if (_rc != FIB_OK) return _rc; } while (0)
+
+int h2d(void *dst, const void *src, size_t bytes) {
+    FIB_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return FIB_OK;
+}
+int d2h(void *dst, const void *src, size_t bytes) {
+    FIB_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return FIB_OK;
+}
+
+}  // namespace
+
+extern "C" int fib_dti_fit(int device, const float *dwi, int nx, int ny, int nz, int nvol,
+                           const void *mask, int mask_dtype, const float *bval, const float *bvec,
+                           const fib_dti_out *out) {
+    FIB_CHECK(bval != nullptr && nvol > 0, FIB_ERR_MISSING_BVAL, "Missing b-value table from input DWI structure");
+    FIB_CHECK(bvec != nullptr, FIB_ERR_MISSING_BVEC, "Missing gradient table from input DWI structure");
+    FIB_CHECK(dwi && mask && out, FIB_ERR_INVALID, "NULL argument");
+    FIB_CHECK(nx > 0 && ny > 0 && nz > 0, FIB_ERR_INVALID, "volume dimensions must be positive");
+    fib::DeviceGuard guard;
+    RC(fib::use_device(device));
+    const int64_t nvox = (int64_t)nx * ny * nz;
+    fib_dti_plan *praw = nullptr;
+    RC(fib_dti_plan_create(device, bval, bvec, nvol, &praw));
+    std::unique_ptr<fib_dti_plan, PlanDeleter> plan(praw);
+    std::vector<uint8_t> m8;
+    RC(mask_convert(mask, mask_dtype, nvox, false, m8));
+    fib::DevBuf<float> d_dwi, d_out;
+    fib::DevBuf<uint8_t> d_mask;
+    RC(d_dwi.alloc((size_t)nvox * nvol));
+    RC(d_mask.alloc((size_t)nvox));
+    RC(d_out.alloc((size_t)nvox * 16));
+    RC(h2d(d_dwi.p, dwi, sizeof(float) * nvox * nvol));
+    RC(h2d(d_mask.p, m8.data(), (size_t)nvox));
+    float *b = d_out.p;
+    fib_dti_out dev{b, b + nvox, b + 2 * nvox, b + 3 * nvox, b + 4 * nvox, b + 7 * nvox, b + 10 * nvox,
+                    b + 13 * nvox, b + 14 * nvox, b + 15 * nvox};
+    RC(fibd_dti_fit(plan.get(), d_dwi.p, d_mask.p, nvox, &dev, nullptr));
+    FIB_HIP(hipDeviceSynchronize());
+    const size_t sb = sizeof(float) * nvox;
+    RC(d2h(out->s0, dev.s0, sb));
+    RC(d2h(out->eigval1, dev.eigval1, sb));
+    RC(d2h(out->eigval2, dev.eigval2, sb));
+    RC(d2h(out->eigval3, dev.eigval3, sb));
+    RC(d2h(out->eigvec1, dev.eigvec1, 3 * sb));
+    RC(d2h(out->eigvec2, dev.eigvec2, 3 * sb));
+    RC(d2h(out->eigvec3, dev.eigvec3, 3 * sb));
+    RC(d2h(out->rd, dev.rd, sb));
+    RC(d2h(out->md, dev.md, sb));
+    RC(d2h(out->fa, dev.fa, sb));
+    return FIB_OK;
+}
+
+extern "C" int fib_adc_fit(int device, const float *dwi, int nx, int ny, int nz, int nvol,
+                           const void *mask, int mask_dtype, const float *bval, float *adc, float *s0) {
+    FIB_CHECK(bval != nullptr && nvol > 0, FIB_ERR_MISSING_BVAL, "Missing b-value table from input DWI structure");
+    FIB_CHECK(dwi && mask && adc && s0, FIB_ERR_INVALID, "NULL argument");
+    FIB_CHECK(nx > 0 && ny > 0 && nz > 0, FIB_ERR_INVALID, "volume dimensions must be positive");
+    fib::DeviceGuard guard;
+    RC(fib::use_device(device));
+    const int64_t nvox = (int64_t)nx * ny * nz;
+    fib_dti_plan *praw = nullptr;
+    RC(fib_dti_plan_create(device, bval, nullptr, nvol, &praw));
+    std::unique_ptr<fib_dti_plan, PlanDeleter> plan(praw);
+    std::vector<uint8_t> m8;
+    RC(mask_convert(mask, mask_dtype, nvox, false, m8));
+    fib::DevBuf<float> d_dwi, d_out;
+    fib::DevBuf<uint8_t> d_mask;
+    RC(d_dwi.alloc((size_t)nvox * nvol));
+    RC(d_mask.alloc((size_t)nvox));
+    RC(d_out.alloc((size_t)nvox * 2));
+    RC(h2d(d_dwi.p, dwi, sizeof(float) * nvox * nvol));
+    RC(h2d(d_mask.p, m8.data(), (size_t)nvox));
+    RC(fibd_adc_fit(plan.get(), d_dwi.p, d_mask.p, nvox, d_out.p, d_out.p + nvox, nullptr));
+    FIB_HIP(hipDeviceSynchronize());
+    RC(d2h(adc, d_out.p, sizeof(float) * nvox));
+    RC(d2h(s0, d_out.p + nvox, sizeof(float) * nvox));
+    return FIB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// gqi_rec / dsi_rec
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct OdfPlanDeleter { void operator()(fib_odf_plan *p) const { fib_odf_plan_destroy(p); } };
+
+int odf_rec_host(fib_odf_plan *praw, int nvol, const float *dwi, int nx, int ny, int nz,
+                 const void *mask, int mask_dtype, int nvert, float *pdf, float *odf,
+                 float *const peak[3], float *const qa[3]) {
+    std::unique_ptr<fib_odf_plan, OdfPlanDeleter> plan(praw);
+    FIB_CHECK(dwi && mask && odf && peak && qa, FIB_ERR_INVALID, "NULL argument");
+    FIB_CHECK(nx > 0 && ny > 0 && nz > 0, FIB_ERR_INVALID, "volume dimensions must be positive");
+    for (int k = 0; k < 3; k++) FIB_CHECK(peak[k] && qa[k], FIB_ERR_INVALID, "NULL peak/qa output volume");
+    const int64_t nvox = (int64_t)nx * ny * nz;
+    std::vector<uint8_t> m8;
+    RC(mask_convert(mask, mask_dtype, nvox, false, m8));
+    fib::DevBuf<float> d_dwi, d_odf, d_pdf, d_pq;
+    fib::DevBuf<uint8_t> d_mask;
+    RC(d_dwi.alloc((size_t)nvox * nvol));
+    RC(d_mask.alloc((size_t)nvox));
+    RC(d_odf.alloc((size_t)nvox * nvert));
+    if (pdf) RC(d_pdf.alloc((size_t)nvox * nvol));
+    RC(d_pq.alloc((size_t)nvox * 12));
+    RC(h2d(d_dwi.p, dwi, sizeof(float) * nvox * nvol));
+    RC(h2d(d_mask.p, m8.data(), (size_t)nvox));
+    float *pk[3] = {d_pq.p, d_pq.p + 3 * nvox, d_pq.p + 6 * nvox};
+    float *q[3] = {d_pq.p + 9 * nvox, d_pq.p + 10 * nvox, d_pq.p + 11 * nvox};
+    RC(fibd_odf_rec(plan.get(), d_dwi.p, d_mask.p, nvox, pdf ? d_pdf.p : nullptr, d_odf.p, pk, q, nullptr, 1, nullptr));
+    FIB_HIP(hipDeviceSynchronize());
+    RC(d2h(odf, d_odf.p, sizeof(float) * nvox * nvert));
+    if (pdf) RC(d2h(pdf, d_pdf.p, sizeof(float) * nvox * nvol));
+    for (int k = 0; k < 3; k++) {
+        RC(d2h(peak[k], pk[k], sizeof(float) * nvox * 3));
+        RC(d2h(qa[k], q[k], sizeof(float) * nvox));
+    }
+    return FIB_OK;
+}
+
+}  // namespace
+
+extern "C" int fib_gqi_rec(int device, const float *dwi, int nx, int ny, int nz, int nvol,
+                           const void *mask, int mask_dtype, const float *bval, const float *bvec,
+                           const float *verts, int nverts, const int32_t *faces, int nfaces, float sigma,
+                           float *odf, float *const peak[3], float *const qa[3]) {
+    fib::DeviceGuard guard;
+    fib_odf_plan *p = nullptr;
+    RC(fib_gqi_plan_create(device, bval, bvec, nvol, verts, nverts, faces, nfaces, sigma, &p));
+    FIB_HIP(hipSetDevice(device));
+    return odf_rec_host(p, nvol, dwi, nx, ny, nz, mask, mask_dtype, nverts / 2, nullptr, odf, peak, qa);
+}
+
+extern "C" int fib_dsi_rec(int device, const float *dwi, int nx, int ny, int nz, int nvol,
+                           const void *mask, int mask_dtype, const float *bval, const float *bvec,
+                           const float *verts, int nverts, const int32_t *faces, int nfaces, int hann_width,
+                           float *pdf, float *odf, float *const peak[3], float *const qa[3]) {
+    FIB_CHECK(pdf != nullptr, FIB_ERR_INVALID, "NULL pdf output volume");
+    fib::DeviceGuard guard;
+    fib_odf_plan *p = nullptr;
+    RC(fib_dsi_plan_create(device, bval, bvec, nvol, verts, nverts, faces, nfaces, hann_width, &p));
+    FIB_HIP(hipSetDevice(device));
+    return odf_rec_host(p, nvol, dwi, nx, ny, nz, mask, mask_dtype, nverts / 2, pdf, odf, peak, qa);
+}
+
+// ------------------------------------------------------------------------------------------
+// stream
+// ------------------------------------------------------------------------------------------
+extern "C" void fib_tract_free(fib_tract_out *out) {
+    if (!out) return;
+    free(out->npts); free(out->seed_index); free(out->xyz);
+    out->npts = nullptr; out->seed_index = nullptr; out->xyz = nullptr;
+    out->nlines = 0; out->npoints = 0;
+}
+
+extern "C" int fib_stream(int device, const fib_stream_params *prm, const float *const *ovec, const float *const *f,
+                          float f_thresh, const float *fa, float fa_thresh, const void *mask, int mask_dtype,
+                          const void *seed, int seed_dtype, const float *sublist, int32_t nsub, fib_tract_out *out) {
+    FIB_CHECK(prm && ovec && sublist && out, FIB_ERR_INVALID, "NULL argument");
+    FIB_CHECK(prm->nx > 0 && prm->ny > 0 && prm->nz > 0, FIB_ERR_INVALID, "volume dimensions must be positive");
+    FIB_CHECK(prm->nvec >= 1 && prm->nvec <= 8, FIB_ERR_UNSUPPORTED, "1..8 orientation vectors per voxel are supported");
+    FIB_CHECK(nsub >= 1, FIB_ERR_INVALID, "sublist must hold at least one offset");
+    memset(out, 0, sizeof *out);
+    fib::DeviceGuard guard;
+    RC(fib::use_device(device));
+    const int nvec = prm->nvec;
+    const int64_t nvox = (int64_t)prm->nx * prm->ny * prm->nz;
+    fib::DevBuf<float> d_vec, d_f, d_fa, d_field, d_sub;
+    fib::DevBuf<uint8_t> d_mask, d_mout;
+    RC(d_vec.alloc((size_t)nvox * 3 * nvec));
+    RC(d_field.alloc((size_t)nvox * 4 * nvec));
+    RC(d_mout.alloc((size_t)nvox));
+    const float *dv[8] = {}, *df[8] = {};
+    for (int k = 0; k < nvec; k++) {
+        FIB_CHECK(ovec[k] != nullptr, FIB_ERR_INVALID, "NULL orientation volume %d", k);
+        RC(h2d(d_vec.p + (size_t)k * nvox * 3, ovec[k], sizeof(float) * nvox * 3));
+        dv[k] = d_vec.p + (size_t)k * nvox * 3;
+    }
+    if (f) {
+        RC(d_f.alloc((size_t)nvox * nvec));
+        for (int k = 0; k < nvec; k++) {
+            FIB_CHECK(f[k] != nullptr, FIB_ERR_INVALID, "NULL amplitude volume %d", k);
+            RC(h2d(d_f.p + (size_t)k * nvox, f[k], sizeof(float) * nvox));
+            df[k] = d_f.p + (size_t)k * nvox;
+        }
+    }
+    if (fa) { RC(d_fa.alloc((size_t)nvox)); RC(h2d(d_fa.p, fa, sizeof(float) * nvox)); }
+    std::vector<uint8_t> m8;
+    if (mask) {
+        RC(mask_convert(mask, mask_dtype, nvox, true, m8));        // mask.vol .> 0, stream.jl:102
+        RC(d_mask.alloc((size_t)nvox));
+        RC(h2d(d_mask.p, m8.data(), (size_t)nvox));
+    }
+    RC(fibd_stream_field(nvec, nvox, dv, f ? df : nullptr, f_thresh, fa ? d_fa.p : nullptr, fa_thresh,
+                         mask ? d_mask.p : nullptr, d_field.p, d_mout.p, nullptr));
+    // seed voxels: findall(W.mask) (stream.jl:744) or findall(seed.vol .> 0) (stream.jl:751), column-major order
+    std::vector<uint8_t> s8;
+    if (seed) {
+        RC(mask_convert(seed, seed_dtype, nvox, true, s8));
+    } else {
+        s8.resize((size_t)nvox);
+        FIB_HIP(hipDeviceSynchronize());
+        RC(d2h(s8.data(), d_mout.p, (size_t)nvox));
+    }
+    std::vector<int64_t> seeds;
+    for (int64_t i = 0; i < nvox; i++) if (s8[i]) seeds.push_back(i);
+    fib::DevBuf<int64_t> d_seeds;
+    RC(d_seeds.alloc(seeds.size()));
+    if (!seeds.empty()) RC(h2d(d_seeds.p, seeds.data(), sizeof(int64_t) * seeds.size()));
+    RC(d_sub.alloc((size_t)nsub * 3));
+    RC(h2d(d_sub.p, sublist, sizeof(float) * 3 * nsub));
+    fib_stream_job *job = nullptr;
+    int64_t nl = 0, np = 0;
+    RC(fibd_stream_trace(prm, d_field.p, d_seeds.p, (int64_t)seeds.size(), d_sub.p, nsub, nullptr, &job, &nl, &np));
+    struct JobGuard { fib_stream_job *j; ~JobGuard() { fib_stream_job_destroy(j); } } jg{job};
+    out->nlines = nl; out->npoints = np;
+    out->npts = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nl > 0 ? nl : 1));
+    out->seed_index = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nl > 0 ? nl : 1));
+    out->xyz = (float *)malloc(sizeof(float) * 3 * (size_t)(np > 0 ? np : 1));
+    if (!out->npts || !out->seed_index || !out->xyz) { fib_tract_free(out); return fib::fail(FIB_ERR_NOMEM, "out of host memory"); }
+    if (nl > 0) {
+        fib::DevBuf<int32_t> d_npts;
+        fib::DevBuf<int64_t> d_sidx;
+        fib::DevBuf<float> d_xyz;
+        int rc = d_npts.alloc((size_t)nl);
+        if (rc == FIB_OK) rc = d_sidx.alloc((size_t)nl);
+        if (rc == FIB_OK) rc = d_xyz.alloc((size_t)np * 3);
+        if (rc == FIB_OK) rc = fibd_stream_pack(job, d_npts.p, d_sidx.p, d_xyz.p, nullptr);
+        if (rc == FIB_OK && hipDeviceSynchronize() != hipSuccess) rc = fib::fail(FIB_ERR_HIP, "streamline pack failed");
+        if (rc == FIB_OK) rc = d2h(out->npts, d_npts.p, sizeof(int32_t) * nl);
+        if (rc == FIB_OK) rc = d2h(out->seed_index, d_sidx.p, sizeof(int64_t) * nl);
+        if (rc == FIB_OK) rc = d2h(out->xyz, d_xyz.p, sizeof(float) * 3 * np);
+        if (rc != FIB_OK) { fib_tract_free(out); return rc; }
+    }
+    return FIB_OK;
+}

@@ -1,0 +1,536 @@
+// odf.hip — K2..K5: GQI / DSI ODF reconstruction, ODF peak finder, global QA normalisation (gfx950).
+//
+//   K2/K5  odf_gemm_kernel   O[M x Nvox] = A[M x K] * clamp(S[K x Nvox])   on v_mfma_f32_32x32x2_f32
+//                            (gqi.jl:139-145 `mul!(o, A, s)`; dsi.jl:204-246 recast as two dense maps)
+//   K3     odf_peaks_kernel  find_peaks! + peak/qa extraction (gqi.jl:147-159,180-201; dsi.jl:244-258)
+//   K4     max-of-means reduction + qa ./= odfmax (gqi.jl:164-168; dsi.jl:263-267)
+//
+// GEMM design.  M (ODF vertices, 321 for sphere_642) is small, K (frames, 270) is small, N (voxels,
+// 2.7 M) is huge and contiguous in memory for both S (planar frames) and O (planar vertices).  So the
+// voxel index sits on the MFMA lane (N = column): a wave owns 32 voxels and ALL rows of its M tile;
+// accumulators stay in registers for the whole K loop (MB blocks of 32x32 = 16*MB VGPRs), S is read
+// exactly once straight into VGPRs as the B operand (two 128-B segments per wave load), and the only
+// shared operand, the matrix A (347 KB: larger than LDS), is streamed K-tile by K-tile through a
+// double-buffered LDS ring with direct-to-LDS loads (global_load_lds), laid out K-major so that the
+// A-fragment ds_read_b32 is bank-conflict free.  f32-input MFMA is exact f32 (k-ordered fma chain):
+// the ODF matches a CPU sgemv to rounding, which the strict-inequality peak finder needs.
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KT = 16;        // frames per LDS stage
+constexpr int WG_VOX = 128;   // voxels per workgroup (4 waves x 32)
+
+struct GemmArgs {
+    const float *At;          // [ntile_m][Kpad][MB*32]  K-major tiles, zero padded
+    const float *S;           // [K][nvox] planar DWI
+    const uint8_t *mask;      // [nvox]
+    const float *frame_eff;   // [K] 1 = frame takes part in the "any positive sample" test
+    float *out0;              // rows [0, nrow0)        (DSI: pdf)
+    float *out1;              // rows [nrow0, M)        (odf)
+    int64_t nvox;
+    int K, Kpad, M, nrow0, ntile_m;
+    int scale_frame;          // DSI: frame whose clamped sample times scale_coef is sum(p); -1: no scaling
+    float scale_coef;
+};
+
+template <int MB>
+__global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
+    constexpr int MW = MB * 32;
+    constexpr int TILE = KT * MW;                       // floats per stage
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, kh = lane >> 5;
+    const int tile_m = blockIdx.x % a.ntile_m;
+    const int64_t tile_n = blockIdx.x / a.ntile_m;
+    const int64_t vox = tile_n * WG_VOX + wave * 32 + col;
+    const bool inb = vox < a.nvox;
+    const float *Sp = a.S + (inb ? vox : 0);
+    const float *Atile = a.At + (size_t)tile_m * a.Kpad * MW;
+    const int ntiles = a.Kpad / KT;
+
+    f32x16 acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[m][r] = 0.0f;
+
+    // one stage = TILE*4 bytes contiguous in global memory; each wave-instruction moves 1 KiB
+    constexpr int NPIECE = TILE * 4 / 1024;             // MB*32*16*4/1024 = 2*MB
+    auto stage_A = [&](int t, int buf) {
+        const char *g = reinterpret_cast<const char *>(Atile + (size_t)t * TILE);
+        char *l = reinterpret_cast<char *>(lds + buf * TILE);
+        for (int p = wave; p < NPIECE; p += 4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + p * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void *)(l + p * 1024), 16, 0, 0);
+    };
+    float bcur[KT / 2], bnext[KT / 2];
+    bool anypos = false;
+    auto load_B = [&](int t, float (&b)[KT / 2]) {
+#pragma unroll
+        for (int kk = 0; kk < KT / 2; kk++) {
+            const int k = t * KT + 2 * kk + kh;
+            float s = 0.0f;
+            if (inb && k < a.K) s = Sp[(int64_t)k * a.nvox];
+            b[kk] = s;
+        }
+    };
+    auto clamp_B = [&](int t, float (&b)[KT / 2]) {
+#pragma unroll
+        for (int kk = 0; kk < KT / 2; kk++) {
+            const int k = t * KT + 2 * kk + kh;
+            const float s = b[kk];
+            if (k < a.K && !(s <= 0.0f) && a.frame_eff[k] != 0.0f) anypos = true;   // positive or NaN (gqi.jl:142, dsi.jl:207)
+            b[kk] = s < 0.0f ? 0.0f : s;                                             // gqi.jl:140, dsi.jl:209
+        }
+    };
+
+    stage_A(0, 0);
+    load_B(0, bcur);
+    clamp_B(0, bcur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < ntiles; t++) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) {
+            stage_A(t + 1, cur ^ 1);
+            load_B(t + 1, bnext);
+        }
+        const float *L = lds + cur * TILE + kh * MW + col;
+#pragma unroll
+        for (int kk = 0; kk < KT / 2; kk++) {
+            const float b = bcur[kk];
+#pragma unroll
+            for (int m = 0; m < MB; m++) {
+                const float av = L[2 * kk * MW + m * 32];
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[m], 0, 0, 0);
+            }
+        }
+        if (t + 1 < ntiles) {
+            clamp_B(t + 1, bnext);
+#pragma unroll
+            for (int kk = 0; kk < KT / 2; kk++) bcur[kk] = bnext[kk];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stage's direct-to-LDS loads have landed
+        __syncthreads();
+    }
+
+    // the two k-halves of a voxel live in lanes l and l^32
+    const bool valid_half = anypos;
+    const bool other = __shfl_xor((int)valid_half, 32) != 0;
+    bool valid = inb && (valid_half || other) && a.mask[inb ? vox : 0] != 0;
+    float scale = 1.0f;
+    if (a.scale_frame >= 0 && inb) {
+        float s = Sp[(int64_t)a.scale_frame * a.nvox];
+        s = s < 0.0f ? 0.0f : s;
+        scale = 1.0f / (a.scale_coef * s);              // p ./ sum(p), dsi.jl:225 (0 -> Inf/NaN like the reference)
+    }
+    if (!inb) return;
+#pragma unroll
+    for (int m = 0; m < MB; m++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = tile_m * MW + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (row >= a.M) continue;
+            float v = valid ? acc[m][r] : 0.0f;
+            if (a.scale_frame >= 0 && valid) v *= scale;
+            if (row < a.nrow0) a.out0[(int64_t)row * a.nvox + vox] = v;
+            else               a.out1[(int64_t)(row - a.nrow0) * a.nvox + vox] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// peak finder
+// ------------------------------------------------------------------------------------------
+constexpr int PV = 32;        // voxels per workgroup tile
+constexpr int PG = 8;         // vertex groups (256 threads)
+
+__device__ __forceinline__ bool jl_isless(float x, float y) {   // Base.isless on floats
+    if (x != x) return false;
+    if (y != y) return true;
+    if (x == y) return (__float_as_uint(x) >> 31) && !(__float_as_uint(y) >> 31);
+    return x < y;
+}
+// position in sortperm!(…, rev=true): descending value, ties keep ascending index (gqi.jl:198)
+__device__ __forceinline__ bool sorts_before(float va, int ia, float vb, int ib) {
+    return jl_isless(vb, va) || (!jl_isless(va, vb) && ia < ib);
+}
+
+struct Top3 { float v[3]; int i[3]; };
+__device__ __forceinline__ void top3_insert(Top3 &t, float x, int idx) {
+    // entries are kept sorted; empty slots (i < 0) only at the tail
+    const bool b2 = t.i[2] >= 0 && !sorts_before(x, idx, t.v[2], t.i[2]);
+    if (b2) return;
+    const bool b1 = t.i[1] >= 0 && !sorts_before(x, idx, t.v[1], t.i[1]);
+    const bool b0 = t.i[0] >= 0 && !sorts_before(x, idx, t.v[0], t.i[0]);
+    if (b1) { t.v[2] = x; t.i[2] = idx; return; }
+    t.v[2] = t.v[1]; t.i[2] = t.i[1];
+    if (b0) { t.v[1] = x; t.i[1] = idx; return; }
+    t.v[1] = t.v[0]; t.i[1] = t.i[0];
+    t.v[0] = x; t.i[0] = idx;
+}
+
+struct PeakArgs {
+    const float *odf;         // [nvert][nvox]
+    const int16_t *nbr;       // [nvert][maxdeg], -1 padded
+    const float *verts;       // [nvert][3] first-half vertex coordinates (gqi.jl:155)
+    float *peak[3];           // [3][nvox] each (or NULL in find-peaks mode)
+    float *qa[3];             // [nvox] each
+    int32_t *isort_top;       // [3][nvox] (find-peaks mode) or NULL
+    int32_t *nvalid;          // [nvox]    (find-peaks mode) or NULL
+    unsigned *maxenc;         // [2]: ordered-uint max of per-voxel means, NaN flag (may be NULL)
+    int64_t nvox;
+    int nvert, maxdeg;
+};
+
+__device__ __forceinline__ unsigned enc_ordered(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float dec_ordered(unsigned e) {
+    return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
+}
+
+__global__ __launch_bounds__(256) void odf_peaks_kernel(const PeakArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *o = smem;                                            // [nvert][PV]
+    int16_t *nb = reinterpret_cast<int16_t *>(o + (size_t)a.nvert * PV);   // [nvert][maxdeg]
+    const int nnb = a.nvert * a.maxdeg;
+    float *mrg = reinterpret_cast<float *>(nb + ((nnb + 1) & ~1));          // merge area
+    const int tid = threadIdx.x, j = tid & (PV - 1), g = tid / PV;
+    const int64_t vox = (int64_t)blockIdx.x * PV + j;
+    const bool inb = vox < a.nvox;
+    for (int i = tid; i < nnb; i += 256) nb[i] = a.nbr[i];
+    for (int v = g; v < a.nvert; v += PG) o[v * PV + j] = inb ? a.odf[(int64_t)v * a.nvox + vox] : 0.0f;
+    __syncthreads();
+
+    Top3 t;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { t.v[k] = 0.0f; t.i[k] = -1; }
+    int npos = 0;
+    float vmin = INFINITY, vsum = 0.0f;
+    bool hasnan = false;
+    for (int v = g; v < a.nvert; v += PG) {
+        const float x = o[v * PV + j];
+        bool survive = true;
+        for (int d = 0; d < a.maxdeg; d++) {
+            const int u = nb[v * a.maxdeg + d];
+            if (u < 0) break;
+            if (o[u * PV + j] >= x) survive = false;            // gqi.jl:185-196: o[b] >= o[a] || o[c] >= o[a]
+        }
+        const float pk = survive ? x : 0.0f;                    // odf_peak
+        if (pk > 0.0f) npos++;                                  // gqi.jl:200
+        top3_insert(t, pk, v);
+        hasnan |= (x != x);
+        vmin = fminf(vmin, x);
+        vsum += x;
+    }
+    // merge the PG partial results of each voxel: [PG][PV] records of 3 val + 3 idx + npos + min + sum + nan
+    float *rec = mrg + (size_t)(g * PV + j) * 10;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { rec[k] = t.v[k]; rec[3 + k] = __int_as_float(t.i[k]); }
+    rec[6] = __int_as_float(npos); rec[7] = vmin; rec[8] = vsum; rec[9] = hasnan ? 1.0f : 0.0f;
+    __syncthreads();
+    float mean = 0.0f;
+    bool mean_nan = false;
+    if (g == 0) {
+        for (int gg = 1; gg < PG; gg++) {
+            const float *r = mrg + (size_t)(gg * PV + j) * 10;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int idx = __float_as_int(r[3 + k]);
+                if (idx >= 0) top3_insert(t, r[k], idx);
+            }
+            npos += __float_as_int(r[6]);
+            vmin = fminf(vmin, r[7]);
+            vsum += r[8];
+            hasnan |= r[9] != 0.0f;
+        }
+        if (hasnan) vmin = NAN;                                 // minimum() propagates NaN (gqi.jl:147)
+        mean = vsum * (1.0f / (float)a.nvert);                  // mean(odf, dims=4), gqi.jl:164
+        mean_nan = mean != mean;
+        if (inb) {
+            if (a.isort_top) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) a.isort_top[(int64_t)k * a.nvox + vox] = t.i[k];
+                a.nvalid[vox] = npos;
+            } else {
+                const int n = npos < 3 ? npos : 3;              // gqi.jl:151
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    float px = 0.0f, py = 0.0f, pz = 0.0f, q = 0.0f;
+                    if (k < n) {
+                        const int iv = t.i[k];
+                        px = a.verts[3 * iv]; py = a.verts[3 * iv + 1]; pz = a.verts[3 * iv + 2];
+                        q = o[iv * PV + j] - vmin;              // gqi.jl:157-158
+                    }
+                    a.peak[k][vox] = px; a.peak[k][a.nvox + vox] = py; a.peak[k][2 * a.nvox + vox] = pz;
+                    a.qa[k][vox] = q;
+                }
+            }
+        }
+    }
+    if (a.maxenc && tid < 64) {                                 // wave 0 holds g==0 (lanes 0..31) and g==1
+        const bool mine = (g == 0) && inb;
+        unsigned e = mine && !mean_nan ? enc_ordered(mean) : 0u;
+        unsigned long long nanb = __ballot(mine && mean_nan);
+        for (int off = 32; off >= 1; off >>= 1) { const unsigned oth = __shfl_xor((int)e, off); e = oth > e ? oth : e; }
+        if (tid == 0) {
+            if (e) atomicMax(&a.maxenc[0], e);
+            if (nanb) atomicOr(&a.maxenc[1], 1u);
+        }
+    }
+}
+
+__global__ void odfmax_finalize_kernel(const unsigned *enc, float *out) {
+    const bool nan = enc[1] != 0;
+    const float m = enc[0] ? dec_ordered(enc[0]) : -INFINITY;
+    out[0] = nan ? NAN : m;                                     // maximum() propagates NaN
+    out[1] = nan ? 1.0f : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void qa_normalize_kernel(float *q0, float *q1, float *q2, int64_t nvox,
+                                                          const float *odfmax_dev, float odfmax_val) {
+    const float d = odfmax_dev ? odfmax_dev[0] : odfmax_val;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvox; i += (int64_t)gridDim.x * blockDim.x) {
+        q0[i] = q0[i] / d;                                      // qa[ipeak].vol /= odfmax, gqi.jl:167
+        q1[i] = q1[i] / d;
+        q2[i] = q2[i] / d;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------
+struct fib_odf_plan {
+    int device = 0;
+    int nvol = 0, nvert = 0, nrows = 0, nrow0 = 0;   // nrow0 = rows that go to the pdf output (DSI), else 0
+    int MB = 11, ntile_m = 1, Kpad = 0, maxdeg = 0;
+    int scale_frame = -1;
+    float scale_coef = 0.0f;
+    std::vector<float> A;                            // host copy [nrows x nvol] column-major
+    fib::DevBuf<float> At, frame_eff, verts;
+    fib::DevBuf<int16_t> nbr;
+    mutable fib::DevBuf<unsigned> maxenc;
+    mutable fib::DevBuf<float> odfmax;
+};
+
+namespace {
+
+const int kMBChoices[] = {12, 11, 10, 9, 8, 7, 6};
+
+int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *faces, int nfaces,
+                const std::vector<float> &frame_eff) {
+    const int M = p->nrows, K = p->nvol;
+    int best = -1, bestpad = INT32_MAX, bestnt = 1;
+    for (int mb : kMBChoices) {
+        const int nt = (M + mb * 32 - 1) / (mb * 32), pad = nt * mb * 32;
+        if (pad < bestpad) { bestpad = pad; best = mb; bestnt = nt; }
+    }
+    p->MB = best; p->ntile_m = bestnt;
+    p->Kpad = (K + KT - 1) / KT * KT;
+    const int MW = p->MB * 32;
+    std::vector<float> At((size_t)p->ntile_m * p->Kpad * MW, 0.0f);
+    for (int k = 0; k < K; k++)
+        for (int r = 0; r < M; r++) {
+            const int tm = r / MW, rr = r % MW;
+            At[((size_t)tm * p->Kpad + k) * MW + rr] = p->A[r + (size_t)M * k];
+        }
+    std::vector<int32_t> nbr32;
+    int rc = fib::host_neighbours(faces, nfaces, nverts, nbr32, &p->maxdeg);
+    if (rc != FIB_OK) return rc;
+    if (p->maxdeg < 1) p->maxdeg = 1;
+    if (nbr32.size() < (size_t)p->nvert * p->maxdeg) nbr32.assign((size_t)p->nvert * p->maxdeg, -1);
+    std::vector<int16_t> nbr(nbr32.begin(), nbr32.end());
+    std::vector<float> v3((size_t)p->nvert * 3);
+    for (int v = 0; v < p->nvert; v++)
+        for (int c = 0; c < 3; c++) v3[3 * v + c] = verts[v + (size_t)nverts * c];
+    if ((rc = p->At.alloc(At.size())) != FIB_OK) return rc;
+    if ((rc = p->frame_eff.alloc(frame_eff.size())) != FIB_OK) return rc;
+    if ((rc = p->verts.alloc(v3.size())) != FIB_OK) return rc;
+    if ((rc = p->nbr.alloc(nbr.size())) != FIB_OK) return rc;
+    if ((rc = p->maxenc.alloc(2)) != FIB_OK) return rc;
+    if ((rc = p->odfmax.alloc(2)) != FIB_OK) return rc;
+    FIB_HIP(hipMemcpy(p->At.p, At.data(), At.size() * sizeof(float), hipMemcpyHostToDevice));
+    FIB_HIP(hipMemcpy(p->frame_eff.p, frame_eff.data(), frame_eff.size() * sizeof(float), hipMemcpyHostToDevice));
+    FIB_HIP(hipMemcpy(p->verts.p, v3.data(), v3.size() * sizeof(float), hipMemcpyHostToDevice));
+    FIB_HIP(hipMemcpy(p->nbr.p, nbr.data(), nbr.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+    return FIB_OK;
+}
+
+int check_plan_args(const float *bval, const float *bvec, int nvol, const float *verts, int nverts,
+                    const int32_t *faces, int nfaces, fib_odf_plan **plan) {
+    FIB_CHECK(plan != nullptr, FIB_ERR_INVALID, "plan output pointer is NULL");
+    *plan = nullptr;
+    FIB_CHECK(bval != nullptr && nvol > 0, FIB_ERR_MISSING_BVAL, "Missing b-value table from input DWI structure");
+    FIB_CHECK(bvec != nullptr, FIB_ERR_MISSING_BVEC, "Missing gradient table from input DWI structure");
+    FIB_CHECK(verts && faces && nverts >= 2 && nverts % 2 == 0 && nfaces > 0, FIB_ERR_INVALID, "invalid ODF tessellation");
+    FIB_CHECK(nverts / 2 < 32768, FIB_ERR_UNSUPPORTED, "too many ODF vertices");
+    return FIB_OK;
+}
+
+}  // namespace
+
+extern "C" int fib_gqi_plan_create(int device, const float *bval, const float *bvec, int nvol,
+                                   const float *verts, int nverts, const int32_t *faces, int nfaces,
+                                   float sigma, fib_odf_plan **plan) {
+    int rc = check_plan_args(bval, bvec, nvol, verts, nverts, faces, nfaces, plan);
+    if (rc != FIB_OK) return rc;
+    fib::DeviceGuard guard;
+    if ((rc = fib::use_device(device)) != FIB_OK) return rc;
+    fib_odf_plan *p = new (std::nothrow) fib_odf_plan();
+    FIB_CHECK(p != nullptr, FIB_ERR_NOMEM, "out of host memory");
+    p->device = device; p->nvol = nvol; p->nvert = nverts / 2; p->nrows = p->nvert; p->nrow0 = 0;
+    p->A.resize((size_t)p->nrows * nvol);
+    fib::host_gqi_matrix(bval, bvec, nvol, verts, nverts, sigma, p->A.data());
+    std::vector<float> eff((size_t)nvol, 1.0f);
+    rc = finish_plan(p, verts, nverts, faces, nfaces, eff);
+    if (rc != FIB_OK) { delete p; return rc; }
+    *plan = p;
+    return FIB_OK;
+}
+
+extern "C" int fib_dsi_plan_create(int device, const float *bval, const float *bvec, int nvol,
+                                   const float *verts, int nverts, const int32_t *faces, int nfaces,
+                                   int hann_width, fib_odf_plan **plan) {
+    int rc = check_plan_args(bval, bvec, nvol, verts, nverts, faces, nfaces, plan);
+    if (rc != FIB_OK) return rc;
+    FIB_CHECK(hann_width >= 0, FIB_ERR_INVALID, "hann_width must be >= 0");
+    fib::DeviceGuard guard;
+    if ((rc = fib::use_device(device)) != FIB_OK) return rc;
+    fib_odf_plan *p = new (std::nothrow) fib_odf_plan();
+    FIB_CHECK(p != nullptr, FIB_ERR_NOMEM, "out of host memory");
+    p->device = device; p->nvol = nvol; p->nvert = nverts / 2; p->nrows = nvol + p->nvert; p->nrow0 = nvol;
+    p->A.resize((size_t)p->nrows * nvol);
+    rc = fib::host_dsi_matrix(bval, bvec, nvol, verts, nverts, hann_width, p->A.data(), &p->scale_frame, &p->scale_coef);
+    if (rc != FIB_OK) { delete p; return rc; }
+    // a frame overwritten by a later one on the same lattice point never reaches X (dsi.jl:205): its column is 0
+    std::vector<float> eff((size_t)nvol, 0.0f);
+    for (int j = 0; j < nvol; j++)
+        for (int r = 0; r < p->nrows; r++) if (p->A[r + (size_t)p->nrows * j] != 0.0f) { eff[j] = 1.0f; break; }
+    if (p->scale_frame < 0) { p->scale_frame = 0; p->scale_coef = 0.0f; }   // no q=0 sample: sum(p) = 0 -> Inf/NaN
+    rc = finish_plan(p, verts, nverts, faces, nfaces, eff);
+    if (rc != FIB_OK) { delete p; return rc; }
+    *plan = p;
+    return FIB_OK;
+}
+
+extern "C" void fib_odf_plan_destroy(fib_odf_plan *plan) {
+    if (!plan) return;
+    fib::DeviceGuard guard;
+    (void)hipSetDevice(plan->device);
+    delete plan;
+}
+
+extern "C" int fib_odf_plan_matrix(const fib_odf_plan *plan, float *A, int *nrows, int *nvol, int *nvert) {
+    FIB_CHECK(plan != nullptr, FIB_ERR_INVALID, "plan is NULL");
+    if (nrows) *nrows = plan->nrows;
+    if (nvol) *nvol = plan->nvol;
+    if (nvert) *nvert = plan->nvert;
+    if (A) memcpy(A, plan->A.data(), plan->A.size() * sizeof(float));
+    return FIB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// launches
+// ------------------------------------------------------------------------------------------
+namespace {
+
+template <int MB>
+void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
+    hipLaunchKernelGGL((odf_gemm_kernel<MB>), dim3(grid), dim3(256), 0, st, ga);
+}
+
+size_t peaks_smem(const fib_odf_plan *p) {
+    const size_t nnb = (size_t)p->nvert * p->maxdeg;
+    return (size_t)p->nvert * PV * 4 + ((nnb + 1) & ~(size_t)1) * 2 + (size_t)PG * PV * 10 * 4;
+}
+
+int launch_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox, float *const peak[3], float *const qa[3],
+                 int32_t *isort_top, int32_t *nvalid, bool reduce, hipStream_t st) {
+    PeakArgs pa{};
+    pa.odf = odf; pa.nbr = plan->nbr.p; pa.verts = plan->verts.p;
+    for (int k = 0; k < 3; k++) { pa.peak[k] = peak ? peak[k] : nullptr; pa.qa[k] = qa ? qa[k] : nullptr; }
+    pa.isort_top = isort_top; pa.nvalid = nvalid;
+    pa.maxenc = reduce ? plan->maxenc.p : nullptr;
+    pa.nvox = nvox; pa.nvert = plan->nvert; pa.maxdeg = plan->maxdeg;
+    const size_t smem = peaks_smem(plan);
+    FIB_CHECK(smem <= 160 * 1024, FIB_ERR_UNSUPPORTED, "ODF with %d vertices does not fit the peak finder's LDS tile", plan->nvert);
+    FIB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(odf_peaks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    fib::ProfScope prof("odf_peaks", st);
+    hipLaunchKernelGGL(odf_peaks_kernel, dim3((unsigned)fib::cdiv(nvox, PV)), dim3(256), smem, st, pa);
+    FIB_HIP(hipGetLastError());
+    return FIB_OK;
+}
+
+}  // namespace
+
+extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const uint8_t *mask, int64_t nvox,
+                            float *pdf, float *odf, float *const peak[3], float *const qa[3],
+                            float *odfmax_dev, int normalize, void *stream) {
+    FIB_CHECK(plan && dwi && mask && odf && peak && qa, FIB_ERR_INVALID, "NULL argument");
+    FIB_CHECK(nvox > 0, FIB_ERR_INVALID, "nvox must be positive");
+    FIB_CHECK(plan->nrow0 == 0 || pdf != nullptr, FIB_ERR_INVALID, "DSI plans need a pdf output volume");
+    for (int k = 0; k < 3; k++) FIB_CHECK(peak[k] && qa[k], FIB_ERR_INVALID, "NULL peak/qa output volume");
+    fib::DeviceGuard guard;
+    FIB_HIP(hipSetDevice(plan->device));
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs ga{};
+    ga.At = plan->At.p; ga.S = dwi; ga.mask = mask; ga.frame_eff = plan->frame_eff.p;
+    ga.out0 = pdf; ga.out1 = odf; ga.nvox = nvox;
+    ga.K = plan->nvol; ga.Kpad = plan->Kpad; ga.M = plan->nrows; ga.nrow0 = plan->nrow0; ga.ntile_m = plan->ntile_m;
+    ga.scale_frame = plan->nrow0 > 0 ? plan->scale_frame : -1;
+    ga.scale_coef = plan->scale_coef;
+    const int64_t nblk = fib::cdiv(nvox, WG_VOX) * plan->ntile_m;
+    FIB_CHECK(nblk < ((int64_t)1 << 31), FIB_ERR_UNSUPPORTED, "volume too large for one launch");
+    const unsigned grid = (unsigned)nblk;
+    { fib::ProfScope prof("odf_gemm", st);
+    switch (plan->MB) {
+        case 6: launch_gemm<6>(ga, grid, st); break;
+        case 7: launch_gemm<7>(ga, grid, st); break;
+        case 8: launch_gemm<8>(ga, grid, st); break;
+        case 9: launch_gemm<9>(ga, grid, st); break;
+        case 10: launch_gemm<10>(ga, grid, st); break;
+        case 11: launch_gemm<11>(ga, grid, st); break;
+        case 12: launch_gemm<12>(ga, grid, st); break;
+        default: return fib::fail(FIB_ERR_INVALID, "internal: bad MB %d", plan->MB);
+    }
+    }
+    FIB_HIP(hipGetLastError());
+    FIB_HIP(hipMemsetAsync(plan->maxenc.p, 0, 2 * sizeof(unsigned), st));
+    int rc = launch_peaks(plan, odf, nvox, peak, qa, nullptr, nullptr, true, st);
+    if (rc != FIB_OK) return rc;
+    float *om = odfmax_dev ? odfmax_dev : plan->odfmax.p;
+    hipLaunchKernelGGL(odfmax_finalize_kernel, dim3(1), dim3(1), 0, st, plan->maxenc.p, om);
+    FIB_HIP(hipGetLastError());
+    if (normalize) {
+        fib::ProfScope prof("qa_normalize", st);
+        hipLaunchKernelGGL(qa_normalize_kernel, dim3(2048), dim3(256), 0, st, qa[0], qa[1], qa[2], nvox, om, 0.0f);
+        FIB_HIP(hipGetLastError());
+    }
+    return FIB_OK;
+}
+
+extern "C" int fibd_qa_normalize(float *const qa[3], int64_t nvox, float odfmax, void *stream) {
+    FIB_CHECK(qa && qa[0] && qa[1] && qa[2] && nvox > 0, FIB_ERR_INVALID, "NULL argument");
+    hipLaunchKernelGGL(qa_normalize_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, qa[0], qa[1], qa[2], nvox,
+                       (const float *)nullptr, odfmax);
+    FIB_HIP(hipGetLastError());
+    return FIB_OK;
+}
+
+extern "C" int fibd_find_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox,
+                               int32_t *isort_top, int32_t *nvalid, void *stream) {
+    FIB_CHECK(plan && odf && isort_top && nvalid && nvox > 0, FIB_ERR_INVALID, "NULL argument");
+    fib::DeviceGuard guard;
+    FIB_HIP(hipSetDevice(plan->device));
+    return launch_peaks(plan, odf, nvox, nullptr, nullptr, isort_top, nvalid, false, (hipStream_t)stream);
+}

@@ -1,0 +1,404 @@
+// stream.hip — K6/K7: deterministic streamline tractography (nearest-voxel lookup + fixed-step Euler).
+//
+// Replaces StreamWork's mask/vector repack (stream.jl:95-145), stream_new_line (stream.jl:625-690),
+// stream_new_point! (stream.jl:501-541), stream_pick_by_angle! (stream.jl:340-374) and the seed loop /
+// len_min filter / concatenation of `stream` (stream.jl:761-787), for the non-LCM macro-scale path.
+//
+// Layout.  The orientation field is repacked to float4 [nvox][nvec] (xyz0): one aligned 16-byte gather
+// per candidate vector per step; vectors of masked-out voxels are zero, which makes the reference's
+// separate mask lookup (stream.jl:520) redundant (an all-zero voxel fails stream_pick_by_angle! the same
+// way).  One lane integrates one (seed, sub-voxel offset) line, forward then backward, writing points
+// into a fixed-stride scratch row [line][len_max+2] (the HBM budget of an MI355X makes worst-case rows
+// affordable: 1 M lines x 142 points x 12 B = 1.7 GB).  A scan over the per-line counts then gives every
+// kept line its offset, and the pack kernel (one wave per line) emits the reference's point order
+// [fwd_N .. fwd_1, bwd_1 .. bwd_M] (prepend!/append!, stream.jl:652) fully coalesced.
+//
+// Arithmetic.  No a*b+c contraction anywhere in this file: positions are compared after round-to-nearest-
+// even (stream.jl:514) so one ulp moves a line to another voxel; with contraction off every operation is
+// an IEEE single/double operation in the reference's order and the CPU restatement is matched bit for bit.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <mutex>
+
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+struct FieldArgs {
+    const float *ovec[8];
+    const float *f[8];
+    const float *fa;
+    const uint8_t *mask;
+    float4 *field;
+    uint8_t *mask_out;
+    int64_t nvox;
+    int nvec;
+    int has_f;
+    float f_thresh, fa_thresh;
+};
+
+__global__ __launch_bounds__(256) void stream_field_kernel(const FieldArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.nvox) return;
+    float v[8][3];
+    bool any = false;
+    for (int k = 0; k < a.nvec; k++)
+        for (int c = 0; c < 3; c++) {
+            v[k][c] = a.ovec[k][(int64_t)c * a.nvox + i];
+            any |= v[k][c] != 0.0f;                               // any(x -> x != 0, ...), stream.jl:99
+        }
+    bool m = a.mask ? a.mask[i] != 0 : any;                       // stream.jl:95-103 (mask already '> 0'-tested)
+    if (a.fa) m = m && (a.fa[i] >= a.fa_thresh);                  // stream.jl:116
+    for (int k = 0; k < a.nvec; k++) {
+        bool om = m;
+        if (a.has_f) om = m && (a.f[k][i] >= a.f_thresh);         // stream.jl:138
+        a.field[i * a.nvec + k] = om ? make_float4(v[k][0], v[k][1], v[k][2], 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    if (a.mask_out) a.mask_out[i] = m ? 1 : 0;
+}
+
+struct TraceArgs {
+    const float4 *field;        // [nvox][nvec]
+    const int64_t *seeds;       // [nseed] 0-based linear voxel index
+    const float *sublist;       // [nsub][3]
+    float *scratch;             // [nlines][stride][3]
+    int32_t *npts, *nfwd;       // [nlines]
+    int64_t line0, nlines;      // this batch covers global lines [line0, line0+nlines)
+    int nx, ny, nz, nvec, nsub, len_max, stride;
+    float cosang, step, smooth;
+};
+
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return ax * bx + ay * by + az * bz;                           // (x+y)+z, no fma
+}
+
+template <int NVEC>   // NVEC > 0: compile-time vector count; 0: runtime
+__global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
+    const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= a.nlines) return;
+    const int nvec = NVEC > 0 ? NVEC : a.nvec;
+    const int64_t line = a.line0 + li;
+    const int64_t iseed = line / a.nsub;
+    const int isub = (int)(line - iseed * a.nsub);
+    const int64_t lin = a.seeds[iseed];
+    const int sx = (int)(lin % a.nx), sy = (int)((lin / a.nx) % a.ny), sz = (int)(lin / ((int64_t)a.nx * a.ny));
+    const float p0x = (float)(sx + 1) + a.sublist[3 * isub];      // pos_now .= seed_vox .+ sub_vox, stream.jl:649
+    const float p0y = (float)(sy + 1) + a.sublist[3 * isub + 1];
+    const float p0z = (float)(sz + 1) + a.sublist[3 * isub + 2];
+    float *dst = a.scratch + (int64_t)li * a.stride * 3;
+    const float fnx = (float)a.nx, fny = (float)a.ny, fnz = (float)a.nz;
+    const float omc = 1.0f - a.smooth;
+    int ivec = 0, npts = 0, nf = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        const float fwd = pass == 0 ? 1.0f : -1.0f;
+        float px = p0x, py = p0y, pz = p0z;
+        const float4 s = a.field[lin * nvec + ivec];              // view(W.ovecs, :, ivec_next, seed...), stream.jl:650
+        float vx = s.x * fwd, vy = s.y * fwd, vz = s.z * fwd;
+        for (;;) {
+            const float nxp = px + vx * a.step, nyp = py + vy * a.step, nzp = pz + vz * a.step;   // stream.jl:512
+            const float rx = rintf(nxp), ry = rintf(nyp), rz = rintf(nzp);                        // stream.jl:514
+            if (!(rx >= 1.0f && rx <= fnx && ry >= 1.0f && ry <= fny && rz >= 1.0f && rz <= fnz)) break;   // :517
+            const int64_t vox = ((int)rx - 1) + (int64_t)a.nx * (((int)ry - 1) + (int64_t)a.ny * ((int)rz - 1));
+            const float4 *cand = a.field + vox * nvec;
+            float bx = 0.0f, by = 0.0f, bz = 0.0f, bestc = 0.0f, besta = 0.0f;
+            int best = 0;
+#pragma unroll
+            for (int k = 0; k < nvec; k++) {                      // stream_pick_by_angle!, stream.jl:350-361
+                const float4 w = cand[k];
+                float c, ca;
+                if (w.x == 0.0f && w.y == 0.0f && w.z == 0.0f) { c = -INFINITY; ca = -INFINITY; }
+                else { c = dot3(vx, vy, vz, w.x, w.y, w.z); ca = fabsf(c); }
+                // argmax: first maximum, NaN wins over everything
+                if (k == 0 || (!(besta != besta) && ((ca != ca) || ca > besta))) {
+                    best = k; besta = ca; bestc = c; bx = w.x; by = w.y; bz = w.z;
+                }
+            }
+            if (!(fabsf(bestc) < INFINITY)) break;                // !isfinite -> false, stream.jl:363
+            float wx, wy, wz;
+            if (bestc > 0.0f) { wx = bx; wy = by; wz = bz; } else { wx = -bx; wy = -by; wz = -bz; }   // :365-369
+            ivec = best;                                          // stream.jl:371
+            dst[3 * npts] = px; dst[3 * npts + 1] = py; dst[3 * npts + 2] = pz;                       // :660
+            npts++;
+            if (pass == 0) nf++;
+            if (dot3(vx, vy, vz, wx, wy, wz) < a.cosang) break;   // stream.jl:670
+            if (npts > a.len_max) break;                          // stream.jl:674
+            if (a.smooth != 0.0f) {                               // stream.jl:677-681
+                wx = a.smooth * vx + omc * wx;
+                wy = a.smooth * vy + omc * wy;
+                wz = a.smooth * vz + omc * wz;
+                // LinearAlgebra.norm (generic_norm2): squares in Float32, sum and sqrt in Float64
+                const float m = fmaxf(fabsf(wx), fmaxf(fabsf(wy), fabsf(wz)));
+                float n;
+                if (m == 0.0f || !(m < INFINITY)) n = m;
+                else {
+                    double acc = (double)(wx * wx);
+                    acc += (double)(wy * wy);
+                    acc += (double)(wz * wz);
+                    n = (float)sqrt(acc);
+                }
+                wx = wx / n; wy = wy / n; wz = wz / n;
+            }
+            px = nxp; py = nyp; pz = nzp;                         // stream.jl:684-685
+            vx = wx; vy = wy; vz = wz;
+        }
+    }
+    a.npts[li] = npts;
+    a.nfwd[li] = nf;
+}
+
+// ---- exclusive scan of (kept ? npts : 0, kept ? 1 : 0) over the lines, int64 pairs --------------------
+struct Pair { int64_t pts, lines; };
+constexpr int SCAN_T = 256, SCAN_E = 8, SCAN_B = SCAN_T * SCAN_E;
+
+__global__ __launch_bounds__(SCAN_T) void scan_block_kernel(const int32_t *npts, int64_t n, int len_min,
+                                                            Pair *excl, Pair *block_tot) {
+    __shared__ Pair sh[SCAN_T];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_B + (int64_t)threadIdx.x * SCAN_E;
+    Pair loc[SCAN_E], run{0, 0};
+#pragma unroll
+    for (int e = 0; e < SCAN_E; e++) {
+        const int64_t i = base + e;
+        const int np = i < n ? npts[i] : 0;
+        const bool keep = i < n && np >= len_min;                 // size(strline, 2) < W.len_min && continue, stream.jl:769
+        loc[e] = run;
+        run.pts += keep ? np : 0;
+        run.lines += keep ? 1 : 0;
+    }
+    sh[threadIdx.x] = run;
+    __syncthreads();
+    for (int off = 1; off < SCAN_T; off <<= 1) {
+        Pair t{0, 0};
+        if ((int)threadIdx.x >= off) t = sh[threadIdx.x - off];
+        __syncthreads();
+        sh[threadIdx.x].pts += t.pts; sh[threadIdx.x].lines += t.lines;
+        __syncthreads();
+    }
+    const Pair before = threadIdx.x ? sh[threadIdx.x - 1] : Pair{0, 0};
+#pragma unroll
+    for (int e = 0; e < SCAN_E; e++) {
+        const int64_t i = base + e;
+        if (i < n) excl[i] = Pair{loc[e].pts + before.pts, loc[e].lines + before.lines};
+    }
+    if (threadIdx.x == SCAN_T - 1) block_tot[blockIdx.x] = sh[SCAN_T - 1];
+}
+
+// exclusive scan of the per-block totals in place (single workgroup, chunks of SCAN_T with a running carry)
+__global__ __launch_bounds__(SCAN_T) void scan_totals_kernel(Pair *block_tot, int nblocks, Pair *total) {
+    __shared__ Pair sh[SCAN_T];
+    Pair carry{0, 0};
+    for (int base = 0; base < nblocks; base += SCAN_T) {
+        const int i = base + (int)threadIdx.x;
+        const Pair mine = i < nblocks ? block_tot[i] : Pair{0, 0};
+        sh[threadIdx.x] = mine;
+        __syncthreads();
+        for (int off = 1; off < SCAN_T; off <<= 1) {
+            Pair t{0, 0};
+            if ((int)threadIdx.x >= off) t = sh[threadIdx.x - off];
+            __syncthreads();
+            sh[threadIdx.x].pts += t.pts; sh[threadIdx.x].lines += t.lines;
+            __syncthreads();
+        }
+        const Pair incl = sh[threadIdx.x], last = sh[SCAN_T - 1];
+        if (i < nblocks) block_tot[i] = Pair{carry.pts + incl.pts - mine.pts, carry.lines + incl.lines - mine.lines};
+        carry.pts += last.pts; carry.lines += last.lines;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+struct PackArgs {
+    const float *scratch;
+    const int32_t *npts, *nfwd;
+    const Pair *excl, *block_off;
+    int32_t *out_npts;
+    int64_t *out_seed;
+    float *out_xyz;
+    int64_t nlines, line0, out_line0, out_pt0;
+    int stride, len_min;
+};
+
+// one wave per line: reversed forward part, then the backward part (stream.jl:652)
+__global__ __launch_bounds__(256) void stream_pack_kernel(const PackArgs a) {
+    const int64_t li = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (li >= a.nlines) return;
+    const int n = a.npts[li];
+    if (n < a.len_min) return;
+    const int lane = threadIdx.x & 63, nf = a.nfwd[li];
+    const Pair e = a.excl[li], bo = a.block_off[li / SCAN_B];
+    const int64_t pt0 = a.out_pt0 + e.pts + bo.pts, l0 = a.out_line0 + e.lines + bo.lines;
+    if (lane == 0) { a.out_npts[l0] = n; a.out_seed[l0] = a.line0 + li; }
+    const float *src = a.scratch + (int64_t)li * a.stride * 3;
+    float *dst = a.out_xyz + pt0 * 3;
+    for (int i = lane; i < 3 * n; i += 64) {
+        const int p = i / 3, c = i - 3 * p;
+        const int sp = p < nf ? nf - 1 - p : p;
+        dst[i] = src[3 * sp + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_i32_kernel(const int32_t *src, int32_t *dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// grow-only scratch cache, one per device: avoids a multi-GB hipMalloc/hipFree per call
+struct ScratchCache {
+    std::mutex mu;
+    void *p[16] = {};
+    size_t bytes[16] = {};
+    bool busy[16] = {};
+};
+ScratchCache g_cache;
+
+}  // namespace
+
+struct fib_stream_job {
+    int device = 0;
+    fib_stream_params prm{};
+    int64_t nseed = 0, nlines = 0;
+    int nsub = 1, stride = 0;
+    float *scratch = nullptr;
+    bool scratch_from_cache = false;
+    fib::DevBuf<int32_t> npts, nfwd;
+    fib::DevBuf<Pair> excl, block_tot, total;
+    int64_t kept_lines = 0, kept_pts = 0;
+};
+
+extern "C" void fib_stream_job_destroy(fib_stream_job *job) {
+    if (!job) return;
+    fib::DeviceGuard guard;
+    (void)hipSetDevice(job->device);
+    if (job->scratch) {
+        if (job->scratch_from_cache) {
+            std::lock_guard<std::mutex> lk(g_cache.mu);
+            g_cache.busy[job->device & 15] = false;
+        } else {
+            (void)hipFree(job->scratch);
+        }
+    }
+    delete job;
+}
+
+extern "C" int fibd_stream_field(int32_t nvec, int64_t nvox, const float *const *ovec, const float *const *f,
+                                 float f_thresh, const float *fa, float fa_thresh, const uint8_t *mask,
+                                 float *field4, uint8_t *mask_out, void *stream) {
+    FIB_CHECK(ovec && field4 && nvox > 0, FIB_ERR_INVALID, "NULL argument");
+    FIB_CHECK(nvec >= 1 && nvec <= 8, FIB_ERR_UNSUPPORTED, "1..8 orientation vectors per voxel are supported (got %d)", nvec);
+    FieldArgs a{};
+    for (int k = 0; k < nvec; k++) {
+        FIB_CHECK(ovec[k] != nullptr, FIB_ERR_INVALID, "NULL orientation volume %d", k);
+        a.ovec[k] = ovec[k];
+        if (f) { FIB_CHECK(f[k] != nullptr, FIB_ERR_INVALID, "NULL amplitude volume %d", k); a.f[k] = f[k]; }
+    }
+    a.fa = fa; a.mask = mask; a.field = reinterpret_cast<float4 *>(field4); a.mask_out = mask_out;
+    a.nvox = nvox; a.nvec = nvec; a.has_f = f ? 1 : 0; a.f_thresh = f_thresh; a.fa_thresh = fa_thresh;
+    hipLaunchKernelGGL(stream_field_kernel, dim3((unsigned)fib::cdiv(nvox, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    FIB_HIP(hipGetLastError());
+    return FIB_OK;
+}
+
+extern "C" int fibd_stream_trace(const fib_stream_params *prm, const float *field4, const int64_t *seeds, int64_t nseed,
+                                 const float *sublist, int32_t nsub, void *stream,
+                                 fib_stream_job **job_out, int64_t *nlines_out, int64_t *npoints_out) {
+    FIB_CHECK(prm && field4 && job_out && nlines_out && npoints_out, FIB_ERR_INVALID, "NULL argument");
+    *job_out = nullptr;
+    FIB_CHECK(nseed >= 0 && (nseed == 0 || seeds), FIB_ERR_INVALID, "invalid seed list");
+    FIB_CHECK(nsub >= 1 && sublist, FIB_ERR_INVALID, "sublist must hold at least one offset (use [0,0,0] for nsub=0, stream.jl:180)");
+    FIB_CHECK(prm->nx > 0 && prm->ny > 0 && prm->nz > 0 && prm->nvec >= 1 && prm->nvec <= 8, FIB_ERR_INVALID, "invalid volume / nvec");
+    FIB_CHECK(prm->len_max >= 0 && prm->len_max < (1 << 24), FIB_ERR_INVALID, "invalid len_max");
+    int device = 0;
+    FIB_HIP(hipGetDevice(&device));
+    hipStream_t st = (hipStream_t)stream;
+    fib_stream_job *job = new (std::nothrow) fib_stream_job();
+    FIB_CHECK(job != nullptr, FIB_ERR_NOMEM, "out of host memory");
+    job->device = device; job->prm = *prm; job->nseed = nseed; job->nsub = nsub;
+    job->nlines = nseed * nsub; job->stride = prm->len_max + 2;
+    const int64_t nl = job->nlines;
+    *nlines_out = 0; *npoints_out = 0;
+    if (nl == 0) { *job_out = job; return FIB_OK; }
+    int rc = FIB_OK;
+    auto bail = [&](int code) { fib_stream_job_destroy(job); return code; };
+    const size_t sbytes = (size_t)nl * job->stride * 3 * sizeof(float);
+    {   // scratch: reuse the per-device cache when it is free
+        std::lock_guard<std::mutex> lk(g_cache.mu);
+        const int d = device & 15;
+        if (!g_cache.busy[d]) {
+            if (g_cache.bytes[d] < sbytes) {
+                if (g_cache.p[d]) (void)hipFree(g_cache.p[d]);
+                g_cache.p[d] = nullptr; g_cache.bytes[d] = 0;
+                if (hipMalloc(&g_cache.p[d], sbytes) == hipSuccess) g_cache.bytes[d] = sbytes;
+            }
+            if (g_cache.p[d]) { job->scratch = (float *)g_cache.p[d]; job->scratch_from_cache = true; g_cache.busy[d] = true; }
+        }
+    }
+    if (!job->scratch) {
+        hipError_t e = hipMalloc((void **)&job->scratch, sbytes);
+        if (e != hipSuccess) { job->scratch = nullptr; return bail(fib::fail(FIB_ERR_NOMEM, "cannot allocate %zu bytes of streamline scratch: %s", sbytes, hipGetErrorString(e))); }
+    }
+    const int nblocks = (int)fib::cdiv(nl, SCAN_B);
+    if ((rc = job->npts.alloc((size_t)nl)) != FIB_OK) return bail(rc);
+    if ((rc = job->nfwd.alloc((size_t)nl)) != FIB_OK) return bail(rc);
+    if ((rc = job->excl.alloc((size_t)nl)) != FIB_OK) return bail(rc);
+    if ((rc = job->block_tot.alloc((size_t)nblocks)) != FIB_OK) return bail(rc);
+    if ((rc = job->total.alloc(1)) != FIB_OK) return bail(rc);
+
+    TraceArgs ta{};
+    ta.field = reinterpret_cast<const float4 *>(field4); ta.seeds = seeds; ta.sublist = sublist;
+    ta.scratch = job->scratch; ta.npts = job->npts.p; ta.nfwd = job->nfwd.p;
+    ta.line0 = 0; ta.nlines = nl;
+    ta.nx = prm->nx; ta.ny = prm->ny; ta.nz = prm->nz; ta.nvec = prm->nvec; ta.nsub = nsub;
+    ta.len_max = prm->len_max; ta.stride = job->stride;
+    ta.cosang = prm->cosang_thresh; ta.step = prm->step_size; ta.smooth = prm->smooth_coeff;
+    const unsigned grid = (unsigned)fib::cdiv(nl, 256);
+    { fib::ProfScope prof("stream_trace", st);
+    if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1>), dim3(grid), dim3(256), 0, st, ta);
+    else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3>), dim3(grid), dim3(256), 0, st, ta);
+    else                     hipLaunchKernelGGL((stream_trace_kernel<0>), dim3(grid), dim3(256), 0, st, ta);
+    }
+    { fib::ProfScope prof("stream_scan", st);
+    hipLaunchKernelGGL(scan_block_kernel, dim3(nblocks), dim3(SCAN_T), 0, st, job->npts.p, nl, prm->len_min, job->excl.p, job->block_tot.p);
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(SCAN_T), 0, st, job->block_tot.p, nblocks, job->total.p);
+    }
+    hipError_t e = hipGetLastError();
+    Pair tot{0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(&tot, job->total.p, sizeof(Pair), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return bail(fib::fail(FIB_ERR_HIP, "streamline trace failed: %s", hipGetErrorString(e)));
+    job->kept_lines = tot.lines; job->kept_pts = tot.pts;
+    *nlines_out = tot.lines; *npoints_out = tot.pts;
+    *job_out = job;
+    return FIB_OK;
+}
+
+extern "C" int fibd_stream_pack(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, void *stream) {
+    FIB_CHECK(job != nullptr, FIB_ERR_INVALID, "job is NULL");
+    if (job->kept_lines == 0) return FIB_OK;
+    FIB_CHECK(npts && seed_index && xyz, FIB_ERR_INVALID, "NULL output buffer");
+    fib::DeviceGuard guard;
+    FIB_HIP(hipSetDevice(job->device));
+    PackArgs pa{};
+    pa.scratch = job->scratch; pa.npts = job->npts.p; pa.nfwd = job->nfwd.p;
+    pa.excl = job->excl.p; pa.block_off = job->block_tot.p;
+    pa.out_npts = npts; pa.out_seed = seed_index; pa.out_xyz = xyz;
+    pa.nlines = job->nlines; pa.line0 = 0; pa.out_line0 = 0; pa.out_pt0 = 0;
+    pa.stride = job->stride; pa.len_min = job->prm.len_min;
+    fib::ProfScope prof("stream_pack", (hipStream_t)stream);
+    hipLaunchKernelGGL(stream_pack_kernel, dim3((unsigned)fib::cdiv(job->nlines, 4)), dim3(256), 0, (hipStream_t)stream, pa);
+    FIB_HIP(hipGetLastError());
+    return FIB_OK;
+}
+
+extern "C" int fibd_stream_all_npts(fib_stream_job *job, int32_t *all_npts, void *stream) {
+    FIB_CHECK(job != nullptr, FIB_ERR_INVALID, "job is NULL");
+    if (job->nlines == 0) return FIB_OK;
+    FIB_CHECK(all_npts != nullptr, FIB_ERR_INVALID, "NULL output buffer");
+    fib::DeviceGuard guard;
+    FIB_HIP(hipSetDevice(job->device));
+    hipLaunchKernelGGL(copy_i32_kernel, dim3((unsigned)fib::cdiv(job->nlines, 256)), dim3(256), 0, (hipStream_t)stream,
+                       job->npts.p, all_npts, job->nlines);
+    FIB_HIP(hipGetLastError());
+    return FIB_OK;
+}

@@ -1,0 +1,162 @@
+"""gqi_rec / dsi_rec / find_peaks host mirror (reference: gqi.jl:7 `GQI, gqi_rec, find_peaks!, gqi_write`,
+dsi.jl:7 `DSI, dsi_rec, dsi_write`)."""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+from .dti import _check_tables, _chk_dev, _dwi_arg, _mask_arg, _stream_ptr
+from .mri import MRI
+from .odf import ODF, sphere_642
+
+
+@dataclass
+class GQI:
+    """Container for outputs of a GQI fit (gqi.jl:10-14)"""
+    odf: MRI
+    peak: List[MRI]
+    qa: List[MRI]
+
+
+@dataclass
+class DSI:
+    """Container for outputs of a DSI reconstruction (dsi.jl:10-15)"""
+    pdf: MRI
+    odf: MRI
+    peak: List[MRI]
+    qa: List[MRI]
+
+
+def _odf_args(odf_dirs: ODF):
+    v = np.asfortranarray(odf_dirs.vertices, dtype=np.float32)
+    f = np.asfortranarray(odf_dirs.faces, dtype=np.int32)
+    return v, f
+
+
+def _p3(arrs):
+    return _lib.P3(*[a.vol.ctypes.data if isinstance(a, MRI) else a for a in arrs])
+
+
+def gqi_rec(dwi: MRI, mask: MRI, odf_dirs: ODF = sphere_642, sigma: float = 1.25, device: int = 0) -> GQI:
+    """Generalized q-sampling imaging reconstruction (gqi.jl:109)."""
+    _check_tables(dwi)
+    vol = _dwi_arg(dwi)
+    nx, ny, nz, nvol = vol.shape
+    m, mdt = _mask_arg(mask)
+    v, f = _odf_args(odf_dirs)
+    ref = mask if isinstance(mask, MRI) else dwi
+    odf = MRI.like(ref, odf_dirs.nvert)
+    peak = [MRI.like(ref, 3) for _ in range(3)]
+    qa = [MRI.like(ref, 1) for _ in range(3)]
+    _lib.check(_lib.lib().fib_gqi_rec(device, vol.ctypes.data, nx, ny, nz, nvol, m.ctypes.data, mdt,
+                                      dwi.bval.ctypes.data, dwi.bvec.ctypes.data,
+                                      v.ctypes.data, v.shape[0], f.ctypes.data, f.shape[0], float(sigma),
+                                      odf.vol.ctypes.data, _p3(peak), _p3(qa)))
+    return GQI(odf, peak, qa)
+
+
+def dsi_rec(dwi: MRI, mask: MRI, odf_dirs: ODF = sphere_642, hann_width: int = 32, device: int = 0) -> DSI:
+    """Diffusion spectrum imaging reconstruction (dsi.jl:171)."""
+    _check_tables(dwi)
+    vol = _dwi_arg(dwi)
+    nx, ny, nz, nvol = vol.shape
+    m, mdt = _mask_arg(mask)
+    v, f = _odf_args(odf_dirs)
+    ref = mask if isinstance(mask, MRI) else dwi
+    pdf = MRI.like(ref, nvol)
+    odf = MRI.like(ref, odf_dirs.nvert)
+    peak = [MRI.like(ref, 3) for _ in range(3)]
+    qa = [MRI.like(ref, 1) for _ in range(3)]
+    _lib.check(_lib.lib().fib_dsi_rec(device, vol.ctypes.data, nx, ny, nz, nvol, m.ctypes.data, mdt,
+                                      dwi.bval.ctypes.data, dwi.bvec.ctypes.data,
+                                      v.ctypes.data, v.shape[0], f.ctypes.data, f.shape[0], int(hann_width),
+                                      pdf.vol.ctypes.data, odf.vol.ctypes.data, _p3(peak), _p3(qa)))
+    return DSI(pdf, odf, peak, qa)
+
+
+# ---------------------------------------------------------------------------------------------
+# device-resident form
+# ---------------------------------------------------------------------------------------------
+class OdfPlan:
+    """GQIwork (gqi.jl:32-82) or DSIwork (dsi.jl:41-143) resident on one GPU."""
+
+    def __init__(self, kind: str, bval, bvec, odf_dirs: ODF = sphere_642, sigma: float = 1.25,
+                 hann_width: int = 32, device: int = 0):
+        self._h = C.c_void_p()
+        self.kind, self.device = kind, device
+        bval = np.ascontiguousarray(bval, np.float32)
+        bvec = np.asfortranarray(np.asarray(bvec, np.float32).reshape(-1, 3))
+        v, f = _odf_args(odf_dirs)
+        L = _lib.lib()
+        self.nvol, self.nvert = int(bval.shape[0]), odf_dirs.nvert
+        if kind == "gqi":
+            _lib.check(L.fib_gqi_plan_create(device, bval.ctypes.data, bvec.ctypes.data, self.nvol, v.ctypes.data,
+                                             v.shape[0], f.ctypes.data, f.shape[0], float(sigma), C.byref(self._h)))
+        elif kind == "dsi":
+            _lib.check(L.fib_dsi_plan_create(device, bval.ctypes.data, bvec.ctypes.data, self.nvol, v.ctypes.data,
+                                             v.shape[0], f.ctypes.data, f.shape[0], int(hann_width), C.byref(self._h)))
+        else:
+            raise ValueError("kind must be 'gqi' or 'dsi'")
+
+    def matrix(self):
+        nr, nv, nt = C.c_int(0), C.c_int(0), C.c_int(0)
+        L = _lib.lib()
+        _lib.check(L.fib_odf_plan_matrix(self._h, None, C.byref(nr), C.byref(nv), C.byref(nt)))
+        A = np.zeros((nr.value, nv.value), np.float32, order="F")
+        _lib.check(L.fib_odf_plan_matrix(self._h, A.ctypes.data, None, None, None))
+        return A
+
+    def close(self):
+        if self._h:
+            _lib.lib().fib_odf_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def odf_rec_device(plan: OdfPlan, dwi, mask, out: Optional[dict] = None, normalize: bool = True, stream=None):
+    """dwi: float32 CUDA tensor [nvol, nvox]; mask uint8 [nvox].  Returns dict(odf [nvert,nvox],
+    pdf [nvol,nvox] (DSI), peak [3][3,nvox], qa [3][nvox], odfmax float32[2] = {max, nan flag})."""
+    import torch
+    _chk_dev(dwi, torch.float32, "dwi")
+    _chk_dev(mask, torch.uint8, "mask")
+    nvox = mask.numel()
+    if dwi.numel() != nvox * plan.nvol:
+        raise ValueError("dwi has %d elements, expected nvol*nvox = %d" % (dwi.numel(), nvox * plan.nvol))
+    dev = dwi.device
+    if out is None:
+        out = dict(odf=torch.empty((plan.nvert, nvox), dtype=torch.float32, device=dev),
+                   peak=[torch.empty((3, nvox), dtype=torch.float32, device=dev) for _ in range(3)],
+                   qa=[torch.empty(nvox, dtype=torch.float32, device=dev) for _ in range(3)],
+                   odfmax=torch.empty(2, dtype=torch.float32, device=dev))
+        if plan.kind == "dsi":
+            out["pdf"] = torch.empty((plan.nvol, nvox), dtype=torch.float32, device=dev)
+    pdf_ptr = out["pdf"].data_ptr() if plan.kind == "dsi" else None
+    _lib.check(_lib.lib().fibd_odf_rec(plan._h, dwi.data_ptr(), mask.data_ptr(), nvox, pdf_ptr, out["odf"].data_ptr(),
+                                       _lib.P3(*[t.data_ptr() for t in out["peak"]]),
+                                       _lib.P3(*[t.data_ptr() for t in out["qa"]]),
+                                       out["odfmax"].data_ptr(), 1 if normalize else 0, _stream_ptr(stream)))
+    return out
+
+
+def qa_normalize_device(qa, odfmax: float, stream=None):
+    nvox = qa[0].numel()
+    _lib.check(_lib.lib().fibd_qa_normalize(_lib.P3(*[t.data_ptr() for t in qa]), nvox, float(odfmax), _stream_ptr(stream)))
+
+
+def find_peaks_device(plan: OdfPlan, odf, stream=None):
+    """find_peaks!(W) (gqi.jl:180) over a planar ODF tensor [nvert, nvox] ->
+    (isort_top int32 [3, nvox] 0-based, nvalid int32 [nvox])"""
+    import torch
+    _chk_dev(odf, torch.float32, "odf")
+    nvox = odf.numel() // plan.nvert
+    top = torch.empty((3, nvox), dtype=torch.int32, device=odf.device)
+    nvalid = torch.empty(nvox, dtype=torch.int32, device=odf.device)
+    _lib.check(_lib.lib().fibd_find_peaks(plan._h, odf.data_ptr(), nvox, top.data_ptr(), nvalid.data_ptr(), _stream_ptr(stream)))
+    return top, nvalid

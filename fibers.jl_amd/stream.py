@@ -1,0 +1,195 @@
+"""stream host mirror (reference: stream.jl:7-8 `StreamWork, stream, stream_new_line, ...`): deterministic
+nearest-voxel / fixed-step Euler tractography, angle-picking macro-scale path (non-LCM, non-micro)."""
+import ctypes as C
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _lib
+from .dti import _chk_dev, _mask_arg, _stream_ptr
+from .mri import MRI
+from .tract import Tract
+
+_EPS = float(np.finfo(np.float64).eps)
+
+
+def cosd32(deg) -> np.float32:
+    """cosd(Float32(ang)) (stream.jl:193): exact at multiples of 30/45 degrees like Julia's cosd."""
+    d = float(np.float32(deg)) % 360.0
+    table = {0.0: 1.0, 60.0: 0.5, 90.0: 0.0, 120.0: -0.5, 180.0: -1.0, 240.0: -0.5, 270.0: 0.0, 300.0: 0.5}
+    if d in table:
+        return np.float32(table[d])
+    return np.float32(np.cos(np.deg2rad(np.float64(d))))
+
+
+def make_sublist(nsub: int, rng=None) -> np.ndarray:
+    """Sub-voxel sampling offsets (stream.jl:176-181): nsub uniform draws in (-.5+eps, .5-eps)^3 shared by
+    all seeds; nsub == 0 -> a single zero offset.  The reference draws from Julia's global RNG, which
+    cannot be reproduced: callers that need a specific realisation pass `sublist` explicitly."""
+    if nsub <= 0:
+        return np.zeros((1, 3), np.float32)
+    rng = np.random.default_rng(rng)
+    return rng.uniform(-0.5 + _EPS, 0.5 - _EPS, size=(nsub, 3)).astype(np.float32)
+
+
+def _as_list(x):
+    if x is None:
+        return None
+    return [x] if isinstance(x, (MRI, np.ndarray)) else list(x)
+
+
+def _vol3(m, what):
+    a = m.vol if isinstance(m, MRI) else np.asarray(m)
+    if a.ndim == 4:
+        a = a[..., 0]
+    if a.ndim != 3:
+        raise ValueError("%s must be a 3-D volume" % what)
+    return a
+
+
+def _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff):
+    nx, ny, nz = shape
+    return _lib.StreamParams(nx, ny, nz, nvec, int(len_min), int(len_max if len_max is not None else max(shape)),
+                             float(cosd32(ang_thresh)), float(np.float32(step_size)), float(np.float32(smooth_coeff)))
+
+
+def stream(ovec: Union[MRI, Sequence[MRI]], *, f=None, f_thresh: float = 0.03, fa: Optional[MRI] = None,
+           fa_thresh: float = 0.1, mask: Optional[MRI] = None, seed: Optional[MRI] = None, nsub: Optional[int] = 3,
+           len_min: int = 3, len_max: Optional[int] = None, ang_thresh: Optional[float] = 45,
+           step_size: Optional[float] = 0.5, smooth_coeff: Optional[float] = 0.2, lcms=None,
+           sublist=None, rng=None, device: int = 0) -> Tract:
+    """Streamline tractography (stream.jl:730).  Returns a `Tract` whose lines are in the reference's order
+    (seed voxels in column-major `findall` order, sub-voxel offsets innermost), points in 1-based voxel
+    coordinates, each line ordered [forward reversed, backward] as stream.jl:652 builds it."""
+    if lcms is not None:
+        raise NotImplementedError("LCM-guided tracking (stream.jl:380-495) is outside the accelerated path")
+    ovecs = _as_list(ovec)
+    fs = _as_list(f)
+    if mask is None:
+        raise ValueError("mask is required (the reference builds the Tract header from it, stream.jl:784)")
+    vols = []
+    for o in ovecs:
+        v = o.vol if isinstance(o, MRI) else np.asarray(o)
+        if v.ndim != 4 or v.shape[3] != 3:
+            raise ValueError("Input orientations should be 3D vectors [nx,ny,nz,3] (2-D angle inputs, "
+                             "stream.jl:147-172, are outside the accelerated path)")
+        vols.append(np.asfortranarray(v, dtype=np.float32))
+    shape = vols[0].shape[:3]
+    if min(ovecs[0].volres if isinstance(ovecs[0], MRI) else (1, 1, 1)) <= 0.05:
+        raise NotImplementedError("microscopy-scale tracking (stream.jl:547-619) is outside the accelerated path")
+    # scale-dependent defaults when `nothing` is passed (stream.jl:89-92), macro scale
+    nsub = 3 if nsub is None else nsub
+    ang_thresh = 45 if ang_thresh is None else ang_thresh
+    step_size = 0.5 if step_size is None else step_size
+    smooth_coeff = 0.2 if smooth_coeff is None else smooth_coeff
+    nvec = len(vols)
+    fvols = None
+    if fs is not None:
+        if len(fs) != nvec:
+            raise ValueError("need one amplitude volume per orientation volume")
+        fvols = [np.asfortranarray(_vol3(x, "f"), dtype=np.float32) for x in fs]
+        _warn_thresh("f_thresh", f_thresh, fvols[0], _vol3(mask, "mask") > 0)           # stream.jl:121-127
+    favol = None
+    if fa is not None:
+        favol = np.asfortranarray(_vol3(fa, "fa"), dtype=np.float32)
+        _warn_thresh("fa_thresh", fa_thresh, favol, _vol3(mask, "mask") > 0)            # stream.jl:107-113
+    m, mdt = _mask_arg(mask)
+    if m.shape != shape:
+        raise ValueError("mask shape %s does not match orientation volume %s" % (m.shape, shape))
+    sptr, sdt = None, 0
+    if seed is not None:
+        sv = _vol3(seed, "seed")
+        if sv.shape != m.shape:
+            raise RuntimeError("Dimension mismatch between seed mask %s and brain mask %s"
+                               % (sv.shape, m.shape))                                 # stream.jl:746-749
+        sarr, sdt = _mask_arg(seed)
+        sptr = sarr.ctypes.data
+    sub = make_sublist(nsub, rng) if sublist is None else np.ascontiguousarray(sublist, np.float32).reshape(-1, 3)
+    prm = _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff)
+    ov = (C.c_void_p * nvec)(*[v.ctypes.data for v in vols])
+    fv = None if fvols is None else (C.c_void_p * nvec)(*[v.ctypes.data for v in fvols])
+    out = _lib.TractOut()
+    L = _lib.lib()
+    _lib.check(L.fib_stream(device, C.byref(prm), ov, fv, float(np.float32(f_thresh)),
+                            None if favol is None else favol.ctypes.data, float(np.float32(fa_thresh)),
+                            m.ctypes.data, mdt, sptr, sdt, sub.ctypes.data, sub.shape[0], C.byref(out)))
+    try:
+        nl, npnt = int(out.nlines), int(out.npoints)
+        npts = np.ctypeslib.as_array(out.npts, shape=(max(nl, 1),))[:nl].copy()
+        sidx = np.ctypeslib.as_array(out.seed_index, shape=(max(nl, 1),))[:nl].copy()
+        xyz = np.ctypeslib.as_array(out.xyz, shape=(max(npnt, 1) * 3,))[: npnt * 3].copy().reshape(-1, 3)
+    finally:
+        L.fib_tract_free(C.byref(out))
+    ref = mask if isinstance(mask, MRI) else None
+    return Tract(xyz=xyz, npts=npts, seed_index=sidx, volsize=shape,
+                 volres=tuple(ref.volres) if ref is not None else (1.0, 1.0, 1.0),
+                 vox2ras=ref.vox2ras.copy() if ref is not None else np.eye(4, dtype=np.float32),
+                 sublist=sub)
+
+
+def _warn_thresh(name, thr, vol, maskbool):
+    """`println("WARNING: ...")` on implausible thresholds (stream.jl:109-113, 123-127)"""
+    vals = vol[maskbool]
+    if vals.size == 0:
+        return
+    lo, hi = np.quantile(vals, 1e-5), np.quantile(vals, 0.9)
+    if thr < lo or thr > hi:
+        print("WARNING: The value of %s (%s) is outside the range of most values in the %s volume (%s, %s)"
+              % (name, thr, name.split("_")[0], lo, hi))
+
+
+# ---------------------------------------------------------------------------------------------
+# device-resident form
+# ---------------------------------------------------------------------------------------------
+def stream_field_device(ovec: List, f: Optional[List] = None, f_thresh: float = 0.03, fa=None, fa_thresh: float = 0.1,
+                        mask=None, stream=None):
+    """StreamWork mask + repack on the GPU (stream.jl:95-145).  ovec[k]: float32 CUDA [3, nvox]; f[k], fa: [nvox];
+    mask uint8 [nvox] (already `> 0`-tested) or None.  Returns (field float32 [nvox, nvec, 4], mask uint8 [nvox])."""
+    import torch
+    nvec = len(ovec)
+    nvox = ovec[0].numel() // 3
+    for t in ovec:
+        _chk_dev(t, torch.float32, "ovec")
+    dev = ovec[0].device
+    field = torch.empty((nvox, nvec, 4), dtype=torch.float32, device=dev)
+    mout = torch.empty(nvox, dtype=torch.uint8, device=dev)
+    ov = (C.c_void_p * nvec)(*[t.data_ptr() for t in ovec])
+    fv = None if f is None else (C.c_void_p * nvec)(*[_chk_dev(t, torch.float32, "f").data_ptr() for t in f])
+    _lib.check(_lib.lib().fibd_stream_field(nvec, nvox, ov, fv, float(np.float32(f_thresh)),
+                                            None if fa is None else _chk_dev(fa, torch.float32, "fa").data_ptr(),
+                                            float(np.float32(fa_thresh)),
+                                            None if mask is None else _chk_dev(mask, torch.uint8, "mask").data_ptr(),
+                                            field.data_ptr(), mout.data_ptr(), _stream_ptr(stream)))
+    return field, mout
+
+
+def stream_device(field, shape, seeds, sublist, len_min=3, len_max=None, ang_thresh=45, step_size=0.5,
+                  smooth_coeff=0.2, stream=None, want_all_npts=False):
+    """Trace + pack on the GPU.  field: [nvox, nvec, 4] from stream_field_device; seeds: int64 CUDA tensor of
+    0-based column-major voxel indices (findall order); sublist: float32 CUDA [nsub, 3].
+    Returns dict(npts int32 [nlines], seed_index int64 [nlines], xyz float32 [npoints, 3])."""
+    import torch
+    _chk_dev(field, torch.float32, "field")
+    _chk_dev(seeds, torch.int64, "seeds")
+    _chk_dev(sublist, torch.float32, "sublist")
+    nvec = field.shape[1]
+    prm = _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff)
+    job = C.c_void_p()
+    nl, npnt = C.c_int64(0), C.c_int64(0)
+    L = _lib.lib()
+    sp = _stream_ptr(stream)
+    _lib.check(L.fibd_stream_trace(C.byref(prm), field.data_ptr(), seeds.data_ptr(), seeds.numel(),
+                                   sublist.data_ptr(), sublist.shape[0], sp, C.byref(job), C.byref(nl), C.byref(npnt)))
+    try:
+        dev = field.device
+        out = dict(npts=torch.empty(nl.value, dtype=torch.int32, device=dev),
+                   seed_index=torch.empty(nl.value, dtype=torch.int64, device=dev),
+                   xyz=torch.empty((npnt.value, 3), dtype=torch.float32, device=dev))
+        _lib.check(L.fibd_stream_pack(job, out["npts"].data_ptr(), out["seed_index"].data_ptr(), out["xyz"].data_ptr(), sp))
+        if want_all_npts:
+            out["all_npts"] = torch.empty(seeds.numel() * sublist.shape[0], dtype=torch.int32, device=dev)
+            _lib.check(L.fibd_stream_all_npts(job, out["all_npts"].data_ptr(), sp))
+        torch.cuda.current_stream().synchronize() if stream is None else None
+    finally:
+        L.fib_stream_job_destroy(job)
+    return out

@@ -1,0 +1,219 @@
+/*
+ * fibers_hip.h — C ABI of libfibers_hip.so, the MI355X (gfx950) back end for the
+ * Fibers.jl per-voxel reconstruction + streamline hot path.
+ *
+ * The reference (lincbrain/Fibers.jl) has no FFI: its boundary is the exported Julia
+ * function surface plus the MRI / Tract field layouts.  Each entry point below names the
+ * reference function (file:line under the reference's src/) whose body it replaces; the
+ * Julia `ccall` stubs a maintainer would add are in INTEGRATION.md.
+ *
+ * Conventions
+ *   - All volumes are float32, Julia column-major [nx,ny,nz,nframes] exactly as
+ *     `MRI.vol` (mri.jl:81): x fastest, frame slowest ("planar").  nvox = nx*ny*nz.
+ *   - bvec is [nvol x 3] column-major like `MRI.bvec` (mri.jl:129).
+ *   - Streamline coordinates are float32, 1-based voxel coordinates exactly as
+ *     `pos_now` in stream.jl:660.
+ *   - Every function returns FIB_OK (0) or a negative fib_status; the message is
+ *     available from fib_last_error() (thread-local).  No C++ exception and no abort()
+ *     crosses this boundary.  There is NO CPU fallback: without a usable HIP device
+ *     every compute entry point fails with FIB_ERR_NO_DEVICE.
+ *   - fib_*  : host-buffer ("drop-in") entry points; blocking; buffers are caller-owned
+ *              host memory (Julia arrays under GC.@preserve); nothing is retained.
+ *   - fibd_* : device-resident entry points (pointers are HIP device pointers, `stream`
+ *              is a hipStream_t passed as void*, may be NULL); asynchronous on `stream`
+ *              unless stated.  Used by the multi-GPU host layer and by bench.py.
+ */
+#ifndef FIBERS_HIP_H
+#define FIBERS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    FIB_OK = 0,
+    FIB_ERR_INVALID = -1,       /* bad argument (NULL pointer, non-positive size, ...) */
+    FIB_ERR_NO_DEVICE = -2,     /* no HIP device / device index out of range */
+    FIB_ERR_HIP = -3,           /* a HIP runtime call failed; see fib_last_error() */
+    FIB_ERR_MISSING_BVAL = -4,  /* "Missing b-value table from input DWI structure"  (dti.jl:167,224 gqi.jl:112 dsi.jl:174) */
+    FIB_ERR_MISSING_BVEC = -5,  /* "Missing gradient table from input DWI structure" (dti.jl:228 gqi.jl:116 dsi.jl:178) */
+    FIB_ERR_DIM_MISMATCH = -6,  /* "Dimension mismatch between seed mask ... and brain mask ..." (stream.jl:746-749) */
+    FIB_ERR_UNSUPPORTED = -7,   /* e.g. q-space grid other than 16^3, ODF vertex degree too large */
+    FIB_ERR_NOMEM = -8
+} fib_status;
+
+/* element type of a mask / seed volume handed over by the host (any numeric array in Julia) */
+typedef enum {
+    FIB_U8 = 0, FIB_I8 = 1, FIB_I16 = 2, FIB_U16 = 3, FIB_I32 = 4, FIB_U32 = 5,
+    FIB_F32 = 6, FIB_F64 = 7, FIB_I64 = 8, FIB_BOOL = 9
+} fib_dtype;
+
+const char *fib_last_error(void);
+const char *fib_version(void);
+int fib_device_count(void);                 /* number of visible HIP devices (0 if none) */
+
+/* ------------------------------------------------------------------------------------ */
+/* Measurement hooks (bench.py): per-kernel HIP-event timing on the launch stream         */
+/* ------------------------------------------------------------------------------------ */
+/* When enabled, every hot-path kernel launch is bracketed by a hipEvent pair recorded on the
+ * stream it is launched on.  fib_profile_get synchronises the pending events of `kernel`
+ * ("dti_fit", "odf_gemm", "odf_peaks", "qa_normalize", "stream_trace", "stream_pack", ...) and
+ * returns the accumulated device time and launch count since the last fib_profile_reset. */
+int fib_profile_enable(int on);
+int fib_profile_reset(void);
+int fib_profile_get(const char *kernel, double *total_ms, int64_t *count);
+
+/* ------------------------------------------------------------------------------------ */
+/* Plans = the reference's pre-computed work structs, resident on one device             */
+/* ------------------------------------------------------------------------------------ */
+typedef struct fib_dti_plan fib_dti_plan;   /* DTIwork / ADCwork  (dti.jl:39-84, 101-155) */
+typedef struct fib_odf_plan fib_odf_plan;   /* GQIwork (gqi.jl:32-82) or DSIwork (dsi.jl:41-143) */
+
+/* DTIwork(bval, bvec) (dti.jl:110): design matrix A[nvol x 7] and pA = pinv(A); with
+ * bvec == NULL builds ADCwork(bval) (dti.jl:48): A = [-b, 1].  Host tables in, device plan out. */
+int fib_dti_plan_create(int device, const float *bval, const float *bvec, int nvol, fib_dti_plan **plan);
+void fib_dti_plan_destroy(fib_dti_plan *plan);
+/* copies of the host-side tables for inspection/tests: A [nvol x np] and pA [np x nvol], column-major */
+int fib_dti_plan_tables(const fib_dti_plan *plan, float *A, float *pA, int *np);
+
+/* GQIwork(bval, bvec, odf_dirs, sigma) (gqi.jl:42): A = sinc.(V[nvert+1:end,:] * bq') and the
+ * folded face table.  verts [nverts x 3] column-major, faces [nfaces x 3] column-major, 1-based. */
+int fib_gqi_plan_create(int device, const float *bval, const float *bvec, int nvol,
+                        const float *verts, int nverts, const int32_t *faces, int nfaces,
+                        float sigma, fib_odf_plan **plan);
+/* DSIwork(bval, bvec, odf_dirs, hann_width) (dsi.jl:59).  The per-voxel chain
+ * scatter -> Hanning -> centred 16^3 FFT -> Re -> radial trilinear integration (dsi.jl:204-242)
+ * is linear in the clamped signal up to the 1/sum(p) scalar, so the plan holds it as two dense
+ * maps: pdf = C[nvol x nvol] s / sum(p), odf = M[nvert x nvol] s / sum(p). */
+int fib_dsi_plan_create(int device, const float *bval, const float *bvec, int nvol,
+                        const float *verts, int nverts, const int32_t *faces, int nfaces,
+                        int hann_width, fib_odf_plan **plan);
+void fib_odf_plan_destroy(fib_odf_plan *plan);
+/* host copy of the reconstruction matrix [nrows x nvol] column-major (GQI: nrows = nvert;
+ * DSI: nrows = nvol + nvert, pdf rows first); pass NULL to query sizes only. */
+int fib_odf_plan_matrix(const fib_odf_plan *plan, float *A, int *nrows, int *nvol, int *nvert);
+
+/* ------------------------------------------------------------------------------------ */
+/* Device-resident hot path                                                              */
+/* ------------------------------------------------------------------------------------ */
+
+/* 10 output volumes of dti_fit_ls (dti.jl:247-256): scalars [nvox], eigvecs [nvox*3] planar */
+typedef struct {
+    float *s0, *eigval1, *eigval2, *eigval3;
+    float *eigvec1, *eigvec2, *eigvec3;
+    float *rd, *md, *fa;
+} fib_dti_out;
+
+/* dti_fit_ls(dwi::MRI, mask::MRI) volume loop (dti.jl:258-275) + per-voxel fit (dti.jl:286-316)
+ * + dti_maps (dti.jl:325-335).  mask: uint8 [nvox], non-zero = fit (dti.jl:261).  All outputs are
+ * fully written (zeros where the reference leaves its zero-initialised volumes untouched). */
+int fibd_dti_fit(const fib_dti_plan *plan, const float *dwi, const uint8_t *mask, int64_t nvox,
+                 const fib_dti_out *out, void *stream);
+/* adc_fit (dti.jl:164-213) */
+int fibd_adc_fit(const fib_dti_plan *plan, const float *dwi, const uint8_t *mask, int64_t nvox,
+                 float *adc, float *s0, void *stream);
+/* number of voxels the last fibd_dti_fit/fibd_adc_fit call on this plan sent through the
+ * per-voxel pinv branch (dti.jl:297-298, 206-207); synchronises `stream`. */
+int fibd_dti_last_partial_count(const fib_dti_plan *plan, void *stream, int64_t *count);
+
+/* gqi_rec / dsi_rec volume loop + find_peaks! + peak/qa extraction (gqi.jl:132-162,
+ * dsi.jl:197-261).  odf [nvox*nvert] planar; pdf [nvox*nvol] (DSI plans only, else NULL);
+ * peak[k] [nvox*3] planar, qa[k] [nvox].  If `normalize` != 0 the global step
+ * qa ./= maximum(mean(odf, dims=4)) (gqi.jl:164-168, dsi.jl:263-267) is applied in-stream;
+ * otherwise qa is left un-normalised and *odfmax_dev (device float[2]: {max, nan-flag})
+ * holds this call's local maximum so that ranks can all-reduce it and call fibd_qa_normalize. */
+int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const uint8_t *mask, int64_t nvox,
+                 float *pdf, float *odf, float *const peak[3], float *const qa[3],
+                 float *odfmax_dev, int normalize, void *stream);
+/* qa[k] ./= odfmax for all voxels (gqi.jl:166-168) */
+int fibd_qa_normalize(float *const qa[3], int64_t nvox, float odfmax, void *stream);
+
+/* find_peaks!(W) (gqi.jl:180-201) on a planar ODF volume [nvox*nvert]: for every voxel the
+ * indices (0-based, first-half vertex rows) of the first 3 entries of `isort` and `nvalid`.
+ * isort_top [3*nvox] planar int32 (-1 where fewer than k+1 vertices exist). */
+int fibd_find_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox,
+                    int32_t *isort_top, int32_t *nvalid, void *stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Streamlines                                                                            */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t nx, ny, nz, nvec;
+    int32_t len_min;        /* default 3 */
+    int32_t len_max;        /* default max(nx,ny,nz)      (stream.jl:74) */
+    float cosang_thresh;    /* cosd(ang_thresh), default cosd(45) (stream.jl:193) */
+    float step_size;        /* default .5 */
+    float smooth_coeff;     /* default .2 */
+} fib_stream_params;
+
+typedef struct fib_stream_job fib_stream_job;
+
+/* StreamWork mask + vector repack (stream.jl:95-145): mask_out = (mask > 0 | any nonzero vector)
+ * & (fa >= fa_thresh); field[vox][k] = ovec[k][vox,:] * (mask_out & f[k] >= f_thresh), stored as
+ * float4 (xyz0) [nvox*nvec].  ovec[k] planar [nvox*3]; f[k] [nvox] or f == NULL; fa, mask may be NULL. */
+int fibd_stream_field(int32_t nvec, int64_t nvox, const float *const *ovec, const float *const *f,
+                      float f_thresh, const float *fa, float fa_thresh, const uint8_t *mask,
+                      float *field4, uint8_t *mask_out, void *stream);
+
+/* stream_new_line for every (seed, sub-voxel offset) pair (stream.jl:761-781 + 625-690, angle
+ * picking, non-LCM, macro scale).  seeds: int64 [nseed] 0-based column-major linear voxel indices
+ * in the reference's findall order; sublist [nsub*3] (xyz per offset; caller-generated, stream.jl:176-181).
+ * Traces into library-owned scratch, applies len_min (stream.jl:769) and computes output offsets.
+ * Synchronises `stream`; returns the number of kept lines and their total point count. */
+int fibd_stream_trace(const fib_stream_params *prm, const float *field4, const int64_t *seeds, int64_t nseed,
+                      const float *sublist, int32_t nsub, void *stream,
+                      fib_stream_job **job, int64_t *nlines, int64_t *npoints);
+/* packs the kept lines, in (seed, sub) order == reference order, into caller device buffers:
+ * npts [nlines] int32, seed_index [nlines] int64 (= seed*nsub+sub), xyz [3*npoints] (x,y,z per point,
+ * line after line, each line ordered [fwd_N..fwd_1, bwd_1..bwd_M] as stream.jl:652 builds it). */
+int fibd_stream_pack(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, void *stream);
+/* per-(seed,sub) point counts of every traced line, incl. those dropped by len_min: int32 [nseed*nsub] */
+int fibd_stream_all_npts(fib_stream_job *job, int32_t *all_npts, void *stream);
+void fib_stream_job_destroy(fib_stream_job *job);
+
+/* ------------------------------------------------------------------------------------ */
+/* Host-buffer drop-in entry points (what the Julia wrapper ccalls)                       */
+/* ------------------------------------------------------------------------------------ */
+
+/* dti_fit(dwi::MRI, mask::MRI)::DTI (dti.jl:221).  bval/bvec NULL or nvol<=0 reproduce the
+ * reference's error() as FIB_ERR_MISSING_BVAL / FIB_ERR_MISSING_BVEC. */
+int fib_dti_fit(int device, const float *dwi, int nx, int ny, int nz, int nvol,
+                const void *mask, int mask_dtype, const float *bval, const float *bvec,
+                const fib_dti_out *out);
+/* adc_fit(dwi::MRI, mask::MRI) (dti.jl:164) */
+int fib_adc_fit(int device, const float *dwi, int nx, int ny, int nz, int nvol,
+                const void *mask, int mask_dtype, const float *bval, float *adc, float *s0);
+/* gqi_rec(dwi, mask, odf_dirs, sigma)::GQI (gqi.jl:109) */
+int fib_gqi_rec(int device, const float *dwi, int nx, int ny, int nz, int nvol,
+                const void *mask, int mask_dtype, const float *bval, const float *bvec,
+                const float *verts, int nverts, const int32_t *faces, int nfaces, float sigma,
+                float *odf, float *const peak[3], float *const qa[3]);
+/* dsi_rec(dwi, mask, odf_dirs, hann_width)::DSI (dsi.jl:171) */
+int fib_dsi_rec(int device, const float *dwi, int nx, int ny, int nz, int nvol,
+                const void *mask, int mask_dtype, const float *bval, const float *bvec,
+                const float *verts, int nverts, const int32_t *faces, int nfaces, int hann_width,
+                float *pdf, float *odf, float *const peak[3], float *const qa[3]);
+
+/* stream(ovec; f, f_thresh, fa, fa_thresh, mask, seed, ...)::Tract (stream.jl:730), non-LCM macro path.
+ * ovec[k] [nx,ny,nz,3]; f[k] [nx,ny,nz] or f == NULL; fa / mask / seed may be NULL (mask == NULL:
+ * any-nonzero-vector mask, stream.jl:96-100; seed == NULL: brain mask seeds, stream.jl:744).
+ * Output is library-allocated (release with fib_tract_free): */
+typedef struct {
+    int64_t nlines;       /* streamlines kept (npts >= len_min) */
+    int64_t npoints;      /* sum of npts */
+    int32_t *npts;        /* [nlines] */
+    int64_t *seed_index;  /* [nlines] seed*nsub + sub, seeds counted in findall order */
+    float *xyz;           /* [3*npoints] */
+} fib_tract_out;
+
+int fib_stream(int device, const fib_stream_params *prm, const float *const *ovec, const float *const *f,
+               float f_thresh, const float *fa, float fa_thresh, const void *mask, int mask_dtype,
+               const void *seed, int seed_dtype, const float *sublist, int32_t nsub, fib_tract_out *out);
+void fib_tract_free(fib_tract_out *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIBERS_HIP_H */

@@ -15,7 +15,10 @@
  * threading is the reference's: static contiguous blocks of z-slices per
  * thread (Threads.@threads, dti.jl:258, gqi.jl:132, dsi.jl:197) and contiguous
  * seed chunks (stream.jl:757-761).  Build: see oracle/Makefile
- * (-O2 -ffp-contract=off -fopenmp; no fast-math).
+ * (-O2 -mfma -ffp-contract=off -fopenmp; no fast-math).  The two BLAS sgemv calls of the
+ * reference (dti.jl:296 `mul!(d, pA, logs)`, gqi.jl:144 `mul!(o, A, s)`) run in OpenBLAS with an
+ * unknowable blocking / FMA usage; they are restated as a frame-ordered chain of explicit fmaf().
+ * Nothing else is ever contracted (Julia never fuses a*b+c on its own).
  *
  * Third-party arithmetic restated from the published algorithms (packages are
  * not vendored under /root/reference; Project.toml compat pins in brackets):
@@ -226,7 +229,7 @@ void orc_dti_fit(const float *dwi, const uint8_t *mask, int nx, int ny, int nz, 
             if (npos == nvol) {                                /* dti.jl:294-296 */
                 for (int i = 0; i < nvol; i++) logs[i] = logf(s[i]);
                 for (int i = 0; i < nvol; i++)
-                    for (int j = 0; j < 7; j++) d[j] += pA[j + 7 * i] * logs[i];
+                    for (int j = 0; j < 7; j++) d[j] = fmaf(pA[j + 7 * i], logs[i], d[j]);
             } else if (npos > 6 && b0pos) {                    /* dti.jl:297-298 */
                 int64_t slot;
 #pragma omp atomic capture
@@ -274,7 +277,7 @@ void orc_adc_fit(const float *dwi, const uint8_t *mask, int nx, int ny, int nz, 
                 float d0 = 0, d1 = 0;
                 for (int i = 0; i < nvol; i++) {
                     float l = logf(s[i]);
-                    d0 += pA[0 + 2 * i] * l; d1 += pA[1 + 2 * i] * l;
+                    d0 = fmaf(pA[0 + 2 * i], l, d0); d1 = fmaf(pA[1 + 2 * i], l, d1);
                 }
                 adc[vox] = d0; s0[vox] = expf(d1);             /* dti.jl:212 */
             } else if (npos > 6 && b0pos) {                    /* dti.jl:206-207 */
@@ -436,7 +439,7 @@ float orc_gqi_rec(const float *dwi, const uint8_t *mask, int nx, int ny, int nz,
             for (int i = 0; i < nvol; i++) {
                 const float *col = A + (int64_t)i * nvert;
                 float si = s[i];
-                for (int v = 0; v < nvert; v++) o[v] += col[v] * si;
+                for (int v = 0; v < nvert; v++) o[v] = fmaf(col[v], si, o[v]);
             }
             for (int v = 0; v < nvert; v++) odf[(int64_t)v * nvox + vox] = o[v];   /* gqi.jl:145 */
             write_peaks(o, nvert, faces, nfaces, verts, nverts_full, vox, nvox, peak, qa, pk, is, tmp);

@@ -1,0 +1,73 @@
+"""Parity: HIP DTI/ADC fit (through the C ABI) vs the CPU oracle.  Reference: dti.jl:164-335."""
+import numpy as np
+import pytest
+
+from util import assert_dti_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(fj, shape, ndir, nb0, seed, nonpos=0.0, noise=0.02):
+    from fibers_jl_amd import phantom
+    bval, bvec = phantom.scheme_dti(ndir, nb0, 1000.0, seed)
+    dwi, _, _ = phantom.make_volume(shape, bval, bvec, seed, noise_frac=noise, nonpositive_frac=nonpos)
+    rng = np.random.default_rng(seed + 100)
+    mask = (rng.random(shape) < 0.8).astype(np.uint8)
+    return dwi, mask, bval, bvec
+
+
+@pytest.mark.parametrize("shape,ndir,nb0", [((16, 16, 16), 6, 1), ((16, 16, 16), 30, 3), ((7, 5, 3), 6, 1),
+                                            ((10, 9, 7), 12, 2), ((32, 32, 32), 6, 1)])
+def test_dti_fit_matches_oracle(fj, orc, shape, ndir, nb0):
+    dwi, mask, bval, bvec = _case(fj, shape, ndir, nb0, seed=1)
+    ref = orc.dti_fit(dwi, mask, bval, bvec, nthreads=4)
+    got = fj.dti_fit(fj.MRI(dwi, bval, bvec), fj.MRI(mask))
+    assert_dti_close({k: getattr(got, k).vol for k in fj.dti.DTI_FIELDS}, ref, mask, label=str(shape))
+
+
+def test_dti_fit_partial_branch(fj, orc):
+    """voxels with zero / negative samples take the per-voxel pinv branch (dti.jl:297-303)"""
+    dwi, mask, bval, bvec = _case(fj, (12, 12, 12), 30, 3, seed=7, nonpos=0.02)
+    dwi[0, 0, 0, :] = 0                      # all non-positive -> zeros
+    dwi[1, 0, 0, :3] = -1                    # no positive b0 -> zeros
+    mask[:2, 0, 0] = 1
+    ref = orc.dti_fit(dwi, mask, bval, bvec, nthreads=4)
+    assert ref["_npartial"] > 50
+    got = fj.dti_fit(fj.MRI(dwi, bval, bvec), fj.MRI(mask))
+    g = {k: getattr(got, k).vol for k in fj.dti.DTI_FIELDS}
+    # float32-SVD pinv (oracle, like Julia) vs float64 normal equations (GPU): cond(A)*eps32 ~ 1e-4
+    assert_dti_close(g, ref, mask, label="partial", s0_rtol=2e-3, ev_rtol=5e-3, ev_atol=2e-6, fa_atol=5e-3, vec_tol=1e-3, gap=0.2)
+    for k in ("s0", "fa"):
+        assert g[k][0, 0, 0] == 0 and g[k][1, 0, 0] == 0
+
+
+def test_adc_fit_matches_oracle(fj, orc):
+    dwi, mask, bval, bvec = _case(fj, (16, 16, 16), 30, 3, seed=3, nonpos=0.01)
+    radc, rs0 = orc.adc_fit(dwi, mask, bval, nthreads=4)
+    adc, s0 = fj.adc_fit(fj.MRI(dwi, bval, bvec), fj.MRI(mask))
+    np.testing.assert_allclose(adc.vol[..., 0], radc, rtol=2e-3, atol=1e-7)
+    np.testing.assert_allclose(s0.vol[..., 0], rs0, rtol=2e-3)
+
+
+def test_dti_device_tier_and_errors(fj, orc):
+    import torch
+    dwi, mask, bval, bvec = _case(fj, (16, 16, 16), 6, 1, seed=5)
+    plan = fj.DtiPlan(bval, bvec)
+    A, pA = plan.tables()
+    W = orc.dti_work(bval, bvec)
+    np.testing.assert_allclose(A, W["A"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(pA, W["pA"], rtol=2e-3, atol=2e-7 * np.abs(W["pA"]).max())
+    nvox = mask.size
+    d = torch.from_numpy(np.ascontiguousarray(dwi.reshape(nvox, -1, order="F").T)).cuda()
+    m = torch.from_numpy(mask.reshape(-1, order="F").copy()).cuda()
+    out = fj.dti_fit_device(plan, d, m)
+    torch.cuda.synchronize()
+    ref = orc.dti_fit(dwi, mask, bval, bvec, nthreads=2)
+    got = {k: (v.cpu().numpy().T.reshape(mask.shape + (3,), order="F") if v.dim() == 2
+               else v.cpu().numpy().reshape(mask.shape, order="F")) for k, v in out.items()}
+    assert_dti_close(got, ref, mask, label="device")
+    assert plan.last_partial_count() == 0
+    with pytest.raises(RuntimeError, match="Missing b-value table"):
+        fj.dti_fit(fj.MRI(dwi), fj.MRI(mask))
+    with pytest.raises(RuntimeError, match="Missing gradient table"):
+        fj.dti_fit(fj.MRI(dwi, bval), fj.MRI(mask))

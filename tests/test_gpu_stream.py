@@ -1,0 +1,105 @@
+"""Parity: HIP streamline tractography (through the C ABI) vs the CPU oracle.  Reference: stream.jl:74-193,
+340-374, 501-541, 625-690, 730-790.  Both sides use IEEE single/double operations in the reference's order
+with no contraction, so lines are compared EXACTLY (counts, order and coordinates)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _fields(n, seed):
+    rng = np.random.default_rng(seed)
+    x, y, z = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    c = (n - 1) / 2.0
+    circ = np.stack([-(y - c), (x - c), 0.15 * np.ones_like(x, float)], -1).astype(np.float64)
+    circ /= np.maximum(np.linalg.norm(circ, axis=-1, keepdims=True), 1e-9)
+    uni = np.zeros((n, n, n, 3)); uni[..., 0] = 1
+    wavy = np.stack([np.cos(0.2 * x + 0.1 * z), np.sin(0.2 * x + 0.1 * z), 0.3 * np.sin(y / 3.0)], -1)
+    wavy /= np.linalg.norm(wavy, axis=-1, keepdims=True)
+    noisy = wavy + 0.25 * rng.normal(size=wavy.shape)
+    noisy /= np.linalg.norm(noisy, axis=-1, keepdims=True)
+    return {k: np.asfortranarray(v.astype(np.float32)) for k, v in dict(uni=uni, circ=circ, wavy=wavy, noisy=noisy).items()}
+
+
+def _compare(tr, ref):
+    assert tr.nstr == len(ref["npts"]), (tr.nstr, len(ref["npts"]))
+    assert np.array_equal(tr.npts, ref["npts"])
+    assert np.array_equal(tr.seed_index, ref["seed_index"])
+    assert tr.xyz.shape == ref["xyz"].shape
+    if not np.array_equal(tr.xyz, ref["xyz"]):
+        bad = np.flatnonzero(np.any(tr.xyz != ref["xyz"], axis=1))
+        raise AssertionError("%d of %d points differ; first at %d: %s vs %s, max abs diff %g" % (
+            bad.size, tr.xyz.shape[0], bad[0], tr.xyz[bad[0]], ref["xyz"][bad[0]], np.abs(tr.xyz - ref["xyz"]).max()))
+
+
+@pytest.mark.parametrize("name", ["uni", "circ", "wavy", "noisy"])
+@pytest.mark.parametrize("smooth", [0.2, 0.0])
+def test_stream_single_vector_exact(fj, orc, name, smooth):
+    n = 16
+    ov = _fields(n, 1)[name]
+    rng = np.random.default_rng(2)
+    mask = (rng.random((n, n, n)) < 0.95).astype(np.float32)
+    sub = np.array([[0.1, -0.2, 0.3], [-0.45, 0.49, 0.0], [0.25, 0.25, -0.25]], np.float32)
+    ref = orc.stream(ov, sub, mask=mask, smooth_coeff=smooth, nthreads=4)
+    tr = fj.stream(fj.MRI(ov), mask=fj.MRI(mask), sublist=sub, smooth_coeff=smooth)
+    _compare(tr, ref)
+    assert tr.nstr > 100
+
+
+def test_stream_reference_quirks(fj, orc):
+    """uniform +x field: seed emitted once per direction, forward part reversed, len_max+2 cap (stream.jl:625-690)"""
+    n = 16
+    ov = _fields(n, 1)["uni"]
+    mask = np.ones((n, n, n), np.uint8)
+    sub = np.array([[0.1, -0.2, 0.3]], np.float32)
+    tr = fj.stream(fj.MRI(ov), mask=fj.MRI(mask), sublist=sub)
+    l0 = tr.line(0)                                # seed voxel (1,1,1)
+    assert tr.npts[0] == n + 2                     # len_max = max(volsize) = 16 -> at most 18 points
+    assert np.allclose(l0[0], [1.1 + 0.5 * 16, 0.8, 1.3]) and np.array_equal(l0[-1], l0[-2])   # seed twice
+    assert np.all(np.diff(l0[:-1, 0]) < 0)         # forward points are stored reversed
+    ref = orc.stream(ov, sub, mask=mask, nthreads=2)
+    _compare(tr, ref)
+    tr2 = fj.stream(fj.MRI(ov), mask=fj.MRI(mask), sublist=sub, len_max=5, len_min=7)
+    ref2 = orc.stream(ov, sub, mask=mask, len_max=5, len_min=7, nthreads=2)
+    _compare(tr2, ref2)
+    assert tr2.nstr > 0 and tr2.npts.max() == 7
+
+
+def test_stream_multi_vector_thresholds_and_seed(fj, orc):
+    n = 14
+    F = _fields(n, 3)
+    rng = np.random.default_rng(4)
+    ovs = [F["wavy"], F["circ"], F["noisy"]]
+    fs = [np.asfortranarray(rng.uniform(0.0, 0.2, (n, n, n)).astype(np.float32)) for _ in range(3)]
+    fa = np.asfortranarray(rng.uniform(0.0, 1.0, (n, n, n)).astype(np.float32))
+    mask = (rng.random((n, n, n)) < 0.9).astype(np.int16)
+    seed = (rng.random((n, n, n)) < 0.3).astype(np.uint8)
+    ovs[1][2:5, 2:5, 2:5] = 0                       # zero vectors inside the mask (stream.jl:353-354)
+    sub = fj.make_sublist(2, rng=7)
+    kw = dict(f_thresh=0.05, fa_thresh=0.15, len_min=2, ang_thresh=60, step_size=0.75, smooth_coeff=0.35)
+    ref = orc.stream(ovs, sub, f=fs, fa=fa, mask=mask, seed=seed, nthreads=4, **kw)
+    tr = fj.stream([fj.MRI(o) for o in ovs], f=[fj.MRI(x) for x in fs], fa=fj.MRI(fa), mask=fj.MRI(mask),
+                   seed=fj.MRI(seed), sublist=sub, **kw)
+    _compare(tr, ref)
+    assert tr.nstr > 50
+    with pytest.raises(RuntimeError, match="Dimension mismatch between seed mask"):
+        fj.stream(fj.MRI(ovs[0]), mask=fj.MRI(mask), seed=fj.MRI(seed[:-1]), sublist=sub)
+
+
+def test_stream_device_tier(fj, orc):
+    import torch
+    n = 12
+    ov = _fields(n, 5)["wavy"]
+    mask = np.ones((n, n, n), np.uint8)
+    sub = np.array([[0.0, 0.0, 0.0], [0.3, -0.3, 0.2]], np.float32)
+    nvox = n ** 3
+    o = torch.from_numpy(np.ascontiguousarray(ov.reshape(nvox, 3, order="F").T)).cuda()
+    m = torch.from_numpy(mask.reshape(-1, order="F").copy()).cuda()
+    field, mout = fj.stream_field_device([o], mask=m)
+    seeds = torch.nonzero(mout).flatten()
+    out = fj.stream_device(field, (n, n, n), seeds, torch.from_numpy(sub).cuda(), want_all_npts=True)
+    torch.cuda.synchronize()
+    ref = orc.stream(ov, sub, mask=mask, nthreads=2, return_all_npts=True)
+    assert np.array_equal(out["npts"].cpu().numpy(), ref["npts"])
+    assert np.array_equal(out["xyz"].cpu().numpy(), ref["xyz"])
+    assert np.array_equal(out["all_npts"].cpu().numpy(), ref["all_npts"])
