@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X back end (contract: see the task description / DESIGN.md §Measurement).
+
+Metric (BASELINE.json): Mvoxels/s (fit) + Mpoints/s (streamline) on a synthetic 140^3 x 270-direction
+HCP-like volume.  A "step" = one pass of the GQI reconstruction hot path (ODF GEMM on FP32 MFMA + ODF peak
+finder + global QA normalisation; gqi.jl:109-171) over one resident 140^3 x 270 volume per rank; `value` is
+whole-job Mvoxels/s with inputs already in HBM.  The same JSON line carries the DTI fit (140^3 x 64) and the
+streamline tracker (DTI-like field, ball mask, ~1 M seeds) as `extra`, the roofline of the dominant kernel
+and the CPU baseline (the oracle = C restatement of the reference CPU path, bounded sample).
+
+N>1: one process per GPU (torch.distributed, backend nccl == RCCL); every rank reconstructs its own volume
+(weak scaling; voxels are independent) and the only exchange step of the path — odfmax = max over all
+voxels of mean(odf) (gqi.jl:164) — is a 1-float all-reduce(MAX) inside the timed region."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SHAPE = (140, 140, 140)
+PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 MFMA (v_mfma_f32_32x32x2_f32) dense peak
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
+
+
+def prof_get(L, name):
+    import ctypes as C
+    ms, n = C.c_double(0), C.c_int64(0)
+    L.fib_profile_get(name.encode(), C.byref(ms), C.byref(n))
+    return ms.value, n.value
+
+
+def cpu_baseline_gqi(bval, bvec, sph, seed, target_s=12.0):
+    """the oracle (C restatement of the reference CPU path, z-slice threading) on a bounded z-slab"""
+    from oracle import oracle as orc
+    from fibers_jl_amd import phantom
+    cores = orc.max_threads()
+    nx, ny = SHAPE[0], SHAPE[1]
+
+    def run(nz):
+        dwi, _, _ = phantom.make_volume((nx, ny, nz), bval, bvec, seed, noise_frac=0.02, crossing=True)
+        mask = np.ones((nx, ny, nz), np.uint8)
+        t0 = time.perf_counter()
+        orc.gqi_rec(dwi, mask, bval, bvec, sph.vertices, sph.faces, 1.25, nthreads=cores)
+        return time.perf_counter() - t0
+
+    t_probe = run(cores)                                 # one slice per thread
+    nz = int(max(cores, min(SHAPE[2], round(cores * target_s / max(t_probe, 1e-3) / cores) * cores)))
+    t = run(nz)
+    nvox = nx * ny * nz
+    return dict(value=nvox / t / 1e6, unit="Mvoxels/s", cores=cores, kind="port",
+                sample="gqi_rec oracle (C/OpenMP restatement of gqi.jl:109-171, z-slice threads) on a %dx%dx%d x %d-frame slab, %.1f s"
+                       % (nx, ny, nz, len(bval), t))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    import fibers_jl_amd as fj
+    from fibers_jl_amd import phantom
+    L = fj.lib()
+    nvox = SHAPE[0] * SHAPE[1] * SHAPE[2]
+    sph = fj.sphere_642
+
+    # ---- headline: GQI + peaks, 140^3 x 270 ------------------------------------------------------
+    bval, bvec = phantom.scheme_gqi()
+    dwi, axes = phantom.make_dwi_torch(SHAPE, bval, bvec, seed=3 + rank, device=dev)
+    mask = torch.ones(nvox, dtype=torch.uint8, device=dev)
+    plan = fj.OdfPlan("gqi", bval, bvec, sph, sigma=1.25, device=dev.index)
+    out = fj.odf_rec_device(plan, dwi, mask, normalize=False)
+
+    def gqi_step():
+        fj.odf_rec_device(plan, dwi, mask, out=out, normalize=False)
+        if world > 1:
+            dist.all_reduce(out["odfmax"][:1], op=dist.ReduceOp.MAX)      # gqi.jl:164 across ranks
+        # qa ./= odfmax with the (all-reduced) device scalar; no host round trip
+        torch.div(out["qa"][0], out["odfmax"][0], out=out["qa"][0])
+        torch.div(out["qa"][1], out["odfmax"][0], out=out["qa"][1])
+        torch.div(out["qa"][2], out["odfmax"][0], out=out["qa"][2])
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        gqi_step()
+    sync()
+    L.fib_profile_enable(1)
+    L.fib_profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gqi_step()
+    sync()
+    dt = time.perf_counter() - t0
+    L.fib_profile_enable(0)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    gemm_ms, gemm_n = prof_get(L, "odf_gemm")
+    peaks_ms, peaks_n = prof_get(L, "odf_peaks")
+    value = world * nvox * args.steps / dt / 1e6
+
+    nvert, nvol = sph.nvert, len(bval)
+    flops = 2.0 * nvert * nvol * nvox                      # algorithmic: 173 340 flop/voxel
+    gemm_avg_ms = gemm_ms / max(gemm_n, 1)
+    achieved = flops / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0
+    gemm_bytes = (4.0 * nvol + 1 + 4.0 * nvert) * nvox     # read DWI + mask, write ODF
+    roofline = dict(bound="mfma", kernel="odf_gemm_kernel<11> (v_mfma_f32_32x32x2_f32)", achieved=achieved,
+                    peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_F32_TFLOPS,
+                    avg_kernel_ms=gemm_avg_ms, launches=gemm_n, traffic=None,
+                    hbm_secondary=dict(achieved=gemm_bytes / (gemm_avg_ms * 1e-3) / 1e9 if gemm_n else 0.0,
+                                       peak=PEAK_HBM_GBS, unit="GB/s", algorithmic_bytes=gemm_bytes),
+                    peaks_kernel=dict(avg_kernel_ms=peaks_ms / max(peaks_n, 1),
+                                      hbm_gbs=(4.0 * nvert + 48) * nvox / (peaks_ms / max(peaks_n, 1) * 1e-3) / 1e9 if peaks_n else 0.0))
+    tr_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tr_file):
+        try:
+            roofline["traffic"] = json.load(open(tr_file)).get("odf_gemm_bytes_per_launch")
+        except Exception:
+            pass
+
+    extra = {}
+    if not args.no_extra and rank == 0:
+        del out, dwi
+        torch.cuda.empty_cache()
+        # ---- DTI fit, 140^3 x 64 (C2) ------------------------------------------------------------
+        b2, g2 = phantom.scheme_dti(60, 4, 1000.0, seed=2)
+        d2, ax2 = phantom.make_dwi_torch(SHAPE, b2, g2, seed=2, device=dev, nfib=1)
+        p2 = fj.DtiPlan(b2, g2, device=dev.index)
+        o2 = fj.dti_fit_device(p2, d2, mask)
+        torch.cuda.synchronize()
+        L.fib_profile_enable(1); L.fib_profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fj.dti_fit_device(p2, d2, mask, out=o2)
+        torch.cuda.synchronize()
+        t_dti = (time.perf_counter() - t0) / args.steps
+        L.fib_profile_enable(0)
+        k_ms, k_n = prof_get(L, "dti_fit")
+        dbytes = (4.0 * len(b2) + 1 + 64) * nvox
+        extra["dti_fit_140x64"] = dict(mvoxels_per_s=nvox / t_dti / 1e6, ms_per_step=t_dti * 1e3,
+                                       kernel_ms=k_ms / max(k_n, 1), algorithmic_bytes=dbytes,
+                                       hbm_gbs=dbytes / (k_ms / max(k_n, 1) * 1e-3) / 1e9 if k_n else 0.0,
+                                       hbm_frac=dbytes / (k_ms / max(k_n, 1) * 1e-3) / 1e9 / PEAK_HBM_GBS if k_n else 0.0)
+        # ---- streamlines from the DTI principal eigenvector, ball mask (C4) -----------------------
+        bm = phantom.ball_mask_torch(SHAPE, dev)
+        field, mout = fj.stream_field_device([o2["eigvec1"]], fa=o2["fa"], fa_thresh=0.1, mask=bm)
+        seeds = torch.nonzero(mout).flatten()
+        sub = torch.tensor([[0.1, -0.2, 0.3]], dtype=torch.float32, device=dev)
+        res = fj.stream_device(field, SHAPE, seeds, sub)
+        torch.cuda.synchronize()
+        L.fib_profile_enable(1); L.fib_profile_reset()
+        nst = max(2, args.steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(nst):
+            res = fj.stream_device(field, SHAPE, seeds, sub)
+        torch.cuda.synchronize()
+        t_st = (time.perf_counter() - t0) / nst
+        L.fib_profile_enable(0)
+        tr_ms, tr_n = prof_get(L, "stream_trace")
+        pk_ms, pk_n = prof_get(L, "stream_pack")
+        npoints = int(res["xyz"].shape[0])
+        extra["stream_dti_ball"] = dict(seeds=int(seeds.numel()), lines=int(res["npts"].numel()), points=npoints,
+                                        mpoints_per_s=npoints / t_st / 1e6, ms_per_step=t_st * 1e3,
+                                        trace_kernel_ms=tr_ms / max(tr_n, 1), pack_kernel_ms=pk_ms / max(pk_n, 1),
+                                        algorithmic_bytes=25.0 * npoints,
+                                        hbm_gbs_trace=25.0 * npoints / (tr_ms / max(tr_n, 1) * 1e-3) / 1e9 if tr_n else 0.0)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_gqi(bval, bvec, sph, seed=3)
+
+    if rank == 0:
+        line = dict(metric="Mvoxels/s fit (GQI ODF + peaks, 140^3 x 270-dir); Mpoints/s streamline in extra",
+                    value=value, unit="Mvoxels/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                    ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+                    dtype="f32", data="synthetic",
+                    config=dict(workload="gqi_rec + find_peaks + qa normalisation, 140x140x140 x 270 frames "
+                                         "(18 x b=5 + 84 dirs x {1000,2000,3000}), sphere_642, mask = all ones, "
+                                         "one volume per GPU", voxels_per_gpu=nvox, frames=nvol, odf_vertices=nvert,
+                                parallelism="volumes sharded over ranks, 1-float all-reduce(MAX)" if world > 1 else "single GPU"),
+                    roofline=roofline, cpu_baseline=cpu, extra=extra)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,6 +39,21 @@ struct GemmArgs {
     float scale_coef;
 };
 
+// scheduling hint: spread one k-step's fragment reads (ds_read2_b32 = 2 fragments) between the previous
+// k-step's MFMAs instead of "read, wait, 2 MFMA" chains (hipcc otherwise minimises live registers)
+template <int MB>
+__device__ __forceinline__ void interleave_ds_mfma() {
+#pragma unroll
+    for (int i = 0; i < MB / 2; i++) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+    }
+    if (MB & 1) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+}
+
 template <int MB>
 __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
     constexpr int MW = MB * 32;
@@ -71,23 +86,29 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
     };
     float bcur[KT / 2], bnext[KT / 2];
     bool anypos = false;
+    // B operand: unconditional loads (clamped frame index) so that all KT/2 loads of a stage are in flight at once
     auto load_B = [&](int t, float (&b)[KT / 2]) {
 #pragma unroll
         for (int kk = 0; kk < KT / 2; kk++) {
             const int k = t * KT + 2 * kk + kh;
-            float s = 0.0f;
-            if (inb && k < a.K) s = Sp[(int64_t)k * a.nvox];
-            b[kk] = s;
+            const int kc = k < a.K ? k : a.K - 1;
+            b[kk] = Sp[(int64_t)kc * a.nvox];
         }
     };
     auto clamp_B = [&](int t, float (&b)[KT / 2]) {
 #pragma unroll
         for (int kk = 0; kk < KT / 2; kk++) {
             const int k = t * KT + 2 * kk + kh;
-            const float s = b[kk];
-            if (k < a.K && !(s <= 0.0f) && a.frame_eff[k] != 0.0f) anypos = true;   // positive or NaN (gqi.jl:142, dsi.jl:207)
-            b[kk] = s < 0.0f ? 0.0f : s;                                             // gqi.jl:140, dsi.jl:209
+            const bool live = inb && k < a.K;
+            const float s = live ? b[kk] : 0.0f;
+            if (live && !(s <= 0.0f) && a.frame_eff[k] != 0.0f) anypos = true;   // positive or NaN (gqi.jl:142, dsi.jl:207)
+            b[kk] = s < 0.0f ? 0.0f : s;                                          // gqi.jl:140, dsi.jl:209
         }
+    };
+    // A fragments of one k-step: MB conflict-free ds_read_b32 (lane -> row col of block m, frame kh)
+    auto load_A = [&](const float *L, int kk, float (&af)[MB]) {
+#pragma unroll
+        for (int m = 0; m < MB; m++) af[m] = L[2 * kk * MW + m * 32];
     };
 
     stage_A(0, 0);
@@ -102,14 +123,19 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
             load_B(t + 1, bnext);
         }
         const float *L = lds + cur * TILE + kh * MW + col;
+        // software pipeline over the k-steps: fragments of step kk+1 are read while step kk's MFMAs issue
+        float a0[MB], a1[MB];
+        load_A(L, 0, a0);
 #pragma unroll
-        for (int kk = 0; kk < KT / 2; kk++) {
-            const float b = bcur[kk];
+        for (int kk = 0; kk < KT / 2; kk += 2) {
+            load_A(L, kk + 1, a1);
 #pragma unroll
-            for (int m = 0; m < MB; m++) {
-                const float av = L[2 * kk * MW + m * 32];
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[m], 0, 0, 0);
-            }
+            for (int m = 0; m < MB; m++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], bcur[kk], acc[m], 0, 0, 0);
+            interleave_ds_mfma<MB>();
+            if (kk + 2 < KT / 2) load_A(L, kk + 2, a0);
+#pragma unroll
+            for (int m = 0; m < MB; m++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], bcur[kk + 1], acc[m], 0, 0, 0);
+            interleave_ds_mfma<MB>();
         }
         if (t + 1 < ntiles) {
             clamp_B(t + 1, bnext);
@@ -148,8 +174,15 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
 // ------------------------------------------------------------------------------------------
 // peak finder
 // ------------------------------------------------------------------------------------------
+// Tile = 32 voxels x all vertices in LDS ([row][32] floats, 41 KB for sphere_642 -> 3 workgroups per CU so
+// one group's HBM load overlaps the others' LDS-bound scans).  A wave scans TWO vertices at a time: lanes
+// 0-31 hold the 32 voxels for vertex 2i, lanes 32-63 for vertex 2i+1, so the neighbour indices are
+// wave-uniform per half (scalar loads + one select) and every ds_read_b32 is bank-conflict free.
+// Unused neighbour slots point at a sentinel row of NaNs: `NaN >= x` is false, so no branch is needed.
 constexpr int PV = 32;        // voxels per workgroup tile
-constexpr int PG = 8;         // vertex groups (256 threads)
+constexpr int PW = 4;         // waves per workgroup
+constexpr int PG = 2 * PW;    // vertex groups (wave, half)
+constexpr int PREC = 10;      // floats per merge record
 
 __device__ __forceinline__ bool jl_isless(float x, float y) {   // Base.isless on floats
     if (x != x) return false;
@@ -178,7 +211,7 @@ __device__ __forceinline__ void top3_insert(Top3 &t, float x, int idx) {
 
 struct PeakArgs {
     const float *odf;         // [nvert][nvox]
-    const int16_t *nbr;       // [nvert][maxdeg], -1 padded
+    const int32_t *nbr;       // [nvert_even][DEG]: row index of each neighbour, unused slots = sentinel row
     const float *verts;       // [nvert][3] first-half vertex coordinates (gqi.jl:155)
     float *peak[3];           // [3][nvox] each (or NULL in find-peaks mode)
     float *qa[3];             // [nvox] each
@@ -186,7 +219,8 @@ struct PeakArgs {
     int32_t *nvalid;          // [nvox]    (find-peaks mode) or NULL
     unsigned *maxenc;         // [2]: ordered-uint max of per-voxel means, NaN flag (may be NULL)
     int64_t nvox;
-    int nvert, maxdeg;
+    int nvert, rows_pad;      // rows_pad = nvert rounded up to 8; sentinel row index = rows_pad
+    int vec_ok;               // 1: every tile row is 16-byte aligned (nvox % 4 == 0 and aligned base)
 };
 
 __device__ __forceinline__ unsigned enc_ordered(float f) {
@@ -197,51 +231,85 @@ __device__ __forceinline__ float dec_ordered(unsigned e) {
     return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
 }
 
-__global__ __launch_bounds__(256) void odf_peaks_kernel(const PeakArgs a) {
+// DEG = padded neighbour count per vertex; EXACT: keep the full sortperm order (find_peaks! API) instead of
+// only the entries gqi_rec/dsi_rec can use (positive or NaN survivors)
+template <int DEG, bool EXACT>
+__global__ __launch_bounds__(PW * 64) void odf_peaks_kernel(const PeakArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *o = smem;                                            // [nvert][PV]
-    int16_t *nb = reinterpret_cast<int16_t *>(o + (size_t)a.nvert * PV);   // [nvert][maxdeg]
-    const int nnb = a.nvert * a.maxdeg;
-    float *mrg = reinterpret_cast<float *>(nb + ((nnb + 1) & ~1));          // merge area
-    const int tid = threadIdx.x, j = tid & (PV - 1), g = tid / PV;
-    const int64_t vox = (int64_t)blockIdx.x * PV + j;
+    float *o = smem;                                            // [rows_pad + 1][PV]
+    float *mrg = o + (size_t)(a.rows_pad + 1) * PV;             // [PG][PV][PREC]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & (PV - 1), half = lane >> 5;
+    const int64_t vox0 = (int64_t)blockIdx.x * PV;
+    const int64_t vox = vox0 + j;
     const bool inb = vox < a.nvox;
-    for (int i = tid; i < nnb; i += 256) nb[i] = a.nbr[i];
-    for (int v = g; v < a.nvert; v += PG) o[v * PV + j] = inb ? a.odf[(int64_t)v * a.nvox + vox] : 0.0f;
+    const bool full = vox0 + PV <= a.nvox;
+
+    // ---- load the tile: 8 rows x 128 B per direct-to-LDS wave instruction --------------------------
+    if (a.vec_ok && full) {
+        const int npiece = a.rows_pad / 8;
+        for (int p = wave; p < npiece; p += PW) {
+            int row = 8 * p + (lane >> 3);
+            row = row < a.nvert ? row : a.nvert - 1;            // padding rows: any valid address
+            const float *g = a.odf + (int64_t)row * a.nvox + vox0 + 4 * (lane & 7);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                             (__attribute__((address_space(3))) void *)(o + p * 256), 16, 0, 0);
+        }
+    } else {
+        for (int r = wave * 2 + half; r < a.rows_pad; r += PG)
+            o[r * PV + j] = (inb && r < a.nvert) ? a.odf[(int64_t)r * a.nvox + vox] : 0.0f;
+    }
+    if (tid < PV) o[a.rows_pad * PV + tid] = __builtin_nanf("");   // sentinel row
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // ---- scan: this wave's vertex pairs -------------------------------------------------------------
     Top3 t;
 #pragma unroll
     for (int k = 0; k < 3; k++) { t.v[k] = 0.0f; t.i[k] = -1; }
     int npos = 0;
     float vmin = INFINITY, vsum = 0.0f;
     bool hasnan = false;
-    for (int v = g; v < a.nvert; v += PG) {
-        const float x = o[v * PV + j];
-        bool survive = true;
-        for (int d = 0; d < a.maxdeg; d++) {
-            const int u = nb[v * a.maxdeg + d];
-            if (u < 0) break;
-            if (o[u * PV + j] >= x) survive = false;            // gqi.jl:185-196: o[b] >= o[a] || o[c] >= o[a]
-        }
-        const float pk = survive ? x : 0.0f;                    // odf_peak
-        if (pk > 0.0f) npos++;                                  // gqi.jl:200
-        top3_insert(t, pk, v);
-        hasnan |= (x != x);
-        vmin = fminf(vmin, x);
-        vsum += x;
-    }
-    // merge the PG partial results of each voxel: [PG][PV] records of 3 val + 3 idx + npos + min + sum + nan
-    float *rec = mrg + (size_t)(g * PV + j) * 10;
+    const int npair = (a.nvert + 1) / 2;
+    for (int pi = wave; pi < npair; pi += PW) {
+        const int v = 2 * pi + half;
+        const bool live = v < a.nvert;
+        const int32_t *nb = a.nbr + (size_t)2 * pi * DEG;       // wave-uniform: rows 2pi and 2pi+1
+        const float x = o[(live ? v : a.rows_pad) * PV + j];
+        float y[DEG];
 #pragma unroll
-    for (int k = 0; k < 3; k++) { rec[k] = t.v[k]; rec[3 + k] = __int_as_float(t.i[k]); }
-    rec[6] = __int_as_float(npos); rec[7] = vmin; rec[8] = vsum; rec[9] = hasnan ? 1.0f : 0.0f;
+        for (int d = 0; d < DEG; d++) {
+            const int ua = nb[d], ub = nb[DEG + d];
+            y[d] = o[(half ? ub : ua) * PV + j];
+        }
+        bool killed = false;
+#pragma unroll
+        for (int d = 0; d < DEG; d++) killed |= (y[d] >= x);    // gqi.jl:185-196: o[b] >= o[a] || o[c] >= o[a]
+        if (live) {
+            const float pk = killed ? 0.0f : x;                 // odf_peak (gqi.jl:184-196)
+            if (pk > 0.0f) npos++;                              // gqi.jl:200
+            if (EXACT || !(pk <= 0.0f)) top3_insert(t, pk, v);  // positive or NaN entries lead the sort order
+            hasnan |= (x != x);
+            vmin = fminf(vmin, x);
+            vsum += x;
+        }
+    }
+    // ---- merge the PG partial results of each voxel --------------------------------------------------
+    {
+        float *rec = mrg + (size_t)((wave * 2 + half) * PV + j) * PREC;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { rec[k] = t.v[k]; rec[3 + k] = __int_as_float(t.i[k]); }
+        rec[6] = __int_as_float(npos); rec[7] = vmin; rec[8] = vsum; rec[9] = hasnan ? 1.0f : 0.0f;
+    }
     __syncthreads();
+    if (tid >= 64) return;
     float mean = 0.0f;
     bool mean_nan = false;
-    if (g == 0) {
+    const bool owner = half == 0;
+    if (owner) {
         for (int gg = 1; gg < PG; gg++) {
-            const float *r = mrg + (size_t)(gg * PV + j) * 10;
+            const float *r = mrg + (size_t)(gg * PV + j) * PREC;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const int idx = __float_as_int(r[3 + k]);
@@ -276,11 +344,11 @@ __global__ __launch_bounds__(256) void odf_peaks_kernel(const PeakArgs a) {
             }
         }
     }
-    if (a.maxenc && tid < 64) {                                 // wave 0 holds g==0 (lanes 0..31) and g==1
-        const bool mine = (g == 0) && inb;
+    if (a.maxenc) {
+        const bool mine = owner && inb;
         unsigned e = mine && !mean_nan ? enc_ordered(mean) : 0u;
-        unsigned long long nanb = __ballot(mine && mean_nan);
-        for (int off = 32; off >= 1; off >>= 1) { const unsigned oth = __shfl_xor((int)e, off); e = oth > e ? oth : e; }
+        const unsigned long long nanb = __ballot(mine && mean_nan);
+        for (int off = 32; off >= 1; off >>= 1) { const unsigned oth = (unsigned)__shfl_xor((int)e, off); e = oth > e ? oth : e; }
         if (tid == 0) {
             if (e) atomicMax(&a.maxenc[0], e);
             if (nanb) atomicOr(&a.maxenc[1], 1u);
@@ -318,7 +386,8 @@ struct fib_odf_plan {
     float scale_coef = 0.0f;
     std::vector<float> A;                            // host copy [nrows x nvol] column-major
     fib::DevBuf<float> At, frame_eff, verts;
-    fib::DevBuf<int16_t> nbr;
+    fib::DevBuf<int32_t> nbr;        // [nvert_even][deg_pad] LDS row of each neighbour (sentinel-padded)
+    int deg_pad = 6, rows_pad = 0;
     mutable fib::DevBuf<unsigned> maxenc;
     mutable fib::DevBuf<float> odfmax;
 };
@@ -347,9 +416,15 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
     std::vector<int32_t> nbr32;
     int rc = fib::host_neighbours(faces, nfaces, nverts, nbr32, &p->maxdeg);
     if (rc != FIB_OK) return rc;
-    if (p->maxdeg < 1) p->maxdeg = 1;
-    if (nbr32.size() < (size_t)p->nvert * p->maxdeg) nbr32.assign((size_t)p->nvert * p->maxdeg, -1);
-    std::vector<int16_t> nbr(nbr32.begin(), nbr32.end());
+    p->deg_pad = p->maxdeg <= 6 ? 6 : (p->maxdeg <= 8 ? 8 : 16);
+    p->rows_pad = (p->nvert + 7) / 8 * 8;
+    const int nv_even = (p->nvert + 1) / 2 * 2;
+    std::vector<int32_t> nbr((size_t)nv_even * p->deg_pad, p->rows_pad);          // default: sentinel row
+    for (int v = 0; v < p->nvert; v++)
+        for (int d = 0; d < p->maxdeg; d++) {
+            const int32_t u = nbr32[(size_t)v * p->maxdeg + d];
+            if (u >= 0) nbr[(size_t)v * p->deg_pad + d] = u;
+        }
     std::vector<float> v3((size_t)p->nvert * 3);
     for (int v = 0; v < p->nvert; v++)
         for (int c = 0; c < 3; c++) v3[3 * v + c] = verts[v + (size_t)nverts * c];
@@ -362,7 +437,7 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
     FIB_HIP(hipMemcpy(p->At.p, At.data(), At.size() * sizeof(float), hipMemcpyHostToDevice));
     FIB_HIP(hipMemcpy(p->frame_eff.p, frame_eff.data(), frame_eff.size() * sizeof(float), hipMemcpyHostToDevice));
     FIB_HIP(hipMemcpy(p->verts.p, v3.data(), v3.size() * sizeof(float), hipMemcpyHostToDevice));
-    FIB_HIP(hipMemcpy(p->nbr.p, nbr.data(), nbr.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+    FIB_HIP(hipMemcpy(p->nbr.p, nbr.data(), nbr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     return FIB_OK;
 }
 
@@ -450,8 +525,16 @@ void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
 }
 
 size_t peaks_smem(const fib_odf_plan *p) {
-    const size_t nnb = (size_t)p->nvert * p->maxdeg;
-    return (size_t)p->nvert * PV * 4 + ((nnb + 1) & ~(size_t)1) * 2 + (size_t)PG * PV * 10 * 4;
+    return ((size_t)(p->rows_pad + 1) * PV + (size_t)PG * PV * PREC) * sizeof(float);
+}
+
+template <int DEG, bool EXACT>
+int launch_peaks_t(const PeakArgs &pa, size_t smem, unsigned grid, hipStream_t st) {
+    FIB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(odf_peaks_kernel<DEG, EXACT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((odf_peaks_kernel<DEG, EXACT>), dim3(grid), dim3(PW * 64), smem, st, pa);
+    FIB_HIP(hipGetLastError());
+    return FIB_OK;
 }
 
 int launch_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox, float *const peak[3], float *const qa[3],
@@ -461,14 +544,18 @@ int launch_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox, float
     for (int k = 0; k < 3; k++) { pa.peak[k] = peak ? peak[k] : nullptr; pa.qa[k] = qa ? qa[k] : nullptr; }
     pa.isort_top = isort_top; pa.nvalid = nvalid;
     pa.maxenc = reduce ? plan->maxenc.p : nullptr;
-    pa.nvox = nvox; pa.nvert = plan->nvert; pa.maxdeg = plan->maxdeg;
+    pa.nvox = nvox; pa.nvert = plan->nvert; pa.rows_pad = plan->rows_pad;
+    pa.vec_ok = (nvox % 4 == 0 && ((uintptr_t)odf & 15) == 0) ? 1 : 0;
     const size_t smem = peaks_smem(plan);
     FIB_CHECK(smem <= 160 * 1024, FIB_ERR_UNSUPPORTED, "ODF with %d vertices does not fit the peak finder's LDS tile", plan->nvert);
-    FIB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(odf_peaks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const unsigned grid = (unsigned)fib::cdiv(nvox, PV);
+    const bool exact = isort_top != nullptr;
     fib::ProfScope prof("odf_peaks", st);
-    hipLaunchKernelGGL(odf_peaks_kernel, dim3((unsigned)fib::cdiv(nvox, PV)), dim3(256), smem, st, pa);
-    FIB_HIP(hipGetLastError());
-    return FIB_OK;
+    switch (plan->deg_pad) {
+        case 6:  return exact ? launch_peaks_t<6, true>(pa, smem, grid, st) : launch_peaks_t<6, false>(pa, smem, grid, st);
+        case 8:  return exact ? launch_peaks_t<8, true>(pa, smem, grid, st) : launch_peaks_t<8, false>(pa, smem, grid, st);
+        default: return exact ? launch_peaks_t<16, true>(pa, smem, grid, st) : launch_peaks_t<16, false>(pa, smem, grid, st);
+    }
 }
 
 }  // namespace

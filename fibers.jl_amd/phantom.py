@@ -105,3 +105,57 @@ def make_volume(shape, bval, bvec, seed, nfib=1, noise_frac=0.02, nonpositive_fr
         hit = rng.random(dwi.shape) < nonpositive_frac
         dwi[hit] = np.where(rng.random(hit.sum()) < 0.5, 0.0, -3.0).astype(np.float32)
     return np.asfortranarray(dwi), axes, fracs
+
+
+# ---------------------------------------------------------------------------------------------
+# torch variants: build benchmark-size volumes directly in HBM (synthetic data, seeded)
+# ---------------------------------------------------------------------------------------------
+def make_dwi_torch(shape, bval, bvec, seed, device, nfib=2, noise_frac=0.02, floor=1.0, chunk=1 << 17):
+    """Returns (dwi float32 [nvol, nvox] planar == MRI.vol memory order, axes float32 [3, nvox]).
+    Same signal model as make_volume (smooth fibre field + in-plane crossing fibre, S0~U(800,1200),
+    Gaussian noise, clamped to >= floor for the all-positive benchmark variant)."""
+    import torch
+    nx, ny, nz = shape
+    nvox = nx * ny * nz
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    bv = torch.as_tensor(np.asarray(bval, np.float32), device=device)
+    gd = torch.as_tensor(np.asarray(bvec, np.float32), device=device)          # [nvol, 3]
+    nvol = bv.numel()
+    dwi = torch.empty((nvol, nvox), dtype=torch.float32, device=device)
+    axes = torch.empty((3, nvox), dtype=torch.float32, device=device)
+    l1, l2 = 1.7e-3, 0.3e-3
+    for c0 in range(0, nvox, chunk):
+        c1 = min(nvox, c0 + chunk)
+        lin = torch.arange(c0, c1, device=device)
+        x = (lin % nx).float(); y = ((lin // nx) % ny).float(); z = (lin // (nx * ny)).float()
+        th = 0.04 * x + 0.03 * y
+        a1 = torch.stack([torch.cos(th), torch.sin(th), 0.3 * torch.sin(z / 10.0)], 1)
+        a1 = a1 / a1.norm(dim=1, keepdim=True)
+        axes[:, c0:c1] = a1.T
+        s0 = 800.0 + 400.0 * torch.rand(c1 - c0, generator=g, device=device)
+        c = a1 @ gd.T                                                           # [chunk, nvol]
+        sig = torch.exp(-bv * (l2 + (l1 - l2) * c * c))
+        if nfib > 1:
+            a2 = torch.stack([-a1[:, 1], a1[:, 0], torch.zeros_like(a1[:, 0])], 1)
+            a2 = a2 / a2.norm(dim=1, keepdim=True).clamp_min(1e-12)
+            f1 = 0.4 + 0.3 * torch.rand(c1 - c0, generator=g, device=device)
+            c2 = a2 @ gd.T
+            sig = f1[:, None] * sig + (1 - f1)[:, None] * torch.exp(-bv * (l2 + (l1 - l2) * c2 * c2))
+        sig = s0[:, None] * sig
+        if noise_frac:
+            sig = sig + (1000.0 * noise_frac) * torch.randn(sig.shape, generator=g, device=device)
+        if floor is not None:
+            sig = sig.clamp_min(floor)
+        dwi[:, c0:c1] = sig.T
+    return dwi, axes
+
+
+def ball_mask_torch(shape, device, radius=None):
+    import torch
+    nx, ny, nz = shape
+    lin = torch.arange(nx * ny * nz, device=device)
+    x = (lin % nx).float() + 1; y = ((lin // nx) % ny).float() + 1; z = (lin // (nx * ny)).float() + 1
+    r = radius if radius is not None else min(shape) * 62.0 / 140.0
+    c = [(n + 1) / 2.0 for n in shape]
+    return (((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) <= r * r).to(torch.uint8)
