@@ -30,7 +30,7 @@ struct GemmArgs {
     const float *At;          // [ntile_m][Kpad][MB*32]  K-major tiles, zero padded
     const float *S;           // [K][nvox] planar DWI
     const uint8_t *mask;      // [nvox]
-    const float *frame_eff;   // [K] 1 = frame takes part in the "any positive sample" test
+    const uint32_t *effbits;  // [Kpad/KT] bit j of word t: frame t*KT+j exists and takes part in the "any positive sample" test
     float *out0;              // rows [0, nrow0)        (DSI: pdf)
     float *out1;              // rows [nrow0, M)        (odf)
     int64_t nvox;
@@ -96,13 +96,14 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
         }
     };
     auto clamp_B = [&](int t, float (&b)[KT / 2]) {
+        const uint32_t eff = a.effbits[t];                  // wave-uniform: one scalar load per stage
 #pragma unroll
         for (int kk = 0; kk < KT / 2; kk++) {
             const int k = t * KT + 2 * kk + kh;
             const bool live = inb && k < a.K;
             const float s = live ? b[kk] : 0.0f;
-            if (live && !(s <= 0.0f) && a.frame_eff[k] != 0.0f) anypos = true;   // positive or NaN (gqi.jl:142, dsi.jl:207)
-            b[kk] = s < 0.0f ? 0.0f : s;                                          // gqi.jl:140, dsi.jl:209
+            if (live && !(s <= 0.0f) && ((eff >> (2 * kk + kh)) & 1u)) anypos = true;   // positive or NaN (gqi.jl:142, dsi.jl:207)
+            b[kk] = s < 0.0f ? 0.0f : s;                                                 // gqi.jl:140, dsi.jl:209
         }
     };
     // A fragments of one k-step: MB conflict-free ds_read_b32 (lane -> row col of block m, frame kh)
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
         // software pipeline over the k-steps: fragments of step kk+1 are read while step kk's MFMAs issue
         float a0[MB], a1[MB];
         load_A(L, 0, a0);
+        __builtin_amdgcn_sched_group_barrier(0x100, (MB + 1) / 2, 0);   // the first step's reads lead the block
 #pragma unroll
         for (int kk = 0; kk < KT / 2; kk += 2) {
             load_A(L, kk + 1, a1);
@@ -157,16 +159,27 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
         scale = 1.0f / (a.scale_coef * s);              // p ./ sum(p), dsi.jl:225 (0 -> Inf/NaN like the reference)
     }
     if (!inb) return;
+    const bool do_scale = a.scale_frame >= 0;
 #pragma unroll
     for (int m = 0; m < MB; m++) {
+        const int row0 = tile_m * MW + m * 32;               // wave-uniform
+        if (row0 >= a.M) break;
+        const bool whole = row0 + 32 <= a.M && (row0 >= a.nrow0 || row0 + 32 <= a.nrow0);   // uniform fast path
+        float *base = row0 >= a.nrow0 ? a.out1 + (int64_t)(row0 - a.nrow0 + 4 * kh) * a.nvox + vox
+                                      : a.out0 + (int64_t)(row0 + 4 * kh) * a.nvox + vox;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int row = tile_m * MW + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row >= a.M) continue;
+            const int dr = (r & 3) + 8 * (r >> 2);          // row within the block, before the lane-half offset
             float v = valid ? acc[m][r] : 0.0f;
-            if (a.scale_frame >= 0 && valid) v *= scale;
-            if (row < a.nrow0) a.out0[(int64_t)row * a.nvox + vox] = v;
-            else               a.out1[(int64_t)(row - a.nrow0) * a.nvox + vox] = v;
+            if (do_scale) v = valid ? v * scale : 0.0f;
+            if (whole) {
+                base[(int64_t)dr * a.nvox] = v;
+            } else {
+                const int row = row0 + dr + 4 * kh;
+                if (row >= a.M) continue;
+                if (row < a.nrow0) a.out0[(int64_t)row * a.nvox + vox] = v;
+                else               a.out1[(int64_t)(row - a.nrow0) * a.nvox + vox] = v;
+            }
         }
     }
 }
@@ -385,7 +398,8 @@ struct fib_odf_plan {
     int scale_frame = -1;
     float scale_coef = 0.0f;
     std::vector<float> A;                            // host copy [nrows x nvol] column-major
-    fib::DevBuf<float> At, frame_eff, verts;
+    fib::DevBuf<float> At, verts;
+    fib::DevBuf<uint32_t> effbits;
     fib::DevBuf<int32_t> nbr;        // [nvert_even][deg_pad] LDS row of each neighbour (sentinel-padded)
     int deg_pad = 6, rows_pad = 0;
     mutable fib::DevBuf<unsigned> maxenc;
@@ -429,13 +443,15 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
     for (int v = 0; v < p->nvert; v++)
         for (int c = 0; c < 3; c++) v3[3 * v + c] = verts[v + (size_t)nverts * c];
     if ((rc = p->At.alloc(At.size())) != FIB_OK) return rc;
-    if ((rc = p->frame_eff.alloc(frame_eff.size())) != FIB_OK) return rc;
+    std::vector<uint32_t> effbits((size_t)p->Kpad / KT, 0u);
+    for (int k = 0; k < K; k++) if (frame_eff[k] != 0.0f) effbits[k / KT] |= 1u << (k % KT);
+    if ((rc = p->effbits.alloc(effbits.size())) != FIB_OK) return rc;
     if ((rc = p->verts.alloc(v3.size())) != FIB_OK) return rc;
     if ((rc = p->nbr.alloc(nbr.size())) != FIB_OK) return rc;
     if ((rc = p->maxenc.alloc(2)) != FIB_OK) return rc;
     if ((rc = p->odfmax.alloc(2)) != FIB_OK) return rc;
     FIB_HIP(hipMemcpy(p->At.p, At.data(), At.size() * sizeof(float), hipMemcpyHostToDevice));
-    FIB_HIP(hipMemcpy(p->frame_eff.p, frame_eff.data(), frame_eff.size() * sizeof(float), hipMemcpyHostToDevice));
+    FIB_HIP(hipMemcpy(p->effbits.p, effbits.data(), effbits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     FIB_HIP(hipMemcpy(p->verts.p, v3.data(), v3.size() * sizeof(float), hipMemcpyHostToDevice));
     FIB_HIP(hipMemcpy(p->nbr.p, nbr.data(), nbr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     return FIB_OK;
@@ -571,7 +587,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
     FIB_HIP(hipSetDevice(plan->device));
     hipStream_t st = (hipStream_t)stream;
     GemmArgs ga{};
-    ga.At = plan->At.p; ga.S = dwi; ga.mask = mask; ga.frame_eff = plan->frame_eff.p;
+    ga.At = plan->At.p; ga.S = dwi; ga.mask = mask; ga.effbits = plan->effbits.p;
     ga.out0 = pdf; ga.out1 = odf; ga.nvox = nvox;
     ga.K = plan->nvol; ga.Kpad = plan->Kpad; ga.M = plan->nrows; ga.nrow0 = plan->nrow0; ga.ntile_m = plan->ntile_m;
     ga.scale_frame = plan->nrow0 > 0 ? plan->scale_frame : -1;

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Small driver for rocprofv3: runs N steps of one hot-path stage on resident synthetic data.
+usage: prof_step.py {gqi|dti|stream|dsi} [steps]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import fibers_jl_amd as fj  # noqa: E402
+from fibers_jl_amd import phantom  # noqa: E402
+
+what = sys.argv[1] if len(sys.argv) > 1 else "gqi"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+SHAPE = (140, 140, 140)
+nvox = 140 ** 3
+dev = torch.device("cuda", 0)
+mask = torch.ones(nvox, dtype=torch.uint8, device=dev)
+if what == "gqi":
+    bval, bvec = phantom.scheme_gqi()
+    dwi, _ = phantom.make_dwi_torch(SHAPE, bval, bvec, 3, dev)
+    plan = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642)
+    out = fj.odf_rec_device(plan, dwi, mask)
+    for _ in range(steps):
+        fj.odf_rec_device(plan, dwi, mask, out=out)
+elif what == "dsi":
+    bval, bvec = phantom.scheme_dsi()
+    dwi, _ = phantom.make_dwi_torch(SHAPE, bval, bvec, 5, dev)
+    plan = fj.OdfPlan("dsi", bval, bvec, fj.sphere_642)
+    out = fj.odf_rec_device(plan, dwi, mask)
+    for _ in range(steps):
+        fj.odf_rec_device(plan, dwi, mask, out=out)
+elif what == "dti":
+    bval, bvec = phantom.scheme_dti(60, 4, 1000.0, 2)
+    dwi, _ = phantom.make_dwi_torch(SHAPE, bval, bvec, 2, dev, nfib=1)
+    plan = fj.DtiPlan(bval, bvec)
+    out = fj.dti_fit_device(plan, dwi, mask)
+    for _ in range(steps):
+        fj.dti_fit_device(plan, dwi, mask, out=out)
+elif what == "stream":
+    bval, bvec = phantom.scheme_dti(60, 4, 1000.0, 2)
+    dwi, _ = phantom.make_dwi_torch(SHAPE, bval, bvec, 2, dev, nfib=1)
+    plan = fj.DtiPlan(bval, bvec)
+    o = fj.dti_fit_device(plan, dwi, mask)
+    bm = phantom.ball_mask_torch(SHAPE, dev)
+    field, mout = fj.stream_field_device([o["eigvec1"]], fa=o["fa"], fa_thresh=0.1, mask=bm)
+    seeds = torch.nonzero(mout).flatten()
+    sub = torch.tensor([[0.1, -0.2, 0.3]], dtype=torch.float32, device=dev)
+    for _ in range(steps):
+        fj.stream_device(field, SHAPE, seeds, sub)
+torch.cuda.synchronize()
+print("done", what, steps)
