@@ -131,7 +131,7 @@ def main():
     gemm_avg_ms = gemm_ms / max(gemm_n, 1)
     achieved = flops / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0
     gemm_bytes = (4.0 * nvol + 1 + 4.0 * nvert) * nvox     # read DWI + mask, write ODF
-    roofline = dict(bound="mfma", kernel="odf_gemm_kernel<11> (v_mfma_f32_32x32x2_f32)", achieved=achieved,
+    roofline = dict(bound="mfma", kernel="odf_gemm_kernel<MB=10,NX=1> (v_mfma_f32_32x32x2_f32; 320 rows on MFMA + 1 row on VALU)", achieved=achieved,
                     peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_F32_TFLOPS,
                     avg_kernel_ms=gemm_avg_ms, launches=gemm_n, traffic=None,
                     hbm_secondary=dict(achieved=gemm_bytes / (gemm_avg_ms * 1e-3) / 1e9 if gemm_n else 0.0,

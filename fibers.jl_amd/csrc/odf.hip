@@ -27,7 +27,7 @@ constexpr int KT = 16;        // frames per LDS stage
 constexpr int WG_VOX = 128;   // voxels per workgroup (4 waves x 32)
 
 struct GemmArgs {
-    const float *At;          // [ntile_m][Kpad][MB*32]  K-major tiles, zero padded
+    const float *At;          // [ntile_m][Kpad][MW]  K-major tiles (MW = MB*32 [+16 when extra rows]), zero padded
     const float *S;           // [K][nvox] planar DWI
     const uint8_t *mask;      // [nvox]
     const uint32_t *effbits;  // [Kpad/KT] bit j of word t: frame t*KT+j exists and takes part in the "any positive sample" test
@@ -37,6 +37,7 @@ struct GemmArgs {
     int K, Kpad, M, nrow0, ntile_m;
     int scale_frame;          // DSI: frame whose clamped sample times scale_coef is sum(p); -1: no scaling
     float scale_coef;
+    int has_ineff;
 };
 
 // scheduling hint: spread one k-step's fragment reads (ds_read2_b32 = 2 fragments) between the previous
@@ -54,76 +55,111 @@ __device__ __forceinline__ void interleave_ds_mfma() {
     }
 }
 
-template <int MB>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// On gfx950 the f32-input MFMA runs on the same FMA lanes as the vector ALU: every VALU instruction a wave
+// issues costs the SIMD ~4 cycles of MFMA time whether it sits between MFMAs or after them (measured with
+// tools/probes/mfma_probe.hip: +264 v_add per 88 MFMAs = +12 %).  So the K loop is written to issue almost
+// no VALU work: clamp / running-max / non-finite tracking in 3 ops per sample, scalar-base + 32-bit-lane-
+// offset addressing for every global access, fragment reads by immediate LDS offsets.
+//
+// Rows per tile = MB*32 + NX: MB 32-row MFMA blocks plus NX "extra" rows done as one v_fmac per k-step each
+// (4 cycles instead of a 64-cycle MFMA block that would be 31/32 padding: sphere_642 has 321 = 10*32 + 1
+// half-sphere vertices).  The extra rows sum even and odd frames in the two lane halves and add the halves
+// at the end, so their rounding differs from the k-ordered MFMA chain by ~1 ulp.
+template <int MB, int NX>
 __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
-    constexpr int MW = MB * 32;
+    constexpr int MW = MB * 32 + (NX > 0 ? 16 : 0);    // LDS row stride (floats); multiple of 16 -> whole 1-KiB pieces
     constexpr int TILE = KT * MW;                       // floats per stage
+    constexpr int NPIECE = TILE * 4 / 1024;
+    constexpr int ROWS = MB * 32 + NX;                  // output rows per M tile
+    static_assert((TILE * 4) % 1024 == 0, "stage must be a whole number of 1-KiB pieces");
     __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, kh = lane >> 5;
     const int tile_m = blockIdx.x % a.ntile_m;
     const int64_t tile_n = blockIdx.x / a.ntile_m;
-    const int64_t vox = tile_n * WG_VOX + wave * 32 + col;
+    const int64_t vox0 = tile_n * WG_VOX + wave * 32;   // wave-uniform
+    const int64_t vox = vox0 + col;
     const bool inb = vox < a.nvox;
-    const float *Sp = a.S + (inb ? vox : 0);
-    const float *Atile = a.At + (size_t)tile_m * a.Kpad * MW;
     const int ntiles = a.Kpad / KT;
+    // per-lane 32-bit byte offsets; everything else in an address is wave-uniform (SGPR base)
+    const uint32_t c_off = (uint32_t)((inb ? col : 0) * 4);
+    const uint32_t s_off = (uint32_t)(((inb ? col : 0) + (int64_t)kh * a.nvox) * 4);   // frame kh of the pair, this voxel
+    const char *Sbase = reinterpret_cast<const char *>(a.S + (vox0 < a.nvox ? vox0 : 0));
+    const char *Abase = reinterpret_cast<const char *>(a.At + (size_t)tile_m * a.Kpad * MW);
+    const uint32_t a_off = (uint32_t)lane * 16;
+    const int64_t frame_pair_bytes = 2 * a.nvox * 4;
+    const uint8_t mk = a.mask[inb ? vox : 0];           // used in the epilogue only: latency hidden
+
+    auto stage_A = [&](int t, int buf) {                // one stage = TILE*4 contiguous bytes of At
+        const char *g = Abase + (size_t)t * TILE * 4;
+        char *l = reinterpret_cast<char *>(lds + buf * TILE);
+        for (int p = wave; p < NPIECE; p += 4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + p * 1024 + a_off),
+                                             (__attribute__((address_space(3))) void *)(l + p * 1024), 16, 0, 0);
+    };
+    // B operand: KT/2 unconditional loads per stage (frame index clamped to K-1: the padded rows of At are zero)
+    float braw[KT / 2];
+    auto load_B = [&](int t) {
+#pragma unroll
+        for (int kk = 0; kk < KT / 2; kk++) {
+            int kpair = t * (KT / 2) + kk;              // frames 2*kpair, 2*kpair+1 (lane half kh picks one)
+            const int lastpair = (a.K - 1) / 2;
+            kpair = kpair < lastpair ? kpair : lastpair;
+            const uint32_t off = (2 * kpair + 1 >= a.K) ? c_off : s_off;   // odd K: the last pair has one frame only
+            braw[kk] = *reinterpret_cast<const float *>(Sbase + (int64_t)kpair * frame_pair_bytes + off);
+        }
+    };
+    auto load_A = [&](const float *L, int kk, float (&af)[MB]) {   // MB conflict-free ds_read_b32, immediate offsets
+#pragma unroll
+        for (int m = 0; m < MB; m++) af[m] = L[2 * kk * MW + m * 32];
+    };
 
     f32x16 acc[MB];
 #pragma unroll
     for (int m = 0; m < MB; m++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[m][r] = 0.0f;
-
-    // one stage = TILE*4 bytes contiguous in global memory; each wave-instruction moves 1 KiB
-    constexpr int NPIECE = TILE * 4 / 1024;             // MB*32*16*4/1024 = 2*MB
-    auto stage_A = [&](int t, int buf) {
-        const char *g = reinterpret_cast<const char *>(Atile + (size_t)t * TILE);
-        char *l = reinterpret_cast<char *>(lds + buf * TILE);
-        for (int p = wave; p < NPIECE; p += 4)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + p * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void *)(l + p * 1024), 16, 0, 0);
-    };
-    float bcur[KT / 2], bnext[KT / 2];
-    bool anypos = false;
-    // B operand: unconditional loads (clamped frame index) so that all KT/2 loads of a stage are in flight at once
-    auto load_B = [&](int t, float (&b)[KT / 2]) {
+    float xacc[NX > 0 ? NX : 1];
 #pragma unroll
-        for (int kk = 0; kk < KT / 2; kk++) {
-            const int k = t * KT + 2 * kk + kh;
-            const int kc = k < a.K ? k : a.K - 1;
-            b[kk] = Sp[(int64_t)kc * a.nvox];
-        }
-    };
-    auto clamp_B = [&](int t, float (&b)[KT / 2]) {
-        const uint32_t eff = a.effbits[t];                  // wave-uniform: one scalar load per stage
-#pragma unroll
-        for (int kk = 0; kk < KT / 2; kk++) {
-            const int k = t * KT + 2 * kk + kh;
-            const bool live = inb && k < a.K;
-            const float s = live ? b[kk] : 0.0f;
-            if (live && !(s <= 0.0f) && ((eff >> (2 * kk + kh)) & 1u)) anypos = true;   // positive or NaN (gqi.jl:142, dsi.jl:207)
-            b[kk] = s < 0.0f ? 0.0f : s;                                                 // gqi.jl:140, dsi.jl:209
-        }
-    };
-    // A fragments of one k-step: MB conflict-free ds_read_b32 (lane -> row col of block m, frame kh)
-    auto load_A = [&](const float *L, int kk, float (&af)[MB]) {
-#pragma unroll
-        for (int m = 0; m < MB; m++) af[m] = L[2 * kk * MW + m * 32];
-    };
+    for (int x = 0; x < NX; x++) xacc[x] = 0.0f;
+    float vmax = 0.0f;                                  // running max of the samples  -> "any sample > 0"
+    float vnf = 0.0f;                                   // becomes NaN once a sample is NaN or +-Inf
 
     stage_A(0, 0);
-    load_B(0, bcur);
-    clamp_B(0, bcur);
+    load_B(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int t = 0; t < ntiles; t++) {
         const int cur = t & 1;
+        // clamp this stage's samples (gqi.jl:140, dsi.jl:209); track positivity (gqi.jl:142, dsi.jl:207) and NaN/Inf
+        float bcur[KT / 2];
+        if (a.has_ineff) {                              // rare: frames that never reach the model must not count
+            const uint32_t eff = a.effbits[t] >> kh;
+#pragma unroll
+            for (int kk = 0; kk < KT / 2; kk++) {
+                const float s = braw[kk];
+                bcur[kk] = fmaxf(s, 0.0f);
+                vmax = fmaxf(vmax, ((eff >> (2 * kk)) & 1u) ? s : 0.0f);
+                vnf = __builtin_fmaf(s, 0.0f, vnf);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KT / 2; kk++) {
+                const float s = braw[kk];
+                bcur[kk] = fmaxf(s, 0.0f);
+                vmax = fmaxf(vmax, s);
+                vnf = __builtin_fmaf(s, 0.0f, vnf);
+            }
+        }
         if (t + 1 < ntiles) {
             stage_A(t + 1, cur ^ 1);
-            load_B(t + 1, bnext);
+            load_B(t + 1);
         }
         const float *L = lds + cur * TILE + kh * MW + col;
+        const float *LX = lds + cur * TILE + kh * MW + MB * 32;     // extra rows: same address in a lane half (broadcast)
         // software pipeline over the k-steps: fragments of step kk+1 are read while step kk's MFMAs issue
         float a0[MB], a1[MB];
         load_A(L, 0, a0);
@@ -139,48 +175,66 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
             for (int m = 0; m < MB; m++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], bcur[kk + 1], acc[m], 0, 0, 0);
             interleave_ds_mfma<MB>();
         }
-        if (t + 1 < ntiles) {
-            clamp_B(t + 1, bnext);
+        if (NX > 0) {
 #pragma unroll
-            for (int kk = 0; kk < KT / 2; kk++) bcur[kk] = bnext[kk];
+            for (int kk = 0; kk < KT / 2; kk++)
+#pragma unroll
+                for (int x = 0; x < NX; x++) xacc[x] = __builtin_fmaf(LX[2 * kk * MW + x], bcur[kk], xacc[x]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stage's direct-to-LDS loads have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage's direct-to-LDS loads and samples have landed
         __syncthreads();
     }
 
-    // the two k-halves of a voxel live in lanes l and l^32
-    const bool valid_half = anypos;
-    const bool other = __shfl_xor((int)valid_half, 32) != 0;
-    bool valid = inb && (valid_half || other) && a.mask[inb ? vox : 0] != 0;
+    // ---- epilogue: the two k-halves of a voxel live in lanes l and l^32 -----------------------------------
+    float pm = fmaxf(vmax, __shfl_xor(vmax, 32));
+    float pn = vnf + __shfl_xor(vnf, 32);
+    const bool nonfinite = pn != pn;                    // a NaN sample makes every output NaN (NaN * A[v,i] for all v)
+    const bool valid = inb && (pm > 0.0f || nonfinite) && mk != 0;
+    const bool do_scale = a.scale_frame >= 0;
     float scale = 1.0f;
-    if (a.scale_frame >= 0 && inb) {
-        float s = Sp[(int64_t)a.scale_frame * a.nvox];
+    if (do_scale) {
+        float s = *reinterpret_cast<const float *>(Sbase + (int64_t)a.scale_frame * a.nvox * 4 + c_off);
         s = s < 0.0f ? 0.0f : s;
         scale = 1.0f / (a.scale_coef * s);              // p ./ sum(p), dsi.jl:225 (0 -> Inf/NaN like the reference)
     }
+    if (nonfinite) scale = __builtin_nanf("");
+    const bool plain = __all(valid && !nonfinite) && !do_scale;   // wave-uniform: store the accumulators as they are
+    const float mulv = valid ? scale : 0.0f;
+#pragma unroll
+    for (int x = 0; x < NX; x++) xacc[x] += __shfl_xor(xacc[x], 32);
     if (!inb) return;
-    const bool do_scale = a.scale_frame >= 0;
+    const uint32_t o_off = (uint32_t)((col + (int64_t)4 * kh * a.nvox) * 4);
+    auto row_ptr = [&](int row) -> char * {             // wave-uniform row base for this wave's 32 voxels
+        return reinterpret_cast<char *>(row >= a.nrow0 ? a.out1 + (int64_t)(row - a.nrow0) * a.nvox + vox0
+                                                       : a.out0 + (int64_t)row * a.nvox + vox0);
+    };
 #pragma unroll
     for (int m = 0; m < MB; m++) {
-        const int row0 = tile_m * MW + m * 32;               // wave-uniform
+        const int row0 = tile_m * ROWS + m * 32;        // wave-uniform
         if (row0 >= a.M) break;
         const bool whole = row0 + 32 <= a.M && (row0 >= a.nrow0 || row0 + 32 <= a.nrow0);   // uniform fast path
-        float *base = row0 >= a.nrow0 ? a.out1 + (int64_t)(row0 - a.nrow0 + 4 * kh) * a.nvox + vox
-                                      : a.out0 + (int64_t)(row0 + 4 * kh) * a.nvox + vox;
+        char *base = row_ptr(row0);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int dr = (r & 3) + 8 * (r >> 2);          // row within the block, before the lane-half offset
-            float v = valid ? acc[m][r] : 0.0f;
-            if (do_scale) v = valid ? v * scale : 0.0f;
+            const int dr = (r & 3) + 8 * (r >> 2);      // row within the block, before the lane-half offset
+            float v = acc[m][r];
+            if (!plain) v = valid ? v * mulv : 0.0f;
             if (whole) {
-                base[(int64_t)dr * a.nvox] = v;
+                *reinterpret_cast<float *>(base + (int64_t)dr * a.nvox * 4 + o_off) = v;
             } else {
                 const int row = row0 + dr + 4 * kh;
                 if (row >= a.M) continue;
-                if (row < a.nrow0) a.out0[(int64_t)row * a.nvox + vox] = v;
-                else               a.out1[(int64_t)(row - a.nrow0) * a.nvox + vox] = v;
+                *reinterpret_cast<float *>(row_ptr(row) + col * 4) = v;
             }
         }
+    }
+#pragma unroll
+    for (int x = 0; x < NX; x++) {
+        const int row = tile_m * ROWS + MB * 32 + x;    // wave-uniform
+        if (row >= a.M) break;
+        float v = xacc[x];
+        if (!plain) v = valid ? v * mulv : 0.0f;
+        if (kh == 0) *reinterpret_cast<float *>(row_ptr(row) + col * 4) = v;
     }
 }
 
@@ -394,9 +448,10 @@ __global__ __launch_bounds__(256) void qa_normalize_kernel(float *q0, float *q1,
 struct fib_odf_plan {
     int device = 0;
     int nvol = 0, nvert = 0, nrows = 0, nrow0 = 0;   // nrow0 = rows that go to the pdf output (DSI), else 0
-    int MB = 11, ntile_m = 1, Kpad = 0, maxdeg = 0;
+    int MB = 11, NX = 0, ntile_m = 1, Kpad = 0, maxdeg = 0;   // M tile = MB 32-row MFMA blocks + NX VALU rows
     int scale_frame = -1;
     float scale_coef = 0.0f;
+    bool has_ineff = false;                          // some frame never reaches the model (DSI duplicates)
     std::vector<float> A;                            // host copy [nrows x nvol] column-major
     fib::DevBuf<float> At, verts;
     fib::DevBuf<uint32_t> effbits;
@@ -408,23 +463,27 @@ struct fib_odf_plan {
 
 namespace {
 
-const int kMBChoices[] = {12, 11, 10, 9, 8, 7, 6};
 
 int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *faces, int nfaces,
                 const std::vector<float> &frame_eff) {
     const int M = p->nrows, K = p->nvol;
-    int best = -1, bestpad = INT32_MAX, bestnt = 1;
-    for (int mb : kMBChoices) {
-        const int nt = (M + mb * 32 - 1) / (mb * 32), pad = nt * mb * 32;
-        if (pad < bestpad) { bestpad = pad; best = mb; bestnt = nt; }
-    }
-    p->MB = best; p->ntile_m = bestnt;
+    // pick (MB, NX) minimising the per-k-step issue cost ntile*(64*MB + 4*NX) cycles (MFMA block = 64, v_fmac = 4)
+    int best_cost = INT32_MAX;
+    const int nxs[] = {0, 1, 2, 4};
+    for (int mb = 11; mb >= 6; mb--)
+        for (int nx : nxs) {
+            if (nx > 0 && mb > 10) continue;            // register budget
+            const int rows = mb * 32 + nx;
+            const int nt = (M + rows - 1) / rows;
+            const int cost = nt * (64 * mb + 4 * nx);
+            if (cost < best_cost) { best_cost = cost; p->MB = mb; p->NX = nx; p->ntile_m = nt; }
+        }
     p->Kpad = (K + KT - 1) / KT * KT;
-    const int MW = p->MB * 32;
+    const int MW = p->MB * 32 + (p->NX > 0 ? 16 : 0), ROWS = p->MB * 32 + p->NX;
     std::vector<float> At((size_t)p->ntile_m * p->Kpad * MW, 0.0f);
     for (int k = 0; k < K; k++)
         for (int r = 0; r < M; r++) {
-            const int tm = r / MW, rr = r % MW;
+            const int tm = r / ROWS, rr = r % ROWS;
             At[((size_t)tm * p->Kpad + k) * MW + rr] = p->A[r + (size_t)M * k];
         }
     std::vector<int32_t> nbr32;
@@ -444,7 +503,7 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
         for (int c = 0; c < 3; c++) v3[3 * v + c] = verts[v + (size_t)nverts * c];
     if ((rc = p->At.alloc(At.size())) != FIB_OK) return rc;
     std::vector<uint32_t> effbits((size_t)p->Kpad / KT, 0u);
-    for (int k = 0; k < K; k++) if (frame_eff[k] != 0.0f) effbits[k / KT] |= 1u << (k % KT);
+    for (int k = 0; k < K; k++) { if (frame_eff[k] != 0.0f) effbits[k / KT] |= 1u << (k % KT); else p->has_ineff = true; }
     if ((rc = p->effbits.alloc(effbits.size())) != FIB_OK) return rc;
     if ((rc = p->verts.alloc(v3.size())) != FIB_OK) return rc;
     if ((rc = p->nbr.alloc(nbr.size())) != FIB_OK) return rc;
@@ -535,9 +594,9 @@ extern "C" int fib_odf_plan_matrix(const fib_odf_plan *plan, float *A, int *nrow
 // ------------------------------------------------------------------------------------------
 namespace {
 
-template <int MB>
+template <int MB, int NX>
 void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
-    hipLaunchKernelGGL((odf_gemm_kernel<MB>), dim3(grid), dim3(256), 0, st, ga);
+    hipLaunchKernelGGL((odf_gemm_kernel<MB, NX>), dim3(grid), dim3(256), 0, st, ga);
 }
 
 size_t peaks_smem(const fib_odf_plan *p) {
@@ -581,6 +640,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
                             float *odfmax_dev, int normalize, void *stream) {
     FIB_CHECK(plan && dwi && mask && odf && peak && qa, FIB_ERR_INVALID, "NULL argument");
     FIB_CHECK(nvox > 0, FIB_ERR_INVALID, "nvox must be positive");
+    FIB_CHECK(nvox < ((int64_t)1 << 28), FIB_ERR_UNSUPPORTED, "volumes of 2^28 voxels or more are not supported (32-bit lane offsets)");
     FIB_CHECK(plan->nrow0 == 0 || pdf != nullptr, FIB_ERR_INVALID, "DSI plans need a pdf output volume");
     for (int k = 0; k < 3; k++) FIB_CHECK(peak[k] && qa[k], FIB_ERR_INVALID, "NULL peak/qa output volume");
     fib::DeviceGuard guard;
@@ -596,16 +656,15 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
     FIB_CHECK(nblk < ((int64_t)1 << 31), FIB_ERR_UNSUPPORTED, "volume too large for one launch");
     const unsigned grid = (unsigned)nblk;
     { fib::ProfScope prof("odf_gemm", st);
-    switch (plan->MB) {
-        case 6: launch_gemm<6>(ga, grid, st); break;
-        case 7: launch_gemm<7>(ga, grid, st); break;
-        case 8: launch_gemm<8>(ga, grid, st); break;
-        case 9: launch_gemm<9>(ga, grid, st); break;
-        case 10: launch_gemm<10>(ga, grid, st); break;
-        case 11: launch_gemm<11>(ga, grid, st); break;
-        case 12: launch_gemm<12>(ga, grid, st); break;
-        default: return fib::fail(FIB_ERR_INVALID, "internal: bad MB %d", plan->MB);
-    }
+    ga.has_ineff = plan->has_ineff ? 1 : 0;
+#define FIB_GEMM_CASE(MBV, NXV) if (plan->MB == MBV && plan->NX == NXV) { launch_gemm<MBV, NXV>(ga, grid, st); launched = true; }
+    bool launched = false;
+    FIB_GEMM_CASE(6, 0) FIB_GEMM_CASE(7, 0) FIB_GEMM_CASE(8, 0) FIB_GEMM_CASE(9, 0) FIB_GEMM_CASE(10, 0) FIB_GEMM_CASE(11, 0)
+    FIB_GEMM_CASE(6, 1) FIB_GEMM_CASE(7, 1) FIB_GEMM_CASE(8, 1) FIB_GEMM_CASE(9, 1) FIB_GEMM_CASE(10, 1)
+    FIB_GEMM_CASE(6, 2) FIB_GEMM_CASE(7, 2) FIB_GEMM_CASE(8, 2) FIB_GEMM_CASE(9, 2) FIB_GEMM_CASE(10, 2)
+    FIB_GEMM_CASE(6, 4) FIB_GEMM_CASE(7, 4) FIB_GEMM_CASE(8, 4) FIB_GEMM_CASE(9, 4) FIB_GEMM_CASE(10, 4)
+#undef FIB_GEMM_CASE
+    if (!launched) return fib::fail(FIB_ERR_INVALID, "internal: no GEMM variant for MB=%d NX=%d", plan->MB, plan->NX);
     }
     FIB_HIP(hipGetLastError());
     FIB_HIP(hipMemsetAsync(plan->maxenc.p, 0, 2 * sizeof(unsigned), st));

@@ -7,7 +7,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MB = 11, KT = 16, MW = MB * 32, TILE = KT * MW;
 
 // MODE 0: LDS A fragments + barriers + glds staging (no global B)   1: no LDS reads (A const)   2: LDS reads, no staging/barriers
-template <int MODE, int WAVES_PER_SIMD>
+template <int MODE, int WAVES_PER_SIMD, int NT = 0, bool SPREAD = false>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void probe(const float *At, float *out, int ntiles) {
     __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -17,6 +17,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void probe(const float *At, fl
     for (int i = tid; i < 2 * TILE; i += 256) lds[i] = At[i % TILE];
     __syncthreads();
     float b = 1.0f + lane * 1e-6f;
+    float junk[8] = {0, 1, 2, 3, 4, 5, 6, 7};
     for (int t = 0; t < ntiles; t++) {
         const int cur = t & 1;
         if (MODE == 0) {
@@ -33,25 +34,33 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void probe(const float *At, fl
             for (int m = 0; m < MB; m++) {
                 const float av = (MODE == 1) ? b : L[2 * kk * MW + m * 32];
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[m], 0, 0, 0);
+                if (NT > 0 && SPREAD) {
+#pragma unroll
+                    for (int i = 0; i < (NT + 87) / 88; i++) asm volatile("v_add_f32 %0, %0, %1" : "+v"(junk[(m + i) & 7]) : "v"(b));
+                }
             }
+        }
+        if (NT > 0 && !SPREAD) {
+#pragma unroll
+            for (int i = 0; i < NT; i++) asm volatile("v_add_f32 %0, %0, %1" : "+v"(junk[i & 7]) : "v"(b));
         }
         if (MODE == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
     }
-    float s = 0;
+    float s = junk[0] + junk[1] + junk[2] + junk[3] + junk[4] + junk[5] + junk[6] + junk[7];
     for (int m = 0; m < MB; m++) for (int r = 0; r < 16; r++) s += acc[m][r];
     if (s == 123.456f) out[blockIdx.x * 256 + tid] = s;
 }
 
-template <int MODE, int W>
+template <int MODE, int W, int NT = 0, bool SP = false>
 void run(const char *name, const float *At, float *out, int nblk) {
     const int ntiles = 17;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int rep = 0; rep < 2; rep++) {
         hipEventRecord(a);
-        hipLaunchKernelGGL((probe<MODE, W>), dim3(nblk), dim3(256), 0, 0, At, out, ntiles);
+        hipLaunchKernelGGL((probe<MODE, W, NT, SP>), dim3(nblk), dim3(256), 0, 0, At, out, ntiles);
         hipEventRecord(b); hipEventSynchronize(b);
     }
     float ms; hipEventElapsedTime(&ms, a, b);
@@ -71,5 +80,11 @@ int main() {
     run<2, 2>("LDS reads only, 2 w/SIMD", At, out, nblk);
     run<0, 2>("LDS+glds+barrier, 2 w/SIMD", At, out, nblk);
     run<0, 1>("LDS+glds+barrier, 1 w/SIMD", At, out, nblk);
+    run<0, 2, 88>("  + 88 VALU tail/tile", At, out, nblk);
+    run<0, 2, 264>("  + 264 VALU tail/tile", At, out, nblk);
+    run<0, 2, 264, true>("  + 264 VALU spread (3/MFMA)", At, out, nblk);
+    run<0, 2, 528, true>("  + 528 VALU spread (6/MFMA)", At, out, nblk);
+    run<0, 1, 264>("1w: + 264 VALU tail/tile", At, out, nblk);
+    run<0, 1, 264, true>("1w: + 264 VALU spread", At, out, nblk);
     return 0;
 }
