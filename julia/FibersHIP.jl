@@ -1,0 +1,143 @@
+#=
+  FibersHIP.jl — the binding a Fibers.jl maintainer would add to route the hot path through
+  libfibers_hip.so (MI355X / gfx950).  Mechanically derived from include/fibers_hip.h.
+
+  NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no Julia.  It keeps the reference's
+  signatures (dti_fit, adc_fit, gqi_rec, dsi_rec, stream) and result structs; only the bodies change.
+  Include after src/Fibers.jl's own definitions of MRI, ODF, DTI, GQI, DSI, Tract, str_add!.
+=#
+
+const libfibers = get(ENV, "FIBERS_HIP_LIB", "libfibers_hip.so")
+
+const FIB_DTYPE = Dict(UInt8=>0, Int8=>1, Int16=>2, UInt16=>3, Int32=>4, UInt32=>5,
+                       Float32=>6, Float64=>7, Int64=>8, Bool=>9)
+
+function fib_check(rc::Cint)
+  rc == 0 && return
+  msg = unsafe_string(ccall((:fib_last_error, libfibers), Cstring, ()))
+  error(msg)                       # same strings as the reference's error() calls
+end
+
+struct FibDtiOut
+  s0::Ptr{Float32}; eigval1::Ptr{Float32}; eigval2::Ptr{Float32}; eigval3::Ptr{Float32}
+  eigvec1::Ptr{Float32}; eigvec2::Ptr{Float32}; eigvec3::Ptr{Float32}
+  rd::Ptr{Float32}; md::Ptr{Float32}; fa::Ptr{Float32}
+end
+
+"dti_fit(dwi::MRI, mask::MRI) — replaces dti.jl:221-316"
+function dti_fit(dwi::MRI, mask::MRI; device::Integer=0)
+  isempty(dwi.bval) && error("Missing b-value table from input DWI structure")
+  isempty(dwi.bvec) && error("Missing gradient table from input DWI structure")
+  nx, ny, nz, nvol = size(dwi.vol)
+  S0 = MRI(mask, 1, Float32); E1 = MRI(mask, 1, Float32); E2 = MRI(mask, 1, Float32); E3 = MRI(mask, 1, Float32)
+  V1 = MRI(mask, 3, Float32); V2 = MRI(mask, 3, Float32); V3 = MRI(mask, 3, Float32)
+  RD = MRI(mask, 1, Float32); MD = MRI(mask, 1, Float32); FA = MRI(mask, 1, Float32)
+  vol = dwi.vol::Array{Float32,4}; m = mask.vol
+  GC.@preserve vol m S0 E1 E2 E3 V1 V2 V3 RD MD FA begin
+    out = Ref(FibDtiOut(pointer(S0.vol), pointer(E1.vol), pointer(E2.vol), pointer(E3.vol),
+                        pointer(V1.vol), pointer(V2.vol), pointer(V3.vol),
+                        pointer(RD.vol), pointer(MD.vol), pointer(FA.vol)))
+    fib_check(ccall((:fib_dti_fit, libfibers), Cint,
+                    (Cint, Ptr{Float32}, Cint, Cint, Cint, Cint, Ptr{Cvoid}, Cint, Ptr{Float32}, Ptr{Float32}, Ref{FibDtiOut}),
+                    device, vol, nx, ny, nz, nvol, m, FIB_DTYPE[eltype(m)], dwi.bval, dwi.bvec, out))
+  end
+  return DTI(S0, E1, E2, E3, V1, V2, V3, RD, MD, FA)
+end
+
+"adc_fit(dwi::MRI, mask::MRI) — replaces dti.jl:164-213"
+function adc_fit(dwi::MRI, mask::MRI; device::Integer=0)
+  isempty(dwi.bval) && error("Missing b-value table from input DWI structure")
+  nx, ny, nz, nvol = size(dwi.vol)
+  adc = MRI(mask, 1, Float32); s0 = MRI(mask, 1, Float32)
+  vol = dwi.vol::Array{Float32,4}; m = mask.vol
+  GC.@preserve vol m adc s0 fib_check(ccall((:fib_adc_fit, libfibers), Cint,
+      (Cint, Ptr{Float32}, Cint, Cint, Cint, Cint, Ptr{Cvoid}, Cint, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+      device, vol, nx, ny, nz, nvol, m, FIB_DTYPE[eltype(m)], dwi.bval, adc.vol, s0.vol))
+  return adc, s0
+end
+
+"gqi_rec(dwi, mask, odf_dirs, σ) — replaces gqi.jl:109-171 (and find_peaks! gqi.jl:180-201)"
+function gqi_rec(dwi::MRI, mask::MRI, odf_dirs::ODF=sphere_642, σ::Float32=Float32(1.25); device::Integer=0)
+  isempty(dwi.bval) && error("Missing b-value table from input DWI structure")
+  isempty(dwi.bvec) && error("Missing gradient table from input DWI structure")
+  nx, ny, nz, nvol = size(dwi.vol)
+  nvert = div(size(odf_dirs.vertices, 1), 2)
+  odf = MRI(mask, nvert, Float32)
+  peak = [MRI(mask, 3, Float32) for _ in 1:3]; qa = [MRI(mask, 1, Float32) for _ in 1:3]
+  faces = Int32.(odf_dirs.faces); verts = odf_dirs.vertices; vol = dwi.vol::Array{Float32,4}; m = mask.vol
+  pk = [pointer(p.vol) for p in peak]; pq = [pointer(q.vol) for q in qa]
+  GC.@preserve vol m odf peak qa faces verts fib_check(ccall((:fib_gqi_rec, libfibers), Cint,
+      (Cint, Ptr{Float32}, Cint, Cint, Cint, Cint, Ptr{Cvoid}, Cint, Ptr{Float32}, Ptr{Float32},
+       Ptr{Float32}, Cint, Ptr{Int32}, Cint, Cfloat, Ptr{Float32}, Ptr{Ptr{Float32}}, Ptr{Ptr{Float32}}),
+      device, vol, nx, ny, nz, nvol, m, FIB_DTYPE[eltype(m)], dwi.bval, dwi.bvec,
+      verts, size(verts, 1), faces, size(faces, 1), σ, odf.vol, pk, pq))
+  return GQI(odf, peak, qa)
+end
+
+"dsi_rec(dwi, mask, odf_dirs, hann_width) — replaces dsi.jl:171-270"
+function dsi_rec(dwi::MRI, mask::MRI, odf_dirs::ODF=sphere_642, hann_width::Int=32; device::Integer=0)
+  isempty(dwi.bval) && error("Missing b-value table from input DWI structure")
+  isempty(dwi.bvec) && error("Missing gradient table from input DWI structure")
+  nx, ny, nz, nvol = size(dwi.vol)
+  nvert = div(size(odf_dirs.vertices, 1), 2)
+  pdf = MRI(mask, nvol, Float32); odf = MRI(mask, nvert, Float32)
+  peak = [MRI(mask, 3, Float32) for _ in 1:3]; qa = [MRI(mask, 1, Float32) for _ in 1:3]
+  faces = Int32.(odf_dirs.faces); verts = odf_dirs.vertices; vol = dwi.vol::Array{Float32,4}; m = mask.vol
+  pk = [pointer(p.vol) for p in peak]; pq = [pointer(q.vol) for q in qa]
+  GC.@preserve vol m pdf odf peak qa faces verts fib_check(ccall((:fib_dsi_rec, libfibers), Cint,
+      (Cint, Ptr{Float32}, Cint, Cint, Cint, Cint, Ptr{Cvoid}, Cint, Ptr{Float32}, Ptr{Float32},
+       Ptr{Float32}, Cint, Ptr{Int32}, Cint, Cint, Ptr{Float32}, Ptr{Float32}, Ptr{Ptr{Float32}}, Ptr{Ptr{Float32}}),
+      device, vol, nx, ny, nz, nvol, m, FIB_DTYPE[eltype(m)], dwi.bval, dwi.bvec,
+      verts, size(verts, 1), faces, size(faces, 1), hann_width, pdf.vol, odf.vol, pk, pq))
+  return DSI(pdf, odf, peak, qa)
+end
+
+struct FibStreamParams
+  nx::Int32; ny::Int32; nz::Int32; nvec::Int32; len_min::Int32; len_max::Int32
+  cosang_thresh::Float32; step_size::Float32; smooth_coeff::Float32
+end
+
+mutable struct FibTractOut
+  nlines::Int64; npoints::Int64
+  npts::Ptr{Int32}; seed_index::Ptr{Int64}; xyz::Ptr{Float32}
+  FibTractOut() = new(0, 0, C_NULL, C_NULL, C_NULL)
+end
+
+"stream(ovec; ...) — replaces stream.jl:730-790 for the angle-picking macro-scale path (no lcms, volres > 0.05)"
+function stream(ovec::Union{MRI,Vector{MRI}}; f::Union{MRI,Vector{MRI},Nothing}=nothing, f_thresh::Real=.03,
+                fa::Union{MRI,Nothing}=nothing, fa_thresh::Real=.1, mask::Union{MRI,Nothing}=nothing,
+                seed::Union{MRI,Nothing}=nothing, nsub::Union{Integer,Nothing}=3, len_min::Integer=3,
+                len_max::Integer=(isa(ovec,MRI) ? maximum(ovec.volsize) : maximum(ovec[1].volsize)),
+                ang_thresh::Union{Real,Nothing}=45, step_size::Union{Real,Nothing}=.5,
+                smooth_coeff::Union{Real,Nothing}=.2, device::Integer=0)
+  ovecs = isa(ovec, MRI) ? MRI[ovec] : ovec
+  fs    = isa(f, MRI) ? MRI[f] : f
+  nx, ny, nz = size(ovecs[1].vol)[1:3]
+  if !isnothing(seed) && size(seed.vol) != size(mask.vol)
+    error("Dimension mismatch between seed mask " * string(size(seed.vol)) * " and brain mask " * string(size(mask.vol)))
+  end
+  isnothing(nsub) && (nsub = 3); isnothing(ang_thresh) && (ang_thresh = 45)
+  isnothing(step_size) && (step_size = .5); isnothing(smooth_coeff) && (smooth_coeff = .2)
+  # sub-voxel offsets from the GLOBAL RNG, exactly as stream.jl:176-181
+  sublist = nsub > 0 ? hcat([Float32.(rand(Uniform(-.5+eps(), .5-eps()), 3)) for _ in 1:nsub]...) : zeros(Float32, 3, 1)
+  prm = Ref(FibStreamParams(nx, ny, nz, length(ovecs), len_min, len_max,
+                            cosd(Float32(ang_thresh)), Float32(step_size), Float32(smooth_coeff)))
+  pv = [pointer(o.vol) for o in ovecs]
+  pf = isnothing(fs) ? C_NULL : [pointer(x.vol) for x in fs]
+  out = FibTractOut()
+  GC.@preserve ovecs fs fa mask seed sublist pv pf fib_check(ccall((:fib_stream, libfibers), Cint,
+      (Cint, Ref{FibStreamParams}, Ptr{Ptr{Float32}}, Ptr{Ptr{Float32}}, Cfloat, Ptr{Float32}, Cfloat,
+       Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Float32}, Cint, Ref{FibTractOut}),
+      device, prm, pv, pf, Float32(f_thresh), isnothing(fa) ? C_NULL : pointer(fa.vol), Float32(fa_thresh),
+      isnothing(mask) ? C_NULL : pointer(mask.vol), isnothing(mask) ? 0 : FIB_DTYPE[eltype(mask.vol)],
+      isnothing(seed) ? C_NULL : pointer(seed.vol), isnothing(seed) ? 0 : FIB_DTYPE[eltype(seed.vol)],
+      sublist, size(sublist, 2), out))
+  npts = unsafe_wrap(Array, out.npts, out.nlines)
+  xyz  = unsafe_wrap(Array, out.xyz, (3, Int(out.npoints)))
+  off  = cumsum(vcat(0, Int.(npts)))
+  str  = [xyz[:, off[i]+1:off[i+1]] for i in 1:length(npts)]          # Vector{Matrix{Float32}} [3 x npts]
+  ccall((:fib_tract_free, libfibers), Cvoid, (Ref{FibTractOut},), out)
+  tr = Tract{Float32}(mask)
+  str_add!(tr, str)                                                   # stream.jl:784-787
+  return tr
+end
