@@ -251,34 +251,32 @@ constexpr int PW = 4;         // waves per workgroup
 constexpr int PG = 2 * PW;    // vertex groups (wave, half)
 constexpr int PREC = 10;      // floats per merge record
 
-__device__ __forceinline__ bool jl_isless(float x, float y) {   // Base.isless on floats
-    if (x != x) return false;
-    if (y != y) return true;
-    if (x == y) return (__float_as_uint(x) >> 31) && !(__float_as_uint(y) >> 31);
-    return x < y;
+// sortperm!(odf_peak, rev=true) (gqi.jl:198) orders by descending value with Base.isless semantics (NaN above
+// everything, +0.0 above -0.0) and keeps ascending index among equals.  Both are captured by one 64-bit key:
+// high word = order-preserving uint image of the float (NaN canonicalised to the top), low word = ~index.
+// A larger key sorts earlier; key 0 = empty slot.  Keeping the best three is then a branch-free 3-element
+// insertion (3 compares + selects) instead of a comparison-function call per candidate.
+__device__ __forceinline__ unsigned long long peak_key(float x, int idx) {
+    const unsigned b = __float_as_uint(x);
+    unsigned hi = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    if (x != x) hi = 0xffffffffu;
+    return ((unsigned long long)hi << 32) | (unsigned)(~idx);
 }
-// position in sortperm!(…, rev=true): descending value, ties keep ascending index (gqi.jl:198)
-__device__ __forceinline__ bool sorts_before(float va, int ia, float vb, int ib) {
-    return jl_isless(vb, va) || (!jl_isless(va, vb) && ia < ib);
+struct Top3 { unsigned long long k[3]; };
+__device__ __forceinline__ void top3_clear(Top3 &t) { t.k[0] = t.k[1] = t.k[2] = 0ull; }
+__device__ __forceinline__ void top3_insert_key(Top3 &t, unsigned long long k) {
+    const bool g0 = k > t.k[0], g1 = k > t.k[1], g2 = k > t.k[2];
+    t.k[2] = g1 ? t.k[1] : (g2 ? k : t.k[2]);
+    t.k[1] = g0 ? t.k[0] : (g1 ? k : t.k[1]);
+    t.k[0] = g0 ? k : t.k[0];
 }
-
-struct Top3 { float v[3]; int i[3]; };
-__device__ __forceinline__ void top3_insert(Top3 &t, float x, int idx) {
-    // entries are kept sorted; empty slots (i < 0) only at the tail
-    const bool b2 = t.i[2] >= 0 && !sorts_before(x, idx, t.v[2], t.i[2]);
-    if (b2) return;
-    const bool b1 = t.i[1] >= 0 && !sorts_before(x, idx, t.v[1], t.i[1]);
-    const bool b0 = t.i[0] >= 0 && !sorts_before(x, idx, t.v[0], t.i[0]);
-    if (b1) { t.v[2] = x; t.i[2] = idx; return; }
-    t.v[2] = t.v[1]; t.i[2] = t.i[1];
-    if (b0) { t.v[1] = x; t.i[1] = idx; return; }
-    t.v[1] = t.v[0]; t.i[1] = t.i[0];
-    t.v[0] = x; t.i[0] = idx;
-}
+__device__ __forceinline__ void top3_insert(Top3 &t, float x, int idx) { top3_insert_key(t, peak_key(x, idx)); }
+__device__ __forceinline__ int top3_index(const Top3 &t, int k) { return t.k[k] ? (int)~(unsigned)t.k[k] : -1; }
 
 struct PeakArgs {
     const float *odf;         // [nvert][nvox]
-    const int32_t *nbr;       // [nvert_even][DEG]: row index of each neighbour, unused slots = sentinel row
+    const int32_t *nbr;       // [nvert_even][DEG]: row index of each neighbour, unused slots = sentinel row (32-voxel tiles)
+    const int32_t *nbr64;     // same table with sentinel = nvert (64-voxel tiles)
     const float *verts;       // [nvert][3] first-half vertex coordinates (gqi.jl:155)
     float *peak[3];           // [3][nvox] each (or NULL in find-peaks mode)
     float *qa[3];             // [nvox] each
@@ -333,8 +331,7 @@ __global__ __launch_bounds__(PW * 64) void odf_peaks_kernel(const PeakArgs a) {
 
     // ---- scan: this wave's vertex pairs -------------------------------------------------------------
     Top3 t;
-#pragma unroll
-    for (int k = 0; k < 3; k++) { t.v[k] = 0.0f; t.i[k] = -1; }
+    top3_clear(t);
     int npos = 0;
     float vmin = INFINITY, vsum = 0.0f;
     bool hasnan = false;
@@ -366,7 +363,7 @@ __global__ __launch_bounds__(PW * 64) void odf_peaks_kernel(const PeakArgs a) {
     {
         float *rec = mrg + (size_t)((wave * 2 + half) * PV + j) * PREC;
 #pragma unroll
-        for (int k = 0; k < 3; k++) { rec[k] = t.v[k]; rec[3 + k] = __int_as_float(t.i[k]); }
+        for (int k = 0; k < 3; k++) { rec[2 * k] = __uint_as_float((unsigned)t.k[k]); rec[2 * k + 1] = __uint_as_float((unsigned)(t.k[k] >> 32)); }
         rec[6] = __int_as_float(npos); rec[7] = vmin; rec[8] = vsum; rec[9] = hasnan ? 1.0f : 0.0f;
     }
     __syncthreads();
@@ -378,10 +375,8 @@ __global__ __launch_bounds__(PW * 64) void odf_peaks_kernel(const PeakArgs a) {
         for (int gg = 1; gg < PG; gg++) {
             const float *r = mrg + (size_t)(gg * PV + j) * PREC;
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int idx = __float_as_int(r[3 + k]);
-                if (idx >= 0) top3_insert(t, r[k], idx);
-            }
+            for (int k = 0; k < 3; k++)
+                top3_insert_key(t, ((unsigned long long)__float_as_uint(r[2 * k + 1]) << 32) | __float_as_uint(r[2 * k]));
             npos += __float_as_int(r[6]);
             vmin = fminf(vmin, r[7]);
             vsum += r[8];
@@ -393,7 +388,7 @@ __global__ __launch_bounds__(PW * 64) void odf_peaks_kernel(const PeakArgs a) {
         if (inb) {
             if (a.isort_top) {
 #pragma unroll
-                for (int k = 0; k < 3; k++) a.isort_top[(int64_t)k * a.nvox + vox] = t.i[k];
+                for (int k = 0; k < 3; k++) a.isort_top[(int64_t)k * a.nvox + vox] = top3_index(t, k);
                 a.nvalid[vox] = npos;
             } else {
                 const int n = npos < 3 ? npos : 3;              // gqi.jl:151
@@ -401,7 +396,7 @@ __global__ __launch_bounds__(PW * 64) void odf_peaks_kernel(const PeakArgs a) {
                 for (int k = 0; k < 3; k++) {
                     float px = 0.0f, py = 0.0f, pz = 0.0f, q = 0.0f;
                     if (k < n) {
-                        const int iv = t.i[k];
+                        const int iv = top3_index(t, k);
                         px = a.verts[3 * iv]; py = a.verts[3 * iv + 1]; pz = a.verts[3 * iv + 2];
                         q = o[iv * PV + j] - vmin;              // gqi.jl:157-158
                     }
@@ -420,6 +415,183 @@ __global__ __launch_bounds__(PW * 64) void odf_peaks_kernel(const PeakArgs a) {
             if (e) atomicMax(&a.maxenc[0], e);
             if (nanb) atomicOr(&a.maxenc[1], 1u);
         }
+    }
+}
+
+// ---- v3: 64-voxel tiles, one persistent workgroup of 16 waves per CU -----------------------------------
+// Every lane of a wave owns one voxel and the wave walks its share of the vertices, so vertex and neighbour
+// indices are wave-uniform (scalar loads, SGPR operands) and an LDS address costs one v_add.  The tile
+// (nvert x 64 floats, 82 KB for sphere_642) leaves room for one workgroup per CU only, so the next tile is
+// prefetched into registers (6 x 16 B per lane) while the current one is scanned, and written to LDS after
+// the barrier ("issue early, write late"): the HBM stream never waits for the LDS-bound scan.
+constexpr int P64_W = 16;                    // waves per workgroup
+constexpr int P64_T = P64_W * 64;            // threads
+constexpr int P64_NI = 6;                    // float4 staging registers per lane -> nvert <= 6*1024/16 = 384
+
+struct Peak64Partial { Top3 t; int npos; float vmin, vsum; bool hasnan; };
+
+__device__ __forceinline__ void p64_store(float *rec, const Peak64Partial &p) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { rec[2 * k] = __uint_as_float((unsigned)p.t.k[k]); rec[2 * k + 1] = __uint_as_float((unsigned)(p.t.k[k] >> 32)); }
+    rec[6] = __int_as_float(p.npos); rec[7] = p.vmin; rec[8] = p.vsum; rec[9] = p.hasnan ? 1.0f : 0.0f;
+}
+__device__ __forceinline__ void p64_merge(Peak64Partial &p, const float *r) {
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        top3_insert_key(p.t, ((unsigned long long)__float_as_uint(r[2 * k + 1]) << 32) | __float_as_uint(r[2 * k]));
+    p.npos += __float_as_int(r[6]);
+    p.vmin = fminf(p.vmin, r[7]);
+    p.vsum += r[8];
+    p.hasnan |= r[9] != 0.0f;
+}
+
+template <int DEG, bool EXACT>
+__global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, int64_t ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *o = smem;                                            // [nvert + 1][64]; row nvert = NaN sentinel
+    float *mrg = o + (size_t)(a.nvert + 1) * 64;                // [P64_W][64][PREC]
+    int *nbl = reinterpret_cast<int *>(mrg + (size_t)P64_W * 64 * PREC);   // [nvert][DEG] neighbour rows (LDS copy:
+                                                                // global loads of the table would sit on the critical path)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nq = a.nvert * 16;                                // float4 elements per tile
+    if (tid < 64) o[a.nvert * 64 + tid] = __builtin_nanf("");
+    for (int i = tid; i < a.nvert * DEG; i += P64_T) nbl[i] = a.nbr64[i] * 64;
+
+    // fast path: whole, 16-byte aligned tiles are prefetched into registers; a ragged last tile (or an
+    // unaligned volume) is loaded synchronously with guards when its turn comes.  The staging registers are
+    // six named float4s (an array indexed inside conditionals ends up in scratch memory).
+    static_assert(P64_NI == 6, "staging is written out for six registers");
+    float4 s0, s1, s2, s3, s4, s5;
+    s0 = s1 = s2 = s3 = s4 = s5 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto is_fast = [&](int64_t tile) { return a.vec_ok && tile * 64 + 64 <= a.nvox; };
+    const int rbase = tid >> 4;
+#define FIB_P64_ROW(i) ((rbase + 64 * (i)) < a.nvert ? (rbase + 64 * (i)) : a.nvert - 1)
+#define FIB_P64_FETCH(tile_)                                                                         \
+    do {                                                                                             \
+        const float *g0_ = a.odf + (tile_) * 64 + (tid & 15) * 4;                                    \
+        s0 = *reinterpret_cast<const float4 *>(g0_ + (int64_t)FIB_P64_ROW(0) * a.nvox);              \
+        s1 = *reinterpret_cast<const float4 *>(g0_ + (int64_t)FIB_P64_ROW(1) * a.nvox);              \
+        s2 = *reinterpret_cast<const float4 *>(g0_ + (int64_t)FIB_P64_ROW(2) * a.nvox);              \
+        s3 = *reinterpret_cast<const float4 *>(g0_ + (int64_t)FIB_P64_ROW(3) * a.nvox);              \
+        s4 = *reinterpret_cast<const float4 *>(g0_ + (int64_t)FIB_P64_ROW(4) * a.nvox);              \
+        s5 = *reinterpret_cast<const float4 *>(g0_ + (int64_t)FIB_P64_ROW(5) * a.nvox);              \
+    } while (0)
+#define FIB_P64_PUT(i, reg) if (tid + P64_T * (i) < nq) *reinterpret_cast<float4 *>(o + 4 * (tid + P64_T * (i))) = reg
+
+    int64_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    bool fast = is_fast(tile);
+    if (fast) FIB_P64_FETCH(tile);
+    for (;;) {
+        if (fast) {
+            FIB_P64_PUT(0, s0); FIB_P64_PUT(1, s1); FIB_P64_PUT(2, s2);
+            FIB_P64_PUT(3, s3); FIB_P64_PUT(4, s4); FIB_P64_PUT(5, s5);
+        } else {
+            for (int e = tid; e < a.nvert * 64; e += P64_T) {
+                const int row = e >> 6, c = e & 63;
+                const int64_t vx = tile * 64 + c;
+                o[e] = vx < a.nvox ? a.odf[(int64_t)row * a.nvox + vx] : 0.0f;
+            }
+        }
+        __syncthreads();
+        const int64_t next = tile + gridDim.x;
+        fast = next < ntiles && is_fast(next);
+        if (fast) FIB_P64_FETCH(next);                          // in flight during the scan
+
+        // ---- scan this wave's vertices (uniform v) ------------------------------------------------------
+        Peak64Partial p;
+        top3_clear(p.t);
+        p.npos = 0; p.vmin = INFINITY; p.vsum = 0.0f; p.hasnan = false;
+        // UNR vertices per iteration: their neighbour-table reads and ODF reads are all issued before the
+        // first compare, so each wave keeps ~(1+DEG)*UNR LDS reads in flight instead of a dependent chain
+        constexpr int UNR = 4;
+        for (int v0 = wave; v0 < a.nvert; v0 += P64_W * UNR) {
+            float x[UNR], y[UNR][DEG];
+            int vv[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int v = v0 + u * P64_W;
+                vv[u] = v < a.nvert ? v : a.nvert;              // past the end: sentinel row (never a peak, NaN)
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int *nb = nbl + (vv[u] < a.nvert ? vv[u] : 0) * DEG;   // wave-uniform address: LDS broadcast reads
+                x[u] = o[vv[u] * 64 + lane];
+#pragma unroll
+                for (int d = 0; d < DEG; d++) y[u][d] = o[nb[d] + lane];
+            }
+            float pk[UNR];
+            bool cand = false;
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                bool killed = false;
+#pragma unroll
+                for (int d = 0; d < DEG; d++) killed |= (y[u][d] >= x[u]);   // gqi.jl:185-196
+                const bool live = vv[u] < a.nvert;              // wave-uniform
+                pk[u] = (killed || !live) ? 0.0f : x[u];        // odf_peak
+                if (live) {
+                    if (pk[u] > 0.0f) p.npos++;                 // gqi.jl:200
+                    p.hasnan |= (x[u] != x[u]);
+                    p.vmin = fminf(p.vmin, x[u]);
+                    p.vsum += x[u];
+                    cand |= EXACT || !(pk[u] <= 0.0f);
+                }
+            }
+            if (__any(cand)) {                                  // wave-uniform skip of the insertions
+#pragma unroll
+                for (int u = 0; u < UNR; u++)
+                    if (vv[u] < a.nvert && (EXACT || !(pk[u] <= 0.0f))) top3_insert(p.t, pk[u], vv[u]);
+            }
+        }
+        p64_store(mrg + (size_t)(wave * 64 + lane) * PREC, p);
+        __syncthreads();
+        // ---- two-level merge: waves 0..3 fold 4 partials each, wave 0 folds those -------------------------
+        if (wave < 4) {
+            for (int g = 1; g < 4; g++) p64_merge(p, mrg + (size_t)((wave + 4 * g) * 64 + lane) * PREC);
+            if (wave > 0) p64_store(mrg + (size_t)(wave * 64 + lane) * PREC, p);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int g = 1; g < 4; g++) p64_merge(p, mrg + (size_t)(g * 64 + lane) * PREC);
+            if (p.hasnan) p.vmin = NAN;                         // minimum() propagates NaN (gqi.jl:147)
+            const float mean = p.vsum * (1.0f / (float)a.nvert);   // mean(odf, dims=4), gqi.jl:164
+            const bool mean_nan = mean != mean;
+            const int64_t vox = tile * 64 + lane;
+            const bool inb = vox < a.nvox;
+            if (inb) {
+                if (a.isort_top) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) a.isort_top[(int64_t)k * a.nvox + vox] = top3_index(p.t, k);
+                    a.nvalid[vox] = p.npos;
+                } else {
+                    const int n = p.npos < 3 ? p.npos : 3;     // gqi.jl:151
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        float px = 0.0f, py = 0.0f, pz = 0.0f, q = 0.0f;
+                        if (k < n) {
+                            const int iv = top3_index(p.t, k);
+                            px = a.verts[3 * iv]; py = a.verts[3 * iv + 1]; pz = a.verts[3 * iv + 2];
+                            q = o[iv * 64 + lane] - p.vmin;     // gqi.jl:157-158
+                        }
+                        a.peak[k][vox] = px; a.peak[k][a.nvox + vox] = py; a.peak[k][2 * a.nvox + vox] = pz;
+                        a.qa[k][vox] = q;
+                    }
+                }
+            }
+            if (a.maxenc) {
+                unsigned e = inb && !mean_nan ? enc_ordered(mean) : 0u;
+                const unsigned long long nanb = __ballot(inb && mean_nan);
+                for (int off = 32; off >= 1; off >>= 1) { const unsigned oth = (unsigned)__shfl_xor((int)e, off); e = oth > e ? oth : e; }
+                if (lane == 0) {
+                    if (e) atomicMax(&a.maxenc[0], e);
+                    if (nanb) atomicOr(&a.maxenc[1], 1u);
+                }
+            }
+        }
+        if (next >= ntiles) break;
+        tile = next;
+        __syncthreads();                                        // wave 0 is done reading o[] before it is overwritten
     }
 }
 
@@ -455,7 +627,7 @@ struct fib_odf_plan {
     std::vector<float> A;                            // host copy [nrows x nvol] column-major
     fib::DevBuf<float> At, verts;
     fib::DevBuf<uint32_t> effbits;
-    fib::DevBuf<int32_t> nbr;        // [nvert_even][deg_pad] LDS row of each neighbour (sentinel-padded)
+    fib::DevBuf<int32_t> nbr, nbr64; // [nvert_even][deg_pad] LDS row of each neighbour (sentinel-padded)
     int deg_pad = 6, rows_pad = 0;
     mutable fib::DevBuf<unsigned> maxenc;
     mutable fib::DevBuf<float> odfmax;
@@ -498,6 +670,10 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
             const int32_t u = nbr32[(size_t)v * p->maxdeg + d];
             if (u >= 0) nbr[(size_t)v * p->deg_pad + d] = u;
         }
+    std::vector<int32_t> nbr64(nbr);
+    for (auto &u : nbr64) if (u == p->rows_pad) u = p->nvert;
+    if ((rc = p->nbr64.alloc(nbr64.size())) != FIB_OK) return rc;
+    FIB_HIP(hipMemcpy(p->nbr64.p, nbr64.data(), nbr64.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     std::vector<float> v3((size_t)p->nvert * 3);
     for (int v = 0; v < p->nvert; v++)
         for (int c = 0; c < 3; c++) v3[3 * v + c] = verts[v + (size_t)nverts * c];
@@ -612,10 +788,19 @@ int launch_peaks_t(const PeakArgs &pa, size_t smem, unsigned grid, hipStream_t s
     return FIB_OK;
 }
 
+template <int DEG, bool EXACT>
+int launch_peaks64_t(const PeakArgs &pa, size_t smem, int64_t ntiles, unsigned grid, hipStream_t st) {
+    FIB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(odf_peaks64_kernel<DEG, EXACT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((odf_peaks64_kernel<DEG, EXACT>), dim3(grid), dim3(P64_T), smem, st, pa, ntiles);
+    FIB_HIP(hipGetLastError());
+    return FIB_OK;
+}
+
 int launch_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox, float *const peak[3], float *const qa[3],
                  int32_t *isort_top, int32_t *nvalid, bool reduce, hipStream_t st) {
     PeakArgs pa{};
-    pa.odf = odf; pa.nbr = plan->nbr.p; pa.verts = plan->verts.p;
+    pa.odf = odf; pa.nbr = plan->nbr.p; pa.nbr64 = plan->nbr64.p; pa.verts = plan->verts.p;
     for (int k = 0; k < 3; k++) { pa.peak[k] = peak ? peak[k] : nullptr; pa.qa[k] = qa ? qa[k] : nullptr; }
     pa.isort_top = isort_top; pa.nvalid = nvalid;
     pa.maxenc = reduce ? plan->maxenc.p : nullptr;
@@ -626,6 +811,19 @@ int launch_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox, float
     const unsigned grid = (unsigned)fib::cdiv(nvox, PV);
     const bool exact = isort_top != nullptr;
     fib::ProfScope prof("odf_peaks", st);
+    const size_t smem64 = ((size_t)(plan->nvert + 1) * 64 + (size_t)P64_W * 64 * PREC + (size_t)plan->nvert * plan->deg_pad) * sizeof(float);
+    const char *force32 = getenv("FIBERS_PEAKS_V2");
+    if (plan->nvert * 16 <= P64_NI * P64_T && smem64 <= 160 * 1024 && !(force32 && atoi(force32))) {
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, plan->device);
+        const int64_t ntiles = fib::cdiv(nvox, 64);
+        const unsigned g64 = (unsigned)std::min<int64_t>(ntiles, ncu);
+        switch (plan->deg_pad) {
+            case 6:  return exact ? launch_peaks64_t<6, true>(pa, smem64, ntiles, g64, st) : launch_peaks64_t<6, false>(pa, smem64, ntiles, g64, st);
+            case 8:  return exact ? launch_peaks64_t<8, true>(pa, smem64, ntiles, g64, st) : launch_peaks64_t<8, false>(pa, smem64, ntiles, g64, st);
+            default: return exact ? launch_peaks64_t<16, true>(pa, smem64, ntiles, g64, st) : launch_peaks64_t<16, false>(pa, smem64, ntiles, g64, st);
+        }
+    }
     switch (plan->deg_pad) {
         case 6:  return exact ? launch_peaks_t<6, true>(pa, smem, grid, st) : launch_peaks_t<6, false>(pa, smem, grid, st);
         case 8:  return exact ? launch_peaks_t<8, true>(pa, smem, grid, st) : launch_peaks_t<8, false>(pa, smem, grid, st);

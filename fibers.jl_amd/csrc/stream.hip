@@ -7,11 +7,14 @@
 // Layout.  The orientation field is repacked to float4 [nvox][nvec] (xyz0): one aligned 16-byte gather
 // per candidate vector per step; vectors of masked-out voxels are zero, which makes the reference's
 // separate mask lookup (stream.jl:520) redundant (an all-zero voxel fails stream_pick_by_angle! the same
-// way).  One lane integrates one (seed, sub-voxel offset) line, forward then backward, writing points
-// into a fixed-stride scratch row [line][len_max+2] (the HBM budget of an MI355X makes worst-case rows
-// affordable: 1 M lines x 142 points x 12 B = 1.7 GB).  A scan over the per-line counts then gives every
-// kept line its offset, and the pack kernel (one wave per line) emits the reference's point order
-// [fwd_N .. fwd_1, bwd_1 .. bwd_M] (prepend!/append!, stream.jl:652) fully coalesced.
+// way).  One lane integrates one (seed, sub-voxel offset) line, forward then backward.  Points go to a
+// slot-major scratch [2*(len_max+2) slots][nlines][3]: forward step i -> slot i, backward step j -> slot
+// L+j, so that at every step the 64 lanes of a wave (consecutive lines, same step) store one contiguous
+// 768-byte run.  (Line-major rows cost 2.6x: 12-byte stores to 64 different cache lines per step, partial
+// lines evicted to HBM.)  Worst-case rows are affordable with 288 GB: 1 M lines x 284 slots x 12 B = 3.4 GB.
+// A scan over the per-line counts gives every kept line its offset; the pack kernel transposes 16-slot x
+// 64-line blocks through LDS and emits the reference's point order [fwd_N .. fwd_1, bwd_1 .. bwd_M]
+// (prepend!/append!, stream.jl:652) in 48-byte pieces.
 //
 // Arithmetic.  No a*b+c contraction anywhere in this file: positions are compared after round-to-nearest-
 // even (stream.jl:514) so one ulp moves a line to another voxel; with contraction off every operation is
@@ -64,7 +67,7 @@ struct TraceArgs {
     const float4 *field;        // [nvox][nvec]
     const int64_t *seeds;       // [nseed] 0-based linear voxel index
     const float *sublist;       // [nsub][3]
-    float *scratch;             // [nlines][stride][3]
+    float *scratch;             // [2*stride slots][nlines][3]: forward step i -> slot i, backward step j -> slot stride+j
     int32_t *npts, *nfwd;       // [nlines]
     int64_t line0, nlines;      // this batch covers global lines [line0, line0+nlines)
     int nx, ny, nz, nvec, nsub, len_max, stride;
@@ -88,7 +91,8 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
     const float p0x = (float)(sx + 1) + a.sublist[3 * isub];      // pos_now .= seed_vox .+ sub_vox, stream.jl:649
     const float p0y = (float)(sy + 1) + a.sublist[3 * isub + 1];
     const float p0z = (float)(sz + 1) + a.sublist[3 * isub + 2];
-    float *dst = a.scratch + (int64_t)li * a.stride * 3;
+    float *dst = a.scratch + li * 3;
+    const int64_t slot_floats = a.nlines * 3;
     const float fnx = (float)a.nx, fny = (float)a.ny, fnz = (float)a.nz;
     const float omc = 1.0f - a.smooth;
     int ivec = 0, npts = 0, nf = 0;
@@ -120,7 +124,10 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
             float wx, wy, wz;
             if (bestc > 0.0f) { wx = bx; wy = by; wz = bz; } else { wx = -bx; wy = -by; wz = -bz; }   // :365-369
             ivec = best;                                          // stream.jl:371
-            dst[3 * npts] = px; dst[3 * npts + 1] = py; dst[3 * npts + 2] = pz;                       // :660
+            {   // push!/prepend! of pos_now (stream.jl:660): slot = step index within this pass
+                float *d = dst + (int64_t)(pass == 0 ? nf : a.stride + (npts - nf)) * slot_floats;
+                d[0] = px; d[1] = py; d[2] = pz;
+            }
             npts++;
             if (pass == 0) nf++;
             if (dot3(vx, vy, vz, wx, wy, wz) < a.cosang) break;   // stream.jl:670
@@ -220,22 +227,69 @@ struct PackArgs {
     int stride, len_min;
 };
 
-// one wave per line: reversed forward part, then the backward part (stream.jl:652)
+// 64 lines per workgroup; 16-slot x 64-line blocks of the slot-major scratch are read coalesced into LDS and
+// written out line by line: thread (line tl, quarter q) emits 4 consecutive points = 48 contiguous bytes.
+// Forward slots are reversed on the way out, backward slots follow (stream.jl:652).
+constexpr int PK_LINES = 64, PK_SLOTS = 16, PK_ROW = PK_LINES * 3 + 1;
 __global__ __launch_bounds__(256) void stream_pack_kernel(const PackArgs a) {
-    const int64_t li = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (li >= a.nlines) return;
-    const int n = a.npts[li];
-    if (n < a.len_min) return;
-    const int lane = threadIdx.x & 63, nf = a.nfwd[li];
-    const Pair e = a.excl[li], bo = a.block_off[li / SCAN_B];
-    const int64_t pt0 = a.out_pt0 + e.pts + bo.pts, l0 = a.out_line0 + e.lines + bo.lines;
-    if (lane == 0) { a.out_npts[l0] = n; a.out_seed[l0] = a.line0 + li; }
-    const float *src = a.scratch + (int64_t)li * a.stride * 3;
-    float *dst = a.out_xyz + pt0 * 3;
-    for (int i = lane; i < 3 * n; i += 64) {
-        const int p = i / 3, c = i - 3 * p;
-        const int sp = p < nf ? nf - 1 - p : p;
-        dst[i] = src[3 * sp + c];
+    __shared__ float tile[PK_SLOTS * PK_ROW];
+    __shared__ int smax[2];
+    const int tid = threadIdx.x, tl = tid >> 2, q = tid & 3;
+    const int64_t line0 = (int64_t)blockIdx.x * PK_LINES;
+    const int64_t li = line0 + tl;
+    int n = 0, nf = 0;
+    int64_t pt0 = 0;
+    bool keep = false;
+    if (li < a.nlines) {
+        n = a.npts[li];
+        nf = a.nfwd[li];
+        keep = n >= a.len_min;                                  // stream.jl:769
+        const Pair e = a.excl[li], bo = a.block_off[li / SCAN_B];
+        pt0 = a.out_pt0 + e.pts + bo.pts;
+        if (keep && q == 0) {
+            const int64_t l0 = a.out_line0 + e.lines + bo.lines;
+            a.out_npts[l0] = n;
+            a.out_seed[l0] = a.line0 + li;
+        }
+    }
+    const int nb = n - nf;
+    if (tid < 2) smax[tid] = 0;
+    __syncthreads();
+    if (keep && q == 0) { atomicMax(&smax[0], nf); atomicMax(&smax[1], nb); }
+    __syncthreads();
+    const int lines_here = (int)((a.nlines - line0) < PK_LINES ? (a.nlines - line0) : PK_LINES);
+    const int row_floats = lines_here * 3;
+    for (int region = 0; region < 2; region++) {
+        const int count = smax[region];
+        const int mine = region == 0 ? nf : nb;
+        const int64_t base_slot = region == 0 ? 0 : a.stride;
+        for (int s0 = 0; s0 < count; s0 += PK_SLOTS) {
+            // threads 0..191 own one float column of the 64-line row each: 16 independent coalesced loads
+            if (tid < PK_LINES * 3) {
+                const float *src = a.scratch + ((base_slot + s0) * a.nlines + line0) * 3 + tid;
+                const bool colok = tid < row_floats;
+                float v[PK_SLOTS];
+#pragma unroll
+                for (int sl = 0; sl < PK_SLOTS; sl++)
+                    v[sl] = (colok && s0 + sl < count) ? src[(int64_t)sl * a.nlines * 3] : 0.0f;
+#pragma unroll
+                for (int sl = 0; sl < PK_SLOTS; sl++) tile[sl * PK_ROW + tid] = v[sl];
+            }
+            __syncthreads();
+            if (keep) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int sl = 4 * q + j, sidx = s0 + sl;
+                    if (sidx < mine) {
+                        const int64_t p = region == 0 ? (int64_t)(nf - 1 - sidx) : (int64_t)nf + sidx;
+                        struct P3 { float x, y, z; };
+                        const float *t = tile + sl * PK_ROW + tl * 3;
+                        *reinterpret_cast<P3 *>(a.out_xyz + (pt0 + p) * 3) = P3{t[0], t[1], t[2]};
+                    }
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -262,8 +316,9 @@ struct fib_stream_job {
     int nsub = 1, stride = 0;
     float *scratch = nullptr;
     bool scratch_from_cache = false;
-    fib::DevBuf<int32_t> npts, nfwd;
-    fib::DevBuf<Pair> excl, block_tot, total;
+    // carved out of the same (cached) arena as the scratch: no hipMalloc/hipFree per call
+    struct View32 { int32_t *p = nullptr; } npts, nfwd;
+    struct ViewP { Pair *p = nullptr; } excl, block_tot, total;
     int64_t kept_lines = 0, kept_pts = 0;
 };
 
@@ -321,7 +376,12 @@ extern "C" int fibd_stream_trace(const fib_stream_params *prm, const float *fiel
     if (nl == 0) { *job_out = job; return FIB_OK; }
     int rc = FIB_OK;
     auto bail = [&](int code) { fib_stream_job_destroy(job); return code; };
-    const size_t sbytes = (size_t)nl * job->stride * 3 * sizeof(float);
+    const int nblocks = (int)fib::cdiv(nl, SCAN_B);
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t b_scratch = up((size_t)nl * job->stride * 2 * 3 * sizeof(float));
+    const size_t b_i32 = up((size_t)nl * sizeof(int32_t)), b_excl = up((size_t)nl * sizeof(Pair));
+    const size_t b_btot = up((size_t)nblocks * sizeof(Pair)), b_tot = 256;
+    const size_t sbytes = b_scratch + 2 * b_i32 + b_excl + b_btot + b_tot;
     {   // scratch: reuse the per-device cache when it is free
         std::lock_guard<std::mutex> lk(g_cache.mu);
         const int d = device & 15;
@@ -338,12 +398,15 @@ extern "C" int fibd_stream_trace(const fib_stream_params *prm, const float *fiel
         hipError_t e = hipMalloc((void **)&job->scratch, sbytes);
         if (e != hipSuccess) { job->scratch = nullptr; return bail(fib::fail(FIB_ERR_NOMEM, "cannot allocate %zu bytes of streamline scratch: %s", sbytes, hipGetErrorString(e))); }
     }
-    const int nblocks = (int)fib::cdiv(nl, SCAN_B);
-    if ((rc = job->npts.alloc((size_t)nl)) != FIB_OK) return bail(rc);
-    if ((rc = job->nfwd.alloc((size_t)nl)) != FIB_OK) return bail(rc);
-    if ((rc = job->excl.alloc((size_t)nl)) != FIB_OK) return bail(rc);
-    if ((rc = job->block_tot.alloc((size_t)nblocks)) != FIB_OK) return bail(rc);
-    if ((rc = job->total.alloc(1)) != FIB_OK) return bail(rc);
+    {
+        char *base = reinterpret_cast<char *>(job->scratch) + b_scratch;
+        job->npts.p = reinterpret_cast<int32_t *>(base); base += b_i32;
+        job->nfwd.p = reinterpret_cast<int32_t *>(base); base += b_i32;
+        job->excl.p = reinterpret_cast<Pair *>(base); base += b_excl;
+        job->block_tot.p = reinterpret_cast<Pair *>(base); base += b_btot;
+        job->total.p = reinterpret_cast<Pair *>(base);
+    }
+    (void)rc;
 
     TraceArgs ta{};
     ta.field = reinterpret_cast<const float4 *>(field4); ta.seeds = seeds; ta.sublist = sublist;
@@ -386,7 +449,7 @@ extern "C" int fibd_stream_pack(fib_stream_job *job, int32_t *npts, int64_t *see
     pa.nlines = job->nlines; pa.line0 = 0; pa.out_line0 = 0; pa.out_pt0 = 0;
     pa.stride = job->stride; pa.len_min = job->prm.len_min;
     fib::ProfScope prof("stream_pack", (hipStream_t)stream);
-    hipLaunchKernelGGL(stream_pack_kernel, dim3((unsigned)fib::cdiv(job->nlines, 4)), dim3(256), 0, (hipStream_t)stream, pa);
+    hipLaunchKernelGGL(stream_pack_kernel, dim3((unsigned)fib::cdiv(job->nlines, PK_LINES)), dim3(256), 0, (hipStream_t)stream, pa);
     FIB_HIP(hipGetLastError());
     return FIB_OK;
 }
