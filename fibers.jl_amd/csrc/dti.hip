@@ -4,8 +4,8 @@
 // per-voxel bodies dti.jl:195-213 / 286-316 + dti_maps dti.jl:325-335.
 //
 // Design (HBM-bound: 4*nvol + 1 bytes in, 64 bytes out per voxel, ~20 VALU ops per sample):
-//   - one thread owns V consecutive voxels (V = 4/2/1 picked from alignment) so that every
-//     frame is read with one 16/8/4-byte load per lane: a wave reads 1 KiB contiguous per frame;
+//   - one thread owns V consecutive voxels; V = 1 with 16 frames in flight per lane and 7 waves/SIMD
+//     measured fastest (5.3 TB/s), wider per-lane loads (V = 2, 4) cost occupancy and lose;
 //   - the pseudo-inverse rows pA[:, i] (padded to 8 floats per frame, 8th = b0 flag) are read
 //     with wave-uniform addresses, i.e. through the scalar cache into SGPRs — no LDS traffic,
 //     no VGPRs; the frame loop is unrolled so ~8 independent loads are in flight per lane;
@@ -190,37 +190,45 @@ template <int V> __device__ __forceinline__ void vstore(float *p, const float (&
 }
 
 // NP = 7: DTI, NP = 2: ADC.  coef: [nvol][8] = pA[:, i] (NP floats), zero pad, [7] = (bval[i]==min) flag
-template <int NP, int V>
+template <int NP, int V, int UNR>
 __global__ __launch_bounds__(256) void fit_kernel(const float *__restrict__ dwi, const uint8_t *__restrict__ mask,
                                                   const float *__restrict__ coef, int nvol, int64_t nvox,
                                                   DtiOutPtrs out, float *__restrict__ adc,
                                                   int64_t *__restrict__ partial_list, int *__restrict__ partial_count) {
     const int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (base >= nvox) return;
-    float d[V][NP];
-    int npos[V], b0pos[V];
+    // Fast path = every sample is a normal positive float (dti.jl:294).  The kernel is VALU-bound, not
+    // HBM-bound, unless the per-sample work is tiny (PMC: 33 VALU/sample -> 77 % VALU busy), so the loop does
+    // only: running minimum (1), log = v_log_f32 * ln2 (2), NP FMAs.  A non-positive / denormal / NaN sample
+    // shows up as min < FLT_MIN or as a NaN in d; such voxels are listed for the complete (slow) kernel.
+    float d[V][NP], smin[V];
 #pragma unroll
     for (int v = 0; v < V; v++) {
-        npos[v] = 0; b0pos[v] = 0;
+        smin[v] = INFINITY;
 #pragma unroll
         for (int j = 0; j < NP; j++) d[v][j] = 0.0f;
     }
     const float *src = dwi + base;
-#pragma unroll 8
+#pragma unroll UNR
     for (int i = 0; i < nvol; i++) {
         float s[V];
         vload<V>(src + (int64_t)i * nvox, s);
         const float *c = coef + 8 * i;          // wave-uniform: scalar loads
-        const bool isb0 = c[7] != 0.0f;
 #pragma unroll
         for (int v = 0; v < V; v++) {
-            const bool pos = s[v] > 0.0f;       // dti.jl:291
-            npos[v] += pos ? 1 : 0;
-            b0pos[v] |= (pos && isb0) ? 1 : 0;
-            const float l = logf(pos ? s[v] : 1.0f);   // dti.jl:295
+            smin[v] = fminf(smin[v], s[v]);
+            const float l = __builtin_amdgcn_logf(s[v]) * 0.693147182464599609375f;   // log.(dwi), dti.jl:295
 #pragma unroll
-            for (int j = 0; j < NP; j++) d[v][j] = __builtin_fmaf(c[j], l, d[v][j]);   // dti.jl:296
+            for (int j = 0; j < NP; j++) d[v][j] = __builtin_fmaf(c[j], l, d[v][j]);   // mul!(d, pA, logs), dti.jl:296
         }
+    }
+    bool fastok[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+        float t = d[v][0];
+#pragma unroll
+        for (int j = 1; j < NP; j++) t += d[v][j];
+        fastok[v] = smin[v] >= 1.17549435e-38f && t == t;
     }
     uint8_t mk[V];
     {
@@ -235,12 +243,12 @@ __global__ __launch_bounds__(256) void fit_kernel(const float *__restrict__ dwi,
 #pragma unroll
             for (int k = 0; k < 16; k++) r[k] = 0.0f;
             if (mk[v] != 0) {                                   // dti.jl:261
-                if (npos[v] == nvol) {                          // dti.jl:294
+                if (fastok[v]) {                                // dti.jl:294
                     dti_finish(d[v], r);
-                } else if (npos[v] > 6 && b0pos[v]) {           // dti.jl:297 -> second kernel
+                } else {                                        // dti.jl:297-303 -> complete kernel
                     const int slot = atomicAdd(partial_count, 1);
                     partial_list[slot] = base + v;
-                }                                               // else zeros, dti.jl:299-303
+                }
             }
 #pragma unroll
             for (int k = 0; k < 16; k++) o[k][v] = r[k];
@@ -264,8 +272,8 @@ __global__ __launch_bounds__(256) void fit_kernel(const float *__restrict__ dwi,
         for (int v = 0; v < V; v++) {
             a[v] = 0.0f; s0[v] = 0.0f;
             if (mk[v] != 0) {
-                if (npos[v] == nvol) { a[v] = d[v][0]; s0[v] = expf(d[v][1]); }          // dti.jl:212
-                else if (npos[v] > 6 && b0pos[v]) {                                       // dti.jl:206
+                if (fastok[v]) { a[v] = d[v][0]; s0[v] = expf(d[v][1]); }                // dti.jl:212
+                else {                                                                    // dti.jl:206-210
                     const int slot = atomicAdd(partial_count, 1);
                     partial_list[slot] = base + v;
                 }
@@ -314,46 +322,67 @@ __device__ void jacobi_sym(double (&A)[N][N], double (&Q)[N][N]) {
     }
 }
 
-// design: [nvol][8] rows of A (NP floats).  One thread per listed voxel.
+// The complete per-voxel fit (dti.jl:286-303) for the voxels the fast kernel could not finish: exact
+// positive count, accurate logf; all positive -> d = pA*log(s); else npos > 6 with a positive b0 -> row-subset
+// least squares (== pinv(A[ipos,:]) * log(s[ipos]), float64 normal equations + Jacobi, LinearAlgebra.pinv's
+// rank cut-off); else zeros.  design/coef: [nvol][8].  One thread per listed voxel; count[1] += subset solves.
 template <int NP>
 __global__ __launch_bounds__(64) void fit_partial_kernel(const float *__restrict__ dwi, const float *__restrict__ design,
+                                                         const float *__restrict__ coef,
                                                          int nvol, int64_t nvox, const int64_t *__restrict__ list,
-                                                         const int *__restrict__ count, DtiOutPtrs out, float *__restrict__ adc) {
+                                                         int *__restrict__ count, DtiOutPtrs out, float *__restrict__ adc) {
   const int total = *count;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
     const int64_t vox = list[t];
-    double N[NP][NP], Q[NP][NP], rhs[NP];
-    for (int i = 0; i < NP; i++) { rhs[i] = 0.0; for (int j = 0; j < NP; j++) N[i][j] = 0.0; }
     int npos = 0;
+    bool b0pos = false;
     for (int i = 0; i < nvol; i++) {
         const float s = dwi[(int64_t)i * nvox + vox];
-        if (!(s > 0.0f)) continue;                              // A[ipos, :], dti.jl:298
-        npos++;
-        const double l = (double)logf(s);
-        double a[NP];
-        for (int j = 0; j < NP; j++) a[j] = (double)design[8 * i + j];
-        for (int j = 0; j < NP; j++) {
-            rhs[j] += a[j] * l;
-            for (int k = 0; k < NP; k++) N[j][k] += a[j] * a[k];
-        }
+        if (s > 0.0f) { npos++; b0pos |= coef[8 * i + 7] != 0.0f; }     // dti.jl:291-292, any(ipos[ib0])
     }
-    jacobi_sym<NP>(N, Q);
-    // pinv(A_sub) b = V diag(1/lambda) V' A_sub' b, singular values sqrt(lambda) <= eps32*min(m,n)*smax dropped
-    double lmax = 0.0;
-    for (int j = 0; j < NP; j++) lmax = fmax(lmax, N[j][j]);
-    const double rt = (double)1.1920929e-07f * (double)(npos < NP ? npos : NP);
-    const double cut = rt * rt * lmax;
     float d[NP];
-    for (int r = 0; r < NP; r++) {
-        double acc = 0.0;
-        for (int j = 0; j < NP; j++) {
-            if (!(N[j][j] > cut)) continue;
-            double proj = 0.0;
-            for (int k = 0; k < NP; k++) proj += Q[k][j] * rhs[k];
-            acc += Q[r][j] * proj / N[j][j];
+    bool solved = true;
+    if (npos == nvol) {                                                  // dti.jl:294-296
+        for (int j = 0; j < NP; j++) d[j] = 0.0f;
+        for (int i = 0; i < nvol; i++) {
+            const float l = logf(dwi[(int64_t)i * nvox + vox]);
+            for (int j = 0; j < NP; j++) d[j] = __builtin_fmaf(coef[8 * i + j], l, d[j]);
         }
-        d[r] = (float)acc;
+    } else if (npos > 6 && b0pos) {                                      // dti.jl:297-298
+        atomicAdd(count + 1, 1);
+        double N[NP][NP], Q[NP][NP], rhs[NP];
+        for (int i = 0; i < NP; i++) { rhs[i] = 0.0; for (int j = 0; j < NP; j++) N[i][j] = 0.0; }
+        for (int i = 0; i < nvol; i++) {
+            const float s = dwi[(int64_t)i * nvox + vox];
+            if (!(s > 0.0f)) continue;                                   // A[ipos, :]
+            const double l = (double)logf(s);
+            double a[NP];
+            for (int j = 0; j < NP; j++) a[j] = (double)design[8 * i + j];
+            for (int j = 0; j < NP; j++) {
+                rhs[j] += a[j] * l;
+                for (int k = 0; k < NP; k++) N[j][k] += a[j] * a[k];
+            }
+        }
+        jacobi_sym<NP>(N, Q);
+        // pinv(A_sub) b = V diag(1/lambda) V' A_sub' b; singular values sqrt(lambda) <= eps32*min(m,n)*smax dropped
+        double lmax = 0.0;
+        for (int j = 0; j < NP; j++) lmax = fmax(lmax, N[j][j]);
+        const double rt = (double)1.1920929e-07f * (double)(npos < NP ? npos : NP);
+        const double cut = rt * rt * lmax;
+        for (int r = 0; r < NP; r++) {
+            double acc = 0.0;
+            for (int j = 0; j < NP; j++) {
+                if (!(N[j][j] > cut)) continue;
+                double proj = 0.0;
+                for (int k = 0; k < NP; k++) proj += Q[k][j] * rhs[k];
+                acc += Q[r][j] * proj / N[j][j];
+            }
+            d[r] = (float)acc;
+        }
+    } else {
+        solved = false;                                                  // dti.jl:299-303: zeros (already written)
     }
+    if (!solved) continue;
     if constexpr (NP == 7) {
         float o[16];
         dti_finish(d, o);
@@ -416,11 +445,11 @@ extern "C" int fib_dti_plan_create(int device, const float *bval, const float *b
     }
     rc = p->coef.alloc(coef.size());
     if (rc == FIB_OK) rc = p->design.alloc(design.size());
-    if (rc == FIB_OK) rc = p->partial_count.alloc(1);
+    if (rc == FIB_OK) rc = p->partial_count.alloc(2);
     if (rc != FIB_OK) { delete p; return rc; }
     hipError_t e = hipMemcpy(p->coef.p, coef.data(), coef.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->design.p, design.data(), design.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(p->partial_count.p, 0, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(p->partial_count.p, 0, 2 * sizeof(int));
     if (e != hipSuccess) { delete p; return fib::fail(FIB_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e)); }
     *plan = p;
     return FIB_OK;
@@ -450,7 +479,7 @@ int launch_fit(const fib_dti_plan *plan, const float *dwi, const uint8_t *mask, 
     FIB_CHECK(nvox < ((int64_t)1 << 31), FIB_ERR_UNSUPPORTED, "volumes of 2^31 voxels or more are not supported");
     int rc = plan->partial_list.ensure((size_t)nvox);
     if (rc != FIB_OK) return rc;
-    FIB_HIP(hipMemsetAsync(plan->partial_count.p, 0, sizeof(int), st));
+    FIB_HIP(hipMemsetAsync(plan->partial_count.p, 0, 2 * sizeof(int), st));
     // widest per-lane access that every frame base and every output base is aligned for
     auto aligned = [&](int v) {
         if (nvox % v) return false;
@@ -459,23 +488,33 @@ int launch_fit(const fib_dti_plan *plan, const float *dwi, const uint8_t *mask, 
         for (const void *q : ptrs) if (q && ((uintptr_t)q & m)) return false;
         return ((uintptr_t)mask & (uintptr_t)(v - 1)) == 0;
     };
-    const int V = aligned(4) ? 4 : (aligned(2) ? 2 : 1);
+    // measured on MI355X (140^3 x 64): 4 voxels/lane (16-B loads, 4 waves/SIMD) 0.185 ms; 2 -> 0.171 ms;
+    // 1 voxel/lane (4-B loads but 7 waves/SIMD and 16 frames in flight per lane) 0.165 ms = 5.3 TB/s
+    const int vmax = aligned(4) ? 4 : (aligned(2) ? 2 : 1);
+    int V = 1, unr = 16;
+    if (const char *e = getenv("FIBERS_DTI_VARIANT")) {          // tuning hook: "<V>x<UNR>"
+        int v = 0, u = 0;
+        if (sscanf(e, "%dx%d", &v, &u) == 2 && (v == 1 || v == 2 || v == 4) && v <= vmax && (u == 8 || u == 16 || u == 32)) { V = v; unr = u; }
+    }
     { fib::ProfScope prof(NP == 7 ? "dti_fit" : "adc_fit", st);
     const int block = 256;
     const int64_t nthreads = nvox / V;
     const unsigned grid = (unsigned)fib::cdiv(nthreads, block);
-    if (V == 4)
-        hipLaunchKernelGGL((fit_kernel<NP, 4>), dim3(grid), dim3(block), 0, st, dwi, mask, plan->coef.p, plan->nvol, nvox, o, adc, plan->partial_list.p, plan->partial_count.p);
-    else if (V == 2)
-        hipLaunchKernelGGL((fit_kernel<NP, 2>), dim3(grid), dim3(block), 0, st, dwi, mask, plan->coef.p, plan->nvol, nvox, o, adc, plan->partial_list.p, plan->partial_count.p);
-    else
-        hipLaunchKernelGGL((fit_kernel<NP, 1>), dim3(grid), dim3(block), 0, st, dwi, mask, plan->coef.p, plan->nvol, nvox, o, adc, plan->partial_list.p, plan->partial_count.p);
+#define FIB_FIT_LAUNCH(VV, UU) hipLaunchKernelGGL((fit_kernel<NP, VV, UU>), dim3(grid), dim3(block), 0, st, dwi, mask, plan->coef.p, plan->nvol, nvox, o, adc, plan->partial_list.p, plan->partial_count.p)
+    if (V == 4 && unr == 8) FIB_FIT_LAUNCH(4, 8);
+    else if (V == 4) FIB_FIT_LAUNCH(4, 16);
+    else if (V == 2 && unr == 8) FIB_FIT_LAUNCH(2, 8);
+    else if (V == 2) FIB_FIT_LAUNCH(2, 16);
+    else if (unr == 8) FIB_FIT_LAUNCH(1, 8);
+    else if (unr == 16) FIB_FIT_LAUNCH(1, 16);
+    else FIB_FIT_LAUNCH(1, 32);
+#undef FIB_FIT_LAUNCH
     }
     FIB_HIP(hipGetLastError());
     fib::ProfScope prof2("fit_partial", st);
     // rare path: fixed small grid, grid-stride over the device-side list (length known only on device)
     const unsigned pgrid = (unsigned)std::min<int64_t>(fib::cdiv(nvox, 64), 2048);
-    hipLaunchKernelGGL((fit_partial_kernel<NP>), dim3(pgrid), dim3(64), 0, st, dwi, plan->design.p,
+    hipLaunchKernelGGL((fit_partial_kernel<NP>), dim3(pgrid), dim3(64), 0, st, dwi, plan->design.p, plan->coef.p,
                        plan->nvol, nvox, plan->partial_list.p, plan->partial_count.p, o, adc);
     FIB_HIP(hipGetLastError());
     return FIB_OK;
@@ -512,7 +551,7 @@ extern "C" int fibd_dti_last_partial_count(const fib_dti_plan *plan, void *strea
     fib::DeviceGuard guard;
     FIB_HIP(hipSetDevice(plan->device));
     int c = 0;
-    FIB_HIP(hipMemcpyAsync(&c, plan->partial_count.p, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    FIB_HIP(hipMemcpyAsync(&c, plan->partial_count.p + 1, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     FIB_HIP(hipStreamSynchronize((hipStream_t)stream));
     *count = c;
     return FIB_OK;
