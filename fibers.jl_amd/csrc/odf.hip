@@ -457,6 +457,8 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
     const int nq = a.nvert * 16;                                // float4 elements per tile
     if (tid < 64) o[a.nvert * 64 + tid] = __builtin_nanf("");
     for (int i = tid; i < a.nvert * DEG; i += P64_T) nbl[i] = a.nbr64[i] * 64;
+    float *vl = reinterpret_cast<float *>(nbl + a.nvert * DEG);             // [nvert][3] vertex coordinates
+    for (int i = tid; i < a.nvert * 3; i += P64_T) vl[i] = a.verts[i];
 
     // fast path: whole, 16-byte aligned tiles are prefetched into registers; a ragged last tile (or an
     // unaligned volume) is loaded synchronously with guards when its turn comes.  The staging registers are
@@ -531,19 +533,21 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
                 const bool live = vv[u] < a.nvert;              // wave-uniform
                 pk[u] = (killed || !live) ? 0.0f : x[u];        // odf_peak
                 if (live) {
-                    if (pk[u] > 0.0f) p.npos++;                 // gqi.jl:200
-                    p.hasnan |= (x[u] != x[u]);
-                    p.vmin = fminf(p.vmin, x[u]);
+                    p.vmin = x[u] < p.vmin ? x[u] : p.vmin;     // NaN-ignoring; NaN is recovered from vsum below
                     p.vsum += x[u];
                     cand |= EXACT || !(pk[u] <= 0.0f);
                 }
             }
-            if (__any(cand)) {                                  // wave-uniform skip of the insertions
+            if (__any(cand)) {                                  // wave-uniform skip of the rare work
 #pragma unroll
                 for (int u = 0; u < UNR; u++)
-                    if (vv[u] < a.nvert && (EXACT || !(pk[u] <= 0.0f))) top3_insert(p.t, pk[u], vv[u]);
+                    if (vv[u] < a.nvert) {
+                        if (pk[u] > 0.0f) p.npos++;             // gqi.jl:200
+                        if (EXACT || !(pk[u] <= 0.0f)) top3_insert(p.t, pk[u], vv[u]);
+                    }
             }
         }
+        p.hasnan = p.vsum != p.vsum;                            // a NaN amplitude makes the sum NaN
         p64_store(mrg + (size_t)(wave * 64 + lane) * PREC, p);
         __syncthreads();
         // ---- two-level merge: waves 0..3 fold 4 partials each, wave 0 folds those -------------------------
@@ -552,33 +556,14 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
             if (wave > 0) p64_store(mrg + (size_t)(wave * 64 + lane) * PREC, p);
         }
         __syncthreads();
+        const int64_t vox = tile * 64 + lane;
+        const bool inb = vox < a.nvox;
         if (wave == 0) {
             for (int g = 1; g < 4; g++) p64_merge(p, mrg + (size_t)(g * 64 + lane) * PREC);
             if (p.hasnan) p.vmin = NAN;                         // minimum() propagates NaN (gqi.jl:147)
             const float mean = p.vsum * (1.0f / (float)a.nvert);   // mean(odf, dims=4), gqi.jl:164
             const bool mean_nan = mean != mean;
-            const int64_t vox = tile * 64 + lane;
-            const bool inb = vox < a.nvox;
-            if (inb) {
-                if (a.isort_top) {
-#pragma unroll
-                    for (int k = 0; k < 3; k++) a.isort_top[(int64_t)k * a.nvox + vox] = top3_index(p.t, k);
-                    a.nvalid[vox] = p.npos;
-                } else {
-                    const int n = p.npos < 3 ? p.npos : 3;     // gqi.jl:151
-#pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        float px = 0.0f, py = 0.0f, pz = 0.0f, q = 0.0f;
-                        if (k < n) {
-                            const int iv = top3_index(p.t, k);
-                            px = a.verts[3 * iv]; py = a.verts[3 * iv + 1]; pz = a.verts[3 * iv + 2];
-                            q = o[iv * 64 + lane] - p.vmin;     // gqi.jl:157-158
-                        }
-                        a.peak[k][vox] = px; a.peak[k][a.nvox + vox] = py; a.peak[k][2 * a.nvox + vox] = pz;
-                        a.qa[k][vox] = q;
-                    }
-                }
-            }
+            p64_store(mrg + (size_t)lane * PREC, p);            // final record of this voxel for the writer waves
             if (a.maxenc) {
                 unsigned e = inb && !mean_nan ? enc_ordered(mean) : 0u;
                 const unsigned long long nanb = __ballot(inb && mean_nan);
@@ -586,6 +571,26 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
                 if (lane == 0) {
                     if (e) atomicMax(&a.maxenc[0], e);
                     if (nanb) atomicOr(&a.maxenc[1], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- outputs: one wave per output row (9 peak components + 3 qa, or 3 indices + nvalid) -------------
+        if (wave < 12 && inb) {
+            const float *r = mrg + (size_t)lane * PREC;
+            const int npos = __float_as_int(r[6]);
+            if (a.isort_top) {
+                if (wave < 3) a.isort_top[(int64_t)wave * a.nvox + vox] = __float_as_uint(r[2 * wave]) | __float_as_uint(r[2 * wave + 1]) ? (int)~__float_as_uint(r[2 * wave]) : -1;
+                else if (wave == 3) a.nvalid[vox] = npos;
+            } else {
+                const int k = wave < 9 ? wave / 3 : wave - 9;
+                const bool have = k < (npos < 3 ? npos : 3);     // gqi.jl:151
+                const int iv = (int)~__float_as_uint(r[2 * k]);
+                if (wave < 9) {
+                    const int c = wave - 3 * k;
+                    a.peak[k][(int64_t)c * a.nvox + vox] = have ? vl[3 * iv + c] : 0.0f;      // gqi.jl:154-155
+                } else {
+                    a.qa[k][vox] = have ? o[iv * 64 + lane] - r[7] : 0.0f;                    // gqi.jl:157-158
                 }
             }
         }
@@ -811,7 +816,7 @@ int launch_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox, float
     const unsigned grid = (unsigned)fib::cdiv(nvox, PV);
     const bool exact = isort_top != nullptr;
     fib::ProfScope prof("odf_peaks", st);
-    const size_t smem64 = ((size_t)(plan->nvert + 1) * 64 + (size_t)P64_W * 64 * PREC + (size_t)plan->nvert * plan->deg_pad) * sizeof(float);
+    const size_t smem64 = ((size_t)(plan->nvert + 1) * 64 + (size_t)P64_W * 64 * PREC + (size_t)plan->nvert * (plan->deg_pad + 3)) * sizeof(float);
     const char *force32 = getenv("FIBERS_PEAKS_V2");
     if (plan->nvert * 16 <= P64_NI * P64_T && smem64 <= 160 * 1024 && !(force32 && atoi(force32))) {
         int ncu = 256;
