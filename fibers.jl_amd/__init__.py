@@ -12,3 +12,6 @@ from .gqi import (DSI, GQI, OdfPlan, dsi_rec, find_peaks_device, gqi_rec, odf_re
                   qa_normalize_device)
 from .tract import Tract  # noqa: F401
 from .stream import make_sublist, stream, stream_device, stream_field_device  # noqa: F401
+from .nifti import (dsi_write, dti_write, gqi_write, load_nifti, mri_read, mri_read_bfiles, mri_write,  # noqa: F401
+                    read_struct)
+from .trk import str_add, stream_to_trk, tract_header, trk_read, trk_write  # noqa: F401

@@ -63,6 +63,7 @@ _PROTOS = {
     "fibd_stream_trace": (i32, [C.POINTER(StreamParams), vp, vp, i64, vp, i32, vp,
                                 C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]),
     "fibd_stream_pack": (i32, [vp, vp, vp, vp, vp]),
+    "fibd_stream_pack_trk": (i32, [vp, C.POINTER(C.c_float * 3), vp, vp]),
     "fibd_stream_all_npts": (i32, [vp, vp, vp]),
     "fib_stream_job_destroy": (None, [vp]),
     "fib_dti_fit": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, C.POINTER(DtiOut)]),

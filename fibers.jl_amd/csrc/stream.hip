@@ -225,6 +225,8 @@ struct PackArgs {
     float *out_xyz;
     int64_t nlines, line0, out_line0, out_pt0;
     int stride, len_min;
+    int trk;                    // 1: out_xyz is a .trk body: [Int32 npts, npts x 3 Float32 ((xyz+.5)*voxel_size)] per line
+    float vs[3];
 };
 
 // 64 lines per workgroup; 16-slot x 64-line blocks of the slot-major scratch are read coalesced into LDS and
@@ -246,11 +248,12 @@ __global__ __launch_bounds__(256) void stream_pack_kernel(const PackArgs a) {
         keep = n >= a.len_min;                                  // stream.jl:769
         const Pair e = a.excl[li], bo = a.block_off[li / SCAN_B];
         pt0 = a.out_pt0 + e.pts + bo.pts;
+        const int64_t l0 = a.out_line0 + e.lines + bo.lines;
         if (keep && q == 0) {
-            const int64_t l0 = a.out_line0 + e.lines + bo.lines;
-            a.out_npts[l0] = n;
-            a.out_seed[l0] = a.line0 + li;
+            if (a.trk) reinterpret_cast<int32_t *>(a.out_xyz)[l0 + 3 * pt0] = n;      // write(io, Int32(npts)), trk.jl:472
+            else { a.out_npts[l0] = n; a.out_seed[l0] = a.line0 + li; }
         }
+        if (a.trk) pt0 = pt0 * 3 + l0 + 1;                      // float index of this line's first coordinate
     }
     const int nb = n - nf;
     if (tid < 2) smax[tid] = 0;
@@ -284,7 +287,12 @@ __global__ __launch_bounds__(256) void stream_pack_kernel(const PackArgs a) {
                         const int64_t p = region == 0 ? (int64_t)(nf - 1 - sidx) : (int64_t)nf + sidx;
                         struct P3 { float x, y, z; };
                         const float *t = tile + sl * PK_ROW + tl * 3;
-                        *reinterpret_cast<P3 *>(a.out_xyz + (pt0 + p) * 3) = P3{t[0], t[1], t[2]};
+                        if (a.trk)                              // T.((xyz .+ .5) .* voxel_size), Float64 arithmetic (trk.jl:475-476)
+                            *reinterpret_cast<P3 *>(a.out_xyz + pt0 + p * 3) =
+                                P3{(float)(((double)t[0] + 0.5) * (double)a.vs[0]), (float)(((double)t[1] + 0.5) * (double)a.vs[1]),
+                                   (float)(((double)t[2] + 0.5) * (double)a.vs[2])};
+                        else
+                            *reinterpret_cast<P3 *>(a.out_xyz + (pt0 + p) * 3) = P3{t[0], t[1], t[2]};
                     }
                 }
             }
@@ -449,6 +457,25 @@ extern "C" int fibd_stream_pack(fib_stream_job *job, int32_t *npts, int64_t *see
     pa.nlines = job->nlines; pa.line0 = 0; pa.out_line0 = 0; pa.out_pt0 = 0;
     pa.stride = job->stride; pa.len_min = job->prm.len_min;
     fib::ProfScope prof("stream_pack", (hipStream_t)stream);
+    hipLaunchKernelGGL(stream_pack_kernel, dim3((unsigned)fib::cdiv(job->nlines, PK_LINES)), dim3(256), 0, (hipStream_t)stream, pa);
+    FIB_HIP(hipGetLastError());
+    return FIB_OK;
+}
+
+extern "C" int fibd_stream_pack_trk(fib_stream_job *job, const float voxel_size[3], void *body, void *stream) {
+    FIB_CHECK(job != nullptr && voxel_size != nullptr, FIB_ERR_INVALID, "NULL argument");
+    if (job->kept_lines == 0) return FIB_OK;
+    FIB_CHECK(body != nullptr, FIB_ERR_INVALID, "NULL output buffer");
+    fib::DeviceGuard guard;
+    FIB_HIP(hipSetDevice(job->device));
+    PackArgs pa{};
+    pa.scratch = job->scratch; pa.npts = job->npts.p; pa.nfwd = job->nfwd.p;
+    pa.excl = job->excl.p; pa.block_off = job->block_tot.p;
+    pa.out_npts = nullptr; pa.out_seed = nullptr; pa.out_xyz = reinterpret_cast<float *>(body);
+    pa.nlines = job->nlines; pa.line0 = 0; pa.out_line0 = 0; pa.out_pt0 = 0;
+    pa.stride = job->stride; pa.len_min = job->prm.len_min;
+    pa.trk = 1; pa.vs[0] = voxel_size[0]; pa.vs[1] = voxel_size[1]; pa.vs[2] = voxel_size[2];
+    fib::ProfScope prof("stream_pack_trk", (hipStream_t)stream);
     hipLaunchKernelGGL(stream_pack_kernel, dim3((unsigned)fib::cdiv(job->nlines, PK_LINES)), dim3(256), 0, (hipStream_t)stream, pa);
     FIB_HIP(hipGetLastError());
     return FIB_OK;

@@ -13,7 +13,9 @@ class MRI:
     bval: Optional[np.ndarray] = None            # [nframes]      (mri.jl:128)
     bvec: Optional[np.ndarray] = None            # [nframes, 3]   (mri.jl:129)
     volres: tuple = (1.0, 1.0, 1.0)              # voxel size, mm (mri.jl:93)
-    vox2ras: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=np.float32))
+    vox2ras: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=np.float32))   # vox2ras0 (mri.jl:104)
+    tr: float = 0.0
+    niftihdr: Optional[dict] = None              # header of the file this volume came from (mri.jl:126)
 
     def __post_init__(self):
         v = np.asarray(self.vol)

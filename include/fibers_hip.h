@@ -169,6 +169,10 @@ int fibd_stream_trace(const fib_stream_params *prm, const float *field4, const i
  * npts [nlines] int32, seed_index [nlines] int64 (= seed*nsub+sub), xyz [3*npoints] (x,y,z per point,
  * line after line, each line ordered [fwd_N..fwd_1, bwd_1..bwd_M] as stream.jl:652 builds it). */
 int fibd_stream_pack(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, void *stream);
+/* same lines serialised as the body of a TrackVis .trk file (everything after the 1000-byte header, as
+ * trk_write emits it, trk.jl:469-485): per line Int32 npts then npts x 3 Float32 = (xyz + .5) * voxel_size.
+ * body: device buffer of 4*nlines + 12*npoints bytes. */
+int fibd_stream_pack_trk(fib_stream_job *job, const float voxel_size[3], void *body, void *stream);
 /* per-(seed,sub) point counts of every traced line, incl. those dropped by len_min: int32 [nseed*nsub] */
 int fibd_stream_all_npts(fib_stream_job *job, int32_t *all_npts, void *stream);
 void fib_stream_job_destroy(fib_stream_job *job);

@@ -1,0 +1,135 @@
+"""Host-side formats either side of the hot path: NIfTI-1 + b-tables (N2), .trk (N1).
+CPU tests check the wire formats against the published layouts and the reference's conventions
+(mri.jl:1394-1672, 1695-1919, 2059-2266; trk.jl:88-144, 358-495); the GPU test checks that the device
+serialiser emits byte-identical .trk bodies."""
+import gzip
+import os
+import struct
+
+import numpy as np
+import pytest
+
+
+def _affine():
+    th = 0.3
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    M = np.eye(4)
+    M[:3, :3] = R @ np.diag([1.5, 1.5, 2.0]) * np.array([-1, 1, 1])      # LAS-like, det < 0 -> qfac = -1
+    M[:3, 3] = [90.0, -126.0, -72.0]
+    return M.astype(np.float32)
+
+
+@pytest.mark.parametrize("ext", [".nii", ".nii.gz"])
+def test_nifti_roundtrip_and_header_layout(fj, tmp_path, ext):
+    rng = np.random.default_rng(0)
+    vol = np.asfortranarray(rng.normal(size=(5, 4, 3, 7)).astype(np.float32))
+    bval = np.array([0, 1000, 1000, 2000, 2000, 3000, 3000], np.float32)
+    bvec = rng.normal(size=(7, 3)).astype(np.float32); bvec[0] = 0
+    m = fj.MRI(vol, bval, bvec, volres=(1.5, 1.5, 2.0), vox2ras=_affine())
+    f = str(tmp_path / ("dwi" + ext))
+    assert fj.mri_write(m, f) is False
+    raw = (gzip.open(f, "rb") if ext.endswith("gz") else open(f, "rb")).read()
+    assert struct.unpack("<i", raw[:4])[0] == 348 and raw[344:348] == b"n+1\0"
+    assert struct.unpack("<8h", raw[40:56]) == (4, 5, 4, 3, 7, 1, 1, 1)
+    assert struct.unpack("<hh", raw[70:74]) == (16, 32) and struct.unpack("<f", raw[108:112])[0] == 352.0
+    assert struct.unpack("<hh", raw[252:256]) == (1, 1)                     # qform_code, sform_code
+    assert np.allclose(struct.unpack("<4f", raw[280:296]), _affine()[0])
+    assert struct.unpack("<f", raw[76:80])[0] == -1.0                       # qfac for a left-handed affine
+    assert len(raw) == 352 + vol.size * 4
+    r = fj.mri_read(f)
+    assert r.vol.dtype == np.float32 and np.array_equal(r.vol, vol)
+    assert np.allclose(r.vox2ras, _affine(), atol=1e-5) and np.allclose(r.volres, (1.5, 1.5, 2.0), atol=1e-5)
+    assert np.allclose(r.niftihdr["qform"], _affine(), atol=1e-4)           # quaternion path reproduces the affine
+    assert np.array_equal(r.bval, bval)
+    nrm = np.linalg.norm(r.bvec, axis=1)
+    assert nrm[0] == 0 and np.allclose(nrm[1:], 1, atol=1e-6)               # normalised, 0/0 -> 0 (mri.jl:711-712)
+
+
+def test_nifti_int16_bigendian_and_scaling(fj, tmp_path):
+    vol = np.arange(2 * 3 * 4, dtype=np.int16).reshape(2, 3, 4, order="F")
+    m = fj.MRI(vol, vox2ras=_affine(), volres=(1.5, 1.5, 2.0))
+    f = str(tmp_path / "a.nii")
+    fj.mri_write(m, f)
+    raw = bytearray(open(f, "rb").read())
+    from fibers_jl_amd import nifti
+    fields = list(nifti._HDR.unpack(bytes(raw[:348])))
+    fields[31], fields[32] = 2.0, 1.0                                        # scl_slope, scl_inter
+    be = struct.Struct(">" + nifti._HDR.format[1:]).pack(*fields) + b"\0" * 4 + vol.astype(">i2").tobytes(order="F")
+    g = str(tmp_path / "b.nii")
+    open(g, "wb").write(be)
+    r = fj.mri_read(g)
+    assert r.niftihdr["do_bswap"] and r.vol.dtype == np.int16
+    assert np.array_equal(r.vol[..., 0], vol * 2 + 1)                        # dtype.(vol*slope + inter), mri.jl:1664-1668
+    with pytest.raises(ValueError, match="Invalid header size"):
+        nifti.load_nifti_hdr(b"\1\2\3\4" + bytes(raw[4:348]))
+
+
+def test_bfiles_any_order_and_layout(fj, tmp_path):
+    b = np.array([5, 1000, 2000, 3000], np.float32)
+    g = np.array([[1, 0, 0], [0, 1, 0], [0, 0.6, 0.8], [0.6, 0, 0.8]], np.float32)   # (a 3x3 table is ambiguous: kept as is)
+    fb, fg = str(tmp_path / "x.bval"), str(tmp_path / "x.bvec")
+    np.savetxt(fb, b[None, :])                                               # single row
+    np.savetxt(fg, g.T)                                                      # 3 rows (FSL layout)
+    for a, c in ((fb, fg), (fg, fb)):
+        bb, gg = fj.mri_read_bfiles(a, c)
+        assert np.array_equal(bb, b) and np.allclose(gg, g)
+    np.savetxt(fg, g[:2])
+    with pytest.raises(ValueError):
+        fj.mri_read_bfiles(fb, fg)
+
+
+def test_result_struct_write_and_reload(fj, tmp_path):
+    ref = fj.MRI(np.zeros((3, 3, 2), np.float32), volres=(2, 2, 2), vox2ras=_affine())
+    rng = np.random.default_rng(1)
+    mk = lambda n: fj.MRI(np.asfortranarray(rng.normal(size=(3, 3, 2, n)).astype(np.float32)), volres=ref.volres, vox2ras=ref.vox2ras)
+    gqi = fj.GQI(mk(5), [mk(3) for _ in range(3)], [mk(1) for _ in range(3)])
+    base = str(tmp_path / "sub01")
+    fj.gqi_write(gqi, base)
+    names = sorted(os.listdir(tmp_path))
+    assert names == ["sub01_odf.nii.gz"] + ["sub01_peak%d.nii.gz" % k for k in (1, 2, 3)] + ["sub01_qa%d.nii.gz" % k for k in (1, 2, 3)]
+    back = fj.read_struct(base, fj.GQI)
+    assert np.array_equal(back.odf.vol, gqi.odf.vol) and all(np.array_equal(a.vol, b.vol) for a, b in zip(back.peak, gqi.peak))
+
+
+def test_trk_header_body_and_roundtrip(fj, tmp_path):
+    ref = fj.MRI(np.zeros((10, 12, 14), np.uint8), volres=(1.5, 1.5, 2.0), vox2ras=_affine())
+    rng = np.random.default_rng(2)
+    npts = np.array([3, 1, 5], np.int32)
+    xyz = rng.uniform(1, 10, size=(9, 3)).astype(np.float32)
+    tr = fj.Tract(xyz=xyz, npts=npts, volsize=ref.volsize, volres=ref.volres, vox2ras=ref.vox2ras)
+    f = str(tmp_path / "t.trk")
+    assert fj.trk_write(tr, f, ref) is False
+    raw = open(f, "rb").read()
+    assert len(raw) == 1000 + 4 * 3 + 12 * 9 and raw[:6] == b"TRACK\0"
+    assert struct.unpack("<3h", raw[6:12]) == (10, 12, 14)
+    assert np.allclose(struct.unpack("<3f", raw[12:24]), (1.5, 1.5, 2.0))
+    assert np.allclose(np.array(struct.unpack("<16f", raw[440:504])).reshape(4, 4), _affine())
+    assert raw[948:952] == b"LAS\0" and struct.unpack("<3i", raw[988:1000]) == (3, 2, 1000)
+    body = np.frombuffer(raw, np.float32, offset=1000)
+    assert body.view(np.int32)[0] == 3 and body.view(np.int32)[10] == 1
+    want = ((xyz[0].astype(np.float64) + 0.5) * np.array([1.5, 1.5, 2.0])).astype(np.float32)   # trk.jl:475-476
+    assert np.array_equal(body[1:4], want)
+    back = fj.trk_read(f)
+    assert np.array_equal(back.npts, npts) and np.allclose(back.xyz, xyz, atol=2e-6)
+    assert len(back.str) == 3 and back.str[2].shape == (3, 5)
+    fj.str_add(back, [np.ones((3, 4), np.float32)])
+    assert back.nstr == 4 and back.npts[-1] == 4
+
+
+@pytest.mark.gpu
+def test_gpu_trk_serialiser_matches_host(fj, tmp_path):
+    import torch
+    from fibers_jl_amd import phantom, trk
+    n = 14
+    ov = np.asfortranarray(phantom.fibre_field(n, n, n).astype(np.float32))
+    ref = fj.MRI(np.ones((n, n, n), np.uint8), volres=(1.25, 1.5, 2.0))
+    o = torch.from_numpy(np.ascontiguousarray(ov.reshape(n ** 3, 3, order="F").T)).cuda()
+    field, mout = fj.stream_field_device([o], mask=torch.ones(n ** 3, dtype=torch.uint8, device="cuda"))
+    seeds = torch.nonzero(mout).flatten()
+    sub = torch.tensor([[0.1, -0.2, 0.3], [0.0, 0.4, -0.4]], dtype=torch.float32, device="cuda")
+    res = fj.stream_device(field, (n, n, n), seeds, sub, len_min=4)
+    tr = fj.Tract(xyz=res["xyz"].cpu().numpy(), npts=res["npts"].cpu().numpy(), volsize=(n, n, n), volres=ref.volres)
+    f1, f2 = str(tmp_path / "host.trk"), str(tmp_path / "gpu.trk")
+    fj.trk_write(tr, f1, ref)
+    info = fj.stream_to_trk(f2, field, (n, n, n), seeds, sub, ref, len_min=4)
+    assert info["nlines"] == tr.nstr and open(f1, "rb").read() == open(f2, "rb").read()
