@@ -192,6 +192,30 @@ def main():
                                         algorithmic_bytes=25.0 * npoints,
                                         hbm_gbs_trace=25.0 * npoints / (tr_ms / max(tr_n, 1) * 1e-3) / 1e9 if tr_n else 0.0)
 
+    if not args.no_extra and rank == 0:
+        # ---- DSI 515-direction reconstruction + peaks (C5 fit part) ------------------------------------
+        del field, res, o2, d2
+        torch.cuda.empty_cache()
+        b5, g5 = phantom.scheme_dsi()
+        d5, _ = phantom.make_dwi_torch(SHAPE, b5, g5, seed=5, device=dev)
+        p5 = fj.OdfPlan("dsi", b5, g5, sph, hann_width=32, device=dev.index)
+        o5 = fj.odf_rec_device(p5, d5, mask)
+        torch.cuda.synchronize()
+        L.fib_profile_enable(1); L.fib_profile_reset()
+        nd = max(2, args.steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(nd):
+            fj.odf_rec_device(p5, d5, mask, out=o5)
+        torch.cuda.synchronize()
+        t_dsi = (time.perf_counter() - t0) / nd
+        L.fib_profile_enable(0)
+        g_ms, g_n = prof_get(L, "odf_gemm")
+        f_ms, f_n = prof_get(L, "dsi_fold")
+        extra["dsi_rec_140x515"] = dict(mvoxels_per_s=nvox / t_dsi / 1e6, ms_per_step=t_dsi * 1e3,
+                                        gemm_kernel_ms=g_ms / max(g_n, 1), fold_kernel_ms=f_ms / max(f_n, 1),
+                                        note="antipodal folding: 258 folded samples x (258 pdf + 321 odf) rows")
+        del o5, d5
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_gqi(bval, bvec, sph, seed=3)

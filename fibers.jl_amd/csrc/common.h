@@ -88,7 +88,7 @@ void host_gqi_matrix(const float *bval, const float *bvec, int nvol, const float
 // DSIwork as dense maps (dsi.jl:59-143 + 204-242): A column-major [(nvol+nvert) x nvol];
 // returns FIB_OK or FIB_ERR_UNSUPPORTED.  scale_frame/scale_coef: sum(p) = scale_coef*max(s[scale_frame],0).
 int host_dsi_matrix(const float *bval, const float *bvec, int nvol, const float *verts, int nverts,
-                    int hann_width, float *A, int *scale_frame, float *scale_coef);
+                    int hann_width, float *A, int *scale_frame, float *scale_coef, std::vector<int> *iq_out = nullptr);
 // folded-face neighbour table (gqi.jl:63-64 + 185-196): nbr [nvert x maxdeg] row-major, -1 padded
 int host_neighbours(const int32_t *faces, int nfaces, int nverts, std::vector<int32_t> &nbr, int *maxdeg);
 

@@ -38,6 +38,7 @@ struct GemmArgs {
     int scale_frame;          // DSI: frame whose clamped sample times scale_coef is sum(p); -1: no scaling
     float scale_coef;
     int has_ineff;
+    const int32_t *rowA, *rowB;   // optional output-row map for rows < nrow0: row r goes to frames rowA[r] and rowB[r] (>= 0)
 };
 
 // scheduling hint: spread one k-step's fragment reads (ds_read2_b32 = 2 fragments) between the previous
@@ -208,11 +209,12 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
         return reinterpret_cast<char *>(row >= a.nrow0 ? a.out1 + (int64_t)(row - a.nrow0) * a.nvox + vox0
                                                        : a.out0 + (int64_t)row * a.nvox + vox0);
     };
+    const bool mapped = a.rowA != nullptr;
 #pragma unroll
     for (int m = 0; m < MB; m++) {
         const int row0 = tile_m * ROWS + m * 32;        // wave-uniform
         if (row0 >= a.M) break;
-        const bool whole = row0 + 32 <= a.M && (row0 >= a.nrow0 || row0 + 32 <= a.nrow0);   // uniform fast path
+        const bool whole = row0 + 32 <= a.M && (row0 >= a.nrow0 || (row0 + 32 <= a.nrow0 && !mapped));   // uniform fast path
         char *base = row_ptr(row0);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -224,7 +226,13 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
             } else {
                 const int row = row0 + dr + 4 * kh;
                 if (row >= a.M) continue;
-                *reinterpret_cast<float *>(row_ptr(row) + col * 4) = v;
+                if (mapped && row < a.nrow0) {           // symmetric DSI: p(r) = p(-r), one computed row feeds two frames
+                    const int fa = a.rowA[row], fb = a.rowB[row];
+                    a.out0[(int64_t)fa * a.nvox + vox] = v;
+                    if (fb >= 0) a.out0[(int64_t)fb * a.nvox + vox] = v;
+                } else {
+                    *reinterpret_cast<float *>(row_ptr(row) + col * 4) = v;
+                }
             }
         }
     }
@@ -234,7 +242,32 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
         if (row >= a.M) break;
         float v = xacc[x];
         if (!plain) v = valid ? v * mulv : 0.0f;
-        if (kh == 0) *reinterpret_cast<float *>(row_ptr(row) + col * 4) = v;
+        if (kh == 0) {
+            if (mapped && row < a.nrow0) {
+                const int fa = a.rowA[row], fb = a.rowB[row];
+                a.out0[(int64_t)fa * a.nvox + vox] = v;
+                if (fb >= 0) a.out0[(int64_t)fb * a.nvox + vox] = v;
+            } else {
+                *reinterpret_cast<float *>(row_ptr(row) + col * 4) = v;
+            }
+        }
+    }
+}
+
+// DSI with an antipodally symmetric q-space lattice: cos(2 pi r.q/n) is even in q, so the frames at q and -q
+// enter every pdf / odf row with the same coefficient.  t[J] = max(s[q_J],0) + max(s[-q_J],0) halves K, and
+// p(r) = p(-r) halves the pdf rows: 2.9x fewer flops for the 515-point scheme.  HBM-bound pre-pass.
+__global__ __launch_bounds__(256) void dsi_fold_kernel(const float *__restrict__ S, const int32_t *__restrict__ fa,
+                                                      const int32_t *__restrict__ fb, int nrep, int64_t nvox,
+                                                      float *__restrict__ T) {
+    const int64_t vox = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vox >= nvox) return;
+    for (int j = 0; j < nrep; j++) {
+        const int a = fa[j], b = fb[j];                     // wave-uniform
+        const float x = S[(int64_t)a * nvox + vox];
+        float t = x < 0.0f ? 0.0f : x;                      // X .= max.(X, 0), dsi.jl:209 (NaN stays NaN)
+        if (b >= 0) { const float y = S[(int64_t)b * nvox + vox]; t += y < 0.0f ? 0.0f : y; }
+        T[(int64_t)j * nvox + vox] = t;
     }
 }
 
@@ -629,6 +662,12 @@ struct fib_odf_plan {
     int scale_frame = -1;
     float scale_coef = 0.0f;
     bool has_ineff = false;                          // some frame never reaches the model (DSI duplicates)
+    // what the GEMM actually runs: G [gM x gK] (== A unless the DSI lattice is folded by symmetry)
+    int gM = 0, gK = 0, gRow0 = 0;
+    std::vector<float> G;
+    bool folded = false;
+    fib::DevBuf<int32_t> foldA, foldB;               // [gK] frames summed into folded sample J; [gRow0] == same tables map pdf rows
+    mutable fib::DevBuf<float> folded_dwi;           // [gK x nvox] scratch of the fold pre-pass (grow-only)
     std::vector<float> A;                            // host copy [nrows x nvol] column-major
     fib::DevBuf<float> At, verts;
     fib::DevBuf<uint32_t> effbits;
@@ -643,11 +682,12 @@ namespace {
 
 int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *faces, int nfaces,
                 const std::vector<float> &frame_eff) {
-    const int M = p->nrows, K = p->nvol;
+    if (p->G.empty()) { p->G = p->A; p->gM = p->nrows; p->gK = p->nvol; p->gRow0 = p->nrow0; }
+    const int M = p->gM, K = p->gK;
     // pick (MB, NX) minimising the per-k-step issue cost ntile*(64*MB + 4*NX) cycles (MFMA block = 64, v_fmac = 4)
     int best_cost = INT32_MAX;
     const int nxs[] = {0, 1, 2, 4};
-    for (int mb = 11; mb >= 6; mb--)
+    for (int mb = 11; mb >= 5; mb--)
         for (int nx : nxs) {
             if (nx > 0 && mb > 10) continue;            // register budget
             const int rows = mb * 32 + nx;
@@ -655,13 +695,19 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
             const int cost = nt * (64 * mb + 4 * nx);
             if (cost < best_cost) { best_cost = cost; p->MB = mb; p->NX = nx; p->ntile_m = nt; }
         }
+    if (const char *e = getenv("FIBERS_GEMM_TILE")) {        // tuning hook: "<MB>x<NX>"
+        int mb = 0, nx = 0;
+        if (sscanf(e, "%dx%d", &mb, &nx) == 2 && mb >= 5 && mb <= 11 && (nx == 0 || nx == 1 || nx == 2 || nx == 4) && !(nx > 0 && mb > 10)) {
+            p->MB = mb; p->NX = nx; p->ntile_m = (M + mb * 32 + nx - 1) / (mb * 32 + nx);
+        }
+    }
     p->Kpad = (K + KT - 1) / KT * KT;
     const int MW = p->MB * 32 + (p->NX > 0 ? 16 : 0), ROWS = p->MB * 32 + p->NX;
     std::vector<float> At((size_t)p->ntile_m * p->Kpad * MW, 0.0f);
     for (int k = 0; k < K; k++)
         for (int r = 0; r < M; r++) {
             const int tm = r / ROWS, rr = r % ROWS;
-            At[((size_t)tm * p->Kpad + k) * MW + rr] = p->A[r + (size_t)M * k];
+            At[((size_t)tm * p->Kpad + k) * MW + rr] = p->G[r + (size_t)M * k];
         }
     std::vector<int32_t> nbr32;
     int rc = fib::host_neighbours(faces, nfaces, nverts, nbr32, &p->maxdeg);
@@ -741,13 +787,47 @@ extern "C" int fib_dsi_plan_create(int device, const float *bval, const float *b
     FIB_CHECK(p != nullptr, FIB_ERR_NOMEM, "out of host memory");
     p->device = device; p->nvol = nvol; p->nvert = nverts / 2; p->nrows = nvol + p->nvert; p->nrow0 = nvol;
     p->A.resize((size_t)p->nrows * nvol);
-    rc = fib::host_dsi_matrix(bval, bvec, nvol, verts, nverts, hann_width, p->A.data(), &p->scale_frame, &p->scale_coef);
+    std::vector<int> iq;
+    rc = fib::host_dsi_matrix(bval, bvec, nvol, verts, nverts, hann_width, p->A.data(), &p->scale_frame, &p->scale_coef, &iq);
     if (rc != FIB_OK) { delete p; return rc; }
     // a frame overwritten by a later one on the same lattice point never reaches X (dsi.jl:205): its column is 0
     std::vector<float> eff((size_t)nvol, 0.0f);
     for (int j = 0; j < nvol; j++)
         for (int r = 0; r < p->nrows; r++) if (p->A[r + (size_t)p->nrows * j] != 0.0f) { eff[j] = 1.0f; break; }
     if (p->scale_frame < 0) { p->scale_frame = 0; p->scale_coef = 0.0f; }   // no q=0 sample: sum(p) = 0 -> Inf/NaN
+    // ---- antipodal folding (see dsi_fold_kernel): every frame needs a partner at -q with an identical column ----
+    {
+        std::vector<int> partner(nvol, -1);
+        bool ok = !getenv("FIBERS_DSI_NOFOLD");
+        for (int j = 0; j < nvol && ok; j++) if (eff[j] == 0.0f) ok = false;
+        for (int j = 0; j < nvol && ok; j++) {
+            for (int k = 0; k < nvol; k++)
+                if (iq[3 * k] == -iq[3 * j] && iq[3 * k + 1] == -iq[3 * j + 1] && iq[3 * k + 2] == -iq[3 * j + 2]) { partner[j] = k; break; }
+            if (partner[j] < 0) ok = false;
+        }
+        for (int j = 0; j < nvol && ok; j++) {
+            const float *cj = &p->A[(size_t)p->nrows * j], *ck = &p->A[(size_t)p->nrows * partner[j]];
+            for (int r = 0; r < p->nrows && ok; r++) if (cj[r] != ck[r]) ok = false;   // cos is even: columns must be identical
+        }
+        if (ok) {
+            std::vector<int32_t> fa, fb;
+            for (int j = 0; j < nvol; j++) if (j <= partner[j]) { fa.push_back(j); fb.push_back(partner[j] == j ? -1 : partner[j]); }
+            const int nrep = (int)fa.size();
+            p->folded = true; p->gK = nrep; p->gRow0 = nrep; p->gM = nrep + p->nvert;
+            p->G.assign((size_t)p->gM * nrep, 0.0f);
+            for (int c = 0; c < nrep; c++) {
+                const float *col = &p->A[(size_t)p->nrows * fa[c]];
+                for (int r = 0; r < nrep; r++) p->G[r + (size_t)p->gM * c] = col[fa[r]];
+                for (int v = 0; v < p->nvert; v++) p->G[nrep + v + (size_t)p->gM * c] = col[nvol + v];
+                if (fa[c] == p->scale_frame) p->scale_frame = -1000 - c;          // re-index below
+            }
+            if (p->scale_frame <= -1000) p->scale_frame = -(p->scale_frame + 1000);
+            if ((rc = p->foldA.alloc(nrep)) != FIB_OK || (rc = p->foldB.alloc(nrep)) != FIB_OK) { delete p; return rc; }
+            (void)hipMemcpy(p->foldA.p, fa.data(), nrep * sizeof(int32_t), hipMemcpyHostToDevice);
+            (void)hipMemcpy(p->foldB.p, fb.data(), nrep * sizeof(int32_t), hipMemcpyHostToDevice);
+            eff.assign((size_t)nrep, 1.0f);
+        }
+    }
     rc = finish_plan(p, verts, nverts, faces, nfaces, eff);
     if (rc != FIB_OK) { delete p; return rc; }
     *plan = p;
@@ -852,7 +932,16 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
     GemmArgs ga{};
     ga.At = plan->At.p; ga.S = dwi; ga.mask = mask; ga.effbits = plan->effbits.p;
     ga.out0 = pdf; ga.out1 = odf; ga.nvox = nvox;
-    ga.K = plan->nvol; ga.Kpad = plan->Kpad; ga.M = plan->nrows; ga.nrow0 = plan->nrow0; ga.ntile_m = plan->ntile_m;
+    ga.K = plan->gK; ga.Kpad = plan->Kpad; ga.M = plan->gM; ga.nrow0 = plan->gRow0; ga.ntile_m = plan->ntile_m;
+    if (plan->folded) {
+        int rcf = plan->folded_dwi.ensure((size_t)plan->gK * nvox);
+        if (rcf != FIB_OK) return rcf;
+        fib::ProfScope prof("dsi_fold", st);
+        hipLaunchKernelGGL(dsi_fold_kernel, dim3((unsigned)fib::cdiv(nvox, 256)), dim3(256), 0, st, dwi, plan->foldA.p, plan->foldB.p,
+                           plan->gK, nvox, plan->folded_dwi.p);
+        ga.S = plan->folded_dwi.p;
+        ga.rowA = plan->foldA.p; ga.rowB = plan->foldB.p;
+    }
     ga.scale_frame = plan->nrow0 > 0 ? plan->scale_frame : -1;
     ga.scale_coef = plan->scale_coef;
     const int64_t nblk = fib::cdiv(nvox, WG_VOX) * plan->ntile_m;
@@ -862,6 +951,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
     ga.has_ineff = plan->has_ineff ? 1 : 0;
 #define FIB_GEMM_CASE(MBV, NXV) if (plan->MB == MBV && plan->NX == NXV) { launch_gemm<MBV, NXV>(ga, grid, st); launched = true; }
     bool launched = false;
+    FIB_GEMM_CASE(5, 0) FIB_GEMM_CASE(5, 1) FIB_GEMM_CASE(5, 2) FIB_GEMM_CASE(5, 4)
     FIB_GEMM_CASE(6, 0) FIB_GEMM_CASE(7, 0) FIB_GEMM_CASE(8, 0) FIB_GEMM_CASE(9, 0) FIB_GEMM_CASE(10, 0) FIB_GEMM_CASE(11, 0)
     FIB_GEMM_CASE(6, 1) FIB_GEMM_CASE(7, 1) FIB_GEMM_CASE(8, 1) FIB_GEMM_CASE(9, 1) FIB_GEMM_CASE(10, 1)
     FIB_GEMM_CASE(6, 2) FIB_GEMM_CASE(7, 2) FIB_GEMM_CASE(8, 2) FIB_GEMM_CASE(9, 2) FIB_GEMM_CASE(10, 2)

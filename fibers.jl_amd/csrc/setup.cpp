@@ -137,7 +137,7 @@ void host_gqi_matrix(const float *bval, const float *bvec, int nvol, const float
 // DSI as two dense maps
 // ------------------------------------------------------------------------------------------
 int host_dsi_matrix(const float *bval, const float *bvec, int nvol, const float *verts, int nverts,
-                    int hann_width, float *A, int *scale_frame, float *scale_coef) {
+                    int hann_width, float *A, int *scale_frame, float *scale_coef, std::vector<int> *iq_out) {
     const int nvert = nverts / 2;
     float bmin = bval[0];
     for (int j = 1; j < nvol; j++) bmin = std::min(bmin, bval[j]);
@@ -156,6 +156,7 @@ int host_dsi_matrix(const float *bval, const float *bvec, int nvol, const float 
             lo = std::min(lo, v); hi = std::max(hi, v);
         }
     }
+    if (iq_out) *iq_out = iq;
     int nfft = 1;
     while (nfft < hi - lo + 1) nfft *= 2;                             // dsi.jl:70-71
     const int shift = nfft / 2 + 1;                                   // dsi.jl:73 (1-based)
@@ -177,7 +178,8 @@ int host_dsi_matrix(const float *bval, const float *bvec, int nvol, const float 
         H[j] = (float)((1.0 + std::cos(r * (2.0 * M_PI / hann_width))) * 0.5);   // dsi.jl:84
     }
     std::vector<double> ctab(nfft);
-    for (int k = 0; k < nfft; k++) ctab[k] = std::cos(2.0 * M_PI * k / nfft);
+    for (int k = 0; k <= nfft / 2; k++) ctab[k] = std::cos(2.0 * M_PI * k / nfft);
+    for (int k = nfft / 2 + 1; k < nfft; k++) ctab[k] = ctab[nfft - k];   // exactly even: columns of q and -q are bit-identical
     auto cosk = [&](int64_t k) { int64_t r = k % nfft; if (r < 0) r += nfft; return ctab[r]; };
 
     *scale_frame = -1; *scale_coef = 0.0f;
