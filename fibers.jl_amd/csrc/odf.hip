@@ -33,7 +33,8 @@ struct GemmArgs {
     const uint32_t *effbits;  // [Kpad/KT] bit j of word t: frame t*KT+j exists and takes part in the "any positive sample" test
     float *out0;              // rows [0, nrow0)        (DSI: pdf)
     float *out1;              // rows [nrow0, M)        (odf)
-    int64_t nvox;
+    int64_t nvox;             // voxels in this launch
+    int64_t stride;           // frame / row stride of S, out0, out1 (voxels of the whole volume)
     int K, Kpad, M, nrow0, ntile_m;
     int scale_frame;          // DSI: frame whose clamped sample times scale_coef is sum(p); -1: no scaling
     float scale_coef;
@@ -87,11 +88,11 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
     const int ntiles = a.Kpad / KT;
     // per-lane 32-bit byte offsets; everything else in an address is wave-uniform (SGPR base)
     const uint32_t c_off = (uint32_t)((inb ? col : 0) * 4);
-    const uint32_t s_off = (uint32_t)(((inb ? col : 0) + (int64_t)kh * a.nvox) * 4);   // frame kh of the pair, this voxel
+    const uint32_t s_off = (uint32_t)(((inb ? col : 0) + (int64_t)kh * a.stride) * 4);   // frame kh of the pair, this voxel
     const char *Sbase = reinterpret_cast<const char *>(a.S + (vox0 < a.nvox ? vox0 : 0));
     const char *Abase = reinterpret_cast<const char *>(a.At + (size_t)tile_m * a.Kpad * MW);
     const uint32_t a_off = (uint32_t)lane * 16;
-    const int64_t frame_pair_bytes = 2 * a.nvox * 4;
+    const int64_t frame_pair_bytes = 2 * a.stride * 4;
     const uint8_t mk = a.mask[inb ? vox : 0];           // used in the epilogue only: latency hidden
 
     auto stage_A = [&](int t, int buf) {                // one stage = TILE*4 contiguous bytes of At
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
     const bool do_scale = a.scale_frame >= 0;
     float scale = 1.0f;
     if (do_scale) {
-        float s = *reinterpret_cast<const float *>(Sbase + (int64_t)a.scale_frame * a.nvox * 4 + c_off);
+        float s = *reinterpret_cast<const float *>(Sbase + (int64_t)a.scale_frame * a.stride * 4 + c_off);
         s = s < 0.0f ? 0.0f : s;
         scale = 1.0f / (a.scale_coef * s);              // p ./ sum(p), dsi.jl:225 (0 -> Inf/NaN like the reference)
     }
@@ -204,10 +205,10 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
 #pragma unroll
     for (int x = 0; x < NX; x++) xacc[x] += __shfl_xor(xacc[x], 32);
     if (!inb) return;
-    const uint32_t o_off = (uint32_t)((col + (int64_t)4 * kh * a.nvox) * 4);
+    const uint32_t o_off = (uint32_t)((col + (int64_t)4 * kh * a.stride) * 4);
     auto row_ptr = [&](int row) -> char * {             // wave-uniform row base for this wave's 32 voxels
-        return reinterpret_cast<char *>(row >= a.nrow0 ? a.out1 + (int64_t)(row - a.nrow0) * a.nvox + vox0
-                                                       : a.out0 + (int64_t)row * a.nvox + vox0);
+        return reinterpret_cast<char *>(row >= a.nrow0 ? a.out1 + (int64_t)(row - a.nrow0) * a.stride + vox0
+                                                       : a.out0 + (int64_t)row * a.stride + vox0);
     };
     const bool mapped = a.rowA != nullptr;
 #pragma unroll
@@ -222,14 +223,14 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
             float v = acc[m][r];
             if (!plain) v = valid ? v * mulv : 0.0f;
             if (whole) {
-                *reinterpret_cast<float *>(base + (int64_t)dr * a.nvox * 4 + o_off) = v;
+                *reinterpret_cast<float *>(base + (int64_t)dr * a.stride * 4 + o_off) = v;
             } else {
                 const int row = row0 + dr + 4 * kh;
                 if (row >= a.M) continue;
                 if (mapped && row < a.nrow0) {           // symmetric DSI: p(r) = p(-r), one computed row feeds two frames
                     const int fa = a.rowA[row], fb = a.rowB[row];
-                    a.out0[(int64_t)fa * a.nvox + vox] = v;
-                    if (fb >= 0) a.out0[(int64_t)fb * a.nvox + vox] = v;
+                    a.out0[(int64_t)fa * a.stride + vox] = v;
+                    if (fb >= 0) a.out0[(int64_t)fb * a.stride + vox] = v;
                 } else {
                     *reinterpret_cast<float *>(row_ptr(row) + col * 4) = v;
                 }
@@ -245,8 +246,8 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
         if (kh == 0) {
             if (mapped && row < a.nrow0) {
                 const int fa = a.rowA[row], fb = a.rowB[row];
-                a.out0[(int64_t)fa * a.nvox + vox] = v;
-                if (fb >= 0) a.out0[(int64_t)fb * a.nvox + vox] = v;
+                a.out0[(int64_t)fa * a.stride + vox] = v;
+                if (fb >= 0) a.out0[(int64_t)fb * a.stride + vox] = v;
             } else {
                 *reinterpret_cast<float *>(row_ptr(row) + col * 4) = v;
             }
@@ -316,7 +317,8 @@ struct PeakArgs {
     int32_t *isort_top;       // [3][nvox] (find-peaks mode) or NULL
     int32_t *nvalid;          // [nvox]    (find-peaks mode) or NULL
     unsigned *maxenc;         // [2]: ordered-uint max of per-voxel means, NaN flag (may be NULL)
-    int64_t nvox;
+    int64_t nvox;             // voxels in this launch
+    int64_t stride;           // row stride of odf / component stride of the outputs
     int nvert, rows_pad;      // rows_pad = nvert rounded up to 8; sentinel row index = rows_pad
     int vec_ok;               // 1: every tile row is 16-byte aligned (nvox % 4 == 0 and aligned base)
 };
@@ -350,13 +352,13 @@ __global__ __launch_bounds__(PW * 64) void odf_peaks_kernel(const PeakArgs a) {
         for (int p = wave; p < npiece; p += PW) {
             int row = 8 * p + (lane >> 3);
             row = row < a.nvert ? row : a.nvert - 1;            // padding rows: any valid address
-            const float *g = a.odf + (int64_t)row * a.nvox + vox0 + 4 * (lane & 7);
+            const float *g = a.odf + (int64_t)row * a.stride + vox0 + 4 * (lane & 7);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                              (__attribute__((address_space(3))) void *)(o + p * 256), 16, 0, 0);
         }
     } else {
         for (int r = wave * 2 + half; r < a.rows_pad; r += PG)
-            o[r * PV + j] = (inb && r < a.nvert) ? a.odf[(int64_t)r * a.nvox + vox] : 0.0f;
+            o[r * PV + j] = (inb && r < a.nvert) ? a.odf[(int64_t)r * a.stride + vox] : 0.0f;
     }
     if (tid < PV) o[a.rows_pad * PV + tid] = __builtin_nanf("");   // sentinel row
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(PW * 64) void odf_peaks_kernel(const PeakArgs a) {
         if (inb) {
             if (a.isort_top) {
 #pragma unroll
-                for (int k = 0; k < 3; k++) a.isort_top[(int64_t)k * a.nvox + vox] = top3_index(t, k);
+                for (int k = 0; k < 3; k++) a.isort_top[(int64_t)k * a.stride + vox] = top3_index(t, k);
                 a.nvalid[vox] = npos;
             } else {
                 const int n = npos < 3 ? npos : 3;              // gqi.jl:151
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(PW * 64) void odf_peaks_kernel(const PeakArgs a) {
                         px = a.verts[3 * iv]; py = a.verts[3 * iv + 1]; pz = a.verts[3 * iv + 2];
                         q = o[iv * PV + j] - vmin;              // gqi.jl:157-158
                     }
-                    a.peak[k][vox] = px; a.peak[k][a.nvox + vox] = py; a.peak[k][2 * a.nvox + vox] = pz;
+                    a.peak[k][vox] = px; a.peak[k][a.stride + vox] = py; a.peak[k][2 * a.stride + vox] = pz;
                     a.qa[k][vox] = q;
                 }
             }
@@ -505,12 +507,12 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
 #define FIB_P64_FETCH(tile_)                                                                         \
     do {                                                                                             \
         const float *g0_ = a.odf + (tile_) * 64 + (tid & 15) * 4;                                    \
-        s0 = *reinterpret_cast<const float4 *>(g0_ + (int64_t)FIB_P64_ROW(0) * a.nvox);              \
-        s1 = *reinterpret_cast<const float4 *>(g0_ + (int64_t)FIB_P64_ROW(1) * a.nvox);              \
-        s2 = *reinterpret_cast<const float4 *>(g0_ + (int64_t)FIB_P64_ROW(2) * a.nvox);              \
-        s3 = *reinterpret_cast<const float4 *>(g0_ + (int64_t)FIB_P64_ROW(3) * a.nvox);              \
-        s4 = *reinterpret_cast<const float4 *>(g0_ + (int64_t)FIB_P64_ROW(4) * a.nvox);              \
-        s5 = *reinterpret_cast<const float4 *>(g0_ + (int64_t)FIB_P64_ROW(5) * a.nvox);              \
+        s0 = *reinterpret_cast<const float4 *>(g0_ + (int64_t)FIB_P64_ROW(0) * a.stride);              \
+        s1 = *reinterpret_cast<const float4 *>(g0_ + (int64_t)FIB_P64_ROW(1) * a.stride);              \
+        s2 = *reinterpret_cast<const float4 *>(g0_ + (int64_t)FIB_P64_ROW(2) * a.stride);              \
+        s3 = *reinterpret_cast<const float4 *>(g0_ + (int64_t)FIB_P64_ROW(3) * a.stride);              \
+        s4 = *reinterpret_cast<const float4 *>(g0_ + (int64_t)FIB_P64_ROW(4) * a.stride);              \
+        s5 = *reinterpret_cast<const float4 *>(g0_ + (int64_t)FIB_P64_ROW(5) * a.stride);              \
     } while (0)
 #define FIB_P64_PUT(i, reg) if (tid + P64_T * (i) < nq) *reinterpret_cast<float4 *>(o + 4 * (tid + P64_T * (i))) = reg
 
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
             for (int e = tid; e < a.nvert * 64; e += P64_T) {
                 const int row = e >> 6, c = e & 63;
                 const int64_t vx = tile * 64 + c;
-                o[e] = vx < a.nvox ? a.odf[(int64_t)row * a.nvox + vx] : 0.0f;
+                o[e] = vx < a.nvox ? a.odf[(int64_t)row * a.stride + vx] : 0.0f;
             }
         }
         __syncthreads();
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
             const float *r = mrg + (size_t)lane * PREC;
             const int npos = __float_as_int(r[6]);
             if (a.isort_top) {
-                if (wave < 3) a.isort_top[(int64_t)wave * a.nvox + vox] = __float_as_uint(r[2 * wave]) | __float_as_uint(r[2 * wave + 1]) ? (int)~__float_as_uint(r[2 * wave]) : -1;
+                if (wave < 3) a.isort_top[(int64_t)wave * a.stride + vox] = __float_as_uint(r[2 * wave]) | __float_as_uint(r[2 * wave + 1]) ? (int)~__float_as_uint(r[2 * wave]) : -1;
                 else if (wave == 3) a.nvalid[vox] = npos;
             } else {
                 const int k = wave < 9 ? wave / 3 : wave - 9;
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
                 const int iv = (int)~__float_as_uint(r[2 * k]);
                 if (wave < 9) {
                     const int c = wave - 3 * k;
-                    a.peak[k][(int64_t)c * a.nvox + vox] = have ? vl[3 * iv + c] : 0.0f;      // gqi.jl:154-155
+                    a.peak[k][(int64_t)c * a.stride + vox] = have ? vl[3 * iv + c] : 0.0f;      // gqi.jl:154-155
                 } else {
                     a.qa[k][vox] = have ? o[iv * 64 + lane] - r[7] : 0.0f;                    // gqi.jl:157-158
                 }
@@ -882,15 +884,15 @@ int launch_peaks64_t(const PeakArgs &pa, size_t smem, int64_t ntiles, unsigned g
     return FIB_OK;
 }
 
-int launch_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox, float *const peak[3], float *const qa[3],
-                 int32_t *isort_top, int32_t *nvalid, bool reduce, hipStream_t st) {
+int launch_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox, int64_t stride, float *const peak[3], float *const qa[3],
+                 int32_t *isort_top, int32_t *nvalid, bool reduce, hipStream_t st, bool small_tiles = false) {
     PeakArgs pa{};
     pa.odf = odf; pa.nbr = plan->nbr.p; pa.nbr64 = plan->nbr64.p; pa.verts = plan->verts.p;
     for (int k = 0; k < 3; k++) { pa.peak[k] = peak ? peak[k] : nullptr; pa.qa[k] = qa ? qa[k] : nullptr; }
     pa.isort_top = isort_top; pa.nvalid = nvalid;
     pa.maxenc = reduce ? plan->maxenc.p : nullptr;
-    pa.nvox = nvox; pa.nvert = plan->nvert; pa.rows_pad = plan->rows_pad;
-    pa.vec_ok = (nvox % 4 == 0 && ((uintptr_t)odf & 15) == 0) ? 1 : 0;
+    pa.nvox = nvox; pa.stride = stride; pa.nvert = plan->nvert; pa.rows_pad = plan->rows_pad;
+    pa.vec_ok = (stride % 4 == 0 && ((uintptr_t)odf & 15) == 0) ? 1 : 0;
     const size_t smem = peaks_smem(plan);
     FIB_CHECK(smem <= 160 * 1024, FIB_ERR_UNSUPPORTED, "ODF with %d vertices does not fit the peak finder's LDS tile", plan->nvert);
     const unsigned grid = (unsigned)fib::cdiv(nvox, PV);
@@ -898,7 +900,7 @@ int launch_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox, float
     fib::ProfScope prof("odf_peaks", st);
     const size_t smem64 = ((size_t)(plan->nvert + 1) * 64 + (size_t)P64_W * 64 * PREC + (size_t)plan->nvert * (plan->deg_pad + 3)) * sizeof(float);
     const char *force32 = getenv("FIBERS_PEAKS_V2");
-    if (plan->nvert * 16 <= P64_NI * P64_T && smem64 <= 160 * 1024 && !(force32 && atoi(force32))) {
+    if (!small_tiles && plan->nvert * 16 <= P64_NI * P64_T && smem64 <= 160 * 1024 && !(force32 && atoi(force32))) {
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, plan->device);
         const int64_t ntiles = fib::cdiv(nvox, 64);
@@ -944,25 +946,65 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
     }
     ga.scale_frame = plan->nrow0 > 0 ? plan->scale_frame : -1;
     ga.scale_coef = plan->scale_coef;
-    const int64_t nblk = fib::cdiv(nvox, WG_VOX) * plan->ntile_m;
-    FIB_CHECK(nblk < ((int64_t)1 << 31), FIB_ERR_UNSUPPORTED, "volume too large for one launch");
-    const unsigned grid = (unsigned)nblk;
-    { fib::ProfScope prof("odf_gemm", st);
+    ga.stride = nvox;
     ga.has_ineff = plan->has_ineff ? 1 : 0;
-#define FIB_GEMM_CASE(MBV, NXV) if (plan->MB == MBV && plan->NX == NXV) { launch_gemm<MBV, NXV>(ga, grid, st); launched = true; }
-    bool launched = false;
-    FIB_GEMM_CASE(5, 0) FIB_GEMM_CASE(5, 1) FIB_GEMM_CASE(5, 2) FIB_GEMM_CASE(5, 4)
-    FIB_GEMM_CASE(6, 0) FIB_GEMM_CASE(7, 0) FIB_GEMM_CASE(8, 0) FIB_GEMM_CASE(9, 0) FIB_GEMM_CASE(10, 0) FIB_GEMM_CASE(11, 0)
-    FIB_GEMM_CASE(6, 1) FIB_GEMM_CASE(7, 1) FIB_GEMM_CASE(8, 1) FIB_GEMM_CASE(9, 1) FIB_GEMM_CASE(10, 1)
-    FIB_GEMM_CASE(6, 2) FIB_GEMM_CASE(7, 2) FIB_GEMM_CASE(8, 2) FIB_GEMM_CASE(9, 2) FIB_GEMM_CASE(10, 2)
-    FIB_GEMM_CASE(6, 4) FIB_GEMM_CASE(7, 4) FIB_GEMM_CASE(8, 4) FIB_GEMM_CASE(9, 4) FIB_GEMM_CASE(10, 4)
-#undef FIB_GEMM_CASE
-    if (!launched) return fib::fail(FIB_ERR_INVALID, "internal: no GEMM variant for MB=%d NX=%d", plan->MB, plan->NX);
-    }
-    FIB_HIP(hipGetLastError());
+    FIB_CHECK(fib::cdiv(nvox, WG_VOX) * plan->ntile_m < ((int64_t)1 << 31), FIB_ERR_UNSUPPORTED, "volume too large for one launch");
     FIB_HIP(hipMemsetAsync(plan->maxenc.p, 0, 2 * sizeof(unsigned), st));
-    int rc = launch_peaks(plan, odf, nvox, peak, qa, nullptr, nullptr, true, st);
-    if (rc != FIB_OK) return rc;
+
+    auto run_gemm = [&](GemmArgs g, hipStream_t s) -> int {
+        const unsigned grid = (unsigned)(fib::cdiv(g.nvox, WG_VOX) * plan->ntile_m);
+        fib::ProfScope prof("odf_gemm", s);
+#define FIB_GEMM_CASE(MBV, NXV) if (plan->MB == MBV && plan->NX == NXV) { launch_gemm<MBV, NXV>(g, grid, s); launched = true; }
+        bool launched = false;
+        FIB_GEMM_CASE(5, 0) FIB_GEMM_CASE(5, 1) FIB_GEMM_CASE(5, 2) FIB_GEMM_CASE(5, 4)
+        FIB_GEMM_CASE(6, 0) FIB_GEMM_CASE(7, 0) FIB_GEMM_CASE(8, 0) FIB_GEMM_CASE(9, 0) FIB_GEMM_CASE(10, 0) FIB_GEMM_CASE(11, 0)
+        FIB_GEMM_CASE(6, 1) FIB_GEMM_CASE(7, 1) FIB_GEMM_CASE(8, 1) FIB_GEMM_CASE(9, 1) FIB_GEMM_CASE(10, 1)
+        FIB_GEMM_CASE(6, 2) FIB_GEMM_CASE(7, 2) FIB_GEMM_CASE(8, 2) FIB_GEMM_CASE(9, 2) FIB_GEMM_CASE(10, 2)
+        FIB_GEMM_CASE(6, 4) FIB_GEMM_CASE(7, 4) FIB_GEMM_CASE(8, 4) FIB_GEMM_CASE(9, 4) FIB_GEMM_CASE(10, 4)
+#undef FIB_GEMM_CASE
+        if (!launched) return fib::fail(FIB_ERR_INVALID, "internal: no GEMM variant for MB=%d NX=%d", plan->MB, plan->NX);
+        FIB_HIP(hipGetLastError());
+        return FIB_OK;
+    };
+
+    // Optional two-stream pipeline (FIBERS_ODF_OVERLAP=<chunks>): the MFMA-bound GEMM of chunk i+1 runs beside the
+    // LDS/latency-bound peak finder of chunk i (32-voxel-tile variant: small enough to share a CU with 2 GEMM groups).
+    int nchunk = 1;
+    if (const char *e = getenv("FIBERS_ODF_OVERLAP")) nchunk = atoi(e);
+    if (nchunk > 1 && nvox >= (int64_t)nchunk * 65536) {
+        static hipStream_t aux[16] = {};
+        static hipEvent_t ev_gemm[16][8] = {}, ev_done[16] = {};
+        const int d = plan->device & 15;
+        if (nchunk > 8) nchunk = 8;
+        if (!aux[d]) {
+            FIB_HIP(hipStreamCreateWithFlags(&aux[d], hipStreamNonBlocking));
+            for (int c = 0; c < 8; c++) FIB_HIP(hipEventCreateWithFlags(&ev_gemm[d][c], hipEventDisableTiming));
+            FIB_HIP(hipEventCreateWithFlags(&ev_done[d], hipEventDisableTiming));
+        }
+        const int64_t per = fib::cdiv(fib::cdiv(nvox, nchunk), 1024) * 1024;
+        FIB_HIP(hipEventRecord(ev_done[d], st));                 // aux work must follow the memset / fold on `st`
+        FIB_HIP(hipStreamWaitEvent(aux[d], ev_done[d], 0));
+        for (int c = 0; c < nchunk; c++) {
+            const int64_t v0 = c * per, n = std::min<int64_t>(per, nvox - v0);
+            if (n <= 0) break;
+            GemmArgs g = ga;
+            g.S = ga.S + v0; g.mask = mask + v0; g.out0 = pdf ? pdf + v0 : nullptr; g.out1 = odf + v0; g.nvox = n;
+            int rc = run_gemm(g, st);
+            if (rc != FIB_OK) return rc;
+            FIB_HIP(hipEventRecord(ev_gemm[d][c], st));
+            FIB_HIP(hipStreamWaitEvent(aux[d], ev_gemm[d][c], 0));
+            float *pk[3] = {peak[0] + v0, peak[1] + v0, peak[2] + v0}, *q[3] = {qa[0] + v0, qa[1] + v0, qa[2] + v0};
+            rc = launch_peaks(plan, odf + v0, n, nvox, pk, q, nullptr, nullptr, true, aux[d], /*small_tiles=*/true);
+            if (rc != FIB_OK) return rc;
+        }
+        FIB_HIP(hipEventRecord(ev_done[d], aux[d]));
+        FIB_HIP(hipStreamWaitEvent(st, ev_done[d], 0));
+    } else {
+        int rc = run_gemm(ga, st);
+        if (rc != FIB_OK) return rc;
+        rc = launch_peaks(plan, odf, nvox, nvox, peak, qa, nullptr, nullptr, true, st);
+        if (rc != FIB_OK) return rc;
+    }
     float *om = odfmax_dev ? odfmax_dev : plan->odfmax.p;
     hipLaunchKernelGGL(odfmax_finalize_kernel, dim3(1), dim3(1), 0, st, plan->maxenc.p, om);
     FIB_HIP(hipGetLastError());
@@ -987,5 +1029,5 @@ extern "C" int fibd_find_peaks(const fib_odf_plan *plan, const float *odf, int64
     FIB_CHECK(plan && odf && isort_top && nvalid && nvox > 0, FIB_ERR_INVALID, "NULL argument");
     fib::DeviceGuard guard;
     FIB_HIP(hipSetDevice(plan->device));
-    return launch_peaks(plan, odf, nvox, nullptr, nullptr, isort_top, nvalid, false, (hipStream_t)stream);
+    return launch_peaks(plan, odf, nvox, nvox, nullptr, nullptr, isort_top, nvalid, false, (hipStream_t)stream);
 }
