@@ -230,12 +230,13 @@ struct PackArgs {
 };
 
 // 64 lines per workgroup; 16-slot x 64-line blocks of the slot-major scratch are read coalesced into LDS and
-// written out line by line: thread (line tl, quarter q) emits 4 consecutive points = 48 contiguous bytes.
+// written out line by line: thread (line tl, quarter q) emits PK_PER consecutive points (96 contiguous bytes).
 // Forward slots are reversed on the way out, backward slots follow (stream.jl:652).
-constexpr int PK_LINES = 64, PK_SLOTS = 16, PK_ROW = PK_LINES * 3 + 1;
+constexpr int PK_LINES = 64, PK_SLOTS = 16, PK_PER = PK_SLOTS / 4, PK_ROW = PK_LINES * 3 + 1;
 __global__ __launch_bounds__(256) void stream_pack_kernel(const PackArgs a) {
-    __shared__ float tile[PK_SLOTS * PK_ROW];
+    __shared__ float tile[2][PK_SLOTS * PK_ROW];
     __shared__ int smax[2];
+    __shared__ int lcnt[2][PK_LINES];                           // per line: forward / backward point counts (0 if dropped)
     const int tid = threadIdx.x, tl = tid >> 2, q = tid & 3;
     const int64_t line0 = (int64_t)blockIdx.x * PK_LINES;
     const int64_t li = line0 + tl;
@@ -257,46 +258,58 @@ __global__ __launch_bounds__(256) void stream_pack_kernel(const PackArgs a) {
     }
     const int nb = n - nf;
     if (tid < 2) smax[tid] = 0;
+    if (q == 0) { lcnt[0][tl] = keep ? nf : 0; lcnt[1][tl] = keep ? nb : 0; }
     __syncthreads();
     if (keep && q == 0) { atomicMax(&smax[0], nf); atomicMax(&smax[1], nb); }
     __syncthreads();
+    const int my0 = tid < PK_LINES * 3 ? lcnt[0][tid / 3] : 0, my1 = tid < PK_LINES * 3 ? lcnt[1][tid / 3] : 0;
     const int lines_here = (int)((a.nlines - line0) < PK_LINES ? (a.nlines - line0) : PK_LINES);
-    const int row_floats = lines_here * 3;
-    for (int region = 0; region < 2; region++) {
-        const int count = smax[region];
+    const bool colok = tid < lines_here * 3;                    // threads 0..191 own one float column of the 64-line row
+    const int cnt0 = smax[0], cnt1 = smax[1];
+    const int nch0 = (cnt0 + PK_SLOTS - 1) / PK_SLOTS, nch = nch0 + (cnt1 + PK_SLOTS - 1) / PK_SLOTS;
+    // chunk c -> (region, first slot): forward chunks first, then backward
+    auto chunk_src = [&](int c, int &region, int &s0, int &count) {
+        region = c < nch0 ? 0 : 1;
+        s0 = (region == 0 ? c : c - nch0) * PK_SLOTS;
+        count = region == 0 ? cnt0 : cnt1;
+    };
+    float v[PK_SLOTS];
+    auto fetch = [&](int c) {                                   // 16 independent coalesced loads per thread
+        int region, s0, count;
+        chunk_src(c, region, s0, count);
+        const float *src = a.scratch + (((int64_t)(region == 0 ? 0 : a.stride) + s0) * a.nlines + line0) * 3 + tid;
+#pragma unroll
+        for (int sl = 0; sl < PK_SLOTS; sl++)
+            v[sl] = (colok && s0 + sl < (region == 0 ? my0 : my1)) ? src[(int64_t)sl * a.nlines * 3] : 0.0f;   // only live slots of this column's line
+    };
+    if (nch > 0 && tid < PK_LINES * 3) fetch(0);
+    for (int c = 0; c < nch; c++) {
+        float *T = tile[c & 1];
+        if (tid < PK_LINES * 3) {
+#pragma unroll
+            for (int sl = 0; sl < PK_SLOTS; sl++) T[sl * PK_ROW + tid] = v[sl];
+        }
+        __syncthreads();                                        // one barrier per chunk (double-buffered tile)
+        if (c + 1 < nch && tid < PK_LINES * 3) fetch(c + 1);    // next chunk's loads fly during the write-out
+        int region, s0, count;
+        chunk_src(c, region, s0, count);
         const int mine = region == 0 ? nf : nb;
-        const int64_t base_slot = region == 0 ? 0 : a.stride;
-        for (int s0 = 0; s0 < count; s0 += PK_SLOTS) {
-            // threads 0..191 own one float column of the 64-line row each: 16 independent coalesced loads
-            if (tid < PK_LINES * 3) {
-                const float *src = a.scratch + ((base_slot + s0) * a.nlines + line0) * 3 + tid;
-                const bool colok = tid < row_floats;
-                float v[PK_SLOTS];
+        if (keep) {
 #pragma unroll
-                for (int sl = 0; sl < PK_SLOTS; sl++)
-                    v[sl] = (colok && s0 + sl < count) ? src[(int64_t)sl * a.nlines * 3] : 0.0f;
-#pragma unroll
-                for (int sl = 0; sl < PK_SLOTS; sl++) tile[sl * PK_ROW + tid] = v[sl];
-            }
-            __syncthreads();
-            if (keep) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int sl = 4 * q + j, sidx = s0 + sl;
-                    if (sidx < mine) {
-                        const int64_t p = region == 0 ? (int64_t)(nf - 1 - sidx) : (int64_t)nf + sidx;
-                        struct P3 { float x, y, z; };
-                        const float *t = tile + sl * PK_ROW + tl * 3;
-                        if (a.trk)                              // T.((xyz .+ .5) .* voxel_size), Float64 arithmetic (trk.jl:475-476)
-                            *reinterpret_cast<P3 *>(a.out_xyz + pt0 + p * 3) =
-                                P3{(float)(((double)t[0] + 0.5) * (double)a.vs[0]), (float)(((double)t[1] + 0.5) * (double)a.vs[1]),
-                                   (float)(((double)t[2] + 0.5) * (double)a.vs[2])};
-                        else
-                            *reinterpret_cast<P3 *>(a.out_xyz + (pt0 + p) * 3) = P3{t[0], t[1], t[2]};
-                    }
+            for (int j = 0; j < PK_PER; j++) {
+                const int sl = PK_PER * q + j, sidx = s0 + sl;
+                if (sidx < mine) {
+                    const int64_t p = region == 0 ? (int64_t)(nf - 1 - sidx) : (int64_t)nf + sidx;
+                    struct P3 { float x, y, z; };
+                    const float *t = T + sl * PK_ROW + tl * 3;
+                    if (a.trk)                                  // T.((xyz .+ .5) .* voxel_size), Float64 arithmetic (trk.jl:475-476)
+                        *reinterpret_cast<P3 *>(a.out_xyz + pt0 + p * 3) =
+                            P3{(float)(((double)t[0] + 0.5) * (double)a.vs[0]), (float)(((double)t[1] + 0.5) * (double)a.vs[1]),
+                               (float)(((double)t[2] + 0.5) * (double)a.vs[2])};
+                    else
+                        *reinterpret_cast<P3 *>(a.out_xyz + (pt0 + p) * 3) = P3{t[0], t[1], t[2]};
                 }
             }
-            __syncthreads();
         }
     }
 }
