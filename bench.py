@@ -146,7 +146,7 @@ def main():
             pass
 
     extra = {}
-    if not args.no_extra and rank == 0:
+    if not args.no_extra and rank == 0 and world == 1:       # single-GPU extras only: ranks must leave together
         del out, dwi
         torch.cuda.empty_cache()
         # ---- DTI fit, 140^3 x 64 (C2) ------------------------------------------------------------
@@ -192,7 +192,7 @@ def main():
                                         algorithmic_bytes=25.0 * npoints,
                                         hbm_gbs_trace=25.0 * npoints / (tr_ms / max(tr_n, 1) * 1e-3) / 1e9 if tr_n else 0.0)
 
-    if not args.no_extra and rank == 0:
+    if not args.no_extra and rank == 0 and world == 1:
         # ---- DSI 515-direction reconstruction + peaks (C5 fit part) ------------------------------------
         del field, res, o2, d2
         torch.cuda.empty_cache()

@@ -27,7 +27,7 @@ constexpr int KT = 16;        // frames per LDS stage
 constexpr int WG_VOX = 128;   // voxels per workgroup (4 waves x 32)
 
 struct GemmArgs {
-    const float *At;          // [ntile_m][Kpad][MW]  K-major tiles (MW = MB*32 [+16 when extra rows]), zero padded
+    const float *At;          // [ntile_m][Kpad][MW]  K-major tiles (MW = gemm_row_stride(MB, NX)), zero padded
     const float *S;           // [K][nvox] planar DWI
     const uint8_t *mask;      // [nvox]
     const uint32_t *effbits;  // [Kpad/KT] bit j of word t: frame t*KT+j exists and takes part in the "any positive sample" test
@@ -69,9 +69,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // (4 cycles instead of a 64-cycle MFMA block that would be 31/32 padding: sphere_642 has 321 = 10*32 + 1
 // half-sphere vertices).  The extra rows sum even and odd frames in the two lane halves and add the halves
 // at the end, so their rounding differs from the k-ordered MFMA chain by ~1 ulp.
+// LDS row stride of a stage: a multiple of 64 floats (256 B) so that every fragment offset from one of two
+// base registers (even / odd 32-row block) is a multiple of 256 B and fits ds_read2st64_b32's 8-bit offsets:
+// no per-stage v_add for LDS addresses (they would cost MFMA time, see above).
+__host__ __device__ constexpr int gemm_row_stride(int mb, int nx) { return (mb * 32 + (nx > 0 ? 16 : 0) + 63) / 64 * 64; }
+
 template <int MB, int NX>
 __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
-    constexpr int MW = MB * 32 + (NX > 0 ? 16 : 0);    // LDS row stride (floats); multiple of 16 -> whole 1-KiB pieces
+    constexpr int MW = gemm_row_stride(MB, NX);         // LDS row stride (floats)
     constexpr int TILE = KT * MW;                       // floats per stage
     constexpr int NPIECE = TILE * 4 / 1024;
     constexpr int ROWS = MB * 32 + NX;                  // output rows per M tile
@@ -105,13 +110,19 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
     // B operand: KT/2 unconditional loads per stage (frame index clamped to K-1: the padded rows of At are zero)
     float braw[KT / 2];
     auto load_B = [&](int t) {
+        if (t + 1 < ntiles) {                           // every frame of this stage exists: scalar base + lane offset only
 #pragma unroll
-        for (int kk = 0; kk < KT / 2; kk++) {
-            int kpair = t * (KT / 2) + kk;              // frames 2*kpair, 2*kpair+1 (lane half kh picks one)
-            const int lastpair = (a.K - 1) / 2;
-            kpair = kpair < lastpair ? kpair : lastpair;
-            const uint32_t off = (2 * kpair + 1 >= a.K) ? c_off : s_off;   // odd K: the last pair has one frame only
-            braw[kk] = *reinterpret_cast<const float *>(Sbase + (int64_t)kpair * frame_pair_bytes + off);
+            for (int kk = 0; kk < KT / 2; kk++)
+                braw[kk] = *reinterpret_cast<const float *>(Sbase + (int64_t)(t * (KT / 2) + kk) * frame_pair_bytes + s_off);
+        } else {                                        // last stage: clamp the frame index, odd K has a single-frame pair
+#pragma unroll
+            for (int kk = 0; kk < KT / 2; kk++) {
+                int kpair = t * (KT / 2) + kk;          // frames 2*kpair, 2*kpair+1 (lane half kh picks one)
+                const int lastpair = (a.K - 1) / 2;
+                kpair = kpair < lastpair ? kpair : lastpair;
+                const uint32_t off = (2 * kpair + 1 >= a.K) ? c_off : s_off;
+                braw[kk] = *reinterpret_cast<const float *>(Sbase + (int64_t)kpair * frame_pair_bytes + off);
+            }
         }
     };
     auto load_A = [&](const float *L, int kk, float (&af)[MB]) {   // MB conflict-free ds_read_b32, immediate offsets
@@ -151,8 +162,9 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
 #pragma unroll
             for (int kk = 0; kk < KT / 2; kk++) {
                 const float s = braw[kk];
-                bcur[kk] = fmaxf(s, 0.0f);
-                vmax = fmaxf(vmax, s);
+                // raw v_max_f32: fmaxf() would add a canonicalising v_max(s,s) per sample
+                asm("v_max_f32 %0, 0, %1" : "=v"(bcur[kk]) : "v"(s));
+                asm("v_max_f32 %0, %1, %2" : "=v"(vmax) : "v"(vmax), "v"(s));
                 vnf = __builtin_fmaf(s, 0.0f, vnf);
             }
         }
@@ -704,7 +716,7 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
         }
     }
     p->Kpad = (K + KT - 1) / KT * KT;
-    const int MW = p->MB * 32 + (p->NX > 0 ? 16 : 0), ROWS = p->MB * 32 + p->NX;
+    const int MW = gemm_row_stride(p->MB, p->NX), ROWS = p->MB * 32 + p->NX;
     std::vector<float> At((size_t)p->ntile_m * p->Kpad * MW, 0.0f);
     for (int k = 0; k < K; k++)
         for (int r = 0; r < M; r++) {
