@@ -91,8 +91,10 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
     const float p0x = (float)(sx + 1) + a.sublist[3 * isub];      // pos_now .= seed_vox .+ sub_vox, stream.jl:649
     const float p0y = (float)(sy + 1) + a.sublist[3 * isub + 1];
     const float p0z = (float)(sz + 1) + a.sublist[3 * isub + 2];
-    float *dst = a.scratch + li * 3;
     const int64_t slot_floats = a.nlines * 3;
+    float *dfw = a.scratch + li * 3;                            // next forward slot of this line (advanced per point)
+    float *dbw = dfw + (int64_t)a.stride * slot_floats;         // next backward slot
+    const char *fbase = reinterpret_cast<const char *>(a.field);   // wave-uniform base; per-lane offsets are 32-bit
     const float fnx = (float)a.nx, fny = (float)a.ny, fnz = (float)a.nz;
     const float omc = 1.0f - a.smooth;
     int ivec = 0, npts = 0, nf = 0;
@@ -105,8 +107,8 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
             const float nxp = px + vx * a.step, nyp = py + vy * a.step, nzp = pz + vz * a.step;   // stream.jl:512
             const float rx = rintf(nxp), ry = rintf(nyp), rz = rintf(nzp);                        // stream.jl:514
             if (!(rx >= 1.0f && rx <= fnx && ry >= 1.0f && ry <= fny && rz >= 1.0f && rz <= fnz)) break;   // :517
-            const int64_t vox = ((int)rx - 1) + (int64_t)a.nx * (((int)ry - 1) + (int64_t)a.ny * ((int)rz - 1));
-            const float4 *cand = a.field + vox * nvec;
+            const uint32_t vox = (uint32_t)(((int)rx - 1) + a.nx * (((int)ry - 1) + a.ny * ((int)rz - 1)));   // nvox < 2^28 / nvec
+            const float4 *cand = reinterpret_cast<const float4 *>(fbase + (size_t)(vox * (uint32_t)(nvec * 16)));
             float bx = 0.0f, by = 0.0f, bz = 0.0f, bestc = 0.0f, besta = 0.0f;
             int best = 0;
 #pragma unroll
@@ -125,8 +127,9 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
             if (bestc > 0.0f) { wx = bx; wy = by; wz = bz; } else { wx = -bx; wy = -by; wz = -bz; }   // :365-369
             ivec = best;                                          // stream.jl:371
             {   // push!/prepend! of pos_now (stream.jl:660): slot = step index within this pass
-                float *d = dst + (int64_t)(pass == 0 ? nf : a.stride + (npts - nf)) * slot_floats;
+                float *d = pass == 0 ? dfw : dbw;
                 d[0] = px; d[1] = py; d[2] = pz;
+                if (pass == 0) dfw += slot_floats; else dbw += slot_floats;
             }
             npts++;
             if (pass == 0) nf++;
@@ -385,6 +388,8 @@ extern "C" int fibd_stream_trace(const fib_stream_params *prm, const float *fiel
     FIB_CHECK(nsub >= 1 && sublist, FIB_ERR_INVALID, "sublist must hold at least one offset (use [0,0,0] for nsub=0, stream.jl:180)");
     FIB_CHECK(prm->nx > 0 && prm->ny > 0 && prm->nz > 0 && prm->nvec >= 1 && prm->nvec <= 8, FIB_ERR_INVALID, "invalid volume / nvec");
     FIB_CHECK(prm->len_max >= 0 && prm->len_max < (1 << 24), FIB_ERR_INVALID, "invalid len_max");
+    FIB_CHECK((int64_t)prm->nx * prm->ny * prm->nz * prm->nvec < ((int64_t)1 << 28), FIB_ERR_UNSUPPORTED,
+              "orientation fields of 2^28 vectors or more are not supported (32-bit gather offsets)");
     int device = 0;
     FIB_HIP(hipGetDevice(&device));
     hipStream_t st = (hipStream_t)stream;
