@@ -235,55 +235,54 @@ struct PackArgs {
 // 64 lines per workgroup; 16-slot x 64-line blocks of the slot-major scratch are read coalesced into LDS and
 // written out line by line: thread (line tl, quarter q) emits PK_PER consecutive points (96 contiguous bytes).
 // Forward slots are reversed on the way out, backward slots follow (stream.jl:652).
-constexpr int PK_LINES = 64, PK_SLOTS = 16, PK_PER = PK_SLOTS / 4, PK_ROW = PK_LINES * 3 + 1;
+constexpr int PK_LINES = 64, PK_SLOTS = 16, PK_ROW = PK_LINES * 3 + 1;
 __global__ __launch_bounds__(256) void stream_pack_kernel(const PackArgs a) {
     __shared__ float tile[2][PK_SLOTS * PK_ROW];
     __shared__ int smax[2];
     __shared__ int lcnt[2][PK_LINES];                           // per line: forward / backward point counts (0 if dropped)
-    const int tid = threadIdx.x, tl = tid >> 2, q = tid & 3;
+    __shared__ int64_t lpt0[PK_LINES];                          // per line: float index of its first output coordinate
+    const int tid = threadIdx.x;
     const int64_t line0 = (int64_t)blockIdx.x * PK_LINES;
-    const int64_t li = line0 + tl;
-    int n = 0, nf = 0;
-    int64_t pt0 = 0;
-    bool keep = false;
-    if (li < a.nlines) {
-        n = a.npts[li];
-        nf = a.nfwd[li];
-        keep = n >= a.len_min;                                  // stream.jl:769
-        const Pair e = a.excl[li], bo = a.block_off[li / SCAN_B];
-        pt0 = a.out_pt0 + e.pts + bo.pts;
-        const int64_t l0 = a.out_line0 + e.lines + bo.lines;
-        if (keep && q == 0) {
-            if (a.trk) reinterpret_cast<int32_t *>(a.out_xyz)[l0 + 3 * pt0] = n;      // write(io, Int32(npts)), trk.jl:472
-            else { a.out_npts[l0] = n; a.out_seed[l0] = a.line0 + li; }
-        }
-        if (a.trk) pt0 = pt0 * 3 + l0 + 1;                      // float index of this line's first coordinate
-    }
-    const int nb = n - nf;
     if (tid < 2) smax[tid] = 0;
-    if (q == 0) { lcnt[0][tl] = keep ? nf : 0; lcnt[1][tl] = keep ? nb : 0; }
     __syncthreads();
-    if (keep && q == 0) { atomicMax(&smax[0], nf); atomicMax(&smax[1], nb); }
+    if (tid < PK_LINES) {
+        const int64_t li = line0 + tid;
+        int nf = 0, nb = 0;
+        int64_t p0 = 0;
+        if (li < a.nlines) {
+            const int n = a.npts[li];
+            if (n >= a.len_min) {                               // stream.jl:769
+                nf = a.nfwd[li]; nb = n - nf;
+                const Pair e = a.excl[li], bo = a.block_off[li / SCAN_B];
+                const int64_t pt = a.out_pt0 + e.pts + bo.pts, l0 = a.out_line0 + e.lines + bo.lines;
+                if (a.trk) {
+                    reinterpret_cast<int32_t *>(a.out_xyz)[l0 + 3 * pt] = n;          // write(io, Int32(npts)), trk.jl:472
+                    p0 = pt * 3 + l0 + 1;
+                } else {
+                    a.out_npts[l0] = n; a.out_seed[l0] = a.line0 + li;
+                    p0 = pt * 3;
+                }
+                atomicMax(&smax[0], nf); atomicMax(&smax[1], nb);
+            }
+        }
+        lcnt[0][tid] = nf; lcnt[1][tid] = nb; lpt0[tid] = p0;
+    }
     __syncthreads();
-    const int my0 = tid < PK_LINES * 3 ? lcnt[0][tid / 3] : 0, my1 = tid < PK_LINES * 3 ? lcnt[1][tid / 3] : 0;
     const int lines_here = (int)((a.nlines - line0) < PK_LINES ? (a.nlines - line0) : PK_LINES);
     const bool colok = tid < lines_here * 3;                    // threads 0..191 own one float column of the 64-line row
+    const int my0 = tid < PK_LINES * 3 ? lcnt[0][tid / 3] : 0, my1 = tid < PK_LINES * 3 ? lcnt[1][tid / 3] : 0;
     const int cnt0 = smax[0], cnt1 = smax[1];
     const int nch0 = (cnt0 + PK_SLOTS - 1) / PK_SLOTS, nch = nch0 + (cnt1 + PK_SLOTS - 1) / PK_SLOTS;
-    // chunk c -> (region, first slot): forward chunks first, then backward
-    auto chunk_src = [&](int c, int &region, int &s0, int &count) {
-        region = c < nch0 ? 0 : 1;
-        s0 = (region == 0 ? c : c - nch0) * PK_SLOTS;
-        count = region == 0 ? cnt0 : cnt1;
-    };
+    // write-out mapping: 16 lanes per line, one point each -> a wave-instruction emits 4 runs of 192 contiguous bytes
+    const int lg = tid >> 4, pt = tid & 15;
     float v[PK_SLOTS];
     auto fetch = [&](int c) {                                   // 16 independent coalesced loads per thread
-        int region, s0, count;
-        chunk_src(c, region, s0, count);
+        const int region = c < nch0 ? 0 : 1;
+        const int s0 = (region == 0 ? c : c - nch0) * PK_SLOTS;
         const float *src = a.scratch + (((int64_t)(region == 0 ? 0 : a.stride) + s0) * a.nlines + line0) * 3 + tid;
 #pragma unroll
-        for (int sl = 0; sl < PK_SLOTS; sl++)
-            v[sl] = (colok && s0 + sl < (region == 0 ? my0 : my1)) ? src[(int64_t)sl * a.nlines * 3] : 0.0f;   // only live slots of this column's line
+        for (int sl = 0; sl < PK_SLOTS; sl++)                   // only live slots of this column's line
+            v[sl] = (colok && s0 + sl < (region == 0 ? my0 : my1)) ? src[(int64_t)sl * a.nlines * 3] : 0.0f;
     };
     if (nch > 0 && tid < PK_LINES * 3) fetch(0);
     for (int c = 0; c < nch; c++) {
@@ -294,24 +293,23 @@ __global__ __launch_bounds__(256) void stream_pack_kernel(const PackArgs a) {
         }
         __syncthreads();                                        // one barrier per chunk (double-buffered tile)
         if (c + 1 < nch && tid < PK_LINES * 3) fetch(c + 1);    // next chunk's loads fly during the write-out
-        int region, s0, count;
-        chunk_src(c, region, s0, count);
-        const int mine = region == 0 ? nf : nb;
-        if (keep) {
+        const int region = c < nch0 ? 0 : 1;
+        const int sidx = (region == 0 ? c : c - nch0) * PK_SLOTS + pt;
 #pragma unroll
-            for (int j = 0; j < PK_PER; j++) {
-                const int sl = PK_PER * q + j, sidx = s0 + sl;
-                if (sidx < mine) {
-                    const int64_t p = region == 0 ? (int64_t)(nf - 1 - sidx) : (int64_t)nf + sidx;
-                    struct P3 { float x, y, z; };
-                    const float *t = T + sl * PK_ROW + tl * 3;
-                    if (a.trk)                                  // T.((xyz .+ .5) .* voxel_size), Float64 arithmetic (trk.jl:475-476)
-                        *reinterpret_cast<P3 *>(a.out_xyz + pt0 + p * 3) =
-                            P3{(float)(((double)t[0] + 0.5) * (double)a.vs[0]), (float)(((double)t[1] + 0.5) * (double)a.vs[1]),
-                               (float)(((double)t[2] + 0.5) * (double)a.vs[2])};
-                    else
-                        *reinterpret_cast<P3 *>(a.out_xyz + (pt0 + p) * 3) = P3{t[0], t[1], t[2]};
-                }
+        for (int j = 0; j < PK_LINES / 16; j++) {
+            const int tl = lg + 16 * j;
+            const int nf = lcnt[0][tl];
+            if (sidx < (region == 0 ? nf : lcnt[1][tl])) {
+                const int64_t p = region == 0 ? (int64_t)(nf - 1 - sidx) : (int64_t)nf + sidx;
+                struct P3 { float x, y, z; };
+                const float *t = T + pt * PK_ROW + tl * 3;
+                float *d = a.out_xyz + lpt0[tl] + p * 3;
+                if (a.trk)                                      // T.((xyz .+ .5) .* voxel_size), Float64 arithmetic (trk.jl:475-476)
+                    *reinterpret_cast<P3 *>(d) =
+                        P3{(float)(((double)t[0] + 0.5) * (double)a.vs[0]), (float)(((double)t[1] + 0.5) * (double)a.vs[1]),
+                           (float)(((double)t[2] + 0.5) * (double)a.vs[2])};
+                else
+                    *reinterpret_cast<P3 *>(d) = P3{t[0], t[1], t[2]};
             }
         }
     }
