@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfibers_hip.so")
+LIB_PATH = os.environ.get("FIBERS_HIP_LIB") or os.path.join(_HERE, "libfibers_hip.so")   # override: A/B builds of the same ABI
 
 FIB_OK = 0
 DTYPES = {"uint8": 0, "int8": 1, "int16": 2, "uint16": 3, "int32": 4, "uint32": 5,

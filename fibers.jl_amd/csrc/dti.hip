@@ -201,6 +201,16 @@ __global__ __launch_bounds__(256) void fit_kernel(const float *__restrict__ dwi,
     // HBM-bound, unless the per-sample work is tiny (PMC: 33 VALU/sample -> 77 % VALU busy), so the loop does
     // only: running minimum (1), log = v_log_f32 * ln2 (2), NP FMAs.  A non-positive / denormal / NaN sample
     // shows up as min < FLT_MIN or as a NaN in d; such voxels are listed for the complete (slow) kernel.
+    uint8_t mk[V];
+    {
+        const typename VecT<V>::M t = *reinterpret_cast<const typename VecT<V>::M *>(mask + base);
+        __builtin_memcpy(mk, &t, sizeof t);
+    }
+    bool anymask = false;
+#pragma unroll
+    for (int v = 0; v < V; v++) anymask |= mk[v] != 0;
+    // a wave whose voxels are all outside the mask reads no frame at all (brain masks cover ~1/3 of a volume)
+    const int nframes = __any(anymask) ? nvol : 0;
     float d[V][NP], smin[V];
 #pragma unroll
     for (int v = 0; v < V; v++) {
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(256) void fit_kernel(const float *__restrict__ dwi,
     }
     const float *src = dwi + base;
 #pragma unroll UNR
-    for (int i = 0; i < nvol; i++) {
+    for (int i = 0; i < nframes; i++) {
         float s[V];
         vload<V>(src + (int64_t)i * nvox, s);
         const float *c = coef + 8 * i;          // wave-uniform: scalar loads
@@ -229,11 +239,6 @@ __global__ __launch_bounds__(256) void fit_kernel(const float *__restrict__ dwi,
 #pragma unroll
         for (int j = 1; j < NP; j++) t += d[v][j];
         fastok[v] = smin[v] >= 1.17549435e-38f && t == t;
-    }
-    uint8_t mk[V];
-    {
-        const typename VecT<V>::M t = *reinterpret_cast<const typename VecT<V>::M *>(mask + base);
-        __builtin_memcpy(mk, &t, sizeof t);
     }
     if constexpr (NP == 7) {
         float o[16][V];

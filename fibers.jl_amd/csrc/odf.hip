@@ -29,7 +29,8 @@ constexpr int WG_VOX = 128;   // voxels per workgroup (4 waves x 32)
 struct GemmArgs {
     const float *At;          // [ntile_m][Kpad][MW]  K-major tiles (MW = gemm_row_stride(MB, NX)), zero padded
     const float *S;           // [K][nvox] planar DWI
-    const uint8_t *mask;      // [nvox]
+    const int32_t *vidx;      // [nlive] voxels inside the mask, ascending (mask_compact_*): lane -> voxel gather / scatter
+    const int32_t *nlive;     // device count of vidx
     const uint32_t *effbits;  // [Kpad/KT] bit j of word t: frame t*KT+j exists and takes part in the "any positive sample" test
     float *out0;              // rows [0, nrow0)        (DSI: pdf)
     float *out1;              // rows [nrow0, M)        (odf)
@@ -87,19 +88,15 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
     const int col = lane & 31, kh = lane >> 5;
     const int tile_m = blockIdx.x % a.ntile_m;
     const int64_t tile_n = blockIdx.x / a.ntile_m;
-    const int64_t vox0 = tile_n * WG_VOX + wave * 32;   // wave-uniform
-    const int64_t vox = vox0 + col;
-    const bool inb = vox < a.nvox;
-    const int ntiles = a.Kpad / KT;
-    // per-lane 32-bit byte offsets; everything else in an address is wave-uniform (SGPR base)
-    const uint32_t c_off = (uint32_t)((inb ? col : 0) * 4);
-    const uint32_t s_off = (uint32_t)(((inb ? col : 0) + (int64_t)kh * a.stride) * 4);   // frame kh of the pair, this voxel
-    const char *Sbase = reinterpret_cast<const char *>(a.S + (vox0 < a.nvox ? vox0 : 0));
+    // The workgroup's 128 columns are 128 consecutive entries of the compacted voxel list: voxels outside the mask
+    // cost nothing (brain masks cover about a third of a volume), and a lane's sample loads / output stores were
+    // per-lane addresses anyway.  Workgroups past the end of the list leave at once.
+    // The list entry is fetched before the count is known (the buffer holds nvox entries; those past the count are
+    // stale and replaced by voxel 0) and the first stage of A is already on its way: one memory latency, not three.
+    const int64_t slot = tile_n * WG_VOX + wave * 32 + col;
+    const int32_t vraw = a.vidx[slot < a.nvox ? slot : a.nvox - 1];
     const char *Abase = reinterpret_cast<const char *>(a.At + (size_t)tile_m * a.Kpad * MW);
     const uint32_t a_off = (uint32_t)lane * 16;
-    const int64_t frame_pair_bytes = 2 * a.stride * 4;
-    const uint8_t mk = a.mask[inb ? vox : 0];           // used in the epilogue only: latency hidden
-
     auto stage_A = [&](int t, int buf) {                // one stage = TILE*4 contiguous bytes of At
         const char *g = Abase + (size_t)t * TILE * 4;
         char *l = reinterpret_cast<char *>(lds + buf * TILE);
@@ -109,20 +106,37 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
     };
     // B operand: KT/2 unconditional loads per stage (frame index clamped to K-1: the padded rows of At are zero)
     float braw[KT / 2];
+    stage_A(0, 0);
+    const int nlive = a.nlive[0];
+    if (tile_n * WG_VOX >= nlive) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the direct-to-LDS loads must not outlive the workgroup
+        return;
+    }
+    const bool inb = slot < nlive;
+    const int64_t vox = inb ? vraw : 0;
+    const int ntiles = a.Kpad / KT;
+    // per-lane 32-bit byte offsets; everything else in an address is wave-uniform (SGPR base)
+    const uint32_t c_off = (uint32_t)(vox * 4);
+    const uint32_t s_off = (uint32_t)((vox + (int64_t)kh * a.stride) * 4);   // frame kh of the pair, this voxel
+    const char *Sbase = reinterpret_cast<const char *>(a.S);
+    const int64_t frame_pair_bytes = 2 * a.stride * 4;
+
+    // Buffer loads: SGPR resource (base = the frame pair's two rows, advanced with scalar adds) + one 32-bit lane
+    // offset; flat global loads made hipcc build eight 64-bit per-lane addresses per stage with v_mad_u64_u32.
+    // The resource's range check also replaces the clamping of the last stage: a pair past the last frame gets
+    // num_records = 0 and a single-frame pair (odd K) one row, so those lanes read 0.0 without a memory access
+    // (the padded rows of At are zero, and 0 changes neither the running max nor the non-finite tracker).
+    const int32_t row_bytes = (int32_t)(a.stride * 4);
     auto load_B = [&](int t) {
-        if (t + 1 < ntiles) {                           // every frame of this stage exists: scalar base + lane offset only
+        const char *fb = Sbase + (int64_t)t * (KT / 2) * frame_pair_bytes;               // wave-uniform
+        int rem = a.K - t * KT;                                                           // frames left from this stage on
 #pragma unroll
-            for (int kk = 0; kk < KT / 2; kk++)
-                braw[kk] = *reinterpret_cast<const float *>(Sbase + (int64_t)(t * (KT / 2) + kk) * frame_pair_bytes + s_off);
-        } else {                                        // last stage: clamp the frame index, odd K has a single-frame pair
-#pragma unroll
-            for (int kk = 0; kk < KT / 2; kk++) {
-                int kpair = t * (KT / 2) + kk;          // frames 2*kpair, 2*kpair+1 (lane half kh picks one)
-                const int lastpair = (a.K - 1) / 2;
-                kpair = kpair < lastpair ? kpair : lastpair;
-                const uint32_t off = (2 * kpair + 1 >= a.K) ? c_off : s_off;
-                braw[kk] = *reinterpret_cast<const float *>(Sbase + (int64_t)kpair * frame_pair_bytes + off);
-            }
+        for (int kk = 0; kk < KT / 2; kk++) {
+            const int32_t nrec = rem >= 2 ? 2 * row_bytes : (rem == 1 ? row_bytes : 0);
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(rem > 0 ? fb : Sbase), 0, nrec, 0x00020000);
+            braw[kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)s_off, 0, 0));
+            fb += frame_pair_bytes;
+            rem -= 2;
         }
     };
     auto load_A = [&](const float *L, int kk, float (&af)[MB]) {   // MB conflict-free ds_read_b32, immediate offsets
@@ -141,9 +155,8 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
     float vmax = 0.0f;                                  // running max of the samples  -> "any sample > 0"
     float vnf = 0.0f;                                   // becomes NaN once a sample is NaN or +-Inf
 
-    stage_A(0, 0);
     load_B(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): a builtin, so that hipcc's own wait-count bookkeeping sees it
     __syncthreads();
     for (int t = 0; t < ntiles; t++) {
         const int cur = t & 1;
@@ -195,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
 #pragma unroll
                 for (int x = 0; x < NX; x++) xacc[x] = __builtin_fmaf(LX[2 * kk * MW + x], bcur[kk], xacc[x]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage's direct-to-LDS loads and samples have landed
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): next stage's direct-to-LDS loads and samples have landed
         __syncthreads();
     }
 
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
     float pm = fmaxf(vmax, __shfl_xor(vmax, 32));
     float pn = vnf + __shfl_xor(vnf, 32);
     const bool nonfinite = pn != pn;                    // a NaN sample makes every output NaN (NaN * A[v,i] for all v)
-    const bool valid = inb && (pm > 0.0f || nonfinite) && mk != 0;
+    const bool valid = inb && (pm > 0.0f || nonfinite);
     const bool do_scale = a.scale_frame >= 0;
     float scale = 1.0f;
     if (do_scale) {
@@ -217,10 +230,10 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
 #pragma unroll
     for (int x = 0; x < NX; x++) xacc[x] += __shfl_xor(xacc[x], 32);
     if (!inb) return;
-    const uint32_t o_off = (uint32_t)((col + (int64_t)4 * kh * a.stride) * 4);
-    auto row_ptr = [&](int row) -> char * {             // wave-uniform row base for this wave's 32 voxels
-        return reinterpret_cast<char *>(row >= a.nrow0 ? a.out1 + (int64_t)(row - a.nrow0) * a.stride + vox0
-                                                       : a.out0 + (int64_t)row * a.stride + vox0);
+    const uint32_t o_off = (uint32_t)((vox + (int64_t)4 * kh * a.stride) * 4);   // < 2^32: nvox <= 2^27
+    auto row_ptr = [&](int row) -> char * {             // wave-uniform row base
+        return reinterpret_cast<char *>(row >= a.nrow0 ? a.out1 + (int64_t)(row - a.nrow0) * a.stride
+                                                       : a.out0 + (int64_t)row * a.stride);
     };
     const bool mapped = a.rowA != nullptr;
 #pragma unroll
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
                     a.out0[(int64_t)fa * a.stride + vox] = v;
                     if (fb >= 0) a.out0[(int64_t)fb * a.stride + vox] = v;
                 } else {
-                    *reinterpret_cast<float *>(row_ptr(row) + col * 4) = v;
+                    *reinterpret_cast<float *>(row_ptr(row) + c_off) = v;
                 }
             }
         }
@@ -261,20 +274,115 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
                 a.out0[(int64_t)fa * a.stride + vox] = v;
                 if (fb >= 0) a.out0[(int64_t)fb * a.stride + vox] = v;
             } else {
-                *reinterpret_cast<float *>(row_ptr(row) + col * 4) = v;
+                *reinterpret_cast<float *>(row_ptr(row) + c_off) = v;
             }
         }
+    }
+}
+
+// ---- mask compaction ---------------------------------------------------------------------------------------
+// vidx = ascending list of the voxels inside the mask, tiles = ascending list of the 64-voxel tiles that hold at
+// least one; both counts stay on the device (no host round trip).  Three small launches: per-block counts,
+// one-block exclusive scan, ordered write.  A block covers 1024 voxels as 4 passes x 4 waves x 64 lanes, so a
+// wave-pass is exactly one tile and a ballot gives both counts.
+constexpr int CB = 1024;
+__global__ __launch_bounds__(256) void mask_count_kernel(const uint8_t *__restrict__ mask, int64_t nvox, int2 *__restrict__ blockcnt) {
+    __shared__ int cv[4], ct[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int nv = 0, nt = 0;
+    for (int i = 0; i < 4; i++) {
+        const int64_t vx = (int64_t)blockIdx.x * CB + i * 256 + tid;
+        const unsigned long long b = __ballot(vx < nvox && mask[vx] != 0);
+        nv += __popcll(b);
+        nt += b != 0ull;
+    }
+    if (lane == 0) { cv[wave] = nv; ct[wave] = nt; }
+    __syncthreads();
+    if (tid == 0) blockcnt[blockIdx.x] = make_int2(cv[0] + cv[1] + cv[2] + cv[3], ct[0] + ct[1] + ct[2] + ct[3]);
+}
+// in-place exclusive scan of blockcnt[nb]; totals -> {nlive, ntiles_live}
+__global__ __launch_bounds__(1024) void mask_scan_kernel(int2 *__restrict__ blockcnt, int nb, int32_t *__restrict__ totals) {
+    __shared__ int2 part[1024];
+    const int tid = threadIdx.x;
+    const int per = (nb + 1023) / 1024;
+    const int lo = tid * per, hi = lo + per < nb ? lo + per : nb;
+    int2 sum = make_int2(0, 0);
+    for (int i = lo; i < hi; i++) { sum.x += blockcnt[i].x; sum.y += blockcnt[i].y; }
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan of the 1024 segment sums
+        int2 add = make_int2(0, 0);
+        if (tid >= off) add = part[tid - off];
+        __syncthreads();
+        part[tid].x += add.x; part[tid].y += add.y;
+        __syncthreads();
+    }
+    int2 run = tid ? part[tid - 1] : make_int2(0, 0);
+    for (int i = lo; i < hi; i++) { const int2 c = blockcnt[i]; blockcnt[i] = run; run.x += c.x; run.y += c.y; }
+    if (tid == 1023) { totals[0] = part[1023].x; totals[1] = part[1023].y; }
+}
+__global__ __launch_bounds__(256) void mask_write_kernel(const uint8_t *__restrict__ mask, int64_t nvox, const int2 *__restrict__ blockoff,
+                                                        int32_t *__restrict__ vidx, int32_t *__restrict__ tiles) {
+    __shared__ int cv[16], ct[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long b[4];
+    for (int i = 0; i < 4; i++) {
+        const int64_t vx = (int64_t)blockIdx.x * CB + i * 256 + tid;
+        b[i] = __ballot(vx < nvox && mask[vx] != 0);
+        if (lane == 0) { cv[i * 4 + wave] = __popcll(b[i]); ct[i * 4 + wave] = b[i] != 0ull; }
+    }
+    __syncthreads();
+    const int2 off = blockoff[blockIdx.x];
+    for (int i = 0; i < 4; i++) {
+        int pv = off.x, pt = off.y;
+        for (int c = 0; c < i * 4 + wave; c++) { pv += cv[c]; pt += ct[c]; }
+        const int64_t vx = (int64_t)blockIdx.x * CB + i * 256 + tid;
+        if ((b[i] >> lane) & 1ull) vidx[pv + __popcll(b[i] & ((1ull << lane) - 1ull))] = (int32_t)vx;
+        if (lane == 0 && b[i]) tiles[pt] = (int32_t)(vx >> 6);
+    }
+}
+// outputs of voxels outside the mask are zero (the reference's output volumes start zero-filled): every output
+// row of the GEMM plus the 9 peak components and 3 qa volumes
+struct ZeroArgs { float *out0, *out1, *peak[3], *qa[3]; int n0, n1; int64_t nvox, stride; const uint8_t *mask; const int32_t *nlive; };
+constexpr int ZCH = 8192;      // voxels of one row per thread block: 8 float4 groups per thread
+__global__ __launch_bounds__(256) void zero_dead_kernel(const ZeroArgs z) {
+    // blockIdx.y = output row (strided), blockIdx.x = 8192-voxel chunk of it: a block streams 32 KB of a row at a time.  Groups of 4
+    // voxels that are all outside the mask get one 16-byte store, mixed groups scalar stores.
+    if (z.nlive[0] == z.nvox) return;                       // nothing outside the mask
+    const int nr = z.n0 + z.n1 + 12;
+    for (int r = blockIdx.y; r < nr; r += gridDim.y) {
+    float *row;
+    if (r < z.n0) row = z.out0 + (int64_t)r * z.stride;
+    else if (r < z.n0 + z.n1) row = z.out1 + (int64_t)(r - z.n0) * z.stride;
+    else { const int q = r - z.n0 - z.n1; row = q < 9 ? z.peak[q / 3] + (int64_t)(q % 3) * z.stride : z.qa[q - 9]; }
+    const bool vec = (reinterpret_cast<uintptr_t>(row) & 15) == 0 && (reinterpret_cast<uintptr_t>(z.mask) & 3) == 0;
+    const int64_t base = (int64_t)blockIdx.x * ZCH;
+#pragma unroll
+    for (int g = 0; g < ZCH / 1024; g++) {
+        const int64_t v0 = base + g * 1024 + threadIdx.x * 4;
+        if (v0 >= z.nvox) break;
+        if (vec && v0 + 4 <= z.nvox) {
+            const uint32_t m4 = *reinterpret_cast<const uint32_t *>(z.mask + v0);
+            if (m4 == 0u) { *reinterpret_cast<float4 *>(row + v0) = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+            if ((m4 & 0xffu) == 0u) row[v0] = 0.0f;
+            if ((m4 & 0xff00u) == 0u) row[v0 + 1] = 0.0f;
+            if ((m4 & 0xff0000u) == 0u) row[v0 + 2] = 0.0f;
+            if ((m4 & 0xff000000u) == 0u) row[v0 + 3] = 0.0f;
+        } else {
+            for (int i = 0; i < 4; i++) if (v0 + i < z.nvox && z.mask[v0 + i] == 0) row[v0 + i] = 0.0f;
+        }
+    }
     }
 }
 
 // DSI with an antipodally symmetric q-space lattice: cos(2 pi r.q/n) is even in q, so the frames at q and -q
 // enter every pdf / odf row with the same coefficient.  t[J] = max(s[q_J],0) + max(s[-q_J],0) halves K, and
 // p(r) = p(-r) halves the pdf rows: 2.9x fewer flops for the 515-point scheme.  HBM-bound pre-pass.
-__global__ __launch_bounds__(256) void dsi_fold_kernel(const float *__restrict__ S, const int32_t *__restrict__ fa,
+__global__ __launch_bounds__(256) void dsi_fold_kernel(const float *__restrict__ S, const uint8_t *__restrict__ mask, const int32_t *__restrict__ fa,
                                                       const int32_t *__restrict__ fb, int nrep, int64_t nvox,
                                                       float *__restrict__ T) {
     const int64_t vox = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (vox >= nvox) return;
+    if (vox >= nvox || mask[vox] == 0) return;              // the GEMM only gathers voxels inside the mask
     for (int j = 0; j < nrep; j++) {
         const int a = fa[j], b = fb[j];                     // wave-uniform
         const float x = S[(int64_t)a * nvox + vox];
@@ -333,6 +441,8 @@ struct PeakArgs {
     int64_t stride;           // row stride of odf / component stride of the outputs
     int nvert, rows_pad;      // rows_pad = nvert rounded up to 8; sentinel row index = rows_pad
     int vec_ok;               // 1: every tile row is 16-byte aligned (nvox % 4 == 0 and aligned base)
+    const int32_t *tiles;     // optional: ascending list of the 64-voxel tiles to scan (mask compaction) and its
+    const int32_t *ntl;       // device-side length; tiles not listed keep the zeros zero_dead_kernel wrote
 };
 
 __device__ __forceinline__ unsigned enc_ordered(float f) {
@@ -528,11 +638,21 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
     } while (0)
 #define FIB_P64_PUT(i, reg) if (tid + P64_T * (i) < nq) *reinterpret_cast<float4 *>(o + 4 * (tid + P64_T * (i))) = reg
 
-    int64_t tile = blockIdx.x;
-    if (tile >= ntiles) return;
+    const int64_t nlist = a.tiles ? (int64_t)a.ntl[0] : ntiles;
+    // voxels of unlisted tiles have an all-zero ODF: their mean (0) takes part in odfmax (gqi.jl:164-166)
+    if (a.tiles && a.maxenc && blockIdx.x == 0 && tid == 0 && nlist < ntiles) atomicMax(&a.maxenc[0], enc_ordered(0.0f));
+    auto tile_at = [&](int64_t k) -> int64_t { return k < nlist ? (a.tiles ? (int64_t)a.tiles[k] : k) : -1; };
+    int64_t slot = blockIdx.x;
+    int64_t tile = tile_at(slot);
+    if (tile < 0) return;
+    int64_t next = tile_at(slot + gridDim.x);
     bool fast = is_fast(tile);
     if (fast) FIB_P64_FETCH(tile);
     for (;;) {
+        // list entry of the tile after next: issued before this tile's staging registers are waited for, so the
+        // prefetch of the next tile (below) is never waited on for it
+        slot += gridDim.x;
+        const int64_t next2 = tile_at(slot + gridDim.x);
         if (fast) {
             FIB_P64_PUT(0, s0); FIB_P64_PUT(1, s1); FIB_P64_PUT(2, s2);
             FIB_P64_PUT(3, s3); FIB_P64_PUT(4, s4); FIB_P64_PUT(5, s5);
@@ -544,8 +664,7 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
             }
         }
         __syncthreads();
-        const int64_t next = tile + gridDim.x;
-        fast = next < ntiles && is_fast(next);
+        fast = next >= 0 && is_fast(next);
         if (fast) FIB_P64_FETCH(next);                          // in flight during the scan
 
         // ---- scan this wave's vertices (uniform v) ------------------------------------------------------
@@ -641,8 +760,9 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
                 }
             }
         }
-        if (next >= ntiles) break;
+        if (next < 0) break;
         tile = next;
+        next = next2;
         __syncthreads();                                        // wave 0 is done reading o[] before it is overwritten
     }
 }
@@ -688,6 +808,8 @@ struct fib_odf_plan {
     fib::DevBuf<int32_t> nbr, nbr64; // [nvert_even][deg_pad] LDS row of each neighbour (sentinel-padded)
     int deg_pad = 6, rows_pad = 0;
     mutable fib::DevBuf<unsigned> maxenc;
+    mutable fib::DevBuf<int32_t> live_vox, live_tiles, live_counts;   // mask compaction scratch (grow-only), counts = {voxels, tiles}
+    mutable fib::DevBuf<int2> live_blocks;
     mutable fib::DevBuf<float> odfmax;
 };
 
@@ -749,6 +871,7 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
     if ((rc = p->verts.alloc(v3.size())) != FIB_OK) return rc;
     if ((rc = p->nbr.alloc(nbr.size())) != FIB_OK) return rc;
     if ((rc = p->maxenc.alloc(2)) != FIB_OK) return rc;
+    if ((rc = p->live_counts.alloc(2)) != FIB_OK) return rc;
     if ((rc = p->odfmax.alloc(2)) != FIB_OK) return rc;
     FIB_HIP(hipMemcpy(p->At.p, At.data(), At.size() * sizeof(float), hipMemcpyHostToDevice));
     FIB_HIP(hipMemcpy(p->effbits.p, effbits.data(), effbits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -897,8 +1020,10 @@ int launch_peaks64_t(const PeakArgs &pa, size_t smem, int64_t ntiles, unsigned g
 }
 
 int launch_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox, int64_t stride, float *const peak[3], float *const qa[3],
-                 int32_t *isort_top, int32_t *nvalid, bool reduce, hipStream_t st, bool small_tiles = false) {
+                 int32_t *isort_top, int32_t *nvalid, bool reduce, hipStream_t st, bool small_tiles = false,
+                 const int32_t *tiles = nullptr, const int32_t *ntl = nullptr) {
     PeakArgs pa{};
+    pa.tiles = tiles; pa.ntl = ntl;
     pa.odf = odf; pa.nbr = plan->nbr.p; pa.nbr64 = plan->nbr64.p; pa.verts = plan->verts.p;
     for (int k = 0; k < 3; k++) { pa.peak[k] = peak ? peak[k] : nullptr; pa.qa[k] = qa ? qa[k] : nullptr; }
     pa.isort_top = isort_top; pa.nvalid = nvalid;
@@ -934,24 +1059,37 @@ int launch_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox, int64
 
 extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const uint8_t *mask, int64_t nvox,
                             float *pdf, float *odf, float *const peak[3], float *const qa[3],
-                            float *odfmax_dev, int normalize, void *stream) {
+                            float *odfmax_dev, int flags, void *stream) {
     FIB_CHECK(plan && dwi && mask && odf && peak && qa, FIB_ERR_INVALID, "NULL argument");
     FIB_CHECK(nvox > 0, FIB_ERR_INVALID, "nvox must be positive");
-    FIB_CHECK(nvox < ((int64_t)1 << 28), FIB_ERR_UNSUPPORTED, "volumes of 2^28 voxels or more are not supported (32-bit lane offsets)");
+    FIB_CHECK(nvox <= ((int64_t)1 << 27), FIB_ERR_UNSUPPORTED, "volumes of more than 2^27 voxels are not supported (32-bit lane offsets)");
     FIB_CHECK(plan->nrow0 == 0 || pdf != nullptr, FIB_ERR_INVALID, "DSI plans need a pdf output volume");
     for (int k = 0; k < 3; k++) FIB_CHECK(peak[k] && qa[k], FIB_ERR_INVALID, "NULL peak/qa output volume");
     fib::DeviceGuard guard;
     FIB_HIP(hipSetDevice(plan->device));
     hipStream_t st = (hipStream_t)stream;
     GemmArgs ga{};
-    ga.At = plan->At.p; ga.S = dwi; ga.mask = mask; ga.effbits = plan->effbits.p;
+    // compact the mask: voxel list for the GEMM, 64-voxel tile list for the peak finder (counts stay on the device)
+    {
+        const int nb = (int)fib::cdiv(nvox, CB);
+        int rcc;
+        if ((rcc = plan->live_vox.ensure((size_t)nvox)) != FIB_OK) return rcc;
+        if ((rcc = plan->live_tiles.ensure((size_t)fib::cdiv(nvox, 64))) != FIB_OK) return rcc;
+        if ((rcc = plan->live_blocks.ensure((size_t)nb)) != FIB_OK) return rcc;
+        fib::ProfScope prof("mask_compact", st);
+        hipLaunchKernelGGL(mask_count_kernel, dim3(nb), dim3(256), 0, st, mask, nvox, plan->live_blocks.p);
+        hipLaunchKernelGGL(mask_scan_kernel, dim3(1), dim3(1024), 0, st, plan->live_blocks.p, nb, plan->live_counts.p);
+        hipLaunchKernelGGL(mask_write_kernel, dim3(nb), dim3(256), 0, st, mask, nvox, plan->live_blocks.p, plan->live_vox.p, plan->live_tiles.p);
+        FIB_HIP(hipGetLastError());
+    }
+    ga.At = plan->At.p; ga.S = dwi; ga.vidx = plan->live_vox.p; ga.nlive = plan->live_counts.p; ga.effbits = plan->effbits.p;
     ga.out0 = pdf; ga.out1 = odf; ga.nvox = nvox;
     ga.K = plan->gK; ga.Kpad = plan->Kpad; ga.M = plan->gM; ga.nrow0 = plan->gRow0; ga.ntile_m = plan->ntile_m;
     if (plan->folded) {
         int rcf = plan->folded_dwi.ensure((size_t)plan->gK * nvox);
         if (rcf != FIB_OK) return rcf;
         fib::ProfScope prof("dsi_fold", st);
-        hipLaunchKernelGGL(dsi_fold_kernel, dim3((unsigned)fib::cdiv(nvox, 256)), dim3(256), 0, st, dwi, plan->foldA.p, plan->foldB.p,
+        hipLaunchKernelGGL(dsi_fold_kernel, dim3((unsigned)fib::cdiv(nvox, 256)), dim3(256), 0, st, dwi, mask, plan->foldA.p, plan->foldB.p,
                            plan->gK, nvox, plan->folded_dwi.p);
         ga.S = plan->folded_dwi.p;
         ga.rowA = plan->foldA.p; ga.rowB = plan->foldB.p;
@@ -979,48 +1117,22 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         return FIB_OK;
     };
 
-    // Optional two-stream pipeline (FIBERS_ODF_OVERLAP=<chunks>): the MFMA-bound GEMM of chunk i+1 runs beside the
-    // LDS/latency-bound peak finder of chunk i (32-voxel-tile variant: small enough to share a CU with 2 GEMM groups).
-    int nchunk = 1;
-    if (const char *e = getenv("FIBERS_ODF_OVERLAP")) nchunk = atoi(e);
-    if (nchunk > 1 && nvox >= (int64_t)nchunk * 65536) {
-        static hipStream_t aux[16] = {};
-        static hipEvent_t ev_gemm[16][8] = {}, ev_done[16] = {};
-        const int d = plan->device & 15;
-        if (nchunk > 8) nchunk = 8;
-        if (!aux[d]) {
-            FIB_HIP(hipStreamCreateWithFlags(&aux[d], hipStreamNonBlocking));
-            for (int c = 0; c < 8; c++) FIB_HIP(hipEventCreateWithFlags(&ev_gemm[d][c], hipEventDisableTiming));
-            FIB_HIP(hipEventCreateWithFlags(&ev_done[d], hipEventDisableTiming));
-        }
-        const int64_t per = fib::cdiv(fib::cdiv(nvox, nchunk), 1024) * 1024;
-        FIB_HIP(hipEventRecord(ev_done[d], st));                 // aux work must follow the memset / fold on `st`
-        FIB_HIP(hipStreamWaitEvent(aux[d], ev_done[d], 0));
-        for (int c = 0; c < nchunk; c++) {
-            const int64_t v0 = c * per, n = std::min<int64_t>(per, nvox - v0);
-            if (n <= 0) break;
-            GemmArgs g = ga;
-            g.S = ga.S + v0; g.mask = mask + v0; g.out0 = pdf ? pdf + v0 : nullptr; g.out1 = odf + v0; g.nvox = n;
-            int rc = run_gemm(g, st);
-            if (rc != FIB_OK) return rc;
-            FIB_HIP(hipEventRecord(ev_gemm[d][c], st));
-            FIB_HIP(hipStreamWaitEvent(aux[d], ev_gemm[d][c], 0));
-            float *pk[3] = {peak[0] + v0, peak[1] + v0, peak[2] + v0}, *q[3] = {qa[0] + v0, qa[1] + v0, qa[2] + v0};
-            rc = launch_peaks(plan, odf + v0, n, nvox, pk, q, nullptr, nullptr, true, aux[d], /*small_tiles=*/true);
-            if (rc != FIB_OK) return rc;
-        }
-        FIB_HIP(hipEventRecord(ev_done[d], aux[d]));
-        FIB_HIP(hipStreamWaitEvent(st, ev_done[d], 0));
-    } else {
-        int rc = run_gemm(ga, st);
-        if (rc != FIB_OK) return rc;
-        rc = launch_peaks(plan, odf, nvox, nvox, peak, qa, nullptr, nullptr, true, st);
-        if (rc != FIB_OK) return rc;
+    if (!(flags & FIB_ODF_PREZEROED)) {
+        ZeroArgs z{};
+        z.out0 = pdf; z.out1 = odf; z.n0 = plan->nrow0; z.n1 = plan->nrows - plan->nrow0; z.nvox = nvox; z.stride = nvox; z.mask = mask; z.nlive = plan->live_counts.p;
+        for (int k = 0; k < 3; k++) { z.peak[k] = peak[k]; z.qa[k] = qa[k]; }
+        fib::ProfScope prof("zero_dead", st);
+        hipLaunchKernelGGL(zero_dead_kernel, dim3((unsigned)fib::cdiv(nvox, ZCH), (unsigned)std::min(z.n0 + z.n1 + 12, 64)), dim3(256), 0, st, z);
+        FIB_HIP(hipGetLastError());
     }
+    int rc = run_gemm(ga, st);
+    if (rc != FIB_OK) return rc;
+    rc = launch_peaks(plan, odf, nvox, nvox, peak, qa, nullptr, nullptr, true, st, false, plan->live_tiles.p, plan->live_counts.p + 1);
+    if (rc != FIB_OK) return rc;
     float *om = odfmax_dev ? odfmax_dev : plan->odfmax.p;
     hipLaunchKernelGGL(odfmax_finalize_kernel, dim3(1), dim3(1), 0, st, plan->maxenc.p, om);
     FIB_HIP(hipGetLastError());
-    if (normalize) {
+    if (flags & FIB_ODF_NORMALIZE) {
         fib::ProfScope prof("qa_normalize", st);
         hipLaunchKernelGGL(qa_normalize_kernel, dim3(2048), dim3(256), 0, st, qa[0], qa[1], qa[2], nvox, om, 0.0f);
         FIB_HIP(hipGetLastError());

@@ -120,7 +120,8 @@ class OdfPlan:
             pass
 
 
-def odf_rec_device(plan: OdfPlan, dwi, mask, out: Optional[dict] = None, normalize: bool = True, stream=None):
+def odf_rec_device(plan: OdfPlan, dwi, mask, out: Optional[dict] = None, normalize: bool = True, stream=None,
+                   out_prezeroed: bool = False):
     """dwi: float32 CUDA tensor [nvol, nvox]; mask uint8 [nvox].  Returns dict(odf [nvert,nvox],
     pdf [nvol,nvox] (DSI), peak [3][3,nvox], qa [3][nvox], odfmax float32[2] = {max, nan flag})."""
     import torch
@@ -141,7 +142,7 @@ def odf_rec_device(plan: OdfPlan, dwi, mask, out: Optional[dict] = None, normali
     _lib.check(_lib.lib().fibd_odf_rec(plan._h, dwi.data_ptr(), mask.data_ptr(), nvox, pdf_ptr, out["odf"].data_ptr(),
                                        _lib.P3(*[t.data_ptr() for t in out["peak"]]),
                                        _lib.P3(*[t.data_ptr() for t in out["qa"]]),
-                                       out["odfmax"].data_ptr(), 1 if normalize else 0, _stream_ptr(stream)))
+                                       out["odfmax"].data_ptr(), (1 if normalize else 0) | (2 if out_prezeroed else 0), _stream_ptr(stream)))
     return out
 
 

@@ -120,13 +120,21 @@ int fibd_dti_last_partial_count(const fib_dti_plan *plan, void *stream, int64_t 
 
 /* gqi_rec / dsi_rec volume loop + find_peaks! + peak/qa extraction (gqi.jl:132-162,
  * dsi.jl:197-261).  odf [nvox*nvert] planar; pdf [nvox*nvol] (DSI plans only, else NULL);
- * peak[k] [nvox*3] planar, qa[k] [nvox].  If `normalize` != 0 the global step
- * qa ./= maximum(mean(odf, dims=4)) (gqi.jl:164-168, dsi.jl:263-267) is applied in-stream;
- * otherwise qa is left un-normalised and *odfmax_dev (device float[2]: {max, nan-flag})
- * holds this call's local maximum so that ranks can all-reduce it and call fibd_qa_normalize. */
+ * peak[k] [nvox*3] planar, qa[k] [nvox].  `flags` is a bit set:
+ *   FIB_ODF_NORMALIZE  the global step qa ./= maximum(mean(odf, dims=4)) (gqi.jl:164-168,
+ *                      dsi.jl:263-267) is applied in-stream; without it qa is left un-normalised and
+ *                      *odfmax_dev (device float[2]: {max, nan-flag}) holds this call's local maximum so
+ *                      that ranks can all-reduce it and call fibd_qa_normalize;
+ *   FIB_ODF_PREZEROED  the caller guarantees that every output is already 0 at the voxels outside
+ *                      `mask` (e.g. buffers from a previous call with the same mask); otherwise they
+ *                      are zero-filled here, like the reference's freshly allocated volumes.
+ * Only voxels inside the mask are computed: the mask is compacted on the device into a voxel list
+ * (reconstruction) and a list of 64-voxel tiles (peak finder), so cost scales with the mask. */
+#define FIB_ODF_NORMALIZE 1
+#define FIB_ODF_PREZEROED 2
 int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const uint8_t *mask, int64_t nvox,
                  float *pdf, float *odf, float *const peak[3], float *const qa[3],
-                 float *odfmax_dev, int normalize, void *stream);
+                 float *odfmax_dev, int flags, void *stream);
 /* qa[k] ./= odfmax for all voxels (gqi.jl:166-168) */
 int fibd_qa_normalize(float *const qa[3], int64_t nvox, float odfmax, void *stream);
 

@@ -150,3 +150,62 @@ def test_odf_device_tier_unnormalised(fj, orc):
     qa0 = out["qa"][0].cpu().numpy().reshape(mask.shape, order="F")
     same = np.all(out["peak"][0].cpu().numpy().T.reshape(mask.shape + (3,), order="F") == ref["peak"][0], axis=3)
     np.testing.assert_allclose(qa0[same], ref["qa"][0][same], atol=1e-5, rtol=1e-5)
+
+
+def test_sparse_mask_tile_skipping(fj, orc):
+    """ball mask inside a larger volume: whole waves / workgroups / tiles lie outside the mask and are skipped"""
+    from fibers_jl_amd import phantom
+    shape = (40, 24, 20)
+    bval, bvec = phantom.scheme_gqi(2, 12, (1000.0, 2500.0), 3)
+    dwi, _, _ = phantom.make_volume(shape, bval, bvec, seed=12, crossing=True)
+    mask = phantom.ball_mask(*shape, radius=7.5)
+    assert 0.02 < mask.mean() < 0.2
+    sph = fj.sphere_642
+    ref = orc.gqi_rec(dwi, mask, bval, bvec, sph.vertices, sph.faces, 1.25, nthreads=4)
+    got = fj.gqi_rec(fj.MRI(dwi, bval, bvec), fj.MRI(mask), sph)
+    _check_odf_rec(got.odf.vol, [p.vol for p in got.peak], [q.vol[..., 0] for q in got.qa], ref, mask, label="ball")
+    assert all((q.vol[..., 0][mask == 0] == 0).all() for q in got.qa)
+    b2, g2 = phantom.scheme_dti(12, 2)
+    d2, _, _ = phantom.make_volume(shape, b2, g2, seed=13)
+    r2 = orc.dti_fit(d2, mask, b2, g2, nthreads=4)
+    t2 = fj.dti_fit(fj.MRI(d2, b2, g2), fj.MRI(mask))
+    from util import assert_dti_close
+    assert_dti_close({k: getattr(t2, k).vol for k in fj.dti.DTI_FIELDS}, r2, mask, label="ball")
+
+
+@pytest.mark.gpu
+def test_mask_compaction_device_tier(fj):
+    """device tier: outputs outside the mask are zero-filled over stale buffers; FIB_ODF_PREZEROED skips that fill and
+    gives the same volumes when the buffers are already zero there; an empty mask yields all zeros (odfmax 0);
+    a scattered mask gives the same per-voxel results as the all-ones run (compaction only moves columns)"""
+    import torch
+    from fibers_jl_amd import phantom
+    dev = torch.device("cuda", 0)
+    shape = (37, 11, 9)                                    # odd voxel count: ragged tiles and unaligned rows
+    nvox = shape[0] * shape[1] * shape[2]
+    bval, bvec = phantom.scheme_gqi(2, 10, (1000.0, 2000.0), 5)
+    dwi_h, _, _ = phantom.make_volume(shape, bval, bvec, seed=3, crossing=True)
+    dwi = torch.from_numpy(np.ascontiguousarray(np.moveaxis(dwi_h, -1, 0).reshape(len(bval), -1))).to(dev)
+    # same linearisation for every run, so any fixed order works for this comparison
+    plan = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642)
+    ones = torch.ones(nvox, dtype=torch.uint8, device=dev)
+    full = fj.odf_rec_device(plan, dwi, ones, normalize=False)
+    rng = np.random.default_rng(5)
+    m_h = (rng.random(nvox) < 0.3).astype(np.uint8)
+    m_h[:300] = 0                                          # whole tiles outside the mask
+    m = torch.from_numpy(m_h).to(dev)
+    out = fj.odf_rec_device(plan, dwi, m, normalize=False)
+    stale = {k: ([t.clone().fill_(7.0) for t in v] if isinstance(v, list) else v.clone().fill_(7.0)) for k, v in out.items()}
+    got = fj.odf_rec_device(plan, dwi, m, out=stale, normalize=False)
+    live = m.bool()
+    for a, b, c in [(got["odf"], out["odf"], full["odf"])] + [(got["peak"][k], out["peak"][k], full["peak"][k]) for k in range(3)] \
+            + [(got["qa"][k], out["qa"][k], full["qa"][k]) for k in range(3)]:
+        assert torch.equal(a, b)
+        assert (a.reshape(-1, nvox)[:, ~live] == 0).all()
+        assert torch.equal(a.reshape(-1, nvox)[:, live], c.reshape(-1, nvox)[:, live])
+    pre = fj.odf_rec_device(plan, dwi, m, out=got, normalize=False, out_prezeroed=True)
+    assert torch.equal(pre["odf"], out["odf"]) and all(torch.equal(pre["qa"][k], out["qa"][k]) for k in range(3))
+    assert float(got["odfmax"][0]) == float(torch.maximum(out["odf"].mean(0).max(), torch.zeros((), device=dev)))
+    empty = fj.odf_rec_device(plan, dwi, torch.zeros_like(m), out=stale, normalize=False)
+    assert float(empty["odf"].abs().max()) == 0.0 and float(empty["odfmax"][0]) == 0.0
+    assert all(float(q.abs().max()) == 0.0 for q in empty["qa"])

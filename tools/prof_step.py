@@ -16,6 +16,8 @@ SHAPE = (140, 140, 140)
 nvox = 140 ** 3
 dev = torch.device("cuda", 0)
 mask = torch.ones(nvox, dtype=torch.uint8, device=dev)
+if os.environ.get("PROF_BALL_MASK"):
+    mask = phantom.ball_mask_torch(SHAPE, dev)          # 36 % of the volume, like a brain mask
 if what == "gqi":
     bval, bvec = phantom.scheme_gqi()
     dwi, _ = phantom.make_dwi_torch(SHAPE, bval, bvec, 3, dev)
