@@ -28,6 +28,7 @@ constexpr int WG_VOX = 128;   // voxels per workgroup (4 waves x 32)
 
 struct GemmArgs {
     const float *At;          // [ntile_m][Kpad][MW]  K-major tiles (MW = gemm_row_stride(MB, NX)), zero padded
+    const void *At3;          // split-bf16 kernel: [ntile_m][Kpad/16][3 pieces][MB][64 lanes][8 bf16] (+ 1 KiB of f32 extra rows)
     const float *S;           // [K][nvox] planar DWI
     const int32_t *vidx;      // [nlive] voxels inside the mask, ascending (mask_compact_*): lane -> voxel gather / scatter
     const int32_t *nlive;     // device count of vidx
@@ -75,12 +76,86 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // no per-stage v_add for LDS addresses (they would cost MFMA time, see above).
 __host__ __device__ constexpr int gemm_row_stride(int mb, int nx) { return (mb * 32 + (nx > 0 ? 16 : 0) + 63) / 64 * 64; }
 
+// Epilogue shared by the two GEMM kernels (the C/D layout of the 32x32 MFMAs does not depend on the input type):
+// "any sample > 0" (gqi.jl:142, dsi.jl:207), NaN/Inf poisoning, the DSI 1/sum(p) scale, row -> output mapping.
+template <int MB, int NX>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[MB], float (&xacc)[NX > 0 ? NX : 1], float vmax, float vnf,
+                                              bool inb, int64_t vox, int kh, int tile_m, uint32_t c_off) {
+    constexpr int ROWS = MB * 32 + NX;
+    const char *Sbase = reinterpret_cast<const char *>(a.S);
+    // ---- epilogue: the two k-halves of a voxel live in lanes l and l^32 -----------------------------------
+    float pm = fmaxf(vmax, __shfl_xor(vmax, 32));
+    float pn = vnf + __shfl_xor(vnf, 32);
+    const bool nonfinite = pn != pn;                    // a NaN sample makes every output NaN (NaN * A[v,i] for all v)
+    const bool valid = inb && (pm > 0.0f || nonfinite);
+    const bool do_scale = a.scale_frame >= 0;
+    float scale = 1.0f;
+    if (do_scale) {
+        float s = *reinterpret_cast<const float *>(Sbase + (int64_t)a.scale_frame * a.stride * 4 + c_off);
+        s = s < 0.0f ? 0.0f : s;
+        scale = 1.0f / (a.scale_coef * s);              // p ./ sum(p), dsi.jl:225 (0 -> Inf/NaN like the reference)
+    }
+    if (nonfinite) scale = __builtin_nanf("");
+    const bool plain = __all(valid && !nonfinite) && !do_scale;   // wave-uniform: store the accumulators as they are
+    const float mulv = valid ? scale : 0.0f;
+#pragma unroll
+    for (int x = 0; x < NX; x++) xacc[x] += __shfl_xor(xacc[x], 32);
+    if (!inb) return;
+    const uint32_t o_off = (uint32_t)((vox + (int64_t)4 * kh * a.stride) * 4);   // < 2^32: nvox <= 2^27
+    auto row_ptr = [&](int row) -> char * {             // wave-uniform row base
+        return reinterpret_cast<char *>(row >= a.nrow0 ? a.out1 + (int64_t)(row - a.nrow0) * a.stride
+                                                       : a.out0 + (int64_t)row * a.stride);
+    };
+    const bool mapped = a.rowA != nullptr;
+#pragma unroll
+    for (int m = 0; m < MB; m++) {
+        const int row0 = tile_m * ROWS + m * 32;        // wave-uniform
+        if (row0 >= a.M) break;
+        const bool whole = row0 + 32 <= a.M && (row0 >= a.nrow0 || (row0 + 32 <= a.nrow0 && !mapped));   // uniform fast path
+        char *base = row_ptr(row0);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int dr = (r & 3) + 8 * (r >> 2);      // row within the block, before the lane-half offset
+            float v = acc[m][r];
+            if (!plain) v = valid ? v * mulv : 0.0f;
+            if (whole) {
+                *reinterpret_cast<float *>(base + (int64_t)dr * a.stride * 4 + o_off) = v;
+            } else {
+                const int row = row0 + dr + 4 * kh;
+                if (row >= a.M) continue;
+                if (mapped && row < a.nrow0) {           // symmetric DSI: p(r) = p(-r), one computed row feeds two frames
+                    const int fa = a.rowA[row], fb = a.rowB[row];
+                    a.out0[(int64_t)fa * a.stride + vox] = v;
+                    if (fb >= 0) a.out0[(int64_t)fb * a.stride + vox] = v;
+                } else {
+                    *reinterpret_cast<float *>(row_ptr(row) + c_off) = v;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < NX; x++) {
+        const int row = tile_m * ROWS + MB * 32 + x;    // wave-uniform
+        if (row >= a.M) break;
+        float v = xacc[x];
+        if (!plain) v = valid ? v * mulv : 0.0f;
+        if (kh == 0) {
+            if (mapped && row < a.nrow0) {
+                const int fa = a.rowA[row], fb = a.rowB[row];
+                a.out0[(int64_t)fa * a.stride + vox] = v;
+                if (fb >= 0) a.out0[(int64_t)fb * a.stride + vox] = v;
+            } else {
+                *reinterpret_cast<float *>(row_ptr(row) + c_off) = v;
+            }
+        }
+    }
+}
+
 template <int MB, int NX>
 __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
     constexpr int MW = gemm_row_stride(MB, NX);         // LDS row stride (floats)
     constexpr int TILE = KT * MW;                       // floats per stage
     constexpr int NPIECE = TILE * 4 / 1024;
-    constexpr int ROWS = MB * 32 + NX;                  // output rows per M tile
     static_assert((TILE * 4) % 1024 == 0, "stage must be a whole number of 1-KiB pieces");
     __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -212,72 +287,151 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: the two k-halves of a voxel live in lanes l and l^32 -----------------------------------
-    float pm = fmaxf(vmax, __shfl_xor(vmax, 32));
-    float pn = vnf + __shfl_xor(vnf, 32);
-    const bool nonfinite = pn != pn;                    // a NaN sample makes every output NaN (NaN * A[v,i] for all v)
-    const bool valid = inb && (pm > 0.0f || nonfinite);
-    const bool do_scale = a.scale_frame >= 0;
-    float scale = 1.0f;
-    if (do_scale) {
-        float s = *reinterpret_cast<const float *>(Sbase + (int64_t)a.scale_frame * a.stride * 4 + c_off);
-        s = s < 0.0f ? 0.0f : s;
-        scale = 1.0f / (a.scale_coef * s);              // p ./ sum(p), dsi.jl:225 (0 -> Inf/NaN like the reference)
-    }
-    if (nonfinite) scale = __builtin_nanf("");
-    const bool plain = __all(valid && !nonfinite) && !do_scale;   // wave-uniform: store the accumulators as they are
-    const float mulv = valid ? scale : 0.0f;
-#pragma unroll
-    for (int x = 0; x < NX; x++) xacc[x] += __shfl_xor(xacc[x], 32);
-    if (!inb) return;
-    const uint32_t o_off = (uint32_t)((vox + (int64_t)4 * kh * a.stride) * 4);   // < 2^32: nvox <= 2^27
-    auto row_ptr = [&](int row) -> char * {             // wave-uniform row base
-        return reinterpret_cast<char *>(row >= a.nrow0 ? a.out1 + (int64_t)(row - a.nrow0) * a.stride
-                                                       : a.out0 + (int64_t)row * a.stride);
+    gemm_epilogue<MB, NX>(a, acc, xacc, vmax, vnf, inb, vox, kh, tile_m, c_off);
+}
+
+// ---- K2/K5, second form: the same f32 contraction on the bf16 matrix cores (16x the f32 MFMA rate) ----------
+// An f32 number is EXACTLY the sum of three bf16 numbers (3 x 8 significant bits, round-to-nearest pieces):
+//   a = a1 + a2 + a3 (split once on the host),   s = s1 + s2 + s3 (split in registers as the samples arrive),
+// and a product of two bf16 numbers is exact in f32.  a*s = sum of the nine piece products; the six kept here
+//   a1 s1 + (a1 s2 + a2 s1) + (a1 s3 + a2 s2 + a3 s1)
+// miss only a2 s3 + a3 s2 + a3 s3 <= 2^-25 |a s|: less than half an ulp of the f32 product, i.e. every term enters
+// the f32 accumulator as accurately as the f32 `fma` chain's own product rounding (measured against a float64
+// contraction the result is as close as the f32-MFMA kernel's: tools/gemm_accuracy.py).  Six
+// v_mfma_f32_32x32x16_bf16 (32 cycles each, K = 16) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each):
+// 192 instead of 512 matrix-core cycles per 16 frames, which moves the kernel from the FP32-MFMA roof to
+// roughly the HBM roof.  The bf16 MFMA leaves 24 of its 32 cycles free for other issue, so the splitting
+// (about 20 VALU per sample pair), the A-fragment reads (ds_read_b128) and the sample loads hide beneath it.
+// Layout: lane l (r = l & 31, h = l >> 5) holds A[row r][k = 8h + j] / S[k = 8h + j][voxel r], j = 0..7; a stage
+// (16 frames) of the matrix is 3 pieces x MB blocks x 1 KiB in exactly the order the lanes read it (linear
+// ds_read_b128: conflict free) followed by 1 KiB holding the NX extra rows in f32.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {      // round-to-nearest-even, NaN stays NaN
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+template <int MB, int NX>
+__global__ __launch_bounds__(256, 2) void odf_gemm3_kernel(const GemmArgs a) {
+    constexpr int NPIECE = 3 * MB + (NX > 0 ? 1 : 0);   // 1-KiB pieces per stage
+    constexpr int TILEB = NPIECE * 1024;                // bytes per stage
+    __shared__ __attribute__((aligned(16))) char lds[2 * TILEB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, kh = lane >> 5;
+    const int tile_m = blockIdx.x % a.ntile_m;
+    const int64_t tile_n = blockIdx.x / a.ntile_m;
+    const int64_t slot = tile_n * WG_VOX + wave * 32 + col;
+    const int32_t vraw = a.vidx[slot < a.nvox ? slot : a.nvox - 1];
+    const int ntiles = a.Kpad / KT;
+    const char *Abase = reinterpret_cast<const char *>(a.At3) + (size_t)tile_m * ntiles * TILEB;
+    const uint32_t a_off = (uint32_t)lane * 16;
+    auto stage_A = [&](int t, int buf) {
+        const char *g = Abase + (size_t)t * TILEB;
+        char *l = lds + buf * TILEB;
+        for (int p = wave; p < NPIECE; p += 4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + p * 1024 + a_off),
+                                             (__attribute__((address_space(3))) void *)(l + p * 1024), 16, 0, 0);
     };
-    const bool mapped = a.rowA != nullptr;
-#pragma unroll
-    for (int m = 0; m < MB; m++) {
-        const int row0 = tile_m * ROWS + m * 32;        // wave-uniform
-        if (row0 >= a.M) break;
-        const bool whole = row0 + 32 <= a.M && (row0 >= a.nrow0 || (row0 + 32 <= a.nrow0 && !mapped));   // uniform fast path
-        char *base = row_ptr(row0);
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int dr = (r & 3) + 8 * (r >> 2);      // row within the block, before the lane-half offset
-            float v = acc[m][r];
-            if (!plain) v = valid ? v * mulv : 0.0f;
-            if (whole) {
-                *reinterpret_cast<float *>(base + (int64_t)dr * a.stride * 4 + o_off) = v;
-            } else {
-                const int row = row0 + dr + 4 * kh;
-                if (row >= a.M) continue;
-                if (mapped && row < a.nrow0) {           // symmetric DSI: p(r) = p(-r), one computed row feeds two frames
-                    const int fa = a.rowA[row], fb = a.rowB[row];
-                    a.out0[(int64_t)fa * a.stride + vox] = v;
-                    if (fb >= 0) a.out0[(int64_t)fb * a.stride + vox] = v;
-                } else {
-                    *reinterpret_cast<float *>(row_ptr(row) + c_off) = v;
-                }
-            }
-        }
+    float braw[8];
+    stage_A(0, 0);
+    const int nlive = a.nlive[0];
+    if (tile_n * WG_VOX >= nlive) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
     }
+    const bool inb = slot < nlive;
+    const int64_t vox = inb ? vraw : 0;
+    const uint32_t c_off = (uint32_t)(vox * 4);
+    const uint32_t s_off = (uint32_t)((vox + (int64_t)8 * kh * a.stride) * 4);   // frame 8h of the stage, this voxel (nvox <= 2^26)
+    const char *Sbase = reinterpret_cast<const char *>(a.S);
+    const uint32_t row_bytes = (uint32_t)(a.stride * 4);
+    // sample j of the lane = frame t*16 + 8h + j: the resource of frame t*16 + j spans 9 rows (or 1, or none, at the
+    // end of the frame list: lanes past it read 0.0 without a memory access, and the padded columns of A are zero)
+    auto load_B = [&](int t) {
+        const char *fb = Sbase + (int64_t)t * KT * row_bytes;
+        int rem = a.K - t * KT;
 #pragma unroll
-    for (int x = 0; x < NX; x++) {
-        const int row = tile_m * ROWS + MB * 32 + x;    // wave-uniform
-        if (row >= a.M) break;
-        float v = xacc[x];
-        if (!plain) v = valid ? v * mulv : 0.0f;
-        if (kh == 0) {
-            if (mapped && row < a.nrow0) {
-                const int fa = a.rowA[row], fb = a.rowB[row];
-                a.out0[(int64_t)fa * a.stride + vox] = v;
-                if (fb >= 0) a.out0[(int64_t)fb * a.stride + vox] = v;
-            } else {
-                *reinterpret_cast<float *>(row_ptr(row) + c_off) = v;
-            }
+        for (int j = 0; j < 8; j++) {
+            const uint32_t nrec = rem > 8 ? 9u * row_bytes : (rem > 0 ? row_bytes : 0u);
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(rem > 0 ? fb : Sbase), 0, (int)nrec, 0x00020000);
+            braw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)s_off, 0, 0));
+            fb += row_bytes;
+            rem -= 1;
         }
+    };
+
+    f32x16 acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[m][r] = 0.0f;
+    float xacc[NX > 0 ? NX : 1];
+#pragma unroll
+    for (int x = 0; x < (NX > 0 ? NX : 1); x++) xacc[x] = 0.0f;
+    float vmax = 0.0f, vnf = 0.0f;
+
+    load_B(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    for (int t = 0; t < ntiles; t++) {
+        const int cur = t & 1;
+        const char *L = lds + cur * TILEB;
+        // ---- clamp (gqi.jl:140, dsi.jl:209), positivity / non-finite tracking, exact 3-way bf16 split -------------
+        float c[8];
+        u32x4_t bp[3];
+        const uint32_t eff = a.has_ineff ? (a.effbits[t] >> (8 * kh)) : 0xffu;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const float x0 = braw[2 * jj], x1 = braw[2 * jj + 1];
+            asm("v_max_f32 %0, 0, %1" : "=v"(c[2 * jj]) : "v"(x0));
+            asm("v_max_f32 %0, 0, %1" : "=v"(c[2 * jj + 1]) : "v"(x1));
+            if (a.has_ineff) {
+                vmax = fmaxf(vmax, ((eff >> (2 * jj)) & 1u) ? x0 : 0.0f);
+                vmax = fmaxf(vmax, ((eff >> (2 * jj + 1)) & 1u) ? x1 : 0.0f);
+            } else {
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(vmax) : "v"(vmax), "v"(x0), "v"(x1));
+            }
+            vnf = __builtin_fmaf(x0, 0.0f, vnf);
+            vnf = __builtin_fmaf(x1, 0.0f, vnf);
+            const uint32_t h = cvt_pk_bf16(c[2 * jj], c[2 * jj + 1]);
+            const float r0 = c[2 * jj] - __uint_as_float(h << 16), r1 = c[2 * jj + 1] - __uint_as_float(h & 0xffff0000u);   // exact
+            const uint32_t m = cvt_pk_bf16(r0, r1);
+            const float q0 = r0 - __uint_as_float(m << 16), q1 = r1 - __uint_as_float(m & 0xffff0000u);                     // exact
+            const uint32_t l = cvt_pk_bf16(q0, q1);                                                                        // exact
+            bp[0][jj] = h; bp[1][jj] = m; bp[2][jj] = l;
+        }
+        if (NX > 0) {                                   // extra rows: plain f32 fma on the clamped samples
+            const float *LX = reinterpret_cast<const float *>(L + 3 * MB * 1024) + 8 * kh;
+#pragma unroll
+            for (int x = 0; x < NX; x++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) xacc[x] = __builtin_fmaf(LX[x * 16 + j], c[j], xacc[x]);
+        }
+        if (t + 1 < ntiles) {
+            stage_A(t + 1, cur ^ 1);
+            load_B(t + 1);
+        }
+        const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, bp[0]), b1 = __builtin_bit_cast(bf16x8_t, bp[1]), b2 = __builtin_bit_cast(bf16x8_t, bp[2]);
+        const bf16x8_t *LA = reinterpret_cast<const bf16x8_t *>(L) + lane;
+#pragma unroll
+        for (int m = 0; m < MB; m++) {
+            const bf16x8_t a0 = LA[(0 * MB + m) * 64], a1 = LA[(1 * MB + m) * 64], a2 = LA[(2 * MB + m) * 64];
+            // smallest terms first
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[m], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
     }
+    gemm_epilogue<MB, NX>(a, acc, xacc, vmax, vnf, inb, vox, kh, tile_m, c_off);
 }
 
 // ---- mask compaction ---------------------------------------------------------------------------------------
@@ -804,6 +958,8 @@ struct fib_odf_plan {
     mutable fib::DevBuf<float> folded_dwi;           // [gK x nvox] scratch of the fold pre-pass (grow-only)
     std::vector<float> A;                            // host copy [nrows x nvol] column-major
     fib::DevBuf<float> At, verts;
+    fib::DevBuf<uint16_t> At3;                       // split-bf16 image of G (odf_gemm3_kernel), empty in f32-MFMA mode
+    bool split_bf16 = false;
     fib::DevBuf<uint32_t> effbits;
     fib::DevBuf<int32_t> nbr, nbr64; // [nvert_even][deg_pad] LDS row of each neighbour (sentinel-padded)
     int deg_pad = 6, rows_pad = 0;
@@ -845,6 +1001,50 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
             const int tm = r / ROWS, rr = r % ROWS;
             At[((size_t)tm * p->Kpad + k) * MW + rr] = p->G[r + (size_t)M * k];
         }
+    // which matrix-core path runs the contraction: "bf16x3" (default; f32-exact products from three bf16 pieces per
+    // operand) or "f32" (v_mfma_f32_32x32x2_f32: a k-ordered f32 fma chain, bit-identical to the oracle's loop)
+    {
+        const char *e = getenv("FIBERS_ODF_GEMM");
+        p->split_bf16 = !(e && (!strcmp(e, "f32") || !strcmp(e, "F32")));
+    }
+    if (p->split_bf16) {
+        const int npiece = 3 * p->MB + (p->NX > 0 ? 1 : 0), nst = p->Kpad / KT;
+        std::vector<uint16_t> A3((size_t)p->ntile_m * nst * npiece * 512, 0);
+        auto bf16_rn = [](float f) -> uint16_t {
+            uint32_t u; memcpy(&u, &f, 4);
+            if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+            u += 0x7fffu + ((u >> 16) & 1u);
+            return (uint16_t)(u >> 16);
+        };
+        auto bf16_f = [](uint16_t h) -> float { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+        for (int tm = 0; tm < p->ntile_m; tm++)
+            for (int t = 0; t < nst; t++) {
+                uint16_t *st = A3.data() + ((size_t)tm * nst + t) * npiece * 512;
+                for (int m = 0; m < p->MB; m++)
+                    for (int l = 0; l < 64; l++)
+                        for (int j = 0; j < 8; j++) {
+                            const int row = tm * ROWS + m * 32 + (l & 31), k = t * KT + 8 * (l >> 5) + j;
+                            if (row >= M || row >= (tm + 1) * ROWS || k >= K) continue;
+                            const float v = p->G[row + (size_t)M * k];
+                            const uint16_t h1 = bf16_rn(v);
+                            const float r1 = v - bf16_f(h1);
+                            const uint16_t h2 = bf16_rn(r1);
+                            const float r2 = r1 - bf16_f(h2);
+                            const uint16_t h3 = bf16_rn(r2);
+                            const uint16_t hs[3] = {h1, h2, h3};
+                            for (int pc = 0; pc < 3; pc++) st[((size_t)(pc * p->MB + m) * 64 + l) * 8 + j] = hs[pc];
+                        }
+                float *ex = reinterpret_cast<float *>(st + (size_t)3 * p->MB * 512);
+                for (int x = 0; x < p->NX; x++)
+                    for (int kk = 0; kk < KT; kk++) {
+                        const int row = tm * ROWS + p->MB * 32 + x, k = t * KT + kk;
+                        if (row < M && k < K) ex[x * 16 + kk] = p->G[row + (size_t)M * k];
+                    }
+            }
+        int rc3 = p->At3.alloc(A3.size());
+        if (rc3 != FIB_OK) return rc3;
+        FIB_HIP(hipMemcpy(p->At3.p, A3.data(), A3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     std::vector<int32_t> nbr32;
     int rc = fib::host_neighbours(faces, nfaces, nverts, nbr32, &p->maxdeg);
     if (rc != FIB_OK) return rc;
@@ -994,7 +1194,8 @@ namespace {
 
 template <int MB, int NX>
 void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
-    hipLaunchKernelGGL((odf_gemm_kernel<MB, NX>), dim3(grid), dim3(256), 0, st, ga);
+    if (ga.At3) hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX>), dim3(grid), dim3(256), 0, st, ga);
+    else hipLaunchKernelGGL((odf_gemm_kernel<MB, NX>), dim3(grid), dim3(256), 0, st, ga);
 }
 
 size_t peaks_smem(const fib_odf_plan *p) {
@@ -1082,7 +1283,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         hipLaunchKernelGGL(mask_write_kernel, dim3(nb), dim3(256), 0, st, mask, nvox, plan->live_blocks.p, plan->live_vox.p, plan->live_tiles.p);
         FIB_HIP(hipGetLastError());
     }
-    ga.At = plan->At.p; ga.S = dwi; ga.vidx = plan->live_vox.p; ga.nlive = plan->live_counts.p; ga.effbits = plan->effbits.p;
+    ga.At = plan->At.p; ga.At3 = (plan->split_bf16 && nvox <= ((int64_t)1 << 26)) ? plan->At3.p : nullptr; ga.S = dwi; ga.vidx = plan->live_vox.p; ga.nlive = plan->live_counts.p; ga.effbits = plan->effbits.p;
     ga.out0 = pdf; ga.out1 = odf; ga.nvox = nvox;
     ga.K = plan->gK; ga.Kpad = plan->Kpad; ga.M = plan->gM; ga.nrow0 = plan->gRow0; ga.ntile_m = plan->ntile_m;
     if (plan->folded) {
