@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 SHAPE = (140, 140, 140)
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: FP32 MFMA (v_mfma_f32_32x32x2_f32) dense peak
+PEAK_BF16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: BF16 MFMA dense peak (v_mfma_f32_32x32x16_bf16, 32 cycles each)
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured copy)
 
 
@@ -34,7 +35,7 @@ def prof_get(L, name):
     return ms.value, n.value
 
 
-def cpu_baseline_gqi(bval, bvec, sph, seed, target_s=12.0):
+def cpu_baseline_gqi(bval, bvec, sph, seed, target_s=15.0):
     """the oracle (C restatement of the reference CPU path, z-slice threading) on a bounded z-slab"""
     from oracle import oracle as orc
     from fibers_jl_amd import phantom
@@ -51,10 +52,14 @@ def cpu_baseline_gqi(bval, bvec, sph, seed, target_s=12.0):
     t_probe = run(cores)                                 # one slice per thread
     nz = int(max(cores, min(SHAPE[2], round(cores * target_s / max(t_probe, 1e-3) / cores) * cores)))
     t = run(nz)
+    reps = 1
+    while nz == SHAPE[2] and t * reps < target_s and reps < 8:      # the whole volume is short of the sample: repeat it
+        t = min(t, run(nz)) if False else (t * reps + run(nz)) / (reps + 1)
+        reps += 1
     nvox = nx * ny * nz
     return dict(value=nvox / t / 1e6, unit="Mvoxels/s", cores=cores, kind="port",
-                sample="gqi_rec oracle (C/OpenMP restatement of gqi.jl:109-171, z-slice threads) on a %dx%dx%d x %d-frame slab, %.1f s"
-                       % (nx, ny, nz, len(bval), t))
+                sample="gqi_rec oracle (C/OpenMP restatement of gqi.jl:109-171, z-slice threads) on a %dx%dx%d x %d-frame slab, "
+                       "%d pass(es), %.1f s each" % (nx, ny, nz, len(bval), reps, t))
 
 
 def main():
@@ -131,13 +136,25 @@ def main():
     gemm_avg_ms = gemm_ms / max(gemm_n, 1)
     achieved = flops / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0
     gemm_bytes = (4.0 * nvol + 1 + 4.0 * nvert) * nvox     # read DWI + mask, write ODF
-    roofline = dict(bound="mfma", kernel="odf_gemm_kernel<MB=10,NX=1> (v_mfma_f32_32x32x2_f32; 320 rows on MFMA + 1 row on VALU)", achieved=achieved,
-                    peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_F32_TFLOPS,
-                    avg_kernel_ms=gemm_avg_ms, launches=gemm_n, traffic=None,
-                    hbm_secondary=dict(achieved=gemm_bytes / (gemm_avg_ms * 1e-3) / 1e9 if gemm_n else 0.0,
-                                       peak=PEAK_HBM_GBS, unit="GB/s", algorithmic_bytes=gemm_bytes),
-                    peaks_kernel=dict(avg_kernel_ms=peaks_ms / max(peaks_n, 1),
-                                      hbm_gbs=(4.0 * nvert + 48) * nvox / (peaks_ms / max(peaks_n, 1) * 1e-3) / 1e9 if peaks_n else 0.0))
+    split = os.environ.get("FIBERS_ODF_GEMM", "bf16x3").lower() != "f32"
+    hbm2 = dict(achieved=gemm_bytes / (gemm_avg_ms * 1e-3) / 1e9 if gemm_n else 0.0, peak=PEAK_HBM_GBS, unit="GB/s",
+                algorithmic_bytes=gemm_bytes, frac=gemm_bytes / (gemm_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if gemm_n else 0.0)
+    pk = dict(avg_kernel_ms=peaks_ms / max(peaks_n, 1),
+              hbm_gbs=(4.0 * nvert + 48) * nvox / (peaks_ms / max(peaks_n, 1) * 1e-3) / 1e9 if peaks_n else 0.0)
+    if split:
+        # every f32 product = 6 exact bf16 piece products -> the matrix cores execute 6 x the algorithmic flops (320 of the
+        # 321 rows; K padded 270 -> 272); the binding roof is the BF16 MFMA peak / 6 for the algorithmic f32 flops
+        peak_eff = PEAK_BF16_TFLOPS / 6.0
+        roofline = dict(bound="mfma", kernel="odf_gemm3_kernel<MB=10,NX=1,NW=8> (v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 splits "
+                                             "of both f32 operands: 6 piece products per f32 product; 320 rows on MFMA + 1 row on VALU)",
+                        achieved=achieved, peak=peak_eff, unit="TFLOP/s", frac=achieved / peak_eff,
+                        note="achieved = algorithmic f32 flops (2*321*270 per voxel) / kernel time; peak = 2500 TFLOP/s dense BF16 / 6 piece "
+                             "products; executed BF16 MFMA rate = %.0f TFLOP/s of 2500" % (6.0 * 2.0 * 320 * 272 * nvox / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0),
+                        avg_kernel_ms=gemm_avg_ms, launches=gemm_n, traffic=None, hbm_secondary=hbm2, peaks_kernel=pk)
+    else:
+        roofline = dict(bound="mfma", kernel="odf_gemm_kernel<MB=10,NX=1> (v_mfma_f32_32x32x2_f32; 320 rows on MFMA + 1 row on VALU)", achieved=achieved,
+                        peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_F32_TFLOPS,
+                        avg_kernel_ms=gemm_avg_ms, launches=gemm_n, traffic=None, hbm_secondary=hbm2, peaks_kernel=pk)
     tr_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr_file):
         try:
@@ -224,7 +241,7 @@ def main():
         line = dict(metric="Mvoxels/s fit (GQI ODF + peaks, 140^3 x 270-dir); Mpoints/s streamline in extra",
                     value=value, unit="Mvoxels/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
-                    dtype="f32", data="synthetic",
+                    dtype="f32" if not split else "f32 (exact 3xbf16 operand splits on the bf16 matrix cores, f32 accumulate)", data="synthetic",
                     config=dict(workload="gqi_rec + find_peaks + qa normalisation, 140x140x140 x 270 frames "
                                          "(18 x b=5 + 84 dirs x {1000,2000,3000}), sphere_642, mask = all ones, "
                                          "one volume per GPU", voxels_per_gpu=nvox, frames=nvol, odf_vertices=nvert,

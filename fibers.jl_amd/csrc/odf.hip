@@ -41,6 +41,10 @@ struct GemmArgs {
     int scale_frame;          // DSI: frame whose clamped sample times scale_coef is sum(p); -1: no scaling
     float scale_coef;
     int has_ineff;
+    unsigned long long *dbg;      // timing experiments only (FIBERS_GEMM3_STAMP): 6 words per workgroup
+    const float *Aextra;          // split-bf16 kernel: f32 coefficients of the NX extra rows [ntile_m][Kpad/16][NX][16]
+    int vec_ok;                   // split-bf16 kernel: output rows are 16-byte aligned (dwordx4 stores allowed)
+    int stagger;                  // split-bf16 kernel: largest start delay of a workgroup, in units of 1024 cycles
     const int32_t *rowA, *rowB;   // optional output-row map for rows < nrow0: row r goes to frames rowA[r] and rowB[r] (>= 0)
 };
 
@@ -80,9 +84,8 @@ __host__ __device__ constexpr int gemm_row_stride(int mb, int nx) { return (mb *
 // "any sample > 0" (gqi.jl:142, dsi.jl:207), NaN/Inf poisoning, the DSI 1/sum(p) scale, row -> output mapping.
 template <int MB, int NX>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[MB], float (&xacc)[NX > 0 ? NX : 1], float vmax, float vnf,
-                                              bool inb, int64_t vox, int kh, int tile_m, uint32_t c_off) {
+                                              bool inb, int64_t vox, int kh, int tile_m, uint32_t c_off, float sraw) {
     constexpr int ROWS = MB * 32 + NX;
-    const char *Sbase = reinterpret_cast<const char *>(a.S);
     // ---- epilogue: the two k-halves of a voxel live in lanes l and l^32 -----------------------------------
     float pm = fmaxf(vmax, __shfl_xor(vmax, 32));
     float pn = vnf + __shfl_xor(vnf, 32);
@@ -91,8 +94,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[M
     const bool do_scale = a.scale_frame >= 0;
     float scale = 1.0f;
     if (do_scale) {
-        float s = *reinterpret_cast<const float *>(Sbase + (int64_t)a.scale_frame * a.stride * 4 + c_off);
-        s = s < 0.0f ? 0.0f : s;
+        const float s = sraw < 0.0f ? 0.0f : sraw;
         scale = 1.0f / (a.scale_coef * s);              // p ./ sum(p), dsi.jl:225 (0 -> Inf/NaN like the reference)
     }
     if (nonfinite) scale = __builtin_nanf("");
@@ -287,7 +289,120 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
         __syncthreads();
     }
 
-    gemm_epilogue<MB, NX>(a, acc, xacc, vmax, vnf, inb, vox, kh, tile_m, c_off);
+    float sraw = 0.0f;
+    if (a.scale_frame >= 0) sraw = *reinterpret_cast<const float *>(Sbase + (int64_t)a.scale_frame * a.stride * 4 + c_off);
+    gemm_epilogue<MB, NX>(a, acc, xacc, vmax, vnf, inb, vox, kh, tile_m, c_off, sraw);
+}
+
+// Epilogue of the split-bf16 kernel.  Fast path (wave-uniform): the wave's 32 voxels are contiguous and 16-byte
+// aligned in memory -> each half of a 32x32 block goes through the wave's 2-KiB LDS tile ([16 rows][32 voxels]; rows
+// r and r+4 interleaved so that both lane halves write different banks) and leaves as 2 dwordx4 stores of 8 rows x 128 B.
+template <int MB, int NX>
+__device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[MB], float (&xacc)[NX > 0 ? NX : 1], float vmax, float vnf,
+                                               bool inb, int64_t vox, int lane, int tile_m, float sraw, char *tr) {
+    constexpr int ROWS = MB * 32 + NX;
+    const int col = lane & 31, kh = lane >> 5;
+    float pm = fmaxf(vmax, __shfl_xor(vmax, 32));
+    float pn = vnf + __shfl_xor(vnf, 32);
+    const bool nonfinite = pn != pn;                    // a NaN sample makes every output NaN (NaN * A[v,i] for all v)
+    const bool valid = inb && (pm > 0.0f || nonfinite);
+    const bool do_scale = a.scale_frame >= 0;
+    float scale = 1.0f;
+    if (do_scale) {
+        const float s = sraw < 0.0f ? 0.0f : sraw;
+        scale = 1.0f / (a.scale_coef * s);              // p ./ sum(p), dsi.jl:225 (0 -> Inf/NaN like the reference)
+    }
+    if (nonfinite) scale = __builtin_nanf("");
+    const bool plain = __all(valid && !nonfinite) && !do_scale;   // wave-uniform: store the accumulators as they are
+    const float mulv = valid ? scale : 0.0f;
+#pragma unroll
+    for (int x = 0; x < NX; x++) xacc[x] += __shfl_xor(xacc[x], 32);
+    const int vox0 = __builtin_amdgcn_readfirstlane((int)vox);
+    const bool contig = a.vec_ok && __all(inb && vox == (int64_t)vox0 + col) && (vox0 & 3) == 0;
+    auto row_ptr = [&](int row) -> char * {
+        return reinterpret_cast<char *>(row >= a.nrow0 ? a.out1 + (int64_t)(row - a.nrow0) * a.stride
+                                                       : a.out0 + (int64_t)row * a.stride);
+    };
+    const bool mapped = a.rowA != nullptr;
+    if (contig) {
+        // LDS tile of half a block (16 rows): logical row r lives in physical row (r & 8) | ((r & 3) << 1) | ((r >> 2) & 1)
+        float *tw = reinterpret_cast<float *>(tr) + kh * 32 + col;                // + physical row of (dr + 4 kh)
+        const int P = lane >> 3;                                                  // physical row (within 8) this lane stores
+        const int lrow = ((P >> 1) & 3) | ((P & 1) << 2);                         // its logical row within the 8
+        const float4 *trd = reinterpret_cast<const float4 *>(tr) + lane;
+        const uint32_t voff = (uint32_t)(vox0 + 4 * (lane & 7)) * 4u;
+#pragma unroll
+        for (int m = 0; m < MB; m++) {
+            const int row0 = tile_m * ROWS + m * 32;    // wave-uniform
+            if (row0 >= a.M) break;
+            const bool whole = row0 + 32 <= a.M && !(mapped && row0 < a.nrow0);   // uniform: no row of the block needs a test
+            char *base = row_ptr(row0) + (int64_t)lrow * a.stride * 4 + voff;     // rows of one output volume are equidistant
+            const bool split_out = row0 < a.nrow0 && row0 + 32 > a.nrow0;         // block straddles pdf | odf
+#pragma unroll
+            for (int hb = 0; hb < 2; hb++) {
+#pragma unroll
+                for (int r = 8 * hb; r < 8 * hb + 8; r++) {
+                    float v = acc[m][r];
+                    if (!plain) v = valid ? v * mulv : 0.0f;
+                    tw[(8 * ((r >> 2) & 1) + 2 * (r & 3)) * 32] = v;   // logical row (r&3) + 8(r>>2) + 4kh
+                }
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const float4 v4 = trd[j * 64];
+                    if (whole && !split_out) {
+                        *reinterpret_cast<float4 *>(base + (int64_t)(16 * hb + 8 * j) * a.stride * 4) = v4;
+                        continue;
+                    }
+                    const int row = row0 + 16 * hb + 8 * j + lrow;
+                    if (row >= a.M) continue;
+                    if (mapped && row < a.nrow0) {       // symmetric DSI: p(r) = p(-r), one computed row feeds two frames
+                        const int fa = a.rowA[row], fb = a.rowB[row];
+                        *reinterpret_cast<float4 *>(reinterpret_cast<char *>(a.out0 + (int64_t)fa * a.stride) + voff) = v4;
+                        if (fb >= 0) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(a.out0 + (int64_t)fb * a.stride) + voff) = v4;
+                    } else {
+                        *reinterpret_cast<float4 *>(row_ptr(row) + voff) = v4;
+                    }
+                }
+            }
+        }
+    } else if (inb) {
+        const uint32_t c_off = (uint32_t)(vox * 4);
+#pragma unroll
+        for (int m = 0; m < MB; m++) {
+            const int row0 = tile_m * ROWS + m * 32;
+            if (row0 >= a.M) break;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                float v = acc[m][r];
+                if (!plain) v = valid ? v * mulv : 0.0f;
+                if (row >= a.M) continue;
+                if (mapped && row < a.nrow0) {
+                    const int fa = a.rowA[row], fb = a.rowB[row];
+                    a.out0[(int64_t)fa * a.stride + vox] = v;
+                    if (fb >= 0) a.out0[(int64_t)fb * a.stride + vox] = v;
+                } else {
+                    *reinterpret_cast<float *>(row_ptr(row) + c_off) = v;
+                }
+            }
+        }
+    }
+    if (inb && kh == 0) {
+#pragma unroll
+        for (int x = 0; x < NX; x++) {
+            const int row = tile_m * ROWS + MB * 32 + x;    // wave-uniform
+            if (row >= a.M) break;
+            float v = xacc[x];
+            if (!plain) v = valid ? v * mulv : 0.0f;
+            if (mapped && row < a.nrow0) {
+                const int fa = a.rowA[row], fb = a.rowB[row];
+                a.out0[(int64_t)fa * a.stride + vox] = v;
+                if (fb >= 0) a.out0[(int64_t)fb * a.stride + vox] = v;
+            } else {
+                *reinterpret_cast<float *>(row_ptr(row) + (uint32_t)(vox * 4)) = v;
+            }
+        }
+    }
 }
 
 // ---- K2/K5, second form: the same f32 contraction on the bf16 matrix cores (16x the f32 MFMA rate) ----------
@@ -296,15 +411,21 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
 // and a product of two bf16 numbers is exact in f32.  a*s = sum of the nine piece products; the six kept here
 //   a1 s1 + (a1 s2 + a2 s1) + (a1 s3 + a2 s2 + a3 s1)
 // miss only a2 s3 + a3 s2 + a3 s3 <= 2^-25 |a s|: less than half an ulp of the f32 product, i.e. every term enters
-// the f32 accumulator as accurately as the f32 `fma` chain's own product rounding (measured against a float64
-// contraction the result is as close as the f32-MFMA kernel's: tools/gemm_accuracy.py).  Six
+// the f32 accumulator at least as accurately as the f32 `fma` chain's own product rounding (measured against a
+// float64 contraction the result is closer than the f32-MFMA kernel's: tools/gemm_accuracy.py).  Six
 // v_mfma_f32_32x32x16_bf16 (32 cycles each, K = 16) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each):
-// 192 instead of 512 matrix-core cycles per 16 frames, which moves the kernel from the FP32-MFMA roof to
-// roughly the HBM roof.  The bf16 MFMA leaves 24 of its 32 cycles free for other issue, so the splitting
-// (about 20 VALU per sample pair), the A-fragment reads (ds_read_b128) and the sample loads hide beneath it.
+// 192 instead of 512 matrix-core cycles per 16 frames.  The bf16 MFMA leaves 24 of its 32 cycles free for other
+// issue, so the splitting (about 15 VALU per sample pair), the A-fragment reads (ds_read_b128) and the sample loads
+// are software-pipelined one stage ahead and issued between the MFMAs of the current stage.
 // Layout: lane l (r = l & 31, h = l >> 5) holds A[row r][k = 8h + j] / S[k = 8h + j][voxel r], j = 0..7; a stage
 // (16 frames) of the matrix is 3 pieces x MB blocks x 1 KiB in exactly the order the lanes read it (linear
-// ds_read_b128: conflict free) followed by 1 KiB holding the NX extra rows in f32.
+// ds_read_b128: conflict free).  The NX extra rows stay f32: their coefficients come in by scalar loads.
+// Persistent workgroups: NW waves own NW*32 voxels per work item and walk a list of work items; the stage ring
+// (matrix pieces through LDS, samples through registers) runs across work-item boundaries.  Work items are dealt
+// XCD by XCD so that the M tiles of one voxel group (DSI: 3) run side by side on one XCD and share its L2 copy of
+// the samples.  Epilogue: a wave whose 32 voxels are contiguous in memory transposes each 32x32 block through a
+// private 4-KiB LDS tile and writes it with 4 global_store_dwordx4 (8 rows x 128 B each) instead of 16
+// global_store_dword: dword stores are issue-bound at ~6 B/clk/CU (measured: 30 000 cycles for the 161 rows).
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
@@ -314,124 +435,188 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {      // ro
     return r;
 }
 
-template <int MB, int NX>
-__global__ __launch_bounds__(256, 2) void odf_gemm3_kernel(const GemmArgs a) {
-    constexpr int NPIECE = 3 * MB + (NX > 0 ? 1 : 0);   // 1-KiB pieces per stage
+template <int MB, int NX, int NW, bool STAMP = false, int PROBE = 0>
+__global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a) {
+    constexpr int NPIECE = 3 * MB;                      // 1-KiB pieces per stage
     constexpr int TILEB = NPIECE * 1024;                // bytes per stage
-    __shared__ __attribute__((aligned(16))) char lds[2 * TILEB];
+    constexpr int NA = (NPIECE + NW - 1) / NW;          // direct-to-LDS loads per wave and stage (a surplus load repeats the last piece)
+    constexpr int WGV = NW * 32;                        // voxels per work item
+    constexpr int NXA = NX > 0 ? NX : 1;
+    constexpr int XTAB = NX > 0 ? 4096 : 0;             // coefficients of the extra rows, all stages of all M tiles: [ntile_m][NX][Kpad] f32
+    __shared__ __attribute__((aligned(16))) char lds[2 * TILEB + NW * 2048 + XTAB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, kh = lane >> 5;
-    const int tile_m = blockIdx.x % a.ntile_m;
-    const int64_t tile_n = blockIdx.x / a.ntile_m;
-    const int64_t slot = tile_n * WG_VOX + wave * 32 + col;
-    const int32_t vraw = a.vidx[slot < a.nvox ? slot : a.nvox - 1];
     const int ntiles = a.Kpad / KT;
-    const char *Abase = reinterpret_cast<const char *>(a.At3) + (size_t)tile_m * ntiles * TILEB;
     const uint32_t a_off = (uint32_t)lane * 16;
-    auto stage_A = [&](int t, int buf) {
-        const char *g = Abase + (size_t)t * TILEB;
-        char *l = lds + buf * TILEB;
-        for (int p = wave; p < NPIECE; p += 4)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + p * 1024 + a_off),
-                                             (__attribute__((address_space(3))) void *)(l + p * 1024), 16, 0, 0);
-    };
-    float braw[8];
-    stage_A(0, 0);
-    const int nlive = a.nlive[0];
-    if (tile_n * WG_VOX >= nlive) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
+    if (NX > 0) {
+        float *xt = reinterpret_cast<float *>(lds + 2 * TILEB + NW * 2048);
+        for (int i = tid; i < a.ntile_m * NX * a.Kpad; i += NW * 64) xt[i] = a.Aextra[i];
     }
-    const bool inb = slot < nlive;
-    const int64_t vox = inb ? vraw : 0;
-    const uint32_t c_off = (uint32_t)(vox * 4);
-    const uint32_t s_off = (uint32_t)((vox + (int64_t)8 * kh * a.stride) * 4);   // frame 8h of the stage, this voxel (nvox <= 2^26)
     const char *Sbase = reinterpret_cast<const char *>(a.S);
     const uint32_t row_bytes = (uint32_t)(a.stride * 4);
-    // sample j of the lane = frame t*16 + 8h + j: the resource of frame t*16 + j spans 9 rows (or 1, or none, at the
-    // end of the frame list: lanes past it read 0.0 without a memory access, and the padded columns of A are zero)
-    auto load_B = [&](int t) {
-        const char *fb = Sbase + (int64_t)t * KT * row_bytes;
-        int rem = a.K - t * KT;
+    unsigned long long st0 = 0, rt1 = 0, acc_epi = 0;
+    if (STAMP) { st0 = __builtin_amdgcn_s_memtime(); rt1 = __builtin_amdgcn_s_memrealtime(); }
+
+    // ---- work list of this workgroup ---------------------------------------------------------------------------
+    const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int nlive = a.nlive[0];
+    const int ntile_n = (nlive + WGV - 1) / WGV;
+    struct Work { int tile_m; int tile_n; bool valid; };
+    auto work_at = [&](int i) {
+        const int w = wslot + i * nslot;
+        Work r;
+        r.tile_m = w % a.ntile_m;
+        r.tile_n = (w / a.ntile_m) * 8 + xcd;
+        r.valid = r.tile_n < ntile_n;
+        return r;
+    };
+    auto vidx_at = [&](const Work &w) -> int32_t {       // list entry of this lane's voxel (stale / clamped past the end)
+        const int64_t sl = (int64_t)w.tile_n * WGV + wave * 32 + col;
+        return a.vidx[sl < a.nvox ? sl : a.nvox - 1];
+    };
+    Work cur = work_at(0);
+    if (!cur.valid) return;
+    if (a.stagger > 0) {                                 // spread the workgroups' phases so that their store bursts do not coincide
+        const int n = (int)((((blockIdx.x * 2654435761u) >> 20) & 0xfffu) * (unsigned)a.stagger >> 12);
+        for (int k = 0; k < n; k++) __builtin_amdgcn_s_sleep(16);   // 1024 cycles each
+    }
+    int32_t vraw = vidx_at(cur);
+    Work nxt = work_at(1);
+    int32_t vraw_nxt = nxt.valid ? vidx_at(nxt) : 0;
+
+    auto stage_A = [&](int tile_m, int t, int buf) {
+        const char *g = reinterpret_cast<const char *>(a.At3) + ((size_t)tile_m * ntiles + t) * TILEB;
+        char *l = lds + buf * TILEB;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t nrec = rem > 8 ? 9u * row_bytes : (rem > 0 ? row_bytes : 0u);
-            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(rem > 0 ? fb : Sbase), 0, (int)nrec, 0x00020000);
-            braw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)s_off, 0, 0));
-            fb += row_bytes;
-            rem -= 1;
+        for (int i = 0; i < NA; i++) {
+            int p = wave + i * NW;
+            p = p < NPIECE ? p : NPIECE - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + p * 1024 + a_off),
+                                             (__attribute__((address_space(3))) void *)(l + p * 1024), 16, 0, 0);
         }
+    };
+    float braw[8];
+    // sample j of the lane = frame t*16 + 8h + j.  One buffer resource per stage, based at frame t*16 and ending with the
+    // frame list: loads past it return 0.0 without a memory access (the padded columns of A are zero).  The frame
+    // offsets j*row_bytes go in as scalar offsets, the lane's (voxel + 8h rows) as the 32-bit vector offset.
+    auto load_B = [&](int t, uint32_t s_off, bool live) {
+        const int rem = live ? a.K - t * KT : 0;        // frames from this stage's first to the end of the list
+        const uint64_t span = (uint64_t)(rem > 0 ? rem : 0) * row_bytes;
+        const uint32_t nrec = span > 0xffffffffull ? 0xffffffffu : (uint32_t)span;
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(rem > 0 ? Sbase + (int64_t)t * KT * row_bytes : Sbase), 0, (int)nrec, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            braw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)s_off, (int)(j * row_bytes), 0));
+    };
+    auto lane_state = [&](const Work &w, int32_t vr, bool &inb, int64_t &vox, uint32_t &s_off) {
+        inb = (int64_t)w.tile_n * WGV + wave * 32 + col < nlive;
+        vox = inb ? vr : 0;
+        s_off = (uint32_t)((vox + (int64_t)8 * kh * a.stride) * 4);       // frame 8h of a stage, this voxel (nvox <= 2^26)
     };
 
     f32x16 acc[MB];
-#pragma unroll
-    for (int m = 0; m < MB; m++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[m][r] = 0.0f;
-    float xacc[NX > 0 ? NX : 1];
-#pragma unroll
-    for (int x = 0; x < (NX > 0 ? NX : 1); x++) xacc[x] = 0.0f;
+    float xacc[NXA];
     float vmax = 0.0f, vnf = 0.0f;
+    auto clear = [&]() {
+#pragma unroll
+        for (int m = 0; m < MB; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][r] = 0.0f;
+#pragma unroll
+        for (int x = 0; x < NXA; x++) xacc[x] = 0.0f;
+        vmax = 0.0f; vnf = 0.0f;
+    };
+    clear();
 
-    load_B(0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    for (int t = 0; t < ntiles; t++) {
-        const int cur = t & 1;
-        const char *L = lds + cur * TILEB;
-        // ---- clamp (gqi.jl:140, dsi.jl:209), positivity / non-finite tracking, exact 3-way bf16 split -------------
-        float c[8];
-        u32x4_t bp[3];
-        const uint32_t eff = a.has_ineff ? (a.effbits[t] >> (8 * kh)) : 0xffu;
+    // clamp (gqi.jl:140, dsi.jl:209), positivity / non-finite tracking, exact 3-way bf16 split, extra rows
+    u32x4_t bp[3];
+    auto split = [&](int tile_m, int t) {
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
             const float x0 = braw[2 * jj], x1 = braw[2 * jj + 1];
-            asm("v_max_f32 %0, 0, %1" : "=v"(c[2 * jj]) : "v"(x0));
-            asm("v_max_f32 %0, 0, %1" : "=v"(c[2 * jj + 1]) : "v"(x1));
-            if (a.has_ineff) {
-                vmax = fmaxf(vmax, ((eff >> (2 * jj)) & 1u) ? x0 : 0.0f);
-                vmax = fmaxf(vmax, ((eff >> (2 * jj + 1)) & 1u) ? x1 : 0.0f);
-            } else {
-                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(vmax) : "v"(vmax), "v"(x0), "v"(x1));
-            }
+            float c0, c1;
+            asm("v_max_f32 %0, 0, %1" : "=v"(c0) : "v"(x0));
+            asm("v_max_f32 %0, 0, %1" : "=v"(c1) : "v"(x1));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(vmax) : "v"(vmax), "v"(x0), "v"(x1));
             vnf = __builtin_fmaf(x0, 0.0f, vnf);
             vnf = __builtin_fmaf(x1, 0.0f, vnf);
-            const uint32_t h = cvt_pk_bf16(c[2 * jj], c[2 * jj + 1]);
-            const float r0 = c[2 * jj] - __uint_as_float(h << 16), r1 = c[2 * jj + 1] - __uint_as_float(h & 0xffff0000u);   // exact
+            const uint32_t h = cvt_pk_bf16(c0, c1);
+            const float r0 = c0 - __uint_as_float(h << 16), r1 = c1 - __uint_as_float(h & 0xffff0000u);      // exact
             const uint32_t m = cvt_pk_bf16(r0, r1);
-            const float q0 = r0 - __uint_as_float(m << 16), q1 = r1 - __uint_as_float(m & 0xffff0000u);                     // exact
-            const uint32_t l = cvt_pk_bf16(q0, q1);                                                                        // exact
+            const float q0 = r0 - __uint_as_float(m << 16), q1 = r1 - __uint_as_float(m & 0xffff0000u);      // exact
+            const uint32_t l = cvt_pk_bf16(q0, q1);                                                           // exact
             bp[0][jj] = h; bp[1][jj] = m; bp[2][jj] = l;
-        }
-        if (NX > 0) {                                   // extra rows: plain f32 fma on the clamped samples
-            const float *LX = reinterpret_cast<const float *>(L + 3 * MB * 1024) + 8 * kh;
+            if (NX > 0) {                               // extra rows: f32 fma, coefficients from the LDS table (frames 8h + 2jj, +1)
+                const f32x2 *ex = reinterpret_cast<const f32x2 *>(lds + 2 * TILEB + NW * 2048) + ((tile_m * NX) * a.Kpad + t * KT + 8 * kh) / 2 + jj;
 #pragma unroll
-            for (int x = 0; x < NX; x++)
+                for (int x = 0; x < NX; x++) {
+                    const f32x2 e = ex[x * (a.Kpad / 2)];
+                    xacc[x] = __builtin_fmaf(e[0], c0, xacc[x]);
+                    xacc[x] = __builtin_fmaf(e[1], c1, xacc[x]);
+                }
+            }
+        }
+    };
+
+    bool inb; int64_t vox; uint32_t s_off;
+    lane_state(cur, vraw, inb, vox, s_off);
+    // ---- ring prologue: stage 0's pieces into LDS, its samples into registers ------------------------------------
+    stage_A(cur.tile_m, 0, 0);
+    load_B(0, s_off, true);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();                                     // (also: the extra rows' table is complete)
+    int g = 0;                                           // stages done: ring position
+    for (;;) {
+        float sraw = 0.0f;                               // DSI: the sample that sum(p) is a multiple of (dsi.jl:224-225)
+        if (a.scale_frame >= 0) sraw = *reinterpret_cast<const float *>(Sbase + (int64_t)a.scale_frame * a.stride * 4 + (uint32_t)(vox * 4));
+        bool inb_n = false; int64_t vox_n = 0; uint32_t s_off_n = 0;
+        if (nxt.valid) lane_state(nxt, vraw_nxt, inb_n, vox_n, s_off_n);
+        for (int t = 0; t < ntiles; t++, g++) {
+            const int cb = g & 1;
+            const char *L = lds + cb * TILEB;
+            if (PROBE & 8) { for (int jj = 0; jj < 4; jj++) { bp[0][jj] = __float_as_uint(braw[2 * jj]); bp[1][jj] = __float_as_uint(braw[2 * jj + 1]); bp[2][jj] = bp[0][jj] ^ bp[1][jj]; } }
+            else split(cur.tile_m, t);
+            // the next stage (it may open the next work item): pieces into the other buffer, samples into braw
+            const bool w1 = t + 1 < ntiles;
+            if (!(PROBE & 4) || g < 1) stage_A(w1 ? cur.tile_m : (nxt.valid ? nxt.tile_m : cur.tile_m), w1 ? t + 1 : 0, cb ^ 1);
+            if (!(PROBE & 2)) load_B(w1 ? t + 1 : 0, w1 ? s_off : s_off_n, w1 || nxt.valid);
+            __builtin_amdgcn_sched_barrier(0);          // the requests go out before the MFMA block, not after it
+            const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, bp[0]), b1 = __builtin_bit_cast(bf16x8_t, bp[1]), b2 = __builtin_bit_cast(bf16x8_t, bp[2]);
+            const bf16x8_t *LA = reinterpret_cast<const bf16x8_t *>(L) + lane;
 #pragma unroll
-                for (int j = 0; j < 8; j++) xacc[x] = __builtin_fmaf(LX[x * 16 + j], c[j], xacc[x]);
+            for (int m = 0; m < MB; m++) {
+                bf16x8_t a2, a1, a0;
+                if (PROBE & 16) { a2 = b1; a1 = b2; a0 = b0; }
+                else { a2 = LA[(2 * MB + m) * 64]; a1 = LA[(1 * MB + m) * 64]; a0 = LA[m * 64]; }
+                // smallest terms first
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[m], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): the next stage's pieces and samples have landed
+            if (!(PROBE & 32)) __syncthreads();
         }
-        if (t + 1 < ntiles) {
-            stage_A(t + 1, cur ^ 1);
-            load_B(t + 1);
-        }
-        const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, bp[0]), b1 = __builtin_bit_cast(bf16x8_t, bp[1]), b2 = __builtin_bit_cast(bf16x8_t, bp[2]);
-        const bf16x8_t *LA = reinterpret_cast<const bf16x8_t *>(L) + lane;
-#pragma unroll
-        for (int m = 0; m < MB; m++) {
-            const bf16x8_t a0 = LA[(0 * MB + m) * 64], a1 = LA[(1 * MB + m) * 64], a2 = LA[(2 * MB + m) * 64];
-            // smallest terms first
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[m], 0, 0, 0);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
+        unsigned long long te = 0;
+        if (STAMP) te = __builtin_amdgcn_s_memtime();
+        if (!(PROBE & 1) || !nxt.valid) gemm3_epilogue<MB, NX>(a, acc, xacc, vmax, vnf, inb, vox, lane, cur.tile_m, sraw, lds + 2 * TILEB + wave * 2048);
+        if (STAMP) acc_epi += __builtin_amdgcn_s_memtime() - te;
+        if (!nxt.valid) break;
+        cur = nxt; inb = inb_n; vox = vox_n; s_off = s_off_n;
+        nxt = work_at(g / ntiles + 1);
+        vraw_nxt = nxt.valid ? vidx_at(nxt) : 0;
+        clear();
     }
-    gemm_epilogue<MB, NX>(a, acc, xacc, vmax, vnf, inb, vox, kh, tile_m, c_off);
+    if (STAMP) {
+        const unsigned long long st2 = __builtin_amdgcn_s_memtime(), rt2 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && a.dbg) {
+            unsigned long long *d = a.dbg + (size_t)blockIdx.x * 8;
+            d[0] = st2 - st0; d[1] = acc_epi; d[2] = 0; d[3] = (unsigned long long)(g / ntiles); d[4] = rt2 - rt1; d[5] = 0; d[6] = 0; d[7] = 0;
+        }
+    }
 }
 
 // ---- mask compaction ---------------------------------------------------------------------------------------
@@ -959,6 +1144,7 @@ struct fib_odf_plan {
     std::vector<float> A;                            // host copy [nrows x nvol] column-major
     fib::DevBuf<float> At, verts;
     fib::DevBuf<uint16_t> At3;                       // split-bf16 image of G (odf_gemm3_kernel), empty in f32-MFMA mode
+    fib::DevBuf<float> Aextra;                       // f32 coefficients of the NX extra rows [ntile_m][NX][Kpad]
     bool split_bf16 = false;
     fib::DevBuf<uint32_t> effbits;
     fib::DevBuf<int32_t> nbr, nbr64; // [nvert_even][deg_pad] LDS row of each neighbour (sentinel-padded)
@@ -976,10 +1162,16 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
                 const std::vector<float> &frame_eff) {
     if (p->G.empty()) { p->G = p->A; p->gM = p->nrows; p->gK = p->nvol; p->gRow0 = p->nrow0; }
     const int M = p->gM, K = p->gK;
+    // which matrix-core path runs the contraction: "bf16x3" (default; f32-exact products from three bf16 pieces per
+    // operand) or "f32" (v_mfma_f32_32x32x2_f32: a k-ordered f32 fma chain, bit-identical to the oracle's loop)
+    {
+        const char *e = getenv("FIBERS_ODF_GEMM");
+        p->split_bf16 = !(e && (!strcmp(e, "f32") || !strcmp(e, "F32")));
+    }
     // pick (MB, NX) minimising the per-k-step issue cost ntile*(64*MB + 4*NX) cycles (MFMA block = 64, v_fmac = 4)
     int best_cost = INT32_MAX;
     const int nxs[] = {0, 1, 2, 4};
-    for (int mb = 11; mb >= 5; mb--)
+    for (int mb = p->split_bf16 ? 10 : 11; mb >= 5; mb--)
         for (int nx : nxs) {
             if (nx > 0 && mb > 10) continue;            // register budget
             const int rows = mb * 32 + nx;
@@ -1001,15 +1193,15 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
             const int tm = r / ROWS, rr = r % ROWS;
             At[((size_t)tm * p->Kpad + k) * MW + rr] = p->G[r + (size_t)M * k];
         }
-    // which matrix-core path runs the contraction: "bf16x3" (default; f32-exact products from three bf16 pieces per
-    // operand) or "f32" (v_mfma_f32_32x32x2_f32: a k-ordered f32 fma chain, bit-identical to the oracle's loop)
-    {
-        const char *e = getenv("FIBERS_ODF_GEMM");
-        p->split_bf16 = !(e && (!strcmp(e, "f32") || !strcmp(e, "F32")));
-    }
+    // the split-bf16 kernel needs: every frame effective (DSI frames that share a lattice point are not), >= 2 stages,
+    // MB <= 10 (LDS: two workgroups per CU), and the extra rows' coefficient table within its 4-KiB LDS slot
+    bool any_ineff = false;
+    for (int k = 0; k < K; k++) if (frame_eff[k] == 0.0f) any_ineff = true;
+    if (p->split_bf16 && (any_ineff || p->Kpad / KT < 2 || p->MB > 10 || (size_t)p->ntile_m * p->NX * p->Kpad > 1024)) p->split_bf16 = false;
     if (p->split_bf16) {
-        const int npiece = 3 * p->MB + (p->NX > 0 ? 1 : 0), nst = p->Kpad / KT;
+        const int npiece = 3 * p->MB, nst = p->Kpad / KT;
         std::vector<uint16_t> A3((size_t)p->ntile_m * nst * npiece * 512, 0);
+        std::vector<float> AX((size_t)std::max(1, p->ntile_m * p->NX * p->Kpad), 0.0f);
         auto bf16_rn = [](float f) -> uint16_t {
             uint32_t u; memcpy(&u, &f, 4);
             if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
@@ -1017,14 +1209,14 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
             return (uint16_t)(u >> 16);
         };
         auto bf16_f = [](uint16_t h) -> float { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
-        for (int tm = 0; tm < p->ntile_m; tm++)
+        for (int tm = 0; tm < p->ntile_m; tm++) {
             for (int t = 0; t < nst; t++) {
                 uint16_t *st = A3.data() + ((size_t)tm * nst + t) * npiece * 512;
                 for (int m = 0; m < p->MB; m++)
                     for (int l = 0; l < 64; l++)
                         for (int j = 0; j < 8; j++) {
                             const int row = tm * ROWS + m * 32 + (l & 31), k = t * KT + 8 * (l >> 5) + j;
-                            if (row >= M || row >= (tm + 1) * ROWS || k >= K) continue;
+                            if (row >= M || k >= K) continue;
                             const float v = p->G[row + (size_t)M * k];
                             const uint16_t h1 = bf16_rn(v);
                             const float r1 = v - bf16_f(h1);
@@ -1034,16 +1226,18 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
                             const uint16_t hs[3] = {h1, h2, h3};
                             for (int pc = 0; pc < 3; pc++) st[((size_t)(pc * p->MB + m) * 64 + l) * 8 + j] = hs[pc];
                         }
-                float *ex = reinterpret_cast<float *>(st + (size_t)3 * p->MB * 512);
-                for (int x = 0; x < p->NX; x++)
-                    for (int kk = 0; kk < KT; kk++) {
-                        const int row = tm * ROWS + p->MB * 32 + x, k = t * KT + kk;
-                        if (row < M && k < K) ex[x * 16 + kk] = p->G[row + (size_t)M * k];
-                    }
             }
+            for (int x = 0; x < p->NX; x++)
+                for (int k = 0; k < K; k++) {
+                    const int row = tm * ROWS + p->MB * 32 + x;
+                    if (row < M) AX[((size_t)tm * p->NX + x) * p->Kpad + k] = p->G[row + (size_t)M * k];
+                }
+        }
         int rc3 = p->At3.alloc(A3.size());
         if (rc3 != FIB_OK) return rc3;
+        if ((rc3 = p->Aextra.alloc(AX.size())) != FIB_OK) return rc3;
         FIB_HIP(hipMemcpy(p->At3.p, A3.data(), A3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        FIB_HIP(hipMemcpy(p->Aextra.p, AX.data(), AX.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     std::vector<int32_t> nbr32;
     int rc = fib::host_neighbours(faces, nfaces, nverts, nbr32, &p->maxdeg);
@@ -1194,7 +1388,58 @@ namespace {
 
 template <int MB, int NX>
 void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
-    if (ga.At3) hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX>), dim3(grid), dim3(256), 0, st, ga);
+    if (ga.At3) {
+        // persistent grid: one 8-wave workgroup per CU (or two of 4 waves: FIBERS_GEMM3_WAVES=4; measured 6 % slower), a multiple
+        // of 8 so that blockIdx & 7 is the XCD
+        static const int nw_env = getenv("FIBERS_GEMM3_WAVES") ? atoi(getenv("FIBERS_GEMM3_WAVES")) : 8;
+        static const int stamp = getenv("FIBERS_GEMM3_STAMP") ? atoi(getenv("FIBERS_GEMM3_STAMP")) : 0;
+        int ncu = 256, dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        GemmArgs g2 = ga;
+        static const int stagger = getenv("FIBERS_GEMM3_STAGGER") ? atoi(getenv("FIBERS_GEMM3_STAGGER")) : 0;
+        g2.stagger = stagger;
+        const int nw = nw_env == 4 ? 4 : 8;
+        const int64_t items = fib::cdiv(ga.nvox, nw * 32) * ga.ntile_m;
+        unsigned pg = (unsigned)std::min<int64_t>((int64_t)ncu * (8 / nw), items);
+        pg = (pg + 7) / 8 * 8;
+        if (stamp && MB == 10 && NX == 1) {              // timing experiment: in-kernel clock and epilogue share (stderr, 12th call)
+            static unsigned long long *dbg = nullptr;
+            static int calls = 0;
+            if (!dbg) (void)hipMalloc((void **)&dbg, (size_t)4096 * 8 * 8);
+            g2.dbg = dbg;
+            constexpr int PM = (MB == 10 && NX == 1) ? 10 : 5, PN = (MB == 10 && NX == 1) ? 1 : 0;
+            if (nw == 8) hipLaunchKernelGGL((odf_gemm3_kernel<PM, PN, 8, true>), dim3(pg), dim3(512), 0, st, g2);
+            else hipLaunchKernelGGL((odf_gemm3_kernel<PM, PN, 4, true>), dim3(pg), dim3(256), 0, st, g2);
+            if (++calls == 12) {
+                (void)hipStreamSynchronize(st);
+                std::vector<unsigned long long> h((size_t)pg * 8);
+                (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+                std::vector<double> clk, item, epi;
+                for (unsigned b = 0; b < pg; b++) {
+                    const unsigned long long *d = &h[(size_t)b * 8];
+                    if (d[4] == 0 || d[3] == 0) continue;
+                    const double n = (double)d[3];
+                    clk.push_back((double)d[0] / (double)d[4] * 100.0);
+                    item.push_back((double)d[0] / n); epi.push_back((double)d[1] / n);
+                }
+                auto med = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+                fprintf(stderr, "gemm3 stamps over %zu workgroups: clock %.0f MHz; cycles per work item %.0f (%.1f per MFMA), of which epilogue %.0f\n",
+                        clk.size(), med(clk), med(item), med(item) / (17.0 * 60.0), med(epi));
+            }
+            return;
+        }
+        static const int probe = getenv("FIBERS_GEMM3_PROBE") ? atoi(getenv("FIBERS_GEMM3_PROBE")) : 0;   // timing experiments (wrong results)
+        if (probe && MB == 10 && NX == 1) {
+            constexpr int PM = (MB == 10 && NX == 1) ? 10 : 5, PN = (MB == 10 && NX == 1) ? 1 : 0;
+#define FIB_PROBE_CASE(P) if (probe == P) { if (nw == 8) hipLaunchKernelGGL((odf_gemm3_kernel<PM, PN, 8, false, P>), dim3(pg), dim3(512), 0, st, g2); \
+                                            else hipLaunchKernelGGL((odf_gemm3_kernel<PM, PN, 4, false, P>), dim3(pg), dim3(256), 0, st, g2); return; }
+            FIB_PROBE_CASE(1) FIB_PROBE_CASE(8) FIB_PROBE_CASE(16) FIB_PROBE_CASE(32) FIB_PROBE_CASE(7) FIB_PROBE_CASE(15) FIB_PROBE_CASE(31) FIB_PROBE_CASE(63) FIB_PROBE_CASE(39)
+#undef FIB_PROBE_CASE
+        }
+        if (nw == 8) hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 8>), dim3(pg), dim3(512), 0, st, g2);
+        else hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 4>), dim3(pg), dim3(256), 0, st, g2);
+    }
     else hipLaunchKernelGGL((odf_gemm_kernel<MB, NX>), dim3(grid), dim3(256), 0, st, ga);
 }
 
@@ -1283,7 +1528,9 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         hipLaunchKernelGGL(mask_write_kernel, dim3(nb), dim3(256), 0, st, mask, nvox, plan->live_blocks.p, plan->live_vox.p, plan->live_tiles.p);
         FIB_HIP(hipGetLastError());
     }
-    ga.At = plan->At.p; ga.At3 = (plan->split_bf16 && nvox <= ((int64_t)1 << 26)) ? plan->At3.p : nullptr; ga.S = dwi; ga.vidx = plan->live_vox.p; ga.nlive = plan->live_counts.p; ga.effbits = plan->effbits.p;
+    ga.At = plan->At.p; ga.At3 = (plan->split_bf16 && nvox <= ((int64_t)1 << 26)) ? plan->At3.p : nullptr; ga.S = dwi;
+    ga.Aextra = plan->Aextra.p;
+    ga.vec_ok = (nvox % 4 == 0 && ((uintptr_t)odf & 15) == 0 && (pdf == nullptr || ((uintptr_t)pdf & 15) == 0)) ? 1 : 0; ga.vidx = plan->live_vox.p; ga.nlive = plan->live_counts.p; ga.effbits = plan->effbits.p;
     ga.out0 = pdf; ga.out1 = odf; ga.nvox = nvox;
     ga.K = plan->gK; ga.Kpad = plan->Kpad; ga.M = plan->gM; ga.nrow0 = plan->gRow0; ga.ntile_m = plan->ntile_m;
     if (plan->folded) {

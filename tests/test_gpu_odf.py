@@ -209,3 +209,64 @@ def test_mask_compaction_device_tier(fj):
     empty = fj.odf_rec_device(plan, dwi, torch.zeros_like(m), out=stale, normalize=False)
     assert float(empty["odf"].abs().max()) == 0.0 and float(empty["odfmax"][0]) == 0.0
     assert all(float(q.abs().max()) == 0.0 for q in empty["qa"])
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_gqi_both_matrix_core_paths_full_mask(fj, orc, mode, monkeypatch):
+    """the two contraction kernels (split-bf16 MFMA, f32 MFMA) against the oracle on an all-ones mask: contiguous voxel
+    runs take the LDS-transposed dwordx4 epilogue, the ragged last work item the scalar one"""
+    monkeypatch.setenv("FIBERS_ODF_GEMM", mode)
+    from fibers_jl_amd import phantom
+    shape = (12, 10, 9)                                    # 1080 voxels: a multiple of 4, not of 256
+    bval, bvec = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3)
+    dwi, _, _ = phantom.make_volume(shape, bval, bvec, seed=17, noise_frac=0.02, crossing=True)
+    mask = np.ones(shape, np.uint8)
+    sph = fj.sphere_642
+    ref = orc.gqi_rec(dwi, mask, bval, bvec, sph.vertices, sph.faces, 1.25, nthreads=4)
+    got = fj.gqi_rec(fj.MRI(dwi, bval, bvec), fj.MRI(mask), sph)
+    _check_odf_rec(got.odf.vol, [p.vol for p in got.peak], [q.vol[..., 0] for q in got.qa], ref, mask, label=mode)
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_dsi_both_matrix_core_paths_full_mask(fj, orc, mode, monkeypatch):
+    """DSI (folded lattice: mapped pdf rows, three M tiles per voxel group) on an all-ones mask, both kernels"""
+    monkeypatch.setenv("FIBERS_ODF_GEMM", mode)
+    dwi, _, bval, bvec = _dsi_case((8, 6, 2), seed=8)      # 96 voxels: one full 32-voxel wave run + ragged rest
+    mask = np.ones(dwi.shape[:3], np.uint8)
+    sph = fj.sphere_642
+    ref = orc.dsi_rec(dwi, mask, bval, bvec, sph.vertices, sph.faces, 32, nthreads=4)
+    got = fj.dsi_rec(fj.MRI(dwi, bval, bvec), fj.MRI(mask), sph, 32)
+    scale = np.abs(ref["pdf"]).max(axis=3, keepdims=True) + 1e-30
+    assert (np.abs(got.pdf.vol - ref["pdf"]) / scale).max() < 5e-5
+    _check_odf_rec(got.odf.vol, [p.vol for p in got.peak], [q.vol[..., 0] for q in got.qa], ref, mask,
+                   odf_rtol=1e-4, qa_atol=1e-4, label="dsi " + mode)
+
+
+def test_split_bf16_matches_f32_kernel_large(fj, monkeypatch):
+    """40^3 x 63 frames: the split-bf16 contraction agrees with the f32-MFMA chain to f32 rounding everywhere, with and
+    without a mask (the compacted voxel list changes which lanes / work items a voxel lands in)"""
+    import torch
+    from fibers_jl_amd import phantom
+    dev = torch.device("cuda", 0)
+    shape = (40, 40, 40)
+    nvox = 40 ** 3
+    bval, bvec = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3)
+    dwi, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=4, device=dev)
+    ball = phantom.ball_mask_torch(shape, dev, radius=17.3)
+    outs = {}
+    for mode in ("f32", "bf16x3"):
+        monkeypatch.setenv("FIBERS_ODF_GEMM", mode)
+        plan = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642)
+        for name, m in (("ones", torch.ones(nvox, dtype=torch.uint8, device=dev)), ("ball", ball)):
+            o = fj.odf_rec_device(plan, dwi, m)
+            outs[mode, name] = (o["odf"].clone(), o["peak"][0].clone())
+        plan.close()
+    for name in ("ones", "ball"):
+        a, b = outs["f32", name][0], outs["bf16x3", name][0]
+        vmax = a.abs().max(0).values.clamp_min(1e-30)
+        assert float(((a - b).abs() / vmax).max()) < 5e-6
+        differ = (outs["f32", name][1] != outs["bf16x3", name][1]).any(0).float().mean()
+        assert float(differ) < 1e-3                        # first-peak vertex: only amplitude ties at rounding level may flip
+    live = ball.bool()
+    assert torch.equal(outs["bf16x3", "ones"][0][:, live], outs["bf16x3", "ball"][0][:, live])
+    assert (outs["bf16x3", "ball"][0][:, ~live] == 0).all()
