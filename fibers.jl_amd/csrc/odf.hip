@@ -914,6 +914,16 @@ __global__ __launch_bounds__(PW * 64) void odf_peaks_kernel(const PeakArgs a) {
     }
 }
 
+#include "sphere642_scan.inc"
+// largest of six values and 0, NaNs ignored (v_max3 returns the other operands): `o[b] >= o[a]` is false for a NaN neighbour
+__device__ __forceinline__ float max6_0_f32(float a, float b, float c, float d, float e, float f) {
+    float t;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(a), "v"(b), "v"(c));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(t), "v"(d), "v"(e));
+    asm("v_max3_f32 %0, %1, %2, 0" : "=v"(t) : "v"(t), "v"(f));
+    return t;
+}
+
 // ---- v3: 64-voxel tiles, one persistent workgroup of 16 waves per CU -----------------------------------
 // Every lane of a wave owns one voxel and the wave walks its share of the vertices, so vertex and neighbour
 // indices are wave-uniform (scalar loads, SGPR operands) and an LDS address costs one v_add.  The tile
@@ -941,7 +951,10 @@ __device__ __forceinline__ void p64_merge(Peak64Partial &p, const float *r) {
     p.hasnan |= r[9] != 0.0f;
 }
 
-template <int DEG, bool EXACT>
+// S642: the tessellation is the default sphere_642 -> the scan is straight-line code generated from its neighbour table
+// (sphere642_scan.inc): vertex and neighbour rows are immediate LDS offsets, no table reads, no address arithmetic;
+// "some neighbour >= x" is one compare against the largest neighbour.
+template <int DEG, bool EXACT, bool S642 = false>
 __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, int64_t ntiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *o = smem;                                            // [nvert + 1][64]; row nvert = NaN sentinel
@@ -960,6 +973,7 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
     // unaligned volume) is loaded synchronously with guards when its turn comes.  The staging registers are
     // six named float4s (an array indexed inside conditionals ends up in scratch memory).
     static_assert(P64_NI == 6, "staging is written out for six registers");
+    // (a second staging set, two tiles in flight, was measured slower: 1.35 vs 1.24 ms -- register pressure in the scan)
     float4 s0, s1, s2, s3, s4, s5;
     s0 = s1 = s2 = s3 = s4 = s5 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto is_fast = [&](int64_t tile) { return a.vec_ok && tile * 64 + 64 <= a.nvox; };
@@ -1010,6 +1024,60 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
         Peak64Partial p;
         top3_clear(p.t);
         p.npos = 0; p.vmin = INFINITY; p.vsum = 0.0f; p.hasnan = false;
+        if constexpr (S642) {
+            // Candidate = vertex above all its neighbours and above 0 (or NaN): !(max(neighbours, 0) >= x).  The flag of
+            // each scanned vertex is shifted into a per-lane bit string with one add-with-carry; the few candidates of a
+            // lane (a voxel has a handful of peaks among 321 vertices) are inserted afterwards, one bit per iteration.
+            static_assert(!EXACT, "the specialised scan keeps candidates only");
+            const float *ob = o + lane, *ob1 = o + FIB_S642_BASE1 * 64 + lane;   // two bases: every row within 255 rows of one
+            unsigned bits = 0;
+            int nscan = 0;
+#define FIB_RD(B, R) (((B) == 0 || ((B) == 2 && (R) <= 255)) ? ob[(R) * 64] : ob1[((R) - FIB_S642_BASE1) * 64])
+#define FIB_SCAN_ONE(V, B, A0, A1, A2, A3, A4, A5)                                                          \
+            if ((V) < FIB_S642_NVERT) {                                                                     \
+                const float x = FIB_RD(B, V);                                                               \
+                const float mx = max6_0_f32(FIB_RD(B, A0), FIB_RD(B, A1), FIB_RD(B, A2), FIB_RD(B, A3), FIB_RD(B, A4), FIB_RD(B, A5)); \
+                asm("v_cmp_nge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(mx), "v"(x) : "vcc"); \
+                asm("v_min_f32 %0, %0, %1" : "+v"(p.vmin) : "v"(x));      /* NaN-ignoring; NaN is recovered from vsum */ \
+                p.vsum += x;                                                                                \
+                nscan++;                                                                                    \
+            }
+#define FIB_SCAN_G(V0, B0, a0, a1, a2, a3, a4, a5, V1, B1, b0, b1, b2, b3, b4, b5, V2, B2, c0, c1, c2, c3, c4, c5, V3, B3, d0, d1, d2, d3, d4, d5) \
+            FIB_SCAN_ONE(V0, B0, a0, a1, a2, a3, a4, a5) FIB_SCAN_ONE(V1, B1, b0, b1, b2, b3, b4, b5)       \
+            FIB_SCAN_ONE(V2, B2, c0, c1, c2, c3, c4, c5) FIB_SCAN_ONE(V3, B3, d0, d1, d2, d3, d4, d5)
+            switch (wave) {
+                case 0: FIB_S642_WAVE0(FIB_SCAN_G) break;
+                case 1: FIB_S642_WAVE1(FIB_SCAN_G) break;
+                case 2: FIB_S642_WAVE2(FIB_SCAN_G) break;
+                case 3: FIB_S642_WAVE3(FIB_SCAN_G) break;
+                case 4: FIB_S642_WAVE4(FIB_SCAN_G) break;
+                case 5: FIB_S642_WAVE5(FIB_SCAN_G) break;
+                case 6: FIB_S642_WAVE6(FIB_SCAN_G) break;
+                case 7: FIB_S642_WAVE7(FIB_SCAN_G) break;
+                case 8: FIB_S642_WAVE8(FIB_SCAN_G) break;
+                case 9: FIB_S642_WAVE9(FIB_SCAN_G) break;
+                case 10: FIB_S642_WAVE10(FIB_SCAN_G) break;
+                case 11: FIB_S642_WAVE11(FIB_SCAN_G) break;
+                case 12: FIB_S642_WAVE12(FIB_SCAN_G) break;
+                case 13: FIB_S642_WAVE13(FIB_SCAN_G) break;
+                case 14: FIB_S642_WAVE14(FIB_SCAN_G) break;
+                default: FIB_S642_WAVE15(FIB_SCAN_G) break;
+            }
+#undef FIB_SCAN_G
+#undef FIB_SCAN_ONE
+#undef FIB_RD
+            // bit b of `bits` = the (nscan-1-b)-th vertex this wave scanned = vertex wave + 16*(nscan-1-b)
+            while (__any(bits != 0u)) {
+                if (bits != 0u) {
+                    const int b = __ffs((int)bits) - 1;
+                    bits &= bits - 1u;
+                    const int v = wave + P64_W * (nscan - 1 - b);
+                    const float x = ob[v * 64];
+                    if (x > 0.0f) p.npos++;                                     // gqi.jl:200
+                    top3_insert(p.t, x, v);
+                }
+            }
+        } else {
         // UNR vertices per iteration: their neighbour-table reads and ODF reads are all issued before the
         // first compare, so each wave keeps ~(1+DEG)*UNR LDS reads in flight instead of a dependent chain
         constexpr int UNR = 4;
@@ -1051,6 +1119,7 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
                         if (EXACT || !(pk[u] <= 0.0f)) top3_insert(p.t, pk[u], vv[u]);
                     }
             }
+        }
         }
         p.hasnan = p.vsum != p.vsum;                            // a NaN amplitude makes the sum NaN
         p64_store(mrg + (size_t)(wave * 64 + lane) * PREC, p);
@@ -1149,6 +1218,7 @@ struct fib_odf_plan {
     fib::DevBuf<uint32_t> effbits;
     fib::DevBuf<int32_t> nbr, nbr64; // [nvert_even][deg_pad] LDS row of each neighbour (sentinel-padded)
     int deg_pad = 6, rows_pad = 0;
+    bool is_s642 = false;                            // neighbour table == the compiled-in sphere_642 table (specialised scan)
     mutable fib::DevBuf<unsigned> maxenc;
     mutable fib::DevBuf<int32_t> live_vox, live_tiles, live_counts;   // mask compaction scratch (grow-only), counts = {voxels, tiles}
     mutable fib::DevBuf<int2> live_blocks;
@@ -1251,6 +1321,15 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
             const int32_t u = nbr32[(size_t)v * p->maxdeg + d];
             if (u >= 0) nbr[(size_t)v * p->deg_pad + d] = u;
         }
+    // the default tessellation has a scan specialised at compile time (sphere642_scan.inc): use it iff the tables agree
+    p->is_s642 = p->nvert == FIB_S642_NVERT && p->maxdeg <= FIB_S642_DEG && !getenv("FIBERS_PEAKS_GENERIC");
+    for (int v = 0; v < p->nvert && p->is_s642; v++) {
+        std::vector<int32_t> mine, ref;
+        for (int d = 0; d < p->maxdeg; d++) { const int32_t u = nbr32[(size_t)v * p->maxdeg + d]; if (u >= 0) mine.push_back(u); }
+        for (int d = 0; d < FIB_S642_DEG; d++) if (fib_s642_nbr[v][d] < FIB_S642_NVERT) ref.push_back(fib_s642_nbr[v][d]);
+        std::sort(mine.begin(), mine.end());
+        if (mine != ref) p->is_s642 = false;
+    }
     std::vector<int32_t> nbr64(nbr);
     for (auto &u : nbr64) if (u == p->rows_pad) u = p->nvert;
     if ((rc = p->nbr64.alloc(nbr64.size())) != FIB_OK) return rc;
@@ -1456,11 +1535,11 @@ int launch_peaks_t(const PeakArgs &pa, size_t smem, unsigned grid, hipStream_t s
     return FIB_OK;
 }
 
-template <int DEG, bool EXACT>
+template <int DEG, bool EXACT, bool S642 = false>
 int launch_peaks64_t(const PeakArgs &pa, size_t smem, int64_t ntiles, unsigned grid, hipStream_t st) {
-    FIB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(odf_peaks64_kernel<DEG, EXACT>),
+    FIB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(odf_peaks64_kernel<DEG, EXACT, S642>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL((odf_peaks64_kernel<DEG, EXACT>), dim3(grid), dim3(P64_T), smem, st, pa, ntiles);
+    hipLaunchKernelGGL((odf_peaks64_kernel<DEG, EXACT, S642>), dim3(grid), dim3(P64_T), smem, st, pa, ntiles);
     FIB_HIP(hipGetLastError());
     return FIB_OK;
 }
@@ -1488,6 +1567,7 @@ int launch_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox, int64
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, plan->device);
         const int64_t ntiles = fib::cdiv(nvox, 64);
         const unsigned g64 = (unsigned)std::min<int64_t>(ntiles, ncu);
+        if (plan->is_s642 && !exact) return launch_peaks64_t<6, false, true>(pa, smem64, ntiles, g64, st);
         switch (plan->deg_pad) {
             case 6:  return exact ? launch_peaks64_t<6, true>(pa, smem64, ntiles, g64, st) : launch_peaks64_t<6, false>(pa, smem64, ntiles, g64, st);
             case 8:  return exact ? launch_peaks64_t<8, true>(pa, smem64, ntiles, g64, st) : launch_peaks64_t<8, false>(pa, smem64, ntiles, g64, st);
