@@ -163,55 +163,80 @@ def main():
             pass
 
     extra = {}
-    if not args.no_extra and rank == 0 and world == 1:       # single-GPU extras only: ranks must leave together
+    if not args.no_extra:
+        # Every rank takes part (the ranks leave together).  C2: DTI fit, one 140^3 x 64 volume per rank (weak scaling, no
+        # exchange step).  C4: streamlines from ONE volume's principal eigenvector: rank 0's field is broadcast over
+        # RCCL/xGMI (the path's only bulk collective: 16 B/voxel), seeds shard round-robin, no data-path collective after.
         del out, dwi
         torch.cuda.empty_cache()
-        # ---- DTI fit, 140^3 x 64 (C2) ------------------------------------------------------------
         b2, g2 = phantom.scheme_dti(60, 4, 1000.0, seed=2)
         d2, ax2 = phantom.make_dwi_torch(SHAPE, b2, g2, seed=2, device=dev, nfib=1)
         p2 = fj.DtiPlan(b2, g2, device=dev.index)
         o2 = fj.dti_fit_device(p2, d2, mask)
-        torch.cuda.synchronize()
+        sync()
         L.fib_profile_enable(1); L.fib_profile_reset()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             fj.dti_fit_device(p2, d2, mask, out=o2)
-        torch.cuda.synchronize()
-        t_dti = (time.perf_counter() - t0) / args.steps
+        sync()
+        t_dti = time.perf_counter() - t0
         L.fib_profile_enable(0)
+        if world > 1:
+            tt = torch.tensor([t_dti], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_dti = float(tt.item())
+        t_dti /= args.steps
         k_ms, k_n = prof_get(L, "dti_fit")
         dbytes = (4.0 * len(b2) + 1 + 64) * nvox
-        extra["dti_fit_140x64"] = dict(mvoxels_per_s=nvox / t_dti / 1e6, ms_per_step=t_dti * 1e3,
+        extra["dti_fit_140x64"] = dict(mvoxels_per_s=world * nvox / t_dti / 1e6, ms_per_step=t_dti * 1e3,
                                        kernel_ms=k_ms / max(k_n, 1), algorithmic_bytes=dbytes,
                                        hbm_gbs=dbytes / (k_ms / max(k_n, 1) * 1e-3) / 1e9 if k_n else 0.0,
-                                       hbm_frac=dbytes / (k_ms / max(k_n, 1) * 1e-3) / 1e9 / PEAK_HBM_GBS if k_n else 0.0)
+                                       hbm_frac=dbytes / (k_ms / max(k_n, 1) * 1e-3) / 1e9 / PEAK_HBM_GBS if k_n else 0.0,
+                                       note="one volume per rank; per-kernel figures are rank 0's")
         # ---- streamlines from the DTI principal eigenvector, ball mask (C4) -----------------------
+        from fibers_jl_amd import dist as fd
         bm = phantom.ball_mask_torch(SHAPE, dev)
         field, mout = fj.stream_field_device([o2["eigvec1"]], fa=o2["fa"], fa_thresh=0.1, mask=bm)
-        seeds = torch.nonzero(mout).flatten()
+        seeds_all = torch.nonzero(mout).flatten()
         sub = torch.tensor([[0.1, -0.2, 0.3]], dtype=torch.float32, device=dev)
-        res = fj.stream_device(field, SHAPE, seeds, sub)
-        torch.cuda.synchronize()
+
+        def stream_step():
+            if world > 1:
+                dist.broadcast(field, src=0)                               # shared peak field over xGMI
+            seeds, _ = fd.shard_seeds(seeds_all, world, rank)
+            return fj.stream_device(field, SHAPE, seeds.contiguous(), sub)
+
+        res = stream_step()
+        sync()
         L.fib_profile_enable(1); L.fib_profile_reset()
         nst = max(2, args.steps // 2)
         t0 = time.perf_counter()
         for _ in range(nst):
-            res = fj.stream_device(field, SHAPE, seeds, sub)
-        torch.cuda.synchronize()
-        t_st = (time.perf_counter() - t0) / nst
+            res = stream_step()
+        sync()
+        t_st = time.perf_counter() - t0
         L.fib_profile_enable(0)
+        cnt = torch.tensor([float(res["xyz"].shape[0]), float(res["npts"].numel()), t_st], device=dev, dtype=torch.float64)
+        if world > 1:
+            tmax = cnt[2:].clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(cnt[:2], op=dist.ReduceOp.SUM)
+            cnt[2] = tmax[0]
+        npoints, nlines, t_st = int(cnt[0].item()), int(cnt[1].item()), float(cnt[2].item()) / nst
         tr_ms, tr_n = prof_get(L, "stream_trace")
         pk_ms, pk_n = prof_get(L, "stream_pack")
-        npoints = int(res["xyz"].shape[0])
-        extra["stream_dti_ball"] = dict(seeds=int(seeds.numel()), lines=int(res["npts"].numel()), points=npoints,
+        extra["stream_dti_ball"] = dict(seeds=int(seeds_all.numel()), lines=nlines, points=npoints,
                                         mpoints_per_s=npoints / t_st / 1e6, ms_per_step=t_st * 1e3,
                                         trace_kernel_ms=tr_ms / max(tr_n, 1), pack_kernel_ms=pk_ms / max(pk_n, 1),
                                         algorithmic_bytes=25.0 * npoints,
-                                        hbm_gbs_trace=25.0 * npoints / (tr_ms / max(tr_n, 1) * 1e-3) / 1e9 if tr_n else 0.0)
+                                        hbm_gbs_trace=25.0 * (npoints / world) / (tr_ms / max(tr_n, 1) * 1e-3) / 1e9 if tr_n else 0.0,
+                                        note="one volume, seeds sharded round-robin over the ranks"
+                                             + (", field broadcast from rank 0 inside the timed step" if world > 1 else ""))
+        del res, bm, seeds_all
 
     if not args.no_extra and rank == 0 and world == 1:
         # ---- DSI 515-direction reconstruction + peaks (C5 fit part) ------------------------------------
-        del field, res, o2, d2
+        del field, o2, d2
         torch.cuda.empty_cache()
         b5, g5 = phantom.scheme_dsi()
         d5, _ = phantom.make_dwi_torch(SHAPE, b5, g5, seed=5, device=dev)
@@ -231,7 +256,29 @@ def main():
         extra["dsi_rec_140x515"] = dict(mvoxels_per_s=nvox / t_dsi / 1e6, ms_per_step=t_dsi * 1e3,
                                         gemm_kernel_ms=g_ms / max(g_n, 1), fold_kernel_ms=f_ms / max(f_n, 1),
                                         note="antipodal folding: 258 folded samples x (258 pdf + 321 odf) rows")
-        del o5, d5
+        # ---- C5 tracking: 3 peaks per voxel (f = qa, f_thresh = .03), ball mask, nsub = 10 -> ~10 M lines -------------
+        del d5
+        bm = phantom.ball_mask_torch(SHAPE, dev)
+        field3, mout3 = fj.stream_field_device(o5["peak"], f=o5["qa"], f_thresh=0.03, mask=bm)
+        seeds3 = torch.nonzero(mout3).flatten()
+        sub10 = torch.from_numpy(fj.make_sublist(10, np.random.default_rng(5))).to(dev)
+        r3 = fj.stream_device(field3, SHAPE, seeds3, sub10)
+        torch.cuda.synchronize()
+        L.fib_profile_enable(1); L.fib_profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            r3 = fj.stream_device(field3, SHAPE, seeds3, sub10)
+        torch.cuda.synchronize()
+        t3 = (time.perf_counter() - t0) / 2
+        L.fib_profile_enable(0)
+        tr_ms, tr_n = prof_get(L, "stream_trace")
+        pk_ms, pk_n = prof_get(L, "stream_pack")
+        np3 = int(r3["xyz"].shape[0])
+        extra["stream_dsi_3peaks_10M"] = dict(seeds=int(seeds3.numel()), nsub=10, lines=int(r3["npts"].numel()), points=np3,
+                                              mpoints_per_s=np3 / t3 / 1e6, ms_per_step=t3 * 1e3,
+                                              trace_kernel_ms=tr_ms / max(tr_n, 1), pack_kernel_ms=pk_ms / max(pk_n, 1),
+                                              algorithmic_bytes=49.0 * np3)
+        del o5, r3, field3
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -435,7 +435,7 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {      // ro
     return r;
 }
 
-template <int MB, int NX, int NW, bool STAMP = false, int PROBE = 0>
+template <int MB, int NX, int NW, bool STAMP = false>
 __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a) {
     constexpr int NPIECE = 3 * MB;                      // 1-KiB pieces per stage
     constexpr int TILEB = NPIECE * 1024;                // bytes per stage
@@ -575,34 +575,42 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
         for (int t = 0; t < ntiles; t++, g++) {
             const int cb = g & 1;
             const char *L = lds + cb * TILEB;
-            if (PROBE & 8) { for (int jj = 0; jj < 4; jj++) { bp[0][jj] = __float_as_uint(braw[2 * jj]); bp[1][jj] = __float_as_uint(braw[2 * jj + 1]); bp[2][jj] = bp[0][jj] ^ bp[1][jj]; } }
-            else split(cur.tile_m, t);
+            split(cur.tile_m, t);
             // the next stage (it may open the next work item): pieces into the other buffer, samples into braw
             const bool w1 = t + 1 < ntiles;
-            if (!(PROBE & 4) || g < 1) stage_A(w1 ? cur.tile_m : (nxt.valid ? nxt.tile_m : cur.tile_m), w1 ? t + 1 : 0, cb ^ 1);
-            if (!(PROBE & 2)) load_B(w1 ? t + 1 : 0, w1 ? s_off : s_off_n, w1 || nxt.valid);
+            stage_A(w1 ? cur.tile_m : (nxt.valid ? nxt.tile_m : cur.tile_m), w1 ? t + 1 : 0, cb ^ 1);
+            load_B(w1 ? t + 1 : 0, w1 ? s_off : s_off_n, w1 || nxt.valid);
             __builtin_amdgcn_sched_barrier(0);          // the requests go out before the MFMA block, not after it
             const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, bp[0]), b1 = __builtin_bit_cast(bf16x8_t, bp[1]), b2 = __builtin_bit_cast(bf16x8_t, bp[2]);
             const bf16x8_t *LA = reinterpret_cast<const bf16x8_t *>(L) + lane;
+            // The fragment reads are pinned (sched_barrier) 2-5 MFMAs ahead of their first use, each into the registers
+            // its predecessor has just left: left to itself hipcc sinks every ds_read to the MFMA that needs it.
+            bf16x8_t a2 = LA[(2 * MB) * 64], a1 = LA[(1 * MB) * 64], a0 = LA[0];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MB; m++) {
-                bf16x8_t a2, a1, a0;
-                if (PROBE & 16) { a2 = b1; a1 = b2; a0 = b0; }
-                else { a2 = LA[(2 * MB + m) * 64]; a1 = LA[(1 * MB + m) * 64]; a0 = LA[m * 64]; }
-                // smallest terms first
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[m], 0, 0, 0);
+                bf16x8_t n2 = a2, n1 = a1, n0 = a0;
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[m], 0, 0, 0);     // smallest terms first
+                if (m + 1 < MB) n2 = LA[(2 * MB + m + 1) * 64];
+                __builtin_amdgcn_sched_barrier(0);
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[m], 0, 0, 0);
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[m], 0, 0, 0);
+                if (m + 1 < MB) n0 = LA[(m + 1) * 64];
+                __builtin_amdgcn_sched_barrier(0);
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[m], 0, 0, 0);
+                if (m + 1 < MB) n1 = LA[(1 * MB + m + 1) * 64];
+                __builtin_amdgcn_sched_barrier(0);
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[m], 0, 0, 0);
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                a2 = n2; a1 = n1; a0 = n0;
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): the next stage's pieces and samples have landed
-            if (!(PROBE & 32)) __syncthreads();
+            __syncthreads();
         }
         unsigned long long te = 0;
         if (STAMP) te = __builtin_amdgcn_s_memtime();
-        if (!(PROBE & 1) || !nxt.valid) gemm3_epilogue<MB, NX>(a, acc, xacc, vmax, vnf, inb, vox, lane, cur.tile_m, sraw, lds + 2 * TILEB + wave * 2048);
+        gemm3_epilogue<MB, NX>(a, acc, xacc, vmax, vnf, inb, vox, lane, cur.tile_m, sraw, lds + 2 * TILEB + wave * 2048);
         if (STAMP) acc_epi += __builtin_amdgcn_s_memtime() - te;
         if (!nxt.valid) break;
         cur = nxt; inb = inb_n; vox = vox_n; s_off = s_off_n;
@@ -1468,9 +1476,8 @@ namespace {
 template <int MB, int NX>
 void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
     if (ga.At3) {
-        // persistent grid: one 8-wave workgroup per CU (or two of 4 waves: FIBERS_GEMM3_WAVES=4; measured 6 % slower), a multiple
-        // of 8 so that blockIdx & 7 is the XCD
-        static const int nw_env = getenv("FIBERS_GEMM3_WAVES") ? atoi(getenv("FIBERS_GEMM3_WAVES")) : 8;
+        // persistent grid: one 8-wave workgroup per CU (two 4-wave workgroups per CU were measured 6 % slower), a multiple of 8
+        // so that blockIdx & 7 is the XCD
         static const int stamp = getenv("FIBERS_GEMM3_STAMP") ? atoi(getenv("FIBERS_GEMM3_STAMP")) : 0;
         int ncu = 256, dev = 0;
         (void)hipGetDevice(&dev);
@@ -1478,7 +1485,7 @@ void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
         GemmArgs g2 = ga;
         static const int stagger = getenv("FIBERS_GEMM3_STAGGER") ? atoi(getenv("FIBERS_GEMM3_STAGGER")) : 0;
         g2.stagger = stagger;
-        const int nw = nw_env == 4 ? 4 : 8;
+        const int nw = 8;
         const int64_t items = fib::cdiv(ga.nvox, nw * 32) * ga.ntile_m;
         unsigned pg = (unsigned)std::min<int64_t>((int64_t)ncu * (8 / nw), items);
         pg = (pg + 7) / 8 * 8;
@@ -1488,8 +1495,7 @@ void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
             if (!dbg) (void)hipMalloc((void **)&dbg, (size_t)4096 * 8 * 8);
             g2.dbg = dbg;
             constexpr int PM = (MB == 10 && NX == 1) ? 10 : 5, PN = (MB == 10 && NX == 1) ? 1 : 0;
-            if (nw == 8) hipLaunchKernelGGL((odf_gemm3_kernel<PM, PN, 8, true>), dim3(pg), dim3(512), 0, st, g2);
-            else hipLaunchKernelGGL((odf_gemm3_kernel<PM, PN, 4, true>), dim3(pg), dim3(256), 0, st, g2);
+            hipLaunchKernelGGL((odf_gemm3_kernel<PM, PN, 8, true>), dim3(pg), dim3(512), 0, st, g2);
             if (++calls == 12) {
                 (void)hipStreamSynchronize(st);
                 std::vector<unsigned long long> h((size_t)pg * 8);
@@ -1508,16 +1514,7 @@ void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
             }
             return;
         }
-        static const int probe = getenv("FIBERS_GEMM3_PROBE") ? atoi(getenv("FIBERS_GEMM3_PROBE")) : 0;   // timing experiments (wrong results)
-        if (probe && MB == 10 && NX == 1) {
-            constexpr int PM = (MB == 10 && NX == 1) ? 10 : 5, PN = (MB == 10 && NX == 1) ? 1 : 0;
-#define FIB_PROBE_CASE(P) if (probe == P) { if (nw == 8) hipLaunchKernelGGL((odf_gemm3_kernel<PM, PN, 8, false, P>), dim3(pg), dim3(512), 0, st, g2); \
-                                            else hipLaunchKernelGGL((odf_gemm3_kernel<PM, PN, 4, false, P>), dim3(pg), dim3(256), 0, st, g2); return; }
-            FIB_PROBE_CASE(1) FIB_PROBE_CASE(8) FIB_PROBE_CASE(16) FIB_PROBE_CASE(32) FIB_PROBE_CASE(7) FIB_PROBE_CASE(15) FIB_PROBE_CASE(31) FIB_PROBE_CASE(63) FIB_PROBE_CASE(39)
-#undef FIB_PROBE_CASE
-        }
-        if (nw == 8) hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 8>), dim3(pg), dim3(512), 0, st, g2);
-        else hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 4>), dim3(pg), dim3(256), 0, st, g2);
+        hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 8>), dim3(pg), dim3(512), 0, st, g2);
     }
     else hipLaunchKernelGGL((odf_gemm_kernel<MB, NX>), dim3(grid), dim3(256), 0, st, ga);
 }

@@ -37,10 +37,10 @@ else:
     kind = "gqi"
     if args and args[0] in ("gqi", "dsi"):
         kind = args.pop(0)
-    for cfg in (args or ["W=4,S=0", "W=4,S=32", "W=8,S=0", "W=8,S=32", "W=4,S=0,T=1"]):
+    for cfg in (args or ["A=1", "A=0", "A=1,T=1"]):
         kv = dict(x.split("=") for x in cfg.split(","))
         env = dict(os.environ)
-        env["FIBERS_GEMM3_WAVES"] = kv.get("W", "4"); env["FIBERS_GEMM3_STAGGER"] = kv.get("S", "0"); env["FIBERS_GEMM3_STAMP"] = kv.get("T", "0")
+        env["FIBERS_GEMM3_STAGGER"] = kv.get("S", "0"); env["FIBERS_GEMM3_STAMP"] = kv.get("T", "0")
         if "G" in kv: env["FIBERS_ODF_GEMM"] = kv["G"]
-        env["FIBERS_GEMM3_PROBE"] = kv.get("P", "0")
+        env["FIBERS_GEMM3_ANTIPHASE"] = kv.get("A", "1")
         subprocess.call([sys.executable, os.path.abspath(__file__), "child", kind, cfg], env=env)
