@@ -32,6 +32,7 @@ struct GemmArgs {
     const float *S;           // [K][nvox] planar DWI
     const int32_t *vidx;      // [nlive] voxels inside the mask, ascending (mask_compact_*): lane -> voxel gather / scatter
     const int32_t *nlive;     // device count of vidx
+    const uint8_t *mask;      // [nvox]: voxels of a listed quad that are outside the mask get zeros
     const uint32_t *effbits;  // [Kpad/KT] bit j of word t: frame t*KT+j exists and takes part in the "any positive sample" test
     float *out0;              // rows [0, nrow0)        (DSI: pdf)
     float *out1;              // rows [nrow0, M)        (odf)
@@ -84,13 +85,13 @@ __host__ __device__ constexpr int gemm_row_stride(int mb, int nx) { return (mb *
 // "any sample > 0" (gqi.jl:142, dsi.jl:207), NaN/Inf poisoning, the DSI 1/sum(p) scale, row -> output mapping.
 template <int MB, int NX>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[MB], float (&xacc)[NX > 0 ? NX : 1], float vmax, float vnf,
-                                              bool inb, int64_t vox, int kh, int tile_m, uint32_t c_off, float sraw) {
+                                              bool inb, bool lv, int64_t vox, int kh, int tile_m, uint32_t c_off, float sraw) {
     constexpr int ROWS = MB * 32 + NX;
     // ---- epilogue: the two k-halves of a voxel live in lanes l and l^32 -----------------------------------
     float pm = fmaxf(vmax, __shfl_xor(vmax, 32));
     float pn = vnf + __shfl_xor(vnf, 32);
     const bool nonfinite = pn != pn;                    // a NaN sample makes every output NaN (NaN * A[v,i] for all v)
-    const bool valid = inb && (pm > 0.0f || nonfinite);
+    const bool valid = lv && (pm > 0.0f || nonfinite);
     const bool do_scale = a.scale_frame >= 0;
     float scale = 1.0f;
     if (do_scale) {
@@ -291,21 +292,22 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
 
     float sraw = 0.0f;
     if (a.scale_frame >= 0) sraw = *reinterpret_cast<const float *>(Sbase + (int64_t)a.scale_frame * a.stride * 4 + c_off);
-    gemm_epilogue<MB, NX>(a, acc, xacc, vmax, vnf, inb, vox, kh, tile_m, c_off, sraw);
+    const bool lv = inb && a.mask[vox] != 0;            // the listed quad's voxels outside the mask: zeros
+    gemm_epilogue<MB, NX>(a, acc, xacc, vmax, vnf, inb, lv, vox, kh, tile_m, c_off, sraw);
 }
 
-// Epilogue of the split-bf16 kernel.  Fast path (wave-uniform): the wave's 32 voxels are contiguous and 16-byte
-// aligned in memory -> each half of a 32x32 block goes through the wave's 2-KiB LDS tile ([16 rows][32 voxels]; rows
+// Epilogue of the split-bf16 kernel.  Fast path (16-byte aligned output rows): the wave's 32 voxels are 8 aligned quads
+// of consecutive voxels -> each half of a 32x32 block goes through the wave's 2-KiB LDS tile ([16 rows][32 voxels]; rows
 // r and r+4 interleaved so that both lane halves write different banks) and leaves as 2 dwordx4 stores of 8 rows x 128 B.
 template <int MB, int NX>
 __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[MB], float (&xacc)[NX > 0 ? NX : 1], float vmax, float vnf,
-                                               bool inb, int64_t vox, int lane, int tile_m, float sraw, char *tr) {
+                                               bool inb, bool lv, int64_t vox, int lane, int tile_m, float sraw, char *tr) {
     constexpr int ROWS = MB * 32 + NX;
     const int col = lane & 31, kh = lane >> 5;
     float pm = fmaxf(vmax, __shfl_xor(vmax, 32));
     float pn = vnf + __shfl_xor(vnf, 32);
     const bool nonfinite = pn != pn;                    // a NaN sample makes every output NaN (NaN * A[v,i] for all v)
-    const bool valid = inb && (pm > 0.0f || nonfinite);
+    const bool valid = lv && (pm > 0.0f || nonfinite);
     const bool do_scale = a.scale_frame >= 0;
     float scale = 1.0f;
     if (do_scale) {
@@ -317,8 +319,12 @@ __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[
     const float mulv = valid ? scale : 0.0f;
 #pragma unroll
     for (int x = 0; x < NX; x++) xacc[x] += __shfl_xor(xacc[x], 32);
-    const int vox0 = __builtin_amdgcn_readfirstlane((int)vox);
-    const bool contig = a.vec_ok && __all(inb && vox == (int64_t)vox0 + col) && (vox0 & 3) == 0;
+    // the voxel list is made of aligned quads (mask_write_kernel): lanes 4q..4q+3 hold four consecutive voxels, so the
+    // lane that stores quad q of a row (lane & 7 == q after the transposition) takes its address from lane 4q
+    const bool contig = a.vec_ok != 0;
+    const int qsrc = 4 * (lane & 7);
+    const int32_t qvox = __shfl((int)vox, qsrc);
+    const bool qinb = __shfl((int)inb, qsrc) != 0;
     auto row_ptr = [&](int row) -> char * {
         return reinterpret_cast<char *>(row >= a.nrow0 ? a.out1 + (int64_t)(row - a.nrow0) * a.stride
                                                        : a.out0 + (int64_t)row * a.stride);
@@ -330,7 +336,7 @@ __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[
         const int P = lane >> 3;                                                  // physical row (within 8) this lane stores
         const int lrow = ((P >> 1) & 3) | ((P & 1) << 2);                         // its logical row within the 8
         const float4 *trd = reinterpret_cast<const float4 *>(tr) + lane;
-        const uint32_t voff = (uint32_t)(vox0 + 4 * (lane & 7)) * 4u;
+        const uint32_t voff = (uint32_t)qvox * 4u;
 #pragma unroll
         for (int m = 0; m < MB; m++) {
             const int row0 = tile_m * ROWS + m * 32;    // wave-uniform
@@ -349,6 +355,7 @@ __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     const float4 v4 = trd[j * 64];
+                    if (!qinb) continue;                // ragged end of the voxel list
                     if (whole && !split_out) {
                         *reinterpret_cast<float4 *>(base + (int64_t)(16 * hb + 8 * j) * a.stride * 4) = v4;
                         continue;
@@ -570,6 +577,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
     for (;;) {
         float sraw = 0.0f;                               // DSI: the sample that sum(p) is a multiple of (dsi.jl:224-225)
         if (a.scale_frame >= 0) sraw = *reinterpret_cast<const float *>(Sbase + (int64_t)a.scale_frame * a.stride * 4 + (uint32_t)(vox * 4));
+        const bool lv = inb && a.mask[vox] != 0;         // voxels of a listed quad that are outside the mask: zeros
         bool inb_n = false; int64_t vox_n = 0; uint32_t s_off_n = 0;
         if (nxt.valid) lane_state(nxt, vraw_nxt, inb_n, vox_n, s_off_n);
         for (int t = 0; t < ntiles; t++, g++) {
@@ -610,7 +618,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
         }
         unsigned long long te = 0;
         if (STAMP) te = __builtin_amdgcn_s_memtime();
-        gemm3_epilogue<MB, NX>(a, acc, xacc, vmax, vnf, inb, vox, lane, cur.tile_m, sraw, lds + 2 * TILEB + wave * 2048);
+        gemm3_epilogue<MB, NX>(a, acc, xacc, vmax, vnf, inb, lv, vox, lane, cur.tile_m, sraw, lds + 2 * TILEB + wave * 2048);
         if (STAMP) acc_epi += __builtin_amdgcn_s_memtime() - te;
         if (!nxt.valid) break;
         cur = nxt; inb = inb_n; vox = vox_n; s_off = s_off_n;
@@ -628,11 +636,19 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
 }
 
 // ---- mask compaction ---------------------------------------------------------------------------------------
-// vidx = ascending list of the voxels inside the mask, tiles = ascending list of the 64-voxel tiles that hold at
-// least one; both counts stay on the device (no host round trip).  Three small launches: per-block counts,
+// vidx = ascending list of the voxels of every aligned 4-voxel group ("quad") that holds a voxel inside the mask, so
+// that every four consecutive list entries are four consecutive, 16-byte aligned voxels (dwordx4 row stores in the
+// GEMM epilogue; the GEMM re-tests the mask per voxel and writes zeros for the group's voxels outside it: at most 3
+// wasted columns per run end).  tiles = ascending list of the 64-voxel tiles that hold at least one voxel of the
+// mask; both counts stay on the device (no host round trip).  Three small launches: per-block counts,
 // one-block exclusive scan, ordered write.  A block covers 1024 voxels as 4 passes x 4 waves x 64 lanes, so a
 // wave-pass is exactly one tile and a ballot gives both counts.
 constexpr int CB = 1024;
+// lanes of the quads (aligned groups of 4 lanes = voxels) in which at least one lane's bit is set
+__device__ __forceinline__ unsigned long long quad_expand(unsigned long long b) {
+    unsigned long long q = (b | (b >> 1) | (b >> 2) | (b >> 3)) & 0x1111111111111111ull;
+    return q | (q << 1) | (q << 2) | (q << 3);
+}
 __global__ __launch_bounds__(256) void mask_count_kernel(const uint8_t *__restrict__ mask, int64_t nvox, int2 *__restrict__ blockcnt) {
     __shared__ int cv[4], ct[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -640,7 +656,7 @@ __global__ __launch_bounds__(256) void mask_count_kernel(const uint8_t *__restri
     for (int i = 0; i < 4; i++) {
         const int64_t vx = (int64_t)blockIdx.x * CB + i * 256 + tid;
         const unsigned long long b = __ballot(vx < nvox && mask[vx] != 0);
-        nv += __popcll(b);
+        nv += __popcll(quad_expand(b) & __ballot(vx < nvox));
         nt += b != 0ull;
     }
     if (lane == 0) { cv[wave] = nv; ct[wave] = nt; }
@@ -672,11 +688,12 @@ __global__ __launch_bounds__(256) void mask_write_kernel(const uint8_t *__restri
                                                         int32_t *__restrict__ vidx, int32_t *__restrict__ tiles) {
     __shared__ int cv[16], ct[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long b[4];
+    unsigned long long b[4], e[4];
     for (int i = 0; i < 4; i++) {
         const int64_t vx = (int64_t)blockIdx.x * CB + i * 256 + tid;
         b[i] = __ballot(vx < nvox && mask[vx] != 0);
-        if (lane == 0) { cv[i * 4 + wave] = __popcll(b[i]); ct[i * 4 + wave] = b[i] != 0ull; }
+        e[i] = quad_expand(b[i]) & __ballot(vx < nvox);
+        if (lane == 0) { cv[i * 4 + wave] = __popcll(e[i]); ct[i * 4 + wave] = b[i] != 0ull; }
     }
     __syncthreads();
     const int2 off = blockoff[blockIdx.x];
@@ -684,7 +701,7 @@ __global__ __launch_bounds__(256) void mask_write_kernel(const uint8_t *__restri
         int pv = off.x, pt = off.y;
         for (int c = 0; c < i * 4 + wave; c++) { pv += cv[c]; pt += ct[c]; }
         const int64_t vx = (int64_t)blockIdx.x * CB + i * 256 + tid;
-        if ((b[i] >> lane) & 1ull) vidx[pv + __popcll(b[i] & ((1ull << lane) - 1ull))] = (int32_t)vx;
+        if ((e[i] >> lane) & 1ull) vidx[pv + __popcll(e[i] & ((1ull << lane) - 1ull))] = (int32_t)vx;
         if (lane == 0 && b[i]) tiles[pt] = (int32_t)(vx >> 6);
     }
 }
@@ -1607,7 +1624,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
     }
     ga.At = plan->At.p; ga.At3 = (plan->split_bf16 && nvox <= ((int64_t)1 << 26)) ? plan->At3.p : nullptr; ga.S = dwi;
     ga.Aextra = plan->Aextra.p;
-    ga.vec_ok = (nvox % 4 == 0 && ((uintptr_t)odf & 15) == 0 && (pdf == nullptr || ((uintptr_t)pdf & 15) == 0)) ? 1 : 0; ga.vidx = plan->live_vox.p; ga.nlive = plan->live_counts.p; ga.effbits = plan->effbits.p;
+    ga.vec_ok = (nvox % 4 == 0 && ((uintptr_t)odf & 15) == 0 && (pdf == nullptr || ((uintptr_t)pdf & 15) == 0)) ? 1 : 0; ga.vidx = plan->live_vox.p; ga.nlive = plan->live_counts.p; ga.mask = mask; ga.effbits = plan->effbits.p;
     ga.out0 = pdf; ga.out1 = odf; ga.nvox = nvox;
     ga.K = plan->gK; ga.Kpad = plan->Kpad; ga.M = plan->gM; ga.nrow0 = plan->gRow0; ga.ntile_m = plan->ntile_m;
     if (plan->folded) {
