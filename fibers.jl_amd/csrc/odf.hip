@@ -1106,6 +1106,9 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
         // UNR vertices per iteration: their neighbour-table reads and ODF reads are all issued before the
         // first compare, so each wave keeps ~(1+DEG)*UNR LDS reads in flight instead of a dependent chain
         constexpr int UNR = 4;
+        static_assert(DEG % 2 == 0, "neighbour slots come in pairs (v_max3)");
+        unsigned gbits = 0;
+        int gscan = 0;
         for (int v0 = wave; v0 < a.nvert; v0 += P64_W * UNR) {
             float x[UNR], y[UNR][DEG];
             int vv[UNR];
@@ -1121,6 +1124,21 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
 #pragma unroll
                 for (int d = 0; d < DEG; d++) y[u][d] = o[nb[d] + lane];
             }
+            if constexpr (!EXACT) {
+                // candidates only (see the specialised scan): flag = !(max(neighbours, 0) >= x), shifted into `bits`
+#pragma unroll
+                for (int u = 0; u < UNR; u++) {
+                    if (vv[u] < a.nvert) {                      // wave-uniform
+                        float mx = 0.0f;
+#pragma unroll
+                        for (int d = 0; d + 1 < DEG; d += 2) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(y[u][d]), "v"(y[u][d + 1]));
+                        asm("v_cmp_nge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(gbits) : "v"(mx), "v"(x[u]) : "vcc");
+                        asm("v_min_f32 %0, %0, %1" : "+v"(p.vmin) : "v"(x[u]));      // NaN-ignoring; NaN is recovered from vsum
+                        p.vsum += x[u];
+                        gscan++;
+                    }
+                }
+            } else {
             float pk[UNR];
             bool cand = false;
 #pragma unroll
@@ -1133,16 +1151,30 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
                 if (live) {
                     p.vmin = x[u] < p.vmin ? x[u] : p.vmin;     // NaN-ignoring; NaN is recovered from vsum below
                     p.vsum += x[u];
-                    cand |= EXACT || !(pk[u] <= 0.0f);
+                    cand = true;
                 }
             }
-            if (__any(cand)) {                                  // wave-uniform skip of the rare work
+            if (__any(cand)) {
 #pragma unroll
                 for (int u = 0; u < UNR; u++)
                     if (vv[u] < a.nvert) {
                         if (pk[u] > 0.0f) p.npos++;             // gqi.jl:200
-                        if (EXACT || !(pk[u] <= 0.0f)) top3_insert(p.t, pk[u], vv[u]);
+                        top3_insert(p.t, pk[u], vv[u]);         // EXACT: the full sortperm order (find_peaks! API)
                     }
+            }
+            }
+        }
+        if constexpr (!EXACT) {
+            // bit b of `gbits` = the (gscan-1-b)-th vertex this wave scanned = vertex wave + 16*(gscan-1-b)
+            while (__any(gbits != 0u)) {
+                if (gbits != 0u) {
+                    const int b = __ffs((int)gbits) - 1;
+                    gbits &= gbits - 1u;
+                    const int v = wave + P64_W * (gscan - 1 - b);
+                    const float xv = o[v * 64 + lane];
+                    if (xv > 0.0f) p.npos++;                                    // gqi.jl:200
+                    top3_insert(p.t, xv, v);
+                }
             }
         }
         }
