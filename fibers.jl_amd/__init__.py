@@ -8,7 +8,7 @@ from ._lib import FibersError, LIB_PATH, lib  # noqa: F401
 from .mri import MRI  # noqa: F401
 from .odf import ODF, sphere_362, sphere_642, sphere_724  # noqa: F401
 from .dti import DTI, DtiPlan, adc_fit, adc_fit_device, dti_fit, dti_fit_device  # noqa: F401
-from .gqi import (DSI, GQI, OdfPlan, dsi_rec, find_peaks_device, gqi_rec, odf_rec_device,  # noqa: F401
+from .gqi import (DSI, GQI, OdfPlan, dsi_rec, find_peaks, find_peaks_device, gqi_rec, odf_rec_device,  # noqa: F401
                   qa_normalize_device)
 from .tract import Tract  # noqa: F401
 from .stream import make_sublist, stream, stream_device, stream_field_device  # noqa: F401

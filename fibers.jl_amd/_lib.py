@@ -70,6 +70,7 @@ _PROTOS = {
     "fib_adc_fit": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp]),
     "fib_gqi_rec": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, f32, vp, P3, P3]),
     "fib_dsi_rec": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, vp, vp, P3, P3]),
+    "fib_find_peaks": (i32, [i32, vp, i64, vp, i32, vp, i32, vp, vp]),
     "fib_stream": (i32, [i32, C.POINTER(StreamParams), vp, vp, f32, vp, f32, vp, i32, vp, i32, vp, i32,
                          C.POINTER(TractOut)]),
     "fib_tract_free": (None, [C.POINTER(TractOut)]),

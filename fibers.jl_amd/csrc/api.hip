@@ -179,6 +179,34 @@ extern "C" int fib_dsi_rec(int device, const float *dwi, int nx, int ny, int nz,
     return odf_rec_host(p, nvol, dwi, nx, ny, nz, mask, mask_dtype, nverts / 2, pdf, odf, peak, qa);
 }
 
+// find_peaks!(W) (gqi.jl:180-201) for nvox ODFs held in host memory: odf [nvox x nvert] planar (vertex-major rows of
+// nvox values, like MRI.vol[:,:,:,v]); isort_top [3 x nvox] planar, 0-based first-half vertex rows, -1 where the
+// tessellation has fewer vertices; nvalid [nvox] = count(odf_peak .> 0) (gqi.jl:200).
+extern "C" int fib_find_peaks(int device, const float *odf, int64_t nvox, const float *verts, int nverts,
+                              const int32_t *faces, int nfaces, int32_t *isort_top, int32_t *nvalid) {
+    FIB_CHECK(odf && verts && faces && isort_top && nvalid, FIB_ERR_INVALID, "NULL argument");
+    FIB_CHECK(nvox > 0 && nverts >= 2 && nverts % 2 == 0 && nfaces > 0, FIB_ERR_INVALID, "invalid sizes");
+    fib::DeviceGuard guard;
+    // the plan only contributes the folded neighbour table: one dummy frame is enough
+    const float bval1[1] = {1000.0f}, bvec1[3] = {1.0f, 0.0f, 0.0f};
+    fib_odf_plan *p = nullptr;
+    RC(fib_gqi_plan_create(device, bval1, bvec1, 1, verts, nverts, faces, nfaces, 1.25f, &p));
+    struct PlanDel { fib_odf_plan *p; ~PlanDel() { fib_odf_plan_destroy(p); } } del{p};
+    FIB_HIP(hipSetDevice(device));
+    const int nvert = nverts / 2;
+    fib::DevBuf<float> d_odf;
+    fib::DevBuf<int32_t> d_top, d_nv;
+    RC(d_odf.alloc((size_t)nvox * nvert));
+    RC(d_top.alloc((size_t)nvox * 3));
+    RC(d_nv.alloc((size_t)nvox));
+    FIB_HIP(hipMemcpy(d_odf.p, odf, (size_t)nvox * nvert * sizeof(float), hipMemcpyHostToDevice));
+    RC(fibd_find_peaks(p, d_odf.p, nvox, d_top.p, d_nv.p, nullptr));
+    FIB_HIP(hipDeviceSynchronize());
+    FIB_HIP(hipMemcpy(isort_top, d_top.p, (size_t)nvox * 3 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    FIB_HIP(hipMemcpy(nvalid, d_nv.p, (size_t)nvox * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return FIB_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // stream
 // ------------------------------------------------------------------------------------------

@@ -76,6 +76,25 @@ def dsi_rec(dwi: MRI, mask: MRI, odf_dirs: ODF = sphere_642, hann_width: int = 3
     return DSI(pdf, odf, peak, qa)
 
 
+def find_peaks(odf, odf_dirs: ODF = sphere_642, device: int = 0):
+    """find_peaks!(W) (gqi.jl:180-201) on host ODFs.  odf: [..., nvert] amplitudes on the half sphere (any leading
+    shape, e.g. `GQI.odf.vol`); returns (isort_top int32 [..., 3]: the first three entries of `isort`, 0-based
+    first-half vertex rows, -1 beyond the tessellation; nvalid int32 [...] = count(odf_peak .> 0))."""
+    o = np.asarray(odf, dtype=np.float32)
+    nvert = odf_dirs.nvert
+    if o.shape[-1] != nvert:
+        raise ValueError("last axis of odf must be the %d half-sphere vertices" % nvert)
+    lead = o.shape[:-1]
+    nvox = int(np.prod(lead)) if lead else 1
+    planar = np.ascontiguousarray(o.reshape(nvox, nvert).T)             # [nvert, nvox]
+    v, f = _odf_args(odf_dirs)
+    top = np.empty((3, nvox), np.int32)
+    nvalid = np.empty(nvox, np.int32)
+    _lib.check(_lib.lib().fib_find_peaks(device, planar.ctypes.data, nvox, v.ctypes.data, v.shape[0], f.ctypes.data,
+                                         f.shape[0], top.ctypes.data, nvalid.ctypes.data))
+    return top.T.reshape(lead + (3,)), nvalid.reshape(lead)
+
+
 # ---------------------------------------------------------------------------------------------
 # device-resident form
 # ---------------------------------------------------------------------------------------------

@@ -208,6 +208,12 @@ int fib_dsi_rec(int device, const float *dwi, int nx, int ny, int nz, int nvol,
                 const float *verts, int nverts, const int32_t *faces, int nfaces, int hann_width,
                 float *pdf, float *odf, float *const peak[3], float *const qa[3]);
 
+/* find_peaks!(W) (gqi.jl:180-201) for nvox ODFs in host memory.  odf [nvox x nvert] planar (row v = the nvox
+ * amplitudes of half-sphere vertex v, like MRI.vol[:,:,:,v]); isort_top [3 x nvox] planar: the first three entries
+ * of `isort` (0-based first-half vertex rows, -1 where the sphere has fewer vertices); nvalid [nvox] (gqi.jl:200). */
+int fib_find_peaks(int device, const float *odf, int64_t nvox, const float *verts, int nverts,
+                   const int32_t *faces, int nfaces, int32_t *isort_top, int32_t *nvalid);
+
 /* stream(ovec; f, f_thresh, fa, fa_thresh, mask, seed, ...)::Tract (stream.jl:730), non-LCM macro path.
  * ovec[k] [nx,ny,nz,3]; f[k] [nx,ny,nz] or f == NULL; fa / mask / seed may be NULL (mask == NULL:
  * any-nonzero-vector mask, stream.jl:96-100; seed == NULL: brain mask seeds, stream.jl:744).

@@ -56,6 +56,19 @@ function adc_fit(dwi::MRI, mask::MRI; device::Integer=0)
   return adc, s0
 end
 
+"find_peaks(odf, odf_dirs) — find_peaks!(W) (gqi.jl:180-201) for a whole ODF volume [nx,ny,nz,nvert]:
+ returns (isort_top [nx,ny,nz,3] 1-based first-half vertex rows, 0 where absent; nvalid [nx,ny,nz])"
+function find_peaks(odf::MRI, odf_dirs::ODF=sphere_642; device::Integer=0)
+  nx, ny, nz, nvert = size(odf.vol)
+  nvox = nx * ny * nz
+  top = Array{Int32}(undef, nx, ny, nz, 3); nvalid = Array{Int32}(undef, nx, ny, nz)
+  faces = Int32.(odf_dirs.faces); verts = odf_dirs.vertices; vol = odf.vol::Array{Float32,4}
+  GC.@preserve vol top nvalid faces verts fib_check(ccall((:fib_find_peaks, libfibers), Cint,
+      (Cint, Ptr{Float32}, Int64, Ptr{Float32}, Cint, Ptr{Int32}, Cint, Ptr{Int32}, Ptr{Int32}),
+      device, vol, nvox, verts, size(verts, 1), faces, size(faces, 1), top, nvalid))
+  return top .+ Int32(1), nvalid
+end
+
 "gqi_rec(dwi, mask, odf_dirs, σ) — replaces gqi.jl:109-171 (and find_peaks! gqi.jl:180-201)"
 function gqi_rec(dwi::MRI, mask::MRI, odf_dirs::ODF=sphere_642, σ::Float32=Float32(1.25); device::Integer=0)
   isempty(dwi.bval) && error("Missing b-value table from input DWI structure")

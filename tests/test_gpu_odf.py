@@ -270,3 +270,19 @@ def test_split_bf16_matches_f32_kernel_large(fj, monkeypatch):
     live = ball.bool()
     assert torch.equal(outs["bf16x3", "ones"][0][:, live], outs["bf16x3", "ball"][0][:, live])
     assert (outs["bf16x3", "ball"][0][:, ~live] == 0).all()
+
+
+def test_find_peaks_host_entry(fj, orc):
+    """fib_find_peaks (host buffers): the first three entries of isort and nvalid, for all three tessellations"""
+    rng = np.random.default_rng(9)
+    for sph in (fj.sphere_362, fj.sphere_642, fj.sphere_724):
+        odf = rng.random((7, 5, sph.nvert)).astype(np.float32)
+        odf[0, 0] = 0.0
+        odf[1, 1, :] = np.round(odf[1, 1, :] * 4) / 4            # ties
+        top, nvalid = fj.find_peaks(odf, sph)
+        faces0 = orc.fold_faces(sph.faces, sph.nvert)
+        for i in range(7):
+            for j in range(5):
+                isort, nv, _ = orc.find_peaks(odf[i, j], faces0)
+                assert nv == nvalid[i, j]
+                assert list(isort[:3]) == list(top[i, j])
