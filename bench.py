@@ -240,6 +240,28 @@ def main():
                                         hbm_gbs_trace=25.0 * (npoints / world) / (tr_ms / max(tr_n, 1) * 1e-3) / 1e9 if tr_n else 0.0,
                                         note="one volume, seeds sharded round-robin over the ranks"
                                              + (", field broadcast from rank 0 inside the timed step" if world > 1 else ""))
+        if world == 1:
+            # ---- microscopy regime (stream.jl:547-619) on the same field: every 8th seed, reference defaults ----------
+            sm = seeds_all[::8].contiguous()
+            z1 = torch.zeros((1, 3), dtype=torch.float32, device=dev)
+            kw = dict(ang_thresh=20, step_size=1.0, smooth_coeff=0.0, search_dist=15, search_ang=10)
+            rm = fj.stream_device(field, SHAPE, sm, z1, **kw)
+            torch.cuda.synchronize()
+            L.fib_profile_enable(1); L.fib_profile_reset()
+            t0 = time.perf_counter()
+            rm = fj.stream_device(field, SHAPE, sm, z1, **kw)
+            torch.cuda.synchronize()
+            t_m = time.perf_counter() - t0
+            L.fib_profile_enable(0)
+            mk_ms, mk_n = prof_get(L, "stream_trace_micro")
+            npm = int(rm["xyz"].shape[0])
+            # per emitted point the reference visits the 31^3 search cube; 15 939 of its cells lie in the search ball
+            extra["stream_micro_ball"] = dict(seeds=int(sm.numel()), lines=int(rm["npts"].numel()), points=npm,
+                                              mpoints_per_s=npm / t_m / 1e6, ms_per_step=t_m * 1e3,
+                                              trace_kernel_ms=mk_ms / max(mk_n, 1),
+                                              search_cells_per_s=npm * 29791.0 / (mk_ms / max(mk_n, 1) * 1e-3) if mk_n else 0.0,
+                                              note="search_dist 15, search_ang 10, ang_thresh 20, step 1 (reference defaults of the regime)")
+            del rm
         del res, bm, seeds_all
 
     if not args.no_extra and rank == 0 and world == 1:

@@ -58,7 +58,9 @@ __global__ __launch_bounds__(256) void stream_field_kernel(const FieldArgs a) {
     for (int k = 0; k < a.nvec; k++) {
         bool om = m;
         if (a.has_f) om = m && (a.f[k][i] >= a.f_thresh);         // stream.jl:138
-        a.field[i * a.nvec + k] = om ? make_float4(v[k][0], v[k][1], v[k][2], 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        // w = the voxel mask itself (the microscopy regime tests W.mask apart from the vectors, stream.jl:596)
+        const float w = m ? 1.0f : 0.0f;
+        a.field[i * a.nvec + k] = om ? make_float4(v[k][0], v[k][1], v[k][2], w) : make_float4(0.0f, 0.0f, 0.0f, w);
     }
     if (a.mask_out) a.mask_out[i] = m ? 1 : 0;
 }
@@ -72,6 +74,10 @@ struct TraceArgs {
     int64_t line0, nlines;      // this batch covers global lines [line0, line0+nlines)
     int nx, ny, nz, nvec, nsub, len_max, stride;
     float cosang, step, smooth;
+    // microscopy regime (stream.jl:252-287, 547-619)
+    const float4 *search;       // half of the search cube's cells with rho < 1, column-major order: {unit vector, bits of (kx | ky<<8 | kz<<16)} (0-based cell)
+    int nsearch, search_dist;
+    float search_cosang;
 };
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -157,6 +163,125 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
     }
     a.npts[li] = npts;
     a.nfwd[li] = nf;
+}
+
+// ---- microscopy regime: stream_micro_new_point! (stream.jl:547-619) -------------------------------------------
+// The next point is the voxel, among those within search_dist voxels of the tentative position and inside a cone of
+// search_ang around the current direction, whose first orientation vector is best aligned with the current direction
+// (first maximum of |cos| in the column-major order of the (2d+1)^3 search cube; the position snaps to that voxel).
+// One wave per line: the 64 lanes share out the cells of the search ball each step.  The unit vectors of the cells
+// (search_area, stream.jl:255-277) sit in LDS, one entry per antipodal pair (v(-cell) = -v(cell) exactly, and so is
+// its dot product).  The centre cell's vector is 0/0 = NaN, which passes `iszero` and the `<=` cone test in the
+// reference: the tentative voxel itself is always a candidate (lane 0 adds it).
+__device__ __forceinline__ unsigned long long micro_key(float c, unsigned lin) {
+    const float ca = fabsf(c);
+    unsigned hi = __float_as_uint(ca);                            // |c| >= 0: the bit pattern is order preserving
+    if (ca != ca) hi = 0xffffffffu;                               // NaN wins (Base.argmax)
+    return ((unsigned long long)hi << 32) | (unsigned)(~lin);     // ties: the smaller linear index
+}
+
+__global__ __launch_bounds__(1024) void stream_trace_micro_kernel(const TraceArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 stab[];  // [nsearch]
+    for (int i = threadIdx.x; i < a.nsearch; i += blockDim.x) stab[i] = a.search[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int d = a.search_dist, S = 2 * d + 1;
+    const unsigned lin_centre = (unsigned)(d + S * (d + S * d)), lin_last = (unsigned)(S * S * S - 1);
+    const int64_t slot_floats = a.nlines * 3;
+    const float fnx = (float)a.nx, fny = (float)a.ny, fnz = (float)a.nz;
+    const float omc = 1.0f - a.smooth;
+    for (int64_t li = wave0; li < a.nlines; li += nwaves) {
+        const int64_t line = a.line0 + li;
+        const int64_t iseed = line / a.nsub;
+        const int isub = (int)(line - iseed * a.nsub);
+        const int64_t lin = a.seeds[iseed];
+        const int sx = (int)(lin % a.nx), sy = (int)((lin / a.nx) % a.ny), sz = (int)(lin / ((int64_t)a.nx * a.ny));
+        const float p0x = (float)(sx + 1) + a.sublist[3 * isub];
+        const float p0y = (float)(sy + 1) + a.sublist[3 * isub + 1];
+        const float p0z = (float)(sz + 1) + a.sublist[3 * isub + 2];
+        float *dfw = a.scratch + li * 3;
+        float *dbw = dfw + (int64_t)a.stride * slot_floats;
+        int npts = 0, nf = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            const float fwd = pass == 0 ? 1.0f : -1.0f;
+            float px = p0x, py = p0y, pz = p0z;
+            const float4 s = a.field[lin * a.nvec];               // the first vector of the seed voxel (W.ivec_next stays 1)
+            float vx = s.x * fwd, vy = s.y * fwd, vz = s.z * fwd;
+            for (;;) {
+                const float nxp = px + vx * a.step, nyp = py + vy * a.step, nzp = pz + vz * a.step;   // stream.jl:561
+                const float rx = rintf(nxp), ry = rintf(nyp), rz = rintf(nzp);                        // :563
+                if (!(rx >= 1.0f && rx <= fnx && ry >= 1.0f && ry <= fny && rz >= 1.0f && rz <= fnz)) break;   // :566
+                const int cx = (int)rx - 1, cy = (int)ry - 1, cz = (int)rz - 1;                       // 0-based
+                const float4 fc = a.field[((int64_t)cx + a.nx * ((int64_t)cy + (int64_t)a.ny * cz)) * a.nvec];
+                if (fc.w == 0.0f) break;                                                              // :569
+                unsigned long long best = 0ull;                  // 0 = nothing found (every real key has |c| bits or ~lin != 0)
+                if (lane == 0) best = micro_key(dot3(vx, vy, vz, fc.x, fc.y, fc.z), lin_centre);     // the centre cell
+                for (int e = lane; e < a.nsearch; e += 64) {
+                    const float4 t = stab[e];
+                    const float sdot = dot3(vx, vy, vz, t.x, t.y, t.z);
+                    const unsigned cell = __float_as_uint(t.w);
+                    const int kx = (int)(cell & 255u), ky = (int)((cell >> 8) & 255u), kz = (int)(cell >> 16);
+#pragma unroll
+                    for (int sg = 0; sg < 2; sg++) {             // the cell and its antipode
+                        const float dv = sg ? -sdot : sdot;
+                        if (dv <= a.search_cosang) continue;                                          // :597-598
+                        const int ox = sg ? d - kx : kx - d, oy = sg ? d - ky : ky - d, oz = sg ? d - kz : kz - d;
+                        const int ix = cx + ox, iy = cy + oy, iz = cz + oz;
+                        if (ix < 0 || ix >= a.nx || iy < 0 || iy >= a.ny || iz < 0 || iz >= a.nz) continue;   // :586-588
+                        const float4 f = a.field[((int64_t)ix + a.nx * ((int64_t)iy + (int64_t)a.ny * iz)) * a.nvec];
+                        if (f.w == 0.0f) continue;                                                    // :596
+                        const unsigned l0 = (unsigned)(kx + S * (ky + S * kz));
+                        const unsigned long long k = micro_key(dot3(vx, vy, vz, f.x, f.y, f.z), sg ? lin_last - l0 : l0);   // :600-601
+                        best = k > best ? k : best;
+                    }
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const unsigned long long o = ((unsigned long long)(unsigned)__shfl_xor((int)(best >> 32), off) << 32) |
+                                                 (unsigned)__shfl_xor((int)(unsigned)best, off);
+                    best = o > best ? o : best;
+                }
+                if (best == 0ull) break;                          // (cannot happen: the centre is always a candidate)
+                const unsigned bl = ~(unsigned)best;              // argmax cell, column-major in the cube
+                const int bx = cx + (int)(bl % (unsigned)S) - d, by = cy + (int)((bl / (unsigned)S) % (unsigned)S) - d,
+                          bz = cz + (int)(bl / (unsigned)(S * S)) - d;
+                const float4 fb = a.field[((int64_t)bx + a.nx * ((int64_t)by + (int64_t)a.ny * bz)) * a.nvec];
+                const float bc = dot3(vx, vy, vz, fb.x, fb.y, fb.z);
+                if (!(fabsf(bc) < INFINITY)) break;               // !isfinite, :609
+                float wx, wy, wz;
+                if (bc > 0.0f) { wx = fb.x; wy = fb.y; wz = fb.z; } else { wx = -fb.x; wy = -fb.y; wz = -fb.z; }   // :616-620
+                if (lane == 0) {                                  // addpt!(strline, pos_now), stream.jl:660
+                    float *dp = pass == 0 ? dfw : dbw;
+                    dp[0] = px; dp[1] = py; dp[2] = pz;
+                }
+                if (pass == 0) dfw += slot_floats; else dbw += slot_floats;
+                npts++;
+                if (pass == 0) nf++;
+                if (dot3(vx, vy, vz, wx, wy, wz) < a.cosang) break;   // :670
+                if (npts > a.len_max) break;                          // :674
+                if (a.smooth != 0.0f) {                               // :677-681
+                    wx = a.smooth * vx + omc * wx;
+                    wy = a.smooth * vy + omc * wy;
+                    wz = a.smooth * vz + omc * wz;
+                    const float m = fmaxf(fabsf(wx), fmaxf(fabsf(wy), fabsf(wz)));
+                    float n;
+                    if (m == 0.0f || !(m < INFINITY)) n = m;
+                    else {
+                        double acc = (double)(wx * wx);
+                        acc += (double)(wy * wy);
+                        acc += (double)(wz * wz);
+                        n = (float)sqrt(acc);
+                    }
+                    wx = wx / n; wy = wy / n; wz = wz / n;
+                }
+                px = (float)(bx + 1); py = (float)(by + 1); pz = (float)(bz + 1);   // the position snaps to the voxel found, :612-614
+                vx = wx; vy = wy; vz = wz;
+            }
+        }
+        if (lane == 0) { a.npts[li] = npts; a.nfwd[li] = nf; }
+    }
 }
 
 // ---- exclusive scan of (kept ? npts : 0, kept ? 1 : 0) over the lines, int64 pairs --------------------
@@ -440,6 +565,39 @@ extern "C" int fibd_stream_trace(const fib_stream_params *prm, const float *fiel
     ta.len_max = prm->len_max; ta.stride = job->stride;
     ta.cosang = prm->cosang_thresh; ta.step = prm->step_size; ta.smooth = prm->smooth_coeff;
     const unsigned grid = (unsigned)fib::cdiv(nl, 256);
+    fib::DevBuf<float4> d_search;
+    if (prm->search_dist > 0) {
+        // search_area (stream.jl:255-277), Float32 arithmetic like the reference's T; one entry per antipodal pair
+        const int d = prm->search_dist, S = 2 * d + 1;
+        FIB_CHECK(d <= 60, FIB_ERR_UNSUPPORTED, "search_dist up to 60 voxels is supported (got %d)", d);
+        std::vector<float4> tab;
+        const float den = (float)d + 0.5f;
+        const int64_t ncell = (int64_t)S * S * S;
+        for (int64_t l = 0; l < ncell / 2; l++) {                 // the first half in column-major order; the centre is cell ncell/2
+            const int kx = (int)(l % S), ky = (int)((l / S) % S), kz = (int)(l / ((int64_t)S * S));
+            const float rx = (float)(kx - d) / den, ry = (float)(ky - d) / den, rz = (float)(kz - d) / den;
+            float q = rx * rx; q = q + ry * ry; q = q + rz * rz;
+            const float r = sqrtf(q);
+            if (!(r < 1.0f)) continue;
+            const uint32_t cell = (uint32_t)kx | ((uint32_t)ky << 8) | ((uint32_t)kz << 16);
+            float w; memcpy(&w, &cell, 4);
+            tab.push_back(make_float4(rx / r, ry / r, rz / r, w));
+        }
+        const size_t smem = tab.size() * sizeof(float4);
+        if (smem > 150 * 1024) return bail(fib::fail(FIB_ERR_UNSUPPORTED, "search_dist %d needs %zu bytes of LDS for the search table (max 150 KiB)", d, smem));
+        if ((rc = d_search.alloc(tab.size())) != FIB_OK) return bail(rc);
+        hipError_t ec = hipMemcpyAsync(d_search.p, tab.data(), smem, hipMemcpyHostToDevice, st);
+        if (ec == hipSuccess) ec = hipStreamSynchronize(st);     // (the table is a local: it must outlive the copy)
+        if (ec != hipSuccess) return bail(fib::fail(FIB_ERR_HIP, "search table upload failed: %s", hipGetErrorString(ec)));
+        ta.search = d_search.p; ta.nsearch = (int)tab.size(); ta.search_dist = d; ta.search_cosang = prm->search_cosang;
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+        const unsigned mg = (unsigned)std::min<int64_t>(ncu, fib::cdiv(nl, 16));
+        ec = hipFuncSetAttribute(reinterpret_cast<const void *>(stream_trace_micro_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (ec != hipSuccess) return bail(fib::fail(FIB_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(ec)));
+        fib::ProfScope prof("stream_trace_micro", st);
+        hipLaunchKernelGGL(stream_trace_micro_kernel, dim3(mg), dim3(1024), smem, st, ta);
+    } else
     { fib::ProfScope prof("stream_trace", st);
     if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1>), dim3(grid), dim3(256), 0, st, ta);
     else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3>), dim3(grid), dim3(256), 0, st, ta);

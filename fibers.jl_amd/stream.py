@@ -1,5 +1,6 @@
 """stream host mirror (reference: stream.jl:7-8 `StreamWork, stream, stream_new_line, ...`): deterministic
-nearest-voxel / fixed-step Euler tractography, angle-picking macro-scale path (non-LCM, non-micro)."""
+nearest-voxel / fixed-step Euler tractography: the angle-picking macro-scale path and the microscopy regime
+(cone search); LCM-guided tracking (stream.jl:380-495) is not covered."""
 import ctypes as C
 from typing import List, Optional, Sequence, Union
 
@@ -47,20 +48,24 @@ def _vol3(m, what):
     return a
 
 
-def _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff):
+def _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff, search_dist=0, search_ang=10):
+    """search_dist > 0 selects the microscopy regime (stream.jl:83, 547-619)"""
     nx, ny, nz = shape
     return _lib.StreamParams(nx, ny, nz, nvec, int(len_min), int(len_max if len_max is not None else max(shape)),
-                             float(cosd32(ang_thresh)), float(np.float32(step_size)), float(np.float32(smooth_coeff)))
+                             float(cosd32(ang_thresh)), float(np.float32(step_size)), float(np.float32(smooth_coeff)),
+                             int(search_dist), float(cosd32(search_ang)))
 
 
 def stream(ovec: Union[MRI, Sequence[MRI]], *, f=None, f_thresh: float = 0.03, fa: Optional[MRI] = None,
            fa_thresh: float = 0.1, mask: Optional[MRI] = None, seed: Optional[MRI] = None, nsub: Optional[int] = 3,
            len_min: int = 3, len_max: Optional[int] = None, ang_thresh: Optional[float] = 45,
            step_size: Optional[float] = 0.5, smooth_coeff: Optional[float] = 0.2, lcms=None,
-           sublist=None, rng=None, device: int = 0) -> Tract:
+           search_dist: int = 15, search_ang: float = 10, sublist=None, rng=None, device: int = 0) -> Tract:
     """Streamline tractography (stream.jl:730).  Returns a `Tract` whose lines are in the reference's order
     (seed voxels in column-major `findall` order, sub-voxel offsets innermost), points in 1-based voxel
-    coordinates, each line ordered [forward reversed, backward] as stream.jl:652 builds it."""
+    coordinates, each line ordered [forward reversed, backward] as stream.jl:652 builds it.
+    Volumes with a voxel size of 0.05 mm or less (stream.jl:83) are tracked in the microscopy regime
+    (stream_micro_new_point!, stream.jl:547-619: cone search of `search_dist` voxels / `search_ang` degrees)."""
     if lcms is not None:
         raise NotImplementedError("LCM-guided tracking (stream.jl:380-495) is outside the accelerated path")
     ovecs = _as_list(ovec)
@@ -75,13 +80,13 @@ def stream(ovec: Union[MRI, Sequence[MRI]], *, f=None, f_thresh: float = 0.03, f
                              "stream.jl:147-172, are outside the accelerated path)")
         vols.append(np.asfortranarray(v, dtype=np.float32))
     shape = vols[0].shape[:3]
-    if min(ovecs[0].volres if isinstance(ovecs[0], MRI) else (1, 1, 1)) <= 0.05:
-        raise NotImplementedError("microscopy-scale tracking (stream.jl:547-619) is outside the accelerated path")
-    # scale-dependent defaults when `nothing` is passed (stream.jl:89-92), macro scale
-    nsub = 3 if nsub is None else nsub
-    ang_thresh = 45 if ang_thresh is None else ang_thresh
-    step_size = 0.5 if step_size is None else step_size
-    smooth_coeff = 0.2 if smooth_coeff is None else smooth_coeff
+    # Is this in the microscopy regime (min voxel size under 50 um)?  (stream.jl:83)
+    domicro = min(ovecs[0].volres if isinstance(ovecs[0], MRI) else (1, 1, 1)) <= 0.05
+    # scale-dependent defaults when `nothing` is passed (stream.jl:89-92)
+    nsub = (0 if domicro else 3) if nsub is None else nsub
+    ang_thresh = (20 if domicro else 45) if ang_thresh is None else ang_thresh
+    step_size = (1 if domicro else 0.5) if step_size is None else step_size
+    smooth_coeff = (0 if domicro else 0.2) if smooth_coeff is None else smooth_coeff
     nvec = len(vols)
     fvols = None
     if fs is not None:
@@ -105,7 +110,8 @@ def stream(ovec: Union[MRI, Sequence[MRI]], *, f=None, f_thresh: float = 0.03, f
         sarr, sdt = _mask_arg(seed)
         sptr = sarr.ctypes.data
     sub = make_sublist(nsub, rng) if sublist is None else np.ascontiguousarray(sublist, np.float32).reshape(-1, 3)
-    prm = _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff)
+    prm = _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff,
+                  int(search_dist) if domicro else 0, search_ang)
     ov = (C.c_void_p * nvec)(*[v.ctypes.data for v in vols])
     fv = None if fvols is None else (C.c_void_p * nvec)(*[v.ctypes.data for v in fvols])
     out = _lib.TractOut()
@@ -164,16 +170,18 @@ def stream_field_device(ovec: List, f: Optional[List] = None, f_thresh: float = 
 
 
 def stream_device(field, shape, seeds, sublist, len_min=3, len_max=None, ang_thresh=45, step_size=0.5,
-                  smooth_coeff=0.2, stream=None, want_all_npts=False):
+                  smooth_coeff=0.2, stream=None, want_all_npts=False, search_dist=0, search_ang=10):
     """Trace + pack on the GPU.  field: [nvox, nvec, 4] from stream_field_device; seeds: int64 CUDA tensor of
     0-based column-major voxel indices (findall order); sublist: float32 CUDA [nsub, 3].
+    search_dist > 0: microscopy regime (stream.jl:547-619; reference defaults there: search_dist 15, search_ang 10,
+    ang_thresh 20, step_size 1, smooth_coeff 0, one zero sub-voxel offset).
     Returns dict(npts int32 [nlines], seed_index int64 [nlines], xyz float32 [npoints, 3])."""
     import torch
     _chk_dev(field, torch.float32, "field")
     _chk_dev(seeds, torch.int64, "seeds")
     _chk_dev(sublist, torch.float32, "sublist")
     nvec = field.shape[1]
-    prm = _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff)
+    prm = _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff, search_dist, search_ang)
     job = C.c_void_p()
     nl, npnt = C.c_int64(0), C.c_int64(0)
     L = _lib.lib()

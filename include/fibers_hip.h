@@ -154,6 +154,12 @@ typedef struct {
     float cosang_thresh;    /* cosd(ang_thresh), default cosd(45) (stream.jl:193) */
     float step_size;        /* default .5 */
     float smooth_coeff;     /* default .2 */
+    /* microscopy regime (stream.jl:83: minimum(volres) <= 0.05 mm; 252-287, 547-619): search_dist > 0 selects it.
+     * Each step then moves to the voxel, within search_dist voxels of the tentative position and a cone of
+     * search_ang around the current direction, whose first orientation vector is best aligned with it.
+     * Reference defaults in that regime: search_dist 15, search_ang 10, nsub 0, ang_thresh 20, step 1, smooth 0. */
+    int32_t search_dist;    /* 0: macro-scale tracking */
+    float search_cosang;    /* cosd(search_ang) */
 } fib_stream_params;
 
 typedef struct fib_stream_job fib_stream_job;

@@ -108,6 +108,7 @@ end
 struct FibStreamParams
   nx::Int32; ny::Int32; nz::Int32; nvec::Int32; len_min::Int32; len_max::Int32
   cosang_thresh::Float32; step_size::Float32; smooth_coeff::Float32
+  search_dist::Int32; search_cosang::Float32          # microscopy regime (stream.jl:83, 547-619) when search_dist > 0
 end
 
 mutable struct FibTractOut
@@ -116,25 +117,28 @@ mutable struct FibTractOut
   FibTractOut() = new(0, 0, C_NULL, C_NULL, C_NULL)
 end
 
-"stream(ovec; ...) — replaces stream.jl:730-790 for the angle-picking macro-scale path (no lcms, volres > 0.05)"
+"stream(ovec; ...) — replaces stream.jl:730-790 for the angle-picking path and the microscopy regime (no lcms)"
 function stream(ovec::Union{MRI,Vector{MRI}}; f::Union{MRI,Vector{MRI},Nothing}=nothing, f_thresh::Real=.03,
                 fa::Union{MRI,Nothing}=nothing, fa_thresh::Real=.1, mask::Union{MRI,Nothing}=nothing,
                 seed::Union{MRI,Nothing}=nothing, nsub::Union{Integer,Nothing}=3, len_min::Integer=3,
                 len_max::Integer=(isa(ovec,MRI) ? maximum(ovec.volsize) : maximum(ovec[1].volsize)),
                 ang_thresh::Union{Real,Nothing}=45, step_size::Union{Real,Nothing}=.5,
-                smooth_coeff::Union{Real,Nothing}=.2, device::Integer=0)
+                smooth_coeff::Union{Real,Nothing}=.2, search_dist::Integer=15, search_ang::Real=10,
+                device::Integer=0)
   ovecs = isa(ovec, MRI) ? MRI[ovec] : ovec
   fs    = isa(f, MRI) ? MRI[f] : f
   nx, ny, nz = size(ovecs[1].vol)[1:3]
   if !isnothing(seed) && size(seed.vol) != size(mask.vol)
     error("Dimension mismatch between seed mask " * string(size(seed.vol)) * " and brain mask " * string(size(mask.vol)))
   end
-  isnothing(nsub) && (nsub = 3); isnothing(ang_thresh) && (ang_thresh = 45)
-  isnothing(step_size) && (step_size = .5); isnothing(smooth_coeff) && (smooth_coeff = .2)
+  domicro = minimum(ovecs[1].volres) <= 0.05                                # stream.jl:83
+  isnothing(nsub) && (nsub = domicro ? 0 : 3); isnothing(ang_thresh) && (ang_thresh = domicro ? 20 : 45)   # :89-92
+  isnothing(step_size) && (step_size = domicro ? 1 : .5); isnothing(smooth_coeff) && (smooth_coeff = domicro ? 0 : .2)
   # sub-voxel offsets from the GLOBAL RNG, exactly as stream.jl:176-181
   sublist = nsub > 0 ? hcat([Float32.(rand(Uniform(-.5+eps(), .5-eps()), 3)) for _ in 1:nsub]...) : zeros(Float32, 3, 1)
   prm = Ref(FibStreamParams(nx, ny, nz, length(ovecs), len_min, len_max,
-                            cosd(Float32(ang_thresh)), Float32(step_size), Float32(smooth_coeff)))
+                            cosd(Float32(ang_thresh)), Float32(step_size), Float32(smooth_coeff),
+                            domicro ? Int32(search_dist) : Int32(0), cosd(Float32(search_ang))))
   pv = [pointer(o.vol) for o in ovecs]
   pf = isnothing(fs) ? C_NULL : [pointer(x.vol) for x in fs]
   out = FibTractOut()

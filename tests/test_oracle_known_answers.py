@@ -191,3 +191,31 @@ def test_stream_angle_threshold_and_vector_choice(orc):
     res = orc.stream([ov2, -np.roll(ov1, 0)], np.zeros((1, 3), np.float32), mask=np.ones((n, n, n)), len_max=50)
     l0 = orc.split_lines(res)[0]
     assert np.all(np.diff(l0[:, 1]) <= 0) and np.all(l0[:, 0] == 1) and l0[:, 1].max() >= n - 0.5
+
+
+def test_micro_regime_uniform_field_known_path():
+    """microscopy regime (stream.jl:547-619) on a uniform +x field: every cell of the search cone ties at |cos| = 1, and
+    argmax takes the FIRST maximum in the cube's column-major order = the smallest x.  Going along +x that is the
+    tentative voxel itself (one voxel per step); going along -x it is the farthest cone cell (search_dist + 1 voxels per
+    step).  Positions snap to voxel centres."""
+    from oracle import oracle as orc
+    n, d = 20, 3
+    ov = np.zeros((n, n, n, 3), np.float32, order="F")
+    ov[..., 0] = 1
+    mask = np.ones((n, n, n), np.uint8)
+    seed = np.zeros((n, n, n), np.uint8)
+    seed[9, 9, 9] = 1                                         # 1-based voxel (10, 10, 10)
+    r = orc.stream(ov, np.zeros((1, 3), np.float32), mask=mask, seed=seed, ang_thresh=20, step_size=1.0,
+                   smooth_coeff=0.0, search_dist=d, search_ang=10, len_max=40)
+    fwd = [[x, 10, 10] for x in range(19, 9, -1)]             # forward points 10..19, prepended (stream.jl:652)
+    bwd = [[10, 10, 10], [6, 10, 10], [2, 10, 10]]            # 10 -> 6 -> 2 -> (1) -> out of the volume
+    assert r["npts"].tolist() == [13]
+    assert np.array_equal(r["xyz"], np.array(fwd + bwd, np.float32))
+    # the cone: with search_ang = 50 degrees off-axis cells tie too; the first in column-major order has the smallest z
+    r2 = orc.stream(ov, np.zeros((1, 3), np.float32), mask=mask, seed=seed, ang_thresh=20, step_size=1.0,
+                    smooth_coeff=0.0, search_dist=2, search_ang=50, len_max=40)
+    step1 = r2["xyz"][r2["npts"][0] - 0 - 1] if False else None
+    xyz = r2["xyz"]
+    i10 = [i for i in range(len(xyz)) if tuple(xyz[i]) == (10.0, 10.0, 10.0)]
+    assert len(i10) == 2                                       # the seed point opens both directions
+    assert xyz[i10[0] - 1][2] < 10.0                           # first forward move drops in z (smallest z wins the tie)
