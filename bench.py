@@ -262,6 +262,31 @@ def main():
                                               search_cells_per_s=npm * 29791.0 / (mk_ms / max(mk_n, 1) * 1e-3) if mk_n else 0.0,
                                               note="search_dist 15, search_ang 10, ang_thresh 20, step 1 (reference defaults of the regime)")
             del rm
+            # ---- LCM-guided tracking (stream.jl:380-495) on a synthetic 2-D section: 2048^2 pixels, 3 orientations each ----
+            n2 = 2048
+            g = torch.Generator(device=dev); g.manual_seed(11)
+            ang = [torch.rand(n2 * n2, device=dev, generator=g) - 0.5 + k * 3.14159265 / 3 for k in range(3)]
+            ov2 = [torch.stack([torch.cos(a_), torch.sin(a_), torch.zeros_like(a_)]) for a_ in ang]
+            lc = torch.rand((10, n2 * n2), device=dev, generator=g)
+            fld, mo = fj.stream_field_device(ov2, mask=torch.ones(n2 * n2, dtype=torch.uint8, device=dev))
+            sd2 = torch.nonzero(mo).flatten()
+            s2 = torch.tensor([[0.1, -0.2, 0.0]], dtype=torch.float32, device=dev)
+            kw = dict(lcms=lc, lcm_thresh=0.099, strdims=(0, 1), rng_seed=7, len_max=140)
+            rl = fj.stream_device(fld, (n2, n2, 1), sd2, s2, **kw)
+            torch.cuda.synchronize()
+            L.fib_profile_enable(1); L.fib_profile_reset()
+            t0 = time.perf_counter()
+            rl = fj.stream_device(fld, (n2, n2, 1), sd2, s2, **kw)
+            torch.cuda.synchronize()
+            t_l = time.perf_counter() - t0
+            L.fib_profile_enable(0)
+            lk_ms, lk_n = prof_get(L, "stream_trace_lcm")
+            npl = int(rl["xyz"].shape[0])
+            extra["stream_lcm_2d"] = dict(seeds=int(sd2.numel()), lines=int(rl["npts"].numel()), points=npl,
+                                          mpoints_per_s=npl / t_l / 1e6, ms_per_step=t_l * 1e3,
+                                          trace_kernel_ms=lk_ms / max(lk_n, 1), flagged_fraction=float(rl["flags"].float().mean()),
+                                          note="2048x2048x1 pixels, 3 orientations + one 10-element LCM per pixel, len_max 140")
+            del rl, fld, lc, ov2, ang
         del res, bm, seeds_all
 
     if not args.no_extra and rank == 0 and world == 1:

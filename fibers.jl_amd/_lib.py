@@ -33,7 +33,7 @@ class StreamParams(C.Structure):
 class TractOut(C.Structure):
     _fields_ = [("nlines", C.c_int64), ("npoints", C.c_int64),
                 ("npts", C.POINTER(C.c_int32)), ("seed_index", C.POINTER(C.c_int64)),
-                ("xyz", C.POINTER(C.c_float))]
+                ("xyz", C.POINTER(C.c_float)), ("flags", C.POINTER(C.c_uint8))]
 
 
 _lib = None
@@ -65,6 +65,9 @@ _PROTOS = {
                                 C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]),
     "fibd_stream_pack": (i32, [vp, vp, vp, vp, vp]),
     "fibd_stream_pack_trk": (i32, [vp, C.POINTER(C.c_float * 3), vp, vp]),
+    "fibd_stream_trace_lcm": (i32, [C.POINTER(StreamParams), vp, vp, f32, i32, i32, C.c_uint64, vp, i64, vp, i32, vp,
+                                    C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]),
+    "fibd_stream_pack_flags": (i32, [vp, vp, vp, vp, vp, vp]),
     "fibd_stream_all_npts": (i32, [vp, vp, vp]),
     "fib_stream_job_destroy": (None, [vp]),
     "fib_dti_fit": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, C.POINTER(DtiOut)]),
@@ -74,6 +77,8 @@ _PROTOS = {
     "fib_find_peaks": (i32, [i32, vp, i64, vp, i32, vp, i32, vp, vp]),
     "fib_stream": (i32, [i32, C.POINTER(StreamParams), vp, vp, f32, vp, f32, vp, i32, vp, i32, vp, i32,
                          C.POINTER(TractOut)]),
+    "fib_stream_lcm": (i32, [i32, C.POINTER(StreamParams), vp, vp, f32, vp, f32, vp, i32, vp, i32, vp, i32,
+                             vp, f32, C.c_uint64, C.POINTER(TractOut)]),
     "fib_tract_free": (None, [C.POINTER(TractOut)]),
 }
 

@@ -212,14 +212,36 @@ extern "C" int fib_find_peaks(int device, const float *odf, int64_t nvox, const 
 // ------------------------------------------------------------------------------------------
 extern "C" void fib_tract_free(fib_tract_out *out) {
     if (!out) return;
-    free(out->npts); free(out->seed_index); free(out->xyz);
-    out->npts = nullptr; out->seed_index = nullptr; out->xyz = nullptr;
+    free(out->npts); free(out->seed_index); free(out->xyz); free(out->flags);
+    out->npts = nullptr; out->seed_index = nullptr; out->xyz = nullptr; out->flags = nullptr;
     out->nlines = 0; out->npoints = 0;
 }
+
+static int stream_host(int device, const fib_stream_params *prm, const float *const *ovec, const float *const *f,
+                       float f_thresh, const float *fa, float fa_thresh, const void *mask, int mask_dtype,
+                       const void *seed, int seed_dtype, const float *sublist, int32_t nsub,
+                       const float *lcms, float lcm_thresh, uint64_t rng_seed, fib_tract_out *out);
 
 extern "C" int fib_stream(int device, const fib_stream_params *prm, const float *const *ovec, const float *const *f,
                           float f_thresh, const float *fa, float fa_thresh, const void *mask, int mask_dtype,
                           const void *seed, int seed_dtype, const float *sublist, int32_t nsub, fib_tract_out *out) {
+    return stream_host(device, prm, ovec, f, f_thresh, fa, fa_thresh, mask, mask_dtype, seed, seed_dtype, sublist, nsub,
+                       nullptr, 0.0f, 0, out);
+}
+
+extern "C" int fib_stream_lcm(int device, const fib_stream_params *prm, const float *const *ovec, const float *const *f,
+                              float f_thresh, const float *fa, float fa_thresh, const void *mask, int mask_dtype,
+                              const void *seed, int seed_dtype, const float *sublist, int32_t nsub,
+                              const float *lcms, float lcm_thresh, uint64_t rng_seed, fib_tract_out *out) {
+    FIB_CHECK(lcms != nullptr, FIB_ERR_INVALID, "NULL lcms volume");
+    return stream_host(device, prm, ovec, f, f_thresh, fa, fa_thresh, mask, mask_dtype, seed, seed_dtype, sublist, nsub,
+                       lcms, lcm_thresh, rng_seed, out);
+}
+
+static int stream_host(int device, const fib_stream_params *prm, const float *const *ovec, const float *const *f,
+                       float f_thresh, const float *fa, float fa_thresh, const void *mask, int mask_dtype,
+                       const void *seed, int seed_dtype, const float *sublist, int32_t nsub,
+                       const float *lcms, float lcm_thresh, uint64_t rng_seed, fib_tract_out *out) {
     FIB_CHECK(prm && ovec && sublist && out, FIB_ERR_INVALID, "NULL argument");
     FIB_CHECK(prm->nx > 0 && prm->ny > 0 && prm->nz > 0, FIB_ERR_INVALID, "volume dimensions must be positive");
     FIB_CHECK(prm->nvec >= 1 && prm->nvec <= 8, FIB_ERR_UNSUPPORTED, "1..8 orientation vectors per voxel are supported");
@@ -275,25 +297,43 @@ extern "C" int fib_stream(int device, const fib_stream_params *prm, const float 
     RC(h2d(d_sub.p, sublist, sizeof(float) * 3 * nsub));
     fib_stream_job *job = nullptr;
     int64_t nl = 0, np = 0;
+    fib::DevBuf<float> d_lcms;
+    if (lcms) {
+        // through-plane dimension = the one in which the first orientation volume is zero everywhere (stream.jl:221-223)
+        bool allzero[3] = {true, true, true};
+        for (int c = 0; c < 3; c++)
+            for (int64_t i = 0; i < nvox && allzero[c]; i++) if (ovec[0][(size_t)c * nvox + i] != 0.0f) allzero[c] = false;
+        int strd[3], ns = 0;
+        for (int c = 0; c < 3; c++) if (!allzero[c]) strd[ns++] = c;
+        FIB_CHECK(ns >= 2, FIB_ERR_INVALID, "LCM-guided tracking needs two in-plane dimensions with non-zero orientation components");
+        RC(d_lcms.alloc((size_t)nvox * 10));
+        RC(h2d(d_lcms.p, lcms, sizeof(float) * nvox * 10));
+        RC(fibd_stream_trace_lcm(prm, d_field.p, d_lcms.p, lcm_thresh, strd[0], strd[1], rng_seed, d_seeds.p, (int64_t)seeds.size(),
+                                 d_sub.p, nsub, nullptr, &job, &nl, &np));
+    } else
     RC(fibd_stream_trace(prm, d_field.p, d_seeds.p, (int64_t)seeds.size(), d_sub.p, nsub, nullptr, &job, &nl, &np));
     struct JobGuard { fib_stream_job *j; ~JobGuard() { fib_stream_job_destroy(j); } } jg{job};
     out->nlines = nl; out->npoints = np;
     out->npts = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nl > 0 ? nl : 1));
     out->seed_index = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nl > 0 ? nl : 1));
     out->xyz = (float *)malloc(sizeof(float) * 3 * (size_t)(np > 0 ? np : 1));
-    if (!out->npts || !out->seed_index || !out->xyz) { fib_tract_free(out); return fib::fail(FIB_ERR_NOMEM, "out of host memory"); }
+    if (lcms) out->flags = (uint8_t *)malloc((size_t)(np > 0 ? np : 1));
+    if (!out->npts || !out->seed_index || !out->xyz || (lcms && !out->flags)) { fib_tract_free(out); return fib::fail(FIB_ERR_NOMEM, "out of host memory"); }
     if (nl > 0) {
         fib::DevBuf<int32_t> d_npts;
         fib::DevBuf<int64_t> d_sidx;
         fib::DevBuf<float> d_xyz;
+        fib::DevBuf<uint8_t> d_flags;
         int rc = d_npts.alloc((size_t)nl);
         if (rc == FIB_OK) rc = d_sidx.alloc((size_t)nl);
         if (rc == FIB_OK) rc = d_xyz.alloc((size_t)np * 3);
-        if (rc == FIB_OK) rc = fibd_stream_pack(job, d_npts.p, d_sidx.p, d_xyz.p, nullptr);
+        if (rc == FIB_OK && lcms) rc = d_flags.alloc((size_t)np);
+        if (rc == FIB_OK) rc = fibd_stream_pack_flags(job, d_npts.p, d_sidx.p, d_xyz.p, lcms ? d_flags.p : nullptr, nullptr);
         if (rc == FIB_OK && hipDeviceSynchronize() != hipSuccess) rc = fib::fail(FIB_ERR_HIP, "streamline pack failed");
         if (rc == FIB_OK) rc = d2h(out->npts, d_npts.p, sizeof(int32_t) * nl);
         if (rc == FIB_OK) rc = d2h(out->seed_index, d_sidx.p, sizeof(int64_t) * nl);
         if (rc == FIB_OK) rc = d2h(out->xyz, d_xyz.p, sizeof(float) * 3 * np);
+        if (rc == FIB_OK && lcms) rc = d2h(out->flags, d_flags.p, (size_t)np);
         if (rc != FIB_OK) { fib_tract_free(out); return rc; }
     }
     return FIB_OK;

@@ -75,6 +75,10 @@ struct TraceArgs {
     int nx, ny, nz, nvec, nsub, len_max, stride;
     float cosang, step, smooth;
     // microscopy regime (stream.jl:252-287, 547-619)
+    // LCM-guided tracking (stream.jl:200-236, 380-495)
+    const float *lcm;           // [nvox][10] thresholded local connection matrices (lcm_prepare_kernel)
+    int sd0, sd1;               // in-plane dimensions (0-based)
+    unsigned long long rng_seed;
     const float4 *search;       // half of the search cube's cells with rho < 1, column-major order: {unit vector, bits of (kx | ky<<8 | kz<<16)} (0-based cell)
     int nsearch, search_dist;
     float search_cosang;
@@ -84,7 +88,41 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
     return ax * bx + ay * by + az * bz;                           // (x+y)+z, no fma
 }
 
-template <int NVEC>   // NVEC > 0: compile-time vector count; 0: runtime
+// The random-number contract of LCM-guided tracking (include/fibers_hip.h): the k-th uniform of streamline `line` is
+// splitmix64 of (seed, line, k), top 24 bits -> [0,1).  Same function in the oracle (orc_uniform).
+__host__ __device__ __forceinline__ unsigned long long fib_splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ __forceinline__ float fib_uniform(unsigned long long seed, unsigned long long line, unsigned k) {
+    const unsigned long long h = fib_splitmix64(seed ^ fib_splitmix64(line * 0xD1342543DE82EF95ull + (unsigned long long)k));
+    return (float)(h >> 40) * (1.0f / 16777216.0f);
+}
+
+// lcm_array = permutedims(lcms.vol, (4,1,2,3)) .* (. >= lcm_thresh)  (stream.jl:207,217): [nvox][10] from planar [10][nvox]
+__global__ __launch_bounds__(256) void lcm_prepare_kernel(const float *__restrict__ lcms, float thresh, int64_t nvox, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvox) return;
+    for (int j = 0; j < 10; j++) {
+        const float x = lcms[(int64_t)j * nvox + i];
+        out[i * 10 + j] = x >= thresh ? x : 0.0f;                  // `x * false` is a strong zero in Julia (NaN -> 0)
+    }
+}
+
+// coordinate increments for exiting through edge j = 1..4 (stream.jl:224-226) along dimension c
+__device__ __forceinline__ int lcm_dxyz(int j, int c, int sd0, int sd1) {
+    const int a4 = (j == 1) ? -1 : (j == 3 ? 1 : 0), b4 = (j == 2) ? -1 : (j == 4 ? 1 : 0);
+    return c == sd0 ? a4 : (c == sd1 ? b4 : 0);
+}
+__device__ __forceinline__ int lcm_match_edge(int dx, int dy, int dz, int sd0, int sd1) {
+    for (int j = 1; j <= 4; j++)
+        if (lcm_dxyz(j, 0, sd0, sd1) == dx && lcm_dxyz(j, 1, sd0, sd1) == dy && lcm_dxyz(j, 2, sd0, sd1) == dz) return j;
+    return 0;
+}
+
+template <int NVEC, bool LCM = false>   // NVEC > 0: compile-time vector count; 0: runtime
 __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= a.nlines) return;
@@ -104,6 +142,7 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
     const float fnx = (float)a.nx, fny = (float)a.ny, fnz = (float)a.nz;
     const float omc = 1.0f - a.smooth;
     int ivec = 0, npts = 0, nf = 0;
+    unsigned ndraw = 0;                                           // uniforms consumed by this line (LCM)
     for (int pass = 0; pass < 2; pass++) {
         const float fwd = pass == 0 ? 1.0f : -1.0f;
         float px = p0x, py = p0y, pz = p0z;
@@ -132,14 +171,75 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
             float wx, wy, wz;
             if (bestc > 0.0f) { wx = bx; wy = by; wz = bz; } else { wx = -bx; wy = -by; wz = -bz; }   // :365-369
             ivec = best;                                          // stream.jl:371
+            bool isdiff = false;
+            if (LCM) {
+                // stream_pick_by_lcm! (stream.jl:380-495), after the angle pick above set W.ivec_next (stream.jl:530-531)
+                const int ivec_ang = ivec;
+                const int ix = (int)rx, iy = (int)ry, iz = (int)rz;
+                int dvx = (int)rintf(px) - ix, dvy = (int)rintf(py) - iy, dvz = (int)rintf(pz) - iz;   // :394-398
+                if (dvx == 0 && dvy == 0 && dvz == 0) {           // not entering a new voxel, :400-413
+                    const float4 w = cand[ivec];
+                    if (dot3(vx, vy, vz, w.x, w.y, w.z) > 0.0f) { wx = w.x; wy = w.y; wz = w.z; } else { wx = -w.x; wy = -w.y; wz = -w.z; }
+                } else {
+                    int entry = lcm_match_edge(dvx, dvy, dvz, a.sd0, a.sd1);                         // :416-422
+                    if (entry == 0) {                             // diagonal jump: keep the dimension that changes faster, :424-438
+                        const float p1 = a.sd0 == 0 ? px : (a.sd0 == 1 ? py : pz), q1 = a.sd0 == 0 ? nxp : (a.sd0 == 1 ? nyp : nzp);
+                        const float p2 = a.sd1 == 0 ? px : (a.sd1 == 1 ? py : pz), q2 = a.sd1 == 0 ? nxp : (a.sd1 == 1 ? nyp : nzp);
+                        const int zap = fabsf(p1 - q1) < fabsf(p2 - q2) ? a.sd1 : a.sd0;
+                        if (zap == 0) dvx = 0; else if (zap == 1) dvy = 0; else dvz = 0;
+                        entry = lcm_match_edge(dvx, dvy, dvz, a.sd0, a.sd1);
+                    }
+                    const float *lp = a.lcm + (size_t)vox * 10;
+                    float lcm[10];
+                    bool any = false;
+#pragma unroll
+                    for (int j = 0; j < 10; j++) {                // :441-446
+                        const int e0 = j < 4 ? 1 : (j < 7 ? 2 : (j < 9 ? 3 : 4));
+                        const int e1 = j < 4 ? j + 1 : (j < 7 ? j - 2 : (j < 9 ? j - 4 : 4));
+                        lcm[j] = (e0 == entry || e1 == entry) ? lp[j] : 0.0f;
+                        any |= lcm[j] != 0.0f;
+                    }
+                    if (!any) break;                              // :448, :492
+                    float sum = lcm[0];
+#pragma unroll
+                    for (int j = 1; j < 10; j++) sum += lcm[j];
+#pragma unroll
+                    for (int j = 0; j < 10; j++) lcm[j] = lcm[j] / sum;      // :450
+                    const float u = fib_uniform(a.rng_seed, (unsigned long long)line, ndraw++);
+                    int il = 0;                                   // rand(Categorical(lcm)): first index whose running sum exceeds u
+                    float cp = lcm[0];
+#pragma unroll
+                    for (int j = 1; j < 10; j++) { const bool go = cp <= u && il == j - 1; if (go) { cp += lcm[j]; il = j; } }
+                    const int e0 = il < 4 ? 1 : (il < 7 ? 2 : (il < 9 ? 3 : 4));
+                    const int e1 = il < 4 ? il + 1 : (il < 7 ? il - 2 : (il < 9 ? il - 4 : 4));
+                    const int exitedge = e0 == entry ? e1 : e0;  // :454-456
+                    const float ex = (float)lcm_dxyz(exitedge, 0, a.sd0, a.sd1), ey = (float)lcm_dxyz(exitedge, 1, a.sd0, a.sd1),
+                                ez = (float)lcm_dxyz(exitedge, 2, a.sd0, a.sd1);
+                    float lx = 0.0f, ly = 0.0f, lz = 0.0f, lc = 0.0f, la = 0.0f;
+                    int lb = 0;
+#pragma unroll
+                    for (int k = 0; k < nvec; k++) {              // :462-472
+                        const float4 w = cand[k];
+                        float c, ca;
+                        if (w.x == 0.0f && w.y == 0.0f && w.z == 0.0f) { c = -INFINITY; ca = -INFINITY; }
+                        else { c = dot3(ex, ey, ez, w.x, w.y, w.z); ca = fabsf(c); }
+                        if (k == 0 || (!(la != la) && ((ca != ca) || ca > la))) { lb = k; la = ca; lc = c; lx = w.x; ly = w.y; lz = w.z; }
+                    }
+                    if (!(fabsf(lc) < INFINITY)) break;           // :476
+                    if (lc > 0.0f) { wx = lx; wy = ly; wz = lz; } else { wx = -lx; wy = -ly; wz = -lz; }   // :480-484
+                    ivec = lb;                                    // :486
+                }
+                isdiff = ivec != ivec_ang;                        // :538
+            }
             {   // push!/prepend! of pos_now (stream.jl:660): slot = step index within this pass
                 float *d = pass == 0 ? dfw : dbw;
-                d[0] = px; d[1] = py; d[2] = pz;
+                // LCM runs: the method-difference flag of the point (stream.jl:666) rides in the sign bit of x (x > 0)
+                d[0] = (LCM && isdiff) ? -px : px; d[1] = py; d[2] = pz;
                 if (pass == 0) dfw += slot_floats; else dbw += slot_floats;
             }
             npts++;
             if (pass == 0) nf++;
-            if (dot3(vx, vy, vz, wx, wy, wz) < a.cosang) break;   // stream.jl:670
+            if (!LCM && dot3(vx, vy, vz, wx, wy, wz) < a.cosang) break;   // stream.jl:670 (not used with LCMs, :668)
             if (npts > a.len_max) break;                          // stream.jl:674
             if (a.smooth != 0.0f) {                               // stream.jl:677-681
                 wx = a.smooth * vx + omc * wx;
@@ -467,6 +567,7 @@ struct fib_stream_job {
     struct View32 { int32_t *p = nullptr; } npts, nfwd;
     struct ViewP { Pair *p = nullptr; } excl, block_tot, total;
     int64_t kept_lines = 0, kept_pts = 0;
+    bool lcm = false;               // LCM run: the method-difference flag rides in the sign bit of x until unpacked
 };
 
 extern "C" void fib_stream_job_destroy(fib_stream_job *job) {
@@ -502,9 +603,35 @@ extern "C" int fibd_stream_field(int32_t nvec, int64_t nvox, const float *const 
     return FIB_OK;
 }
 
+namespace {
+struct LcmIn { const float *lcms = nullptr; float thresh = 0.0f; int sd0 = 0, sd1 = 1; unsigned long long seed = 0; };
+int stream_trace_impl(const fib_stream_params *prm, const float *field4, const LcmIn &lin, const int64_t *seeds, int64_t nseed,
+                      const float *sublist, int32_t nsub, void *stream,
+                      fib_stream_job **job_out, int64_t *nlines_out, int64_t *npoints_out);
+}
+
 extern "C" int fibd_stream_trace(const fib_stream_params *prm, const float *field4, const int64_t *seeds, int64_t nseed,
                                  const float *sublist, int32_t nsub, void *stream,
                                  fib_stream_job **job_out, int64_t *nlines_out, int64_t *npoints_out) {
+    return stream_trace_impl(prm, field4, LcmIn{}, seeds, nseed, sublist, nsub, stream, job_out, nlines_out, npoints_out);
+}
+
+extern "C" int fibd_stream_trace_lcm(const fib_stream_params *prm, const float *field4, const float *lcms, float lcm_thresh,
+                                     int32_t strdim0, int32_t strdim1, uint64_t rng_seed,
+                                     const int64_t *seeds, int64_t nseed, const float *sublist, int32_t nsub, void *stream,
+                                     fib_stream_job **job_out, int64_t *nlines_out, int64_t *npoints_out) {
+    FIB_CHECK(lcms != nullptr, FIB_ERR_INVALID, "NULL lcms volume");
+    FIB_CHECK(strdim0 >= 0 && strdim0 < 3 && strdim1 >= 0 && strdim1 < 3 && strdim0 != strdim1, FIB_ERR_INVALID, "invalid in-plane dimensions");
+    FIB_CHECK(prm && prm->search_dist == 0, FIB_ERR_UNSUPPORTED, "LCM-guided tracking is a macro-scale mode (search_dist must be 0)");
+    LcmIn lin;
+    lin.lcms = lcms; lin.thresh = lcm_thresh; lin.sd0 = strdim0; lin.sd1 = strdim1; lin.seed = rng_seed;
+    return stream_trace_impl(prm, field4, lin, seeds, nseed, sublist, nsub, stream, job_out, nlines_out, npoints_out);
+}
+
+namespace {
+int stream_trace_impl(const fib_stream_params *prm, const float *field4, const LcmIn &lin, const int64_t *seeds, int64_t nseed,
+                      const float *sublist, int32_t nsub, void *stream,
+                      fib_stream_job **job_out, int64_t *nlines_out, int64_t *npoints_out) {
     FIB_CHECK(prm && field4 && job_out && nlines_out && npoints_out, FIB_ERR_INVALID, "NULL argument");
     *job_out = nullptr;
     FIB_CHECK(nseed >= 0 && (nseed == 0 || seeds), FIB_ERR_INVALID, "invalid seed list");
@@ -566,6 +693,7 @@ extern "C" int fibd_stream_trace(const fib_stream_params *prm, const float *fiel
     ta.cosang = prm->cosang_thresh; ta.step = prm->step_size; ta.smooth = prm->smooth_coeff;
     const unsigned grid = (unsigned)fib::cdiv(nl, 256);
     fib::DevBuf<float4> d_search;
+    fib::DevBuf<float> d_lcm;
     if (prm->search_dist > 0) {
         // search_area (stream.jl:255-277), Float32 arithmetic like the reference's T; one entry per antipodal pair
         const int d = prm->search_dist, S = 2 * d + 1;
@@ -597,6 +725,16 @@ extern "C" int fibd_stream_trace(const fib_stream_params *prm, const float *fiel
         if (ec != hipSuccess) return bail(fib::fail(FIB_ERR_HIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(ec)));
         fib::ProfScope prof("stream_trace_micro", st);
         hipLaunchKernelGGL(stream_trace_micro_kernel, dim3(mg), dim3(1024), smem, st, ta);
+    } else if (lin.lcms) {
+        const int64_t nvox = (int64_t)prm->nx * prm->ny * prm->nz;
+        if ((rc = d_lcm.alloc((size_t)nvox * 10)) != FIB_OK) return bail(rc);
+        hipLaunchKernelGGL(lcm_prepare_kernel, dim3((unsigned)fib::cdiv(nvox, 256)), dim3(256), 0, st, lin.lcms, lin.thresh, nvox, d_lcm.p);
+        ta.lcm = d_lcm.p; ta.sd0 = lin.sd0; ta.sd1 = lin.sd1; ta.rng_seed = lin.seed;
+        job->lcm = true;
+        fib::ProfScope prof("stream_trace_lcm", st);
+        if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1, true>), dim3(grid), dim3(256), 0, st, ta);
+        else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, true>), dim3(grid), dim3(256), 0, st, ta);
+        else                     hipLaunchKernelGGL((stream_trace_kernel<0, true>), dim3(grid), dim3(256), 0, st, ta);
     } else
     { fib::ProfScope prof("stream_trace", st);
     if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1>), dim3(grid), dim3(256), 0, st, ta);
@@ -617,8 +755,35 @@ extern "C" int fibd_stream_trace(const fib_stream_params *prm, const float *fiel
     *job_out = job;
     return FIB_OK;
 }
+}  // namespace
+
+// flags[i] = sign bit of x of point i, then the sign is cleared (LCM runs; see stream_trace_kernel)
+__global__ __launch_bounds__(256) void stream_unpack_flags_kernel(float *xyz, uint8_t *flags, int64_t npts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npts) return;
+    const float x = xyz[3 * i];
+    if (flags) flags[i] = (__float_as_uint(x) >> 31) ? 1 : 0;
+    xyz[3 * i] = fabsf(x);
+}
+
+static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, void *stream);
+
+extern "C" int fibd_stream_pack_flags(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, uint8_t *flags, void *stream) {
+    int rc = pack_plain(job, npts, seed_index, xyz, stream);
+    if (rc != FIB_OK || job->kept_pts == 0) return rc;
+    if (job->lcm)
+        hipLaunchKernelGGL(stream_unpack_flags_kernel, dim3((unsigned)fib::cdiv(job->kept_pts, 256)), dim3(256), 0, (hipStream_t)stream, xyz, flags, job->kept_pts);
+    else if (flags) FIB_HIP(hipMemsetAsync(flags, 0, (size_t)job->kept_pts, (hipStream_t)stream));
+    else return FIB_OK;
+    FIB_HIP(hipGetLastError());
+    return FIB_OK;
+}
 
 extern "C" int fibd_stream_pack(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, void *stream) {
+    return fibd_stream_pack_flags(job, npts, seed_index, xyz, nullptr, stream);   // (strips the flag bit of LCM runs)
+}
+
+static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, void *stream) {
     FIB_CHECK(job != nullptr, FIB_ERR_INVALID, "job is NULL");
     if (job->kept_lines == 0) return FIB_OK;
     FIB_CHECK(npts && seed_index && xyz, FIB_ERR_INVALID, "NULL output buffer");
@@ -633,11 +798,12 @@ extern "C" int fibd_stream_pack(fib_stream_job *job, int32_t *npts, int64_t *see
     fib::ProfScope prof("stream_pack", (hipStream_t)stream);
     hipLaunchKernelGGL(stream_pack_kernel, dim3((unsigned)fib::cdiv(job->nlines, PK_LINES)), dim3(256), 0, (hipStream_t)stream, pa);
     FIB_HIP(hipGetLastError());
-    return FIB_OK;
+    return FIB_OK;                                      // (LCM jobs: x still carries the flag bit; the caller strips it)
 }
 
 extern "C" int fibd_stream_pack_trk(fib_stream_job *job, const float voxel_size[3], void *body, void *stream) {
     FIB_CHECK(job != nullptr && voxel_size != nullptr, FIB_ERR_INVALID, "NULL argument");
+    FIB_CHECK(!job->lcm, FIB_ERR_UNSUPPORTED, "the .trk body serialiser does not carry the per-point scalars of an LCM run");
     if (job->kept_lines == 0) return FIB_OK;
     FIB_CHECK(body != nullptr, FIB_ERR_INVALID, "NULL output buffer");
     fib::DeviceGuard guard;

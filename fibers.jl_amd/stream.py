@@ -59,15 +59,17 @@ def _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff, 
 def stream(ovec: Union[MRI, Sequence[MRI]], *, f=None, f_thresh: float = 0.03, fa: Optional[MRI] = None,
            fa_thresh: float = 0.1, mask: Optional[MRI] = None, seed: Optional[MRI] = None, nsub: Optional[int] = 3,
            len_min: int = 3, len_max: Optional[int] = None, ang_thresh: Optional[float] = 45,
-           step_size: Optional[float] = 0.5, smooth_coeff: Optional[float] = 0.2, lcms=None,
-           search_dist: int = 15, search_ang: float = 10, sublist=None, rng=None, device: int = 0) -> Tract:
+           step_size: Optional[float] = 0.5, smooth_coeff: Optional[float] = 0.2, lcms=None, lcm_thresh: float = 0.099,
+           search_dist: int = 15, search_ang: float = 10, sublist=None, rng=None, rng_seed: int = 0,
+           device: int = 0) -> Tract:
     """Streamline tractography (stream.jl:730).  Returns a `Tract` whose lines are in the reference's order
     (seed voxels in column-major `findall` order, sub-voxel offsets innermost), points in 1-based voxel
     coordinates, each line ordered [forward reversed, backward] as stream.jl:652 builds it.
     Volumes with a voxel size of 0.05 mm or less (stream.jl:83) are tracked in the microscopy regime
-    (stream_micro_new_point!, stream.jl:547-619: cone search of `search_dist` voxels / `search_ang` degrees)."""
-    if lcms is not None:
-        raise NotImplementedError("LCM-guided tracking (stream.jl:380-495) is outside the accelerated path")
+    (stream_micro_new_point!, stream.jl:547-619: cone search of `search_dist` voxels / `search_ang` degrees).
+    `lcms` [nx,ny,nz,10] switches to LCM-guided tracking (stream.jl:380-495); the reference samples from Julia's global
+    RNG there, this back end from the counter-based stream defined in include/fibers_hip.h (`rng_seed`); the returned
+    Tract then carries the per-point method-difference indicator as `scalars`."""
     ovecs = _as_list(ovec)
     fs = _as_list(f)
     if mask is None:
@@ -116,21 +118,39 @@ def stream(ovec: Union[MRI, Sequence[MRI]], *, f=None, f_thresh: float = 0.03, f
     fv = None if fvols is None else (C.c_void_p * nvec)(*[v.ctypes.data for v in fvols])
     out = _lib.TractOut()
     L = _lib.lib()
-    _lib.check(L.fib_stream(device, C.byref(prm), ov, fv, float(np.float32(f_thresh)),
-                            None if favol is None else favol.ctypes.data, float(np.float32(fa_thresh)),
-                            m.ctypes.data, mdt, sptr, sdt, sub.ctypes.data, sub.shape[0], C.byref(out)))
+    scal = None
+    if lcms is None:
+        _lib.check(L.fib_stream(device, C.byref(prm), ov, fv, float(np.float32(f_thresh)),
+                                None if favol is None else favol.ctypes.data, float(np.float32(fa_thresh)),
+                                m.ctypes.data, mdt, sptr, sdt, sub.ctypes.data, sub.shape[0], C.byref(out)))
+    else:
+        if domicro:
+            raise ValueError("LCM-guided tracking is a macro-scale mode (voxel size > 0.05 mm)")
+        lv = lcms.vol if isinstance(lcms, MRI) else np.asarray(lcms)
+        if lv.shape != shape + (10,):
+            raise ValueError("lcms must be [nx,ny,nz,10] (vectorised 4x4 symmetric local connection matrices)")
+        lv = np.asfortranarray(lv, dtype=np.float32)
+        if lcm_thresh > float(lv.max()):                                      # stream.jl:210-215
+            print("WARNING: The value of lcm_thresh (%s) is greater than the maximum value in the lcms volume (%s)"
+                  % (lcm_thresh, float(lv.max())))
+        _lib.check(L.fib_stream_lcm(device, C.byref(prm), ov, fv, float(np.float32(f_thresh)),
+                                    None if favol is None else favol.ctypes.data, float(np.float32(fa_thresh)),
+                                    m.ctypes.data, mdt, sptr, sdt, sub.ctypes.data, sub.shape[0],
+                                    lv.ctypes.data, float(np.float32(lcm_thresh)), int(rng_seed), C.byref(out)))
     try:
         nl, npnt = int(out.nlines), int(out.npoints)
         npts = np.ctypeslib.as_array(out.npts, shape=(max(nl, 1),))[:nl].copy()
         sidx = np.ctypeslib.as_array(out.seed_index, shape=(max(nl, 1),))[:nl].copy()
         xyz = np.ctypeslib.as_array(out.xyz, shape=(max(npnt, 1) * 3,))[: npnt * 3].copy().reshape(-1, 3)
+        if lcms is not None:
+            scal = np.ctypeslib.as_array(out.flags, shape=(max(npnt, 1),))[:npnt].astype(np.float32)
     finally:
         L.fib_tract_free(C.byref(out))
     ref = mask if isinstance(mask, MRI) else None
     return Tract(xyz=xyz, npts=npts, seed_index=sidx, volsize=shape,
                  volres=tuple(ref.volres) if ref is not None else (1.0, 1.0, 1.0),
                  vox2ras=ref.vox2ras.copy() if ref is not None else np.eye(4, dtype=np.float32),
-                 sublist=sub)
+                 sublist=sub, scalars=scal)
 
 
 def _warn_thresh(name, thr, vol, maskbool):
@@ -170,11 +190,14 @@ def stream_field_device(ovec: List, f: Optional[List] = None, f_thresh: float = 
 
 
 def stream_device(field, shape, seeds, sublist, len_min=3, len_max=None, ang_thresh=45, step_size=0.5,
-                  smooth_coeff=0.2, stream=None, want_all_npts=False, search_dist=0, search_ang=10):
+                  smooth_coeff=0.2, stream=None, want_all_npts=False, search_dist=0, search_ang=10,
+                  lcms=None, lcm_thresh=0.099, strdims=(0, 1), rng_seed=0):
     """Trace + pack on the GPU.  field: [nvox, nvec, 4] from stream_field_device; seeds: int64 CUDA tensor of
     0-based column-major voxel indices (findall order); sublist: float32 CUDA [nsub, 3].
     search_dist > 0: microscopy regime (stream.jl:547-619; reference defaults there: search_dist 15, search_ang 10,
     ang_thresh 20, step_size 1, smooth_coeff 0, one zero sub-voxel offset).
+    lcms (float32 CUDA [10, nvox], planar like MRI.vol[nx,ny,nz,10]): LCM-guided tracking (stream.jl:380-495) over the
+    in-plane dimensions `strdims`, uniforms from the ABI's counter-based stream (`rng_seed`); adds `flags` uint8 [npoints].
     Returns dict(npts int32 [nlines], seed_index int64 [nlines], xyz float32 [npoints, 3])."""
     import torch
     _chk_dev(field, torch.float32, "field")
@@ -186,14 +209,25 @@ def stream_device(field, shape, seeds, sublist, len_min=3, len_max=None, ang_thr
     nl, npnt = C.c_int64(0), C.c_int64(0)
     L = _lib.lib()
     sp = _stream_ptr(stream)
-    _lib.check(L.fibd_stream_trace(C.byref(prm), field.data_ptr(), seeds.data_ptr(), seeds.numel(),
-                                   sublist.data_ptr(), sublist.shape[0], sp, C.byref(job), C.byref(nl), C.byref(npnt)))
+    if lcms is None:
+        _lib.check(L.fibd_stream_trace(C.byref(prm), field.data_ptr(), seeds.data_ptr(), seeds.numel(),
+                                       sublist.data_ptr(), sublist.shape[0], sp, C.byref(job), C.byref(nl), C.byref(npnt)))
+    else:
+        _chk_dev(lcms, torch.float32, "lcms")
+        _lib.check(L.fibd_stream_trace_lcm(C.byref(prm), field.data_ptr(), lcms.data_ptr(), float(np.float32(lcm_thresh)),
+                                           int(strdims[0]), int(strdims[1]), int(rng_seed), seeds.data_ptr(), seeds.numel(),
+                                           sublist.data_ptr(), sublist.shape[0], sp, C.byref(job), C.byref(nl), C.byref(npnt)))
     try:
         dev = field.device
         out = dict(npts=torch.empty(nl.value, dtype=torch.int32, device=dev),
                    seed_index=torch.empty(nl.value, dtype=torch.int64, device=dev),
                    xyz=torch.empty((npnt.value, 3), dtype=torch.float32, device=dev))
-        _lib.check(L.fibd_stream_pack(job, out["npts"].data_ptr(), out["seed_index"].data_ptr(), out["xyz"].data_ptr(), sp))
+        if lcms is None:
+            _lib.check(L.fibd_stream_pack(job, out["npts"].data_ptr(), out["seed_index"].data_ptr(), out["xyz"].data_ptr(), sp))
+        else:
+            out["flags"] = torch.empty(npnt.value, dtype=torch.uint8, device=dev)
+            _lib.check(L.fibd_stream_pack_flags(job, out["npts"].data_ptr(), out["seed_index"].data_ptr(),
+                                                out["xyz"].data_ptr(), out["flags"].data_ptr(), sp))
         if want_all_npts:
             out["all_npts"] = torch.empty(seeds.numel() * sublist.shape[0], dtype=torch.int32, device=dev)
             _lib.check(L.fibd_stream_all_npts(job, out["all_npts"].data_ptr(), sp))

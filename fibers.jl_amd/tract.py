@@ -16,6 +16,8 @@ class Tract:
     volres: tuple = (1.0, 1.0, 1.0)       # trk.jl:17  voxel_size
     vox2ras: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=np.float32))   # trk.jl:28
     sublist: Optional[np.ndarray] = None
+    scalars: Optional[np.ndarray] = None  # float32 [npoints] (n_scalars = 1, trk.jl:19,41): LCM runs store the
+                                          # method-difference indicator of every point here (stream.jl:538, 787)
 
     @property
     def nstr(self) -> int:

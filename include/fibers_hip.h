@@ -183,6 +183,25 @@ int fibd_stream_trace(const fib_stream_params *prm, const float *field4, const i
  * npts [nlines] int32, seed_index [nlines] int64 (= seed*nsub+sub), xyz [3*npoints] (x,y,z per point,
  * line after line, each line ordered [fwd_N..fwd_1, bwd_1..bwd_M] as stream.jl:652 builds it). */
 int fibd_stream_pack(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, void *stream);
+
+/* LCM-guided tracking (stream(...; lcms, lcm_thresh), stream.jl:200-236, 380-495, 526-538): when a line enters a new
+ * voxel the exit edge is drawn from the voxel's local connection matrix restricted to the entry edge, and the
+ * orientation vector best aligned with a jump towards that edge is followed; the angle threshold is not applied
+ * (stream.jl:668).  lcms: planar [10][nvox] = MRI.vol[nx,ny,nz,10]; elements below lcm_thresh are dropped
+ * (stream.jl:217).  strdim0/1: the two in-plane dimensions (0-based; the reference takes the dimension in which the
+ * first orientation volume is zero everywhere as through-plane, stream.jl:221-223).
+ * RANDOM-NUMBER CONTRACT.  The reference draws `rand(Categorical(lcm))` from Julia's global RNG, which no other
+ * implementation can reproduce.  Here the k-th uniform consumed by streamline `line` (= seed*nsub + sub) is
+ *     u = float(splitmix64(rng_seed ^ splitmix64(line * 0xD1342543DE82EF95 + k)) >> 40) * 2^-24   in [0,1),
+ * and the category is the first index whose running sum of the normalised weights exceeds u (what
+ * Distributions.jl's sampler does with its uniform).  Results depend on rng_seed only, not on scheduling.
+ * fibd_stream_pack_flags additionally returns one byte per point: the LCM pick and the angle pick chose different
+ * vectors (the `flags` the reference stores as a per-point scalar of the Tract, stream.jl:538, 666, 787). */
+int fibd_stream_trace_lcm(const fib_stream_params *prm, const float *field4, const float *lcms, float lcm_thresh,
+                          int32_t strdim0, int32_t strdim1, uint64_t rng_seed,
+                          const int64_t *seeds, int64_t nseed, const float *sublist, int32_t nsub, void *stream,
+                          fib_stream_job **job, int64_t *nlines, int64_t *npoints);
+int fibd_stream_pack_flags(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, uint8_t *flags, void *stream);
 /* same lines serialised as the body of a TrackVis .trk file (everything after the 1000-byte header, as
  * trk_write emits it, trk.jl:469-485): per line Int32 npts then npts x 3 Float32 = (xyz + .5) * voxel_size.
  * body: device buffer of 4*nlines + 12*npoints bytes. */
@@ -230,11 +249,18 @@ typedef struct {
     int32_t *npts;        /* [nlines] */
     int64_t *seed_index;  /* [nlines] seed*nsub + sub, seeds counted in findall order */
     float *xyz;           /* [3*npoints] */
+    uint8_t *flags;       /* [npoints] (fib_stream_lcm only, else NULL): LCM and angle pick disagreed at this point */
 } fib_tract_out;
 
 int fib_stream(int device, const fib_stream_params *prm, const float *const *ovec, const float *const *f,
                float f_thresh, const float *fa, float fa_thresh, const void *mask, int mask_dtype,
                const void *seed, int seed_dtype, const float *sublist, int32_t nsub, fib_tract_out *out);
+/* stream(ovec; ..., lcms, lcm_thresh) (stream.jl:730): fib_stream with local connection matrices lcms [nx,ny,nz,10]
+ * (see fibd_stream_trace_lcm for the semantics and the random-number contract); out->flags is filled. */
+int fib_stream_lcm(int device, const fib_stream_params *prm, const float *const *ovec, const float *const *f,
+                   float f_thresh, const float *fa, float fa_thresh, const void *mask, int mask_dtype,
+                   const void *seed, int seed_dtype, const float *sublist, int32_t nsub,
+                   const float *lcms, float lcm_thresh, uint64_t rng_seed, fib_tract_out *out);
 void fib_tract_free(fib_tract_out *out);
 
 #ifdef __cplusplus

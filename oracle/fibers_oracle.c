@@ -594,7 +594,27 @@ typedef struct {
     int search_dist;
     float search_cosang;        /* cosd(search_ang) */
     const float *search_area;   /* [3, S, S, S], S = 2*search_dist+1: unit vectors of the cells with rho < 1, else 0 */
+    /* LCM-guided tracking (stream.jl:200-236, 380-495): lcms != NULL */
+    const float *lcms;          /* [10, nx, ny, nz] column-major, already thresholded (stream.jl:217) */
+    int strdims[2];             /* in-plane dimensions, 0-based (stream.jl:221-223) */
+    uint64_t rng_seed;          /* uniform draws: orc_uniform(rng_seed, line, k) stands in for Julia's global RNG */
 } stream_work;
+
+/* The random-number contract of LCM-guided tracking.  The reference draws `rand(Categorical(lcm))` from Julia's global
+ * RNG (stream.jl:455), which cannot be reproduced; this back end (HIP kernel and oracle alike) takes the k-th uniform
+ * of streamline `line` from a counter-based generator: splitmix64 of (seed, line, k), top 24 bits -> [0,1). */
+static uint64_t orc_splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+float orc_uniform(uint64_t seed, uint64_t line, uint32_t k)
+{
+    uint64_t h = orc_splitmix64(seed ^ orc_splitmix64(line * 0xD1342543DE82EF95ull + (uint64_t)k));
+    return (float)(h >> 40) * (1.0f / 16777216.0f);
+}
 
 /* LinearAlgebra.norm of a 3-vector: squares in Float32, sum + sqrt in Float64 (generic_norm2) */
 static float norm3(const float v[3])
@@ -632,6 +652,101 @@ static int pick_by_angle(const stream_work *W, int ix, int iy, int iz, const flo
     if (bestcos > 0.0f) { vec_next[0] = v[0]; vec_next[1] = v[1]; vec_next[2] = v[2]; }
     else { vec_next[0] = -v[0]; vec_next[1] = -v[1]; vec_next[2] = -v[2]; }        /* :365-369 */
     *ivec_next = best;                                                             /* :371 */
+    return 1;
+}
+
+/* voxel edges connected by the i-th element of a vectorised LCM (stream.jl:228-229), 1-based edge types */
+static const int lcm_edge[2][10] = {{1, 1, 1, 1, 2, 2, 2, 3, 3, 4}, {1, 2, 3, 4, 2, 3, 4, 3, 4, 4}};
+
+/* coordinate increments for exiting through the j-th edge (stream.jl:224-226), j = 1..4 */
+static void lcm_dxyz(const stream_work *W, int j, int d[3])
+{
+    static const int a[4] = {-1, 0, 1, 0}, b[4] = {0, -1, 0, 1};
+    d[0] = d[1] = d[2] = 0;
+    d[W->strdims[0]] = a[j - 1];
+    d[W->strdims[1]] = b[j - 1];
+}
+
+static int lcm_match_edge(const stream_work *W, const int dv[3])
+{
+    for (int j = 1; j <= 4; j++) {
+        int d[3];
+        lcm_dxyz(W, j, d);
+        if (d[0] == dv[0] && d[1] == dv[1] && d[2] == dv[2]) return j;
+    }
+    return 0;
+}
+
+/* stream_pick_by_lcm! (stream.jl:380-495).  *ivec_next is W.ivec_next (on entry: what stream_pick_by_angle! just chose,
+ * stream.jl:530-531).  *ndraw counts the uniforms this line has consumed. */
+static int pick_by_lcm(const stream_work *W, int ix, int iy, int iz, const float pos_now[3], const float pos_next[3],
+                       const float vec_now[3], float vec_next[3], int *ivec_next, uint64_t line, uint32_t *ndraw)
+{
+    const int64_t vox = (ix - 1) + (int64_t)W->nx * ((iy - 1) + (int64_t)W->ny * (iz - 1));
+    const float *v0 = W->ovecs + 3 * (int64_t)W->nvec * vox;
+    int dv[3] = {(int)rintf(pos_now[0]) - ix, (int)rintf(pos_now[1]) - iy, (int)rintf(pos_now[2]) - iz};   /* :394-398 */
+    if (dv[0] == 0 && dv[1] == 0 && dv[2] == 0) {                /* not entering a new voxel, :400-413 */
+        const float *v = v0 + 3 * *ivec_next;
+        if (dot3(vec_now, v) > 0.0f) { vec_next[0] = v[0]; vec_next[1] = v[1]; vec_next[2] = v[2]; }
+        else { vec_next[0] = -v[0]; vec_next[1] = -v[1]; vec_next[2] = -v[2]; }
+        return 1;
+    }
+    int entry = lcm_match_edge(W, dv);                           /* :416-422 */
+    if (entry == 0) {                                            /* a diagonal jump: the dimension that changes faster, :424-438 */
+        const int s1 = W->strdims[0], s2 = W->strdims[1];
+        if (fabsf(pos_now[s1] - pos_next[s1]) < fabsf(pos_now[s2] - pos_next[s2])) dv[s2] = 0; else dv[s1] = 0;
+        entry = lcm_match_edge(W, dv);
+    }
+    float lcm[10];
+    int any = 0;
+    for (int j = 0; j < 10; j++) {                               /* :441-446 */
+        lcm[j] = W->lcms[j + 10 * vox];
+        if (!(lcm_edge[0][j] == entry || lcm_edge[1][j] == entry)) lcm[j] = 0.0f;
+        any |= lcm[j] != 0.0f;
+    }
+    if (!any) return 0;                                          /* while !iszero(lcm) ... iszero(lcm) && return false, :448,492 */
+    float sum = lcm[0];
+    for (int j = 1; j < 10; j++) sum += lcm[j];
+    for (int j = 0; j < 10; j++) lcm[j] = lcm[j] / sum;          /* :450 */
+    const float u = orc_uniform(W->rng_seed, line, (*ndraw)++);
+    int il = 0;                                                  /* rand(Categorical(lcm)): first index whose running sum exceeds u */
+    float cp = lcm[0];
+    while (cp <= u && il < 9) cp += lcm[++il];
+    const int exitedge = lcm_edge[0][il] == entry ? lcm_edge[1][il] : lcm_edge[0][il];   /* :454-456 */
+    int d[3];
+    lcm_dxyz(W, exitedge, d);
+    const float df[3] = {(float)d[0], (float)d[1], (float)d[2]};
+    int best = 0; float bestabs = 0.0f, bestcos = 0.0f;
+    for (int k = 0; k < W->nvec; k++) {                          /* :462-472 */
+        const float *v = v0 + 3 * k;
+        float c, ca;
+        if (v[0] == 0.0f && v[1] == 0.0f && v[2] == 0.0f) c = ca = -INFINITY;
+        else { c = dot3(df, v); ca = fabsf(c); }
+        if (k == 0 || (!isnan(bestabs) && (isnan(ca) || ca > bestabs))) { best = k; bestabs = ca; bestcos = c; }
+    }
+    if (!isfinite(bestcos)) return 0;                            /* :476 */
+    const float *v = v0 + 3 * best;
+    if (bestcos > 0.0f) { vec_next[0] = v[0]; vec_next[1] = v[1]; vec_next[2] = v[2]; }
+    else { vec_next[0] = -v[0]; vec_next[1] = -v[1]; vec_next[2] = -v[2]; }      /* :480-484 */
+    *ivec_next = best;                                           /* :486 */
+    return 1;
+}
+
+/* stream_new_point! with LCMs (stream.jl:526-538): the angle pick first (it can end the line and it sets
+ * W.ivec_next), then the LCM pick; *isdiff = the two methods chose different vectors */
+static int new_point_lcm(const stream_work *W, const float pos_now[3], const float vec_now[3], float pos_next[3],
+                         float vec_next[3], int *ivec_next, int *isdiff, uint64_t line, uint32_t *ndraw)
+{
+    for (int c = 0; c < 3; c++) pos_next[c] = pos_now[c] + vec_now[c] * W->step_size;
+    float rx = rintf(pos_next[0]), ry = rintf(pos_next[1]), rz = rintf(pos_next[2]);
+    if (!(rx >= 1.0f && rx <= (float)W->nx && ry >= 1.0f && ry <= (float)W->ny &&
+          rz >= 1.0f && rz <= (float)W->nz)) return 0;
+    int ix = (int)rx, iy = (int)ry, iz = (int)rz;
+    if (!W->mask[(ix - 1) + (int64_t)W->nx * ((iy - 1) + (int64_t)W->ny * (iz - 1))]) return 0;
+    if (!pick_by_angle(W, ix, iy, iz, vec_now, vec_next, ivec_next)) return 0;   /* :530 */
+    const int ivec_ang = *ivec_next;                                               /* :531 */
+    if (!pick_by_lcm(W, ix, iy, iz, pos_now, pos_next, vec_now, vec_next, ivec_next, line, ndraw)) return 0;   /* :535 */
+    *isdiff = *ivec_next != ivec_ang;                                              /* :538 */
     return 1;
 }
 
@@ -713,9 +828,11 @@ static int micro_new_point(const stream_work *W, const float pos_now[3], const f
  * filled in REFERENCE ORDER [fwd_N..fwd_1, bwd_1..bwd_M]; returns npts, *nfwd = N.
  */
 static int new_line(const stream_work *W, const int seed[3], const float sub[3], float *line, int *nfwd,
-                    float *fwdbuf)
+                    float *fwdbuf, uint64_t lineno, uint8_t *flags)
 {
     int npts = 0, ivec_next = 0, nf = 0, nb = 0;                 /* :638, :645 (0-based here) */
+    uint32_t ndraw = 0;
+    uint8_t *ffwd = flags ? flags + (W->len_max + 2) : NULL, *fbwd = flags ? flags + 2 * (W->len_max + 2) : NULL;
     float *bwd = line;                                           /* assembled after both passes */
     float *bwdbuf = fwdbuf + 3 * (W->len_max + 2);
     (void)bwd;
@@ -729,12 +846,15 @@ static int new_line(const stream_work *W, const int seed[3], const float sub[3],
             vec_now[c] = sv[c] * fwd;                            /* :650 */
         }
         for (;;) {
-            if (!(W->search_dist > 0 ? micro_new_point(W, pos_now, vec_now, pos_next, vec_next)
-                                     : new_point(W, pos_now, vec_now, pos_next, vec_next, &ivec_next))) break;   /* :655-657 */
+            int isdiff = 0;
+            if (!(W->lcms ? new_point_lcm(W, pos_now, vec_now, pos_next, vec_next, &ivec_next, &isdiff, lineno, &ndraw)
+                  : W->search_dist > 0 ? micro_new_point(W, pos_now, vec_now, pos_next, vec_next)
+                                       : new_point(W, pos_now, vec_now, pos_next, vec_next, &ivec_next))) break;   /* :655-657 */
+            if (flags) { if (pass == 0) ffwd[nf] = (uint8_t)isdiff; else fbwd[nb] = (uint8_t)isdiff; }              /* :666 */
             float *dst = pass == 0 ? fwdbuf + 3 * nf++ : bwdbuf + 3 * nb++;                /* :660 */
             dst[0] = pos_now[0]; dst[1] = pos_now[1]; dst[2] = pos_now[2];
             npts++;                                              /* :661 */
-            if (dot3(vec_now, vec_next) < W->cosang_thresh) break;   /* :670 */
+            if (!W->lcms && dot3(vec_now, vec_next) < W->cosang_thresh) break;   /* :670 (not used with LCMs, :668) */
             if (npts > W->len_max) break;                        /* :674 */
             if (W->smooth_coeff != 0.0f) {                       /* :677-681 */
                 float omc = 1.0f - W->smooth_coeff;
@@ -748,6 +868,10 @@ static int new_line(const stream_work *W, const int seed[3], const float sub[3],
     /* prepend! for forward points reverses them; append! keeps backward order (:652) */
     for (int i = 0; i < nf; i++) memcpy(line + 3 * i, fwdbuf + 3 * (nf - 1 - i), 3 * sizeof(float));
     memcpy(line + 3 * nf, bwdbuf, 3 * sizeof(float) * nb);
+    if (flags) {                                                 /* same order as the points */
+        for (int i = 0; i < nf; i++) flags[i] = ffwd[nf - 1 - i];
+        for (int i = 0; i < nb; i++) flags[nf + i] = fbwd[i];
+    }
     *nfwd = nf;
     return npts;
 }
@@ -777,6 +901,14 @@ int64_t orc_stream(const float *ovecs, const uint8_t *mask, int nx, int ny, int 
                             step_size, smooth_coeff, 0, 0.0f, out_npts, out_seed, out_xyz, out_total_pts, all_npts, nthreads);
 }
 
+int64_t orc_stream_full(const float *ovecs, const uint8_t *mask, int nx, int ny, int nz, int nvec,
+                        const int32_t *seeds, int64_t nseed, const float *sublist, int nsub,
+                        int len_min, int len_max, float cosang_thresh, float step_size, float smooth_coeff,
+                        int search_dist, float search_cosang,
+                        const float *lcms, int strdim0, int strdim1, uint64_t rng_seed,
+                        int32_t **out_npts, int64_t **out_seed, float **out_xyz, uint8_t **out_flags, int64_t *out_total_pts,
+                        int32_t *all_npts, int nthreads);
+
 /* same driver; search_dist > 0 selects the microscopy regime (stream.jl:83, 252-287, 547-619) */
 int64_t orc_stream_micro(const float *ovecs, const uint8_t *mask, int nx, int ny, int nz, int nvec,
                          const int32_t *seeds, int64_t nseed, const float *sublist, int nsub,
@@ -785,14 +917,32 @@ int64_t orc_stream_micro(const float *ovecs, const uint8_t *mask, int nx, int ny
                          int32_t **out_npts, int64_t **out_seed, float **out_xyz, int64_t *out_total_pts,
                          int32_t *all_npts, int nthreads)
 {
+    return orc_stream_full(ovecs, mask, nx, ny, nz, nvec, seeds, nseed, sublist, nsub, len_min, len_max, cosang_thresh,
+                           step_size, smooth_coeff, search_dist, search_cosang, NULL, 0, 1, 0, out_npts, out_seed, out_xyz,
+                           NULL, out_total_pts, all_npts, nthreads);
+}
+
+/* the general driver.  lcms != NULL: LCM-guided tracking (stream.jl:200-236, 380-495): lcms [10,nx,ny,nz] already
+ * thresholded, strdim0/1 the in-plane dimensions (0-based), rng_seed the seed of the uniform stream (orc_uniform);
+ * out_flags (one byte per point, in point order) = "the LCM and the angle pick chose different vectors" (stream.jl:538) */
+int64_t orc_stream_full(const float *ovecs, const uint8_t *mask, int nx, int ny, int nz, int nvec,
+                        const int32_t *seeds, int64_t nseed, const float *sublist, int nsub,
+                        int len_min, int len_max, float cosang_thresh, float step_size, float smooth_coeff,
+                        int search_dist, float search_cosang,
+                        const float *lcms, int strdim0, int strdim1, uint64_t rng_seed,
+                        int32_t **out_npts, int64_t **out_seed, float **out_xyz, uint8_t **out_flags, int64_t *out_total_pts,
+                        int32_t *all_npts, int nthreads)
+{
     float *sarea = search_dist > 0 ? micro_search_area(search_dist) : NULL;
     stream_work W = {nx, ny, nz, nvec, ovecs, mask, len_min, len_max, cosang_thresh, step_size, smooth_coeff,
-                     search_dist, search_cosang, sarea};
+                     search_dist, search_cosang, sarea, lcms, {strdim0, strdim1}, rng_seed};
+    const int want_flags = lcms != NULL && out_flags != NULL;
     if (nthreads < 1) nthreads = 1;
     /* chunks of div(n, nthreads)+1 seeds (stream.jl:757-759) */
     int64_t per = nseed / nthreads + 1;
     int nchunks = (int)((nseed + per - 1) / per);
     float **cx = (float **)calloc(nchunks > 0 ? nchunks : 1, sizeof(float *));
+    uint8_t **cf = (uint8_t **)calloc(nchunks > 0 ? nchunks : 1, sizeof(uint8_t *));
     int32_t **cn = (int32_t **)calloc(nchunks > 0 ? nchunks : 1, sizeof(int32_t *));
     int64_t **cs = (int64_t **)calloc(nchunks > 0 ? nchunks : 1, sizeof(int64_t *));
     int64_t *clines = (int64_t *)calloc(nchunks > 0 ? nchunks : 1, sizeof(int64_t));
@@ -802,39 +952,45 @@ int64_t orc_stream_micro(const float *ovecs, const uint8_t *mask, int nx, int ny
         int64_t i0 = ic * per, i1 = i0 + per < nseed ? i0 + per : nseed;
         int64_t capl = 1024, capp = 1 << 16, nl = 0, np = 0;
         float *xyz = (float *)malloc(sizeof(float) * 3 * capp);
+        uint8_t *fl = (uint8_t *)malloc(capp);
         int32_t *npl = (int32_t *)malloc(sizeof(int32_t) * capl);
         int64_t *sd = (int64_t *)malloc(sizeof(int64_t) * capl);
         float *line = (float *)malloc(sizeof(float) * 3 * (len_max + 2));
         float *scratch = (float *)malloc(sizeof(float) * 6 * (len_max + 2));
+        uint8_t *lflags = (uint8_t *)malloc(3 * (size_t)(len_max + 2));
         for (int64_t is = i0; is < i1; is++) {
             for (int isub = 0; isub < nsub; isub++) {
                 int nfwd;
-                int n = new_line(&W, seeds + 3 * is, sublist + 3 * isub, line, &nfwd, scratch);
+                int n = new_line(&W, seeds + 3 * is, sublist + 3 * isub, line, &nfwd, scratch,
+                                 (uint64_t)(is * nsub + isub), lcms ? lflags : NULL);
                 if (all_npts) all_npts[is * nsub + isub] = n;
                 if (n < len_min) continue;                       /* :769 */
                 if (nl == capl) { capl *= 2; npl = realloc(npl, sizeof(int32_t) * capl); sd = realloc(sd, sizeof(int64_t) * capl); }
-                while (np + n > capp) { capp *= 2; xyz = realloc(xyz, sizeof(float) * 3 * capp); }
+                while (np + n > capp) { capp *= 2; xyz = realloc(xyz, sizeof(float) * 3 * capp); fl = realloc(fl, capp); }
                 memcpy(xyz + 3 * np, line, sizeof(float) * 3 * n);
+                if (lcms) memcpy(fl + np, lflags, n);
                 npl[nl] = n; sd[nl] = is * nsub + isub; nl++; np += n;
             }
         }
-        free(line); free(scratch);
-        cx[ic] = xyz; cn[ic] = npl; cs[ic] = sd; clines[ic] = nl; cpts[ic] = np;
+        free(line); free(scratch); free(lflags);
+        cx[ic] = xyz; cf[ic] = fl; cn[ic] = npl; cs[ic] = sd; clines[ic] = nl; cpts[ic] = np;
     }
     int64_t nl = 0, np = 0;
     for (int ic = 0; ic < nchunks; ic++) { nl += clines[ic]; np += cpts[ic]; }
     *out_npts = (int32_t *)malloc(sizeof(int32_t) * (nl > 0 ? nl : 1));
     *out_seed = (int64_t *)malloc(sizeof(int64_t) * (nl > 0 ? nl : 1));
     *out_xyz = (float *)malloc(sizeof(float) * 3 * (np > 0 ? np : 1));
+    if (want_flags) *out_flags = (uint8_t *)malloc(np > 0 ? np : 1);
     int64_t ol = 0, op = 0;
     for (int ic = 0; ic < nchunks; ic++) {                       /* reduce(vcat, W.str)  :787 */
         memcpy(*out_npts + ol, cn[ic], sizeof(int32_t) * clines[ic]);
         memcpy(*out_seed + ol, cs[ic], sizeof(int64_t) * clines[ic]);
         memcpy(*out_xyz + 3 * op, cx[ic], sizeof(float) * 3 * cpts[ic]);
+        if (want_flags) memcpy(*out_flags + op, cf[ic], cpts[ic]);
         ol += clines[ic]; op += cpts[ic];
-        free(cx[ic]); free(cn[ic]); free(cs[ic]);
+        free(cx[ic]); free(cf[ic]); free(cn[ic]); free(cs[ic]);
     }
-    free(cx); free(cn); free(cs); free(clines); free(cpts);
+    free(cx); free(cf); free(cn); free(cs); free(clines); free(cpts);
     free(sarea);
     *out_total_pts = np;
     return nl;

@@ -44,6 +44,8 @@ def lib():
         _LIB.orc_dsi_rec.restype = C.c_float
         _LIB.orc_stream.restype = C.c_int64
         _LIB.orc_stream_micro.restype = C.c_int64
+        _LIB.orc_stream_full.restype = C.c_int64
+        _LIB.orc_uniform.restype = C.c_float
         _LIB.orc_find_peaks.restype = C.c_int
         _LIB.orc_max_threads.restype = C.c_int
     return _LIB
@@ -354,11 +356,14 @@ def seeds_from_mask(maskbool):
 
 def stream(ovec, sublist, f=None, f_thresh=0.03, fa=None, fa_thresh=0.1, mask=None, seed=None,
            len_min=3, len_max=None, ang_thresh=45, step_size=0.5, smooth_coeff=0.2, nthreads=1,
-           return_all_npts=False, search_dist=0, search_ang=10):
+           return_all_npts=False, search_dist=0, search_ang=10, lcms=None, lcm_thresh=0.099, rng_seed=0):
     """stream (stream.jl:730) with an explicit `sublist` [nsub,3] instead of the global RNG
     (stream.jl:176-181).  Returns list of [npts,3] float32 arrays (1-based voxel coords) in
     reference order, plus seed_index (seed*nsub+sub) per kept line.
-    search_dist > 0: the microscopy regime (stream.jl:83: minimum(volres) <= 0.05; 252-287, 547-619)."""
+    search_dist > 0: the microscopy regime (stream.jl:83: minimum(volres) <= 0.05; 252-287, 547-619).
+    lcms [nx,ny,nz,10]: LCM-guided tracking (stream.jl:200-236, 380-495); the uniforms behind `rand(Categorical(lcm))`
+    come from the counter-based stream orc_uniform(rng_seed, line, k) (the random-number contract of this back end);
+    the result then carries `flags` (one per point: the LCM and the angle pick disagreed, stream.jl:538)."""
     mk, arr = stream_work(ovec, f, f_thresh, fa, fa_thresh, mask)
     nx, ny, nz = mk.shape
     if len_max is None:
@@ -377,19 +382,36 @@ def stream(ovec, sublist, f=None, f_thresh=0.03, fa=None, fa_thresh=0.1, mask=No
     total = C.c_int64(0)
     all_npts = np.zeros(max(1, seeds.shape[0] * sub.shape[0]), np.int32)
     L = lib()
-    nl = L.orc_stream_micro(_p(arr), _p(mk.astype(np.uint8, order="F")), nx, ny, nz, arr.shape[1],
+    p_flags = C.POINTER(C.c_uint8)()
+    lcm_arr, sd0, sd1 = None, 0, 1
+    if lcms is not None:
+        lv = np.asarray(lcms, np.float32)
+        lcm_arr = np.asfortranarray(np.transpose(lv, (3, 0, 1, 2)))            # permutedims(lcms.vol, (4,1,2,3)), stream.jl:207
+        lcm_arr = np.asfortranarray(np.where(lcm_arr >= f32(lcm_thresh), lcm_arr, f32(0)))   # .*= (. >= lcm_thresh), :217
+        ov1 = ovec if isinstance(ovec, np.ndarray) else ovec[0]
+        thru = [c for c in range(3) if np.all(np.asarray(ov1)[..., c] == 0)]    # stream.jl:221
+        strd = [c for c in range(3) if c not in thru]                            # :223
+        sd0, sd1 = strd[0], strd[1]
+    nl = L.orc_stream_full(_p(arr), _p(mk.astype(np.uint8, order="F")), nx, ny, nz, arr.shape[1],
                       _p(seeds), C.c_int64(seeds.shape[0]), _p(sub), sub.shape[0],
                       int(len_min), int(len_max), C.c_float(float(cosd32(ang_thresh))),
                       C.c_float(float(f32(step_size))), C.c_float(float(f32(smooth_coeff))),
                       int(search_dist), C.c_float(float(cosd32(search_ang))),
-                      C.byref(p_npts), C.byref(p_seed), C.byref(p_xyz), C.byref(total),
+                      None if lcm_arr is None else _p(lcm_arr), int(sd0), int(sd1), C.c_uint64(int(rng_seed)),
+                      C.byref(p_npts), C.byref(p_seed), C.byref(p_xyz), C.byref(p_flags), C.byref(total),
                       _p(all_npts), int(nthreads))
     npts = np.ctypeslib.as_array(p_npts, shape=(max(nl, 1),))[:nl].copy()
     sidx = np.ctypeslib.as_array(p_seed, shape=(max(nl, 1),))[:nl].copy()
     xyz = np.ctypeslib.as_array(p_xyz, shape=(max(total.value, 1) * 3,))[: total.value * 3].copy().reshape(-1, 3)
+    flags = None
+    if lcm_arr is not None:
+        flags = np.ctypeslib.as_array(p_flags, shape=(max(total.value, 1),))[: total.value].copy()
+        L.orc_free(C.cast(p_flags, C.c_void_p))
     for ptr in (p_npts, p_seed, p_xyz):
         L.orc_free(C.cast(ptr, C.c_void_p))
     res = dict(npts=npts, seed_index=sidx, xyz=xyz, nseeds=seeds.shape[0], nsub=sub.shape[0], seeds=seeds)
+    if flags is not None:
+        res["flags"] = flags
     if return_all_npts:
         res["all_npts"] = all_npts[: seeds.shape[0] * sub.shape[0]]
     return res

