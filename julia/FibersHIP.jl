@@ -113,8 +113,8 @@ end
 
 mutable struct FibTractOut
   nlines::Int64; npoints::Int64
-  npts::Ptr{Int32}; seed_index::Ptr{Int64}; xyz::Ptr{Float32}
-  FibTractOut() = new(0, 0, C_NULL, C_NULL, C_NULL)
+  npts::Ptr{Int32}; seed_index::Ptr{Int64}; xyz::Ptr{Float32}; flags::Ptr{UInt8}
+  FibTractOut() = new(0, 0, C_NULL, C_NULL, C_NULL, C_NULL)
 end
 
 "stream(ovec; ...) — replaces stream.jl:730-790 for the angle-picking path and the microscopy regime (no lcms)"
@@ -124,6 +124,7 @@ function stream(ovec::Union{MRI,Vector{MRI}}; f::Union{MRI,Vector{MRI},Nothing}=
                 len_max::Integer=(isa(ovec,MRI) ? maximum(ovec.volsize) : maximum(ovec[1].volsize)),
                 ang_thresh::Union{Real,Nothing}=45, step_size::Union{Real,Nothing}=.5,
                 smooth_coeff::Union{Real,Nothing}=.2, search_dist::Integer=15, search_ang::Real=10,
+                lcms::Union{MRI,Nothing}=nothing, lcm_thresh::Real=.099, rng_seed::Integer=rand(UInt64),
                 device::Integer=0)
   ovecs = isa(ovec, MRI) ? MRI[ovec] : ovec
   fs    = isa(f, MRI) ? MRI[f] : f
@@ -142,6 +143,16 @@ function stream(ovec::Union{MRI,Vector{MRI}}; f::Union{MRI,Vector{MRI},Nothing}=
   pv = [pointer(o.vol) for o in ovecs]
   pf = isnothing(fs) ? C_NULL : [pointer(x.vol) for x in fs]
   out = FibTractOut()
+  if !isnothing(lcms)     # LCM-guided tracking (stream.jl:380-495); the library's uniform stream replaces the global RNG
+    lv = lcms.vol::Array{Float32,4}
+    GC.@preserve ovecs fs fa mask seed sublist pv pf lv fib_check(ccall((:fib_stream_lcm, libfibers), Cint,
+      (Cint, Ref{FibStreamParams}, Ptr{Ptr{Float32}}, Ptr{Ptr{Float32}}, Cfloat, Ptr{Float32}, Cfloat,
+       Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Float32}, Cint, Ptr{Float32}, Cfloat, UInt64, Ref{FibTractOut}),
+      device, prm, pv, pf, Float32(f_thresh), isnothing(fa) ? C_NULL : pointer(fa.vol), Float32(fa_thresh),
+      isnothing(mask) ? C_NULL : pointer(mask.vol), isnothing(mask) ? 0 : FIB_DTYPE[eltype(mask.vol)],
+      isnothing(seed) ? C_NULL : pointer(seed.vol), isnothing(seed) ? 0 : FIB_DTYPE[eltype(seed.vol)],
+      sublist, size(sublist, 2), lv, Float32(lcm_thresh), UInt64(rng_seed), out))
+  else
   GC.@preserve ovecs fs fa mask seed sublist pv pf fib_check(ccall((:fib_stream, libfibers), Cint,
       (Cint, Ref{FibStreamParams}, Ptr{Ptr{Float32}}, Ptr{Ptr{Float32}}, Cfloat, Ptr{Float32}, Cfloat,
        Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Ptr{Float32}, Cint, Ref{FibTractOut}),
@@ -149,12 +160,15 @@ function stream(ovec::Union{MRI,Vector{MRI}}; f::Union{MRI,Vector{MRI},Nothing}=
       isnothing(mask) ? C_NULL : pointer(mask.vol), isnothing(mask) ? 0 : FIB_DTYPE[eltype(mask.vol)],
       isnothing(seed) ? C_NULL : pointer(seed.vol), isnothing(seed) ? 0 : FIB_DTYPE[eltype(seed.vol)],
       sublist, size(sublist, 2), out))
+  end
   npts = unsafe_wrap(Array, out.npts, out.nlines)
   xyz  = unsafe_wrap(Array, out.xyz, (3, Int(out.npoints)))
   off  = cumsum(vcat(0, Int.(npts)))
   str  = [xyz[:, off[i]+1:off[i+1]] for i in 1:length(npts)]          # Vector{Matrix{Float32}} [3 x npts]
+  flag = isnothing(lcms) ? nothing :
+         (fl = unsafe_wrap(Array, out.flags, Int(out.npoints)); [Float32.(fl[off[i]+1:off[i+1]]) for i in 1:length(npts)])
   ccall((:fib_tract_free, libfibers), Cvoid, (Ref{FibTractOut},), out)
   tr = Tract{Float32}(mask)
-  str_add!(tr, str)                                                   # stream.jl:784-787
+  str_add!(tr, str, flag)                                             # stream.jl:784-787
   return tr
 end
