@@ -287,6 +287,34 @@ def main():
                                           trace_kernel_ms=lk_ms / max(lk_n, 1), flagged_fraction=float(rl["flags"].float().mean()),
                                           note="2048x2048x1 pixels, 3 orientations + one 10-element LCM per pixel, len_max 140")
             del rl, fld, lc, ov2, ang
+        if world == 1:
+            # ---- RUMBA-SD (rusd.jl, row N4): 140^3 x 270 frames, ball mask, sphere_724 (364 compartments), 10 iterations ----
+            torch.cuda.empty_cache()
+            b4, g4 = phantom.scheme_gqi()
+            d4, _ = phantom.make_dwi_torch(SHAPE, b4, g4, seed=3, device=dev)
+            rp = fj.RumbaPlan(b4, g4, fj.sphere_724, device=dev.index)
+            fj.rumba_rec_device(rp, d4, bm, SHAPE, niter=2)
+            torch.cuda.synchronize()
+            L.fib_profile_enable(1); L.fib_profile_reset()
+            nit = 10
+            t0 = time.perf_counter()
+            rr = fj.rumba_rec_device(rp, d4, bm, SHAPE, niter=nit)
+            torch.cuda.synchronize()
+            t_r = time.perf_counter() - t0
+            L.fib_profile_enable(0)
+            gm_ms, gm_n = prof_get(L, "matrix_gemm")
+            tv_ms, tv_n = prof_get(L, "rumba_tv")
+            el_ms, el_n = prof_get(L, "rumba_elementwise")
+            nmask = int(bm.sum())
+            kk, _nd = rp.kernel().shape[1], rp.kernel().shape[0]
+            extra["rumba_140_ball"] = dict(voxels=nmask, compartments=kk, dirs=_nd, iterations=nit, ms_total=t_r * 1e3,
+                                           ms_per_iteration=(gm_ms + tv_ms + el_ms) / nit,
+                                           gemm_ms_per_iteration=gm_ms / nit, tv_ms_per_iteration=tv_ms / nit,
+                                           elementwise_ms_per_iteration=el_ms / nit,
+                                           gemm_tflops=3 * 2.0 * kk * _nd * nmask * nit / (gm_ms * 1e-3) / 1e12 if gm_n else 0.0,
+                                           snr_mean=rr["snr_mean"],
+                                           note="three [364 x 253] contractions per iteration on the split-bf16 MFMA kernel; 600 iterations in the reference's default")
+            del rr, d4, rp
         del res, bm, seeds_all
 
     if not args.no_extra and rank == 0 and world == 1:

@@ -30,6 +30,11 @@ class StreamParams(C.Structure):
                 ("search_dist", C.c_int32), ("search_cosang", C.c_float)]
 
 
+class RumbaOut(C.Structure):
+    _fields_ = [("fodf", C.c_void_p), ("fgm", C.c_void_p), ("fcsf", C.c_void_p), ("gfa", C.c_void_p), ("var", C.c_void_p),
+                ("peak", C.c_void_p * 5)]
+
+
 class TractOut(C.Structure):
     _fields_ = [("nlines", C.c_int64), ("npoints", C.c_int64),
                 ("npts", C.POINTER(C.c_int32)), ("seed_index", C.POINTER(C.c_int64)),
@@ -74,6 +79,13 @@ _PROTOS = {
     "fib_adc_fit": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp]),
     "fib_gqi_rec": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, f32, vp, P3, P3]),
     "fib_dsi_rec": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, vp, vp, P3, P3]),
+    "fib_rumba_plan_create": (i32, [i32, vp, vp, i32, vp, i32, f32, f32, f32, f32, C.POINTER(vp)]),
+    "fib_rumba_plan_destroy": (None, [vp]),
+    "fib_rumba_plan_kernel": (i32, [vp, vp, C.POINTER(i32), C.POINTER(i32)]),
+    "fibd_rumba_rec": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(RumbaOut), C.POINTER(f32),
+                             C.POINTER(f32), vp]),
+    "fib_rumba_rec": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, f32, f32, f32, f32, i32, i32, i32,
+                            i32, C.POINTER(RumbaOut), C.POINTER(f32), C.POINTER(f32)]),
     "fib_find_peaks": (i32, [i32, vp, i64, vp, i32, vp, i32, vp, vp]),
     "fib_stream": (i32, [i32, C.POINTER(StreamParams), vp, vp, f32, vp, f32, vp, i32, vp, i32, vp, i32,
                          C.POINTER(TractOut)]),

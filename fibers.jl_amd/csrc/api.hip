@@ -179,6 +179,44 @@ extern "C" int fib_dsi_rec(int device, const float *dwi, int nx, int ny, int nz,
     return odf_rec_host(p, nvol, dwi, nx, ny, nz, mask, mask_dtype, nverts / 2, pdf, odf, peak, qa);
 }
 
+// rumba_rec (rusd.jl:419-636), host buffers
+extern "C" int fib_rumba_rec(int device, const float *dwi, int nx, int ny, int nz, int nvol, const void *mask, int mask_dtype,
+                             const float *bval, const float *bvec, const float *verts, int nverts, int niter,
+                             float lam_para, float lam_perp, float lam_csf, float lam_gm, int ncoils, int sos_grappa, int ipat_factor,
+                             int use_tv, const fib_rumba_out *out, float *snr_mean, float *snr_std) {
+    FIB_CHECK(dwi && mask && out, FIB_ERR_INVALID, "NULL argument");
+    FIB_CHECK(nx > 0 && ny > 0 && nz > 0, FIB_ERR_INVALID, "volume dimensions must be positive");
+    fib::DeviceGuard guard;
+    fib_rumba_plan *p = nullptr;
+    RC(fib_rumba_plan_create(device, bval, bvec, nvol, verts, nverts, lam_para, lam_perp, lam_csf, lam_gm, &p));
+    struct PlanDel { fib_rumba_plan *p; ~PlanDel() { fib_rumba_plan_destroy(p); } } del{p};
+    FIB_HIP(hipSetDevice(device));
+    const int64_t nvox = (int64_t)nx * ny * nz;
+    const int nvert = nverts / 2;
+    std::vector<uint8_t> m8;
+    RC(mask_convert(mask, mask_dtype, nvox, true, m8));            // mask.vol .> 0, rusd.jl:446
+    fib::DevBuf<float> d_dwi, d_fodf, d_sc, d_pk;
+    fib::DevBuf<uint8_t> d_mask;
+    RC(d_dwi.alloc((size_t)nvox * nvol));
+    RC(d_mask.alloc((size_t)nvox));
+    RC(d_fodf.alloc((size_t)nvox * nvert));
+    RC(d_sc.alloc((size_t)nvox * 4));
+    RC(d_pk.alloc((size_t)nvox * 15));
+    RC(h2d(d_dwi.p, dwi, sizeof(float) * nvox * nvol));
+    RC(h2d(d_mask.p, m8.data(), (size_t)nvox));
+    fib_rumba_out dev{};
+    dev.fodf = d_fodf.p; dev.fgm = d_sc.p; dev.fcsf = d_sc.p + nvox; dev.gfa = d_sc.p + 2 * nvox; dev.var = d_sc.p + 3 * nvox;
+    for (int i = 0; i < 5; i++) dev.peak[i] = d_pk.p + (size_t)i * 3 * nvox;
+    RC(fibd_rumba_rec(p, d_dwi.p, d_mask.p, nx, ny, nz, niter, ncoils, sos_grappa, ipat_factor, use_tv, &dev, snr_mean, snr_std, nullptr));
+    RC(d2h(out->fodf, dev.fodf, sizeof(float) * nvox * nvert));
+    RC(d2h(out->fgm, dev.fgm, sizeof(float) * nvox));
+    RC(d2h(out->fcsf, dev.fcsf, sizeof(float) * nvox));
+    RC(d2h(out->gfa, dev.gfa, sizeof(float) * nvox));
+    RC(d2h(out->var, dev.var, sizeof(float) * nvox));
+    for (int i = 0; i < 5; i++) RC(d2h(out->peak[i], dev.peak[i], sizeof(float) * nvox * 3));
+    return FIB_OK;
+}
+
 // find_peaks!(W) (gqi.jl:180-201) for nvox ODFs held in host memory: odf [nvox x nvert] planar (vertex-major rows of
 // nvox values, like MRI.vol[:,:,:,v]); isort_top [3 x nvox] planar, 0-based first-half vertex rows, -1 where the
 // tessellation has fewer vertices; nvalid [nvox] = count(odf_peak .> 0) (gqi.jl:200).

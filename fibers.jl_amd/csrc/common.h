@@ -92,4 +92,10 @@ int host_dsi_matrix(const float *bval, const float *bvec, int nvol, const float 
 // folded-face neighbour table (gqi.jl:63-64 + 185-196): nbr [nvert x maxdeg] row-major, -1 padded
 int host_neighbours(const int32_t *faces, int nfaces, int nverts, std::vector<int32_t> &nbr, int *maxdeg);
 
+// O[M x n] = A[M x K] * max(S[K x n], 0) on the contraction kernels of odf.hip (row N4, RUMBA-SD): A column-major
+// [nrows x ncols]; S, out planar (row stride n); `ones` = n bytes of 1 on the device; recompact = (re)build the column
+// list (needed once per n)
+int matrix_plan_create(int device, const float *A, int nrows, int ncols, fib_odf_plan **plan);
+int matrix_plan_run(const fib_odf_plan *plan, const float *S, const uint8_t *ones, int64_t n, float *out, bool recompact, void *stream);
+
 }  // namespace fib

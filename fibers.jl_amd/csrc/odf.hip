@@ -1367,8 +1367,13 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
         FIB_HIP(hipMemcpy(p->Aextra.p, AX.data(), AX.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     std::vector<int32_t> nbr32;
-    int rc = fib::host_neighbours(faces, nfaces, nverts, nbr32, &p->maxdeg);
-    if (rc != FIB_OK) return rc;
+    int rc = FIB_OK;
+    if (faces) {
+        rc = fib::host_neighbours(faces, nfaces, nverts, nbr32, &p->maxdeg);
+        if (rc != FIB_OK) return rc;
+    } else {                                            // matrix-only plan (fib::matrix_plan_create): no peak finder tables
+        p->maxdeg = 0;
+    }
     p->deg_pad = p->maxdeg <= 6 ? 6 : (p->maxdeg <= 8 ? 8 : 16);
     p->rows_pad = (p->nvert + 7) / 8 * 8;
     const int nv_even = (p->nvert + 1) / 2 * 2;
@@ -1391,9 +1396,10 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
     for (auto &u : nbr64) if (u == p->rows_pad) u = p->nvert;
     if ((rc = p->nbr64.alloc(nbr64.size())) != FIB_OK) return rc;
     FIB_HIP(hipMemcpy(p->nbr64.p, nbr64.data(), nbr64.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    std::vector<float> v3((size_t)p->nvert * 3);
-    for (int v = 0; v < p->nvert; v++)
-        for (int c = 0; c < 3; c++) v3[3 * v + c] = verts[v + (size_t)nverts * c];
+    std::vector<float> v3((size_t)p->nvert * 3, 0.0f);
+    if (verts)
+        for (int v = 0; v < p->nvert; v++)
+            for (int c = 0; c < 3; c++) v3[3 * v + c] = verts[v + (size_t)nverts * c];
     if ((rc = p->At.alloc(At.size())) != FIB_OK) return rc;
     std::vector<uint32_t> effbits((size_t)p->Kpad / KT, 0u);
     for (int k = 0; k < K; k++) { if (frame_eff[k] != 0.0f) effbits[k / KT] |= 1u << (k % KT); else p->has_ineff = true; }
@@ -1711,6 +1717,61 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         hipLaunchKernelGGL(qa_normalize_kernel, dim3(2048), dim3(256), 0, st, qa[0], qa[1], qa[2], nvox, om, 0.0f);
         FIB_HIP(hipGetLastError());
     }
+    return FIB_OK;
+}
+
+// ---- plain use of the contraction kernels: O[M x n] = A[M x K] * max(S[K x n], 0) (row N4, RUMBA-SD) -----------------
+int fib::matrix_plan_create(int device, const float *A, int nrows, int ncols, fib_odf_plan **plan) {
+    FIB_CHECK(A && plan && nrows > 0 && ncols > 0, FIB_ERR_INVALID, "invalid matrix plan arguments");
+    *plan = nullptr;
+    fib::DeviceGuard guard;
+    int rc = fib::use_device(device);
+    if (rc != FIB_OK) return rc;
+    fib_odf_plan *p = new (std::nothrow) fib_odf_plan();
+    FIB_CHECK(p != nullptr, FIB_ERR_NOMEM, "out of host memory");
+    p->device = device; p->nvol = ncols; p->nvert = 2; p->nrows = nrows; p->nrow0 = 0;
+    p->A.assign(A, A + (size_t)nrows * ncols);
+    std::vector<float> eff((size_t)ncols, 1.0f);
+    rc = finish_plan(p, nullptr, 4, nullptr, 0, eff);
+    if (rc != FIB_OK) { delete p; return rc; }
+    *plan = p;
+    return FIB_OK;
+}
+
+int fib::matrix_plan_run(const fib_odf_plan *plan, const float *S, const uint8_t *ones, int64_t n, float *out, bool recompact, void *stream) {
+    FIB_CHECK(plan && S && ones && out && n > 0, FIB_ERR_INVALID, "NULL argument");
+    FIB_CHECK(n <= ((int64_t)1 << 26), FIB_ERR_UNSUPPORTED, "more than 2^26 columns");
+    hipStream_t st = (hipStream_t)stream;
+    if (recompact) {                                    // the column list of an all-ones mask: kept in the plan between calls
+        const int nb = (int)fib::cdiv(n, CB);
+        int rcc;
+        if ((rcc = plan->live_vox.ensure((size_t)n)) != FIB_OK) return rcc;
+        if ((rcc = plan->live_tiles.ensure((size_t)fib::cdiv(n, 64))) != FIB_OK) return rcc;
+        if ((rcc = plan->live_blocks.ensure((size_t)nb)) != FIB_OK) return rcc;
+        hipLaunchKernelGGL(mask_count_kernel, dim3(nb), dim3(256), 0, st, ones, n, plan->live_blocks.p);
+        hipLaunchKernelGGL(mask_scan_kernel, dim3(1), dim3(1024), 0, st, plan->live_blocks.p, nb, plan->live_counts.p);
+        hipLaunchKernelGGL(mask_write_kernel, dim3(nb), dim3(256), 0, st, ones, n, plan->live_blocks.p, plan->live_vox.p, plan->live_tiles.p);
+    }
+    GemmArgs ga{};
+    ga.At = plan->At.p; ga.At3 = plan->split_bf16 ? plan->At3.p : nullptr; ga.S = S;
+    ga.Aextra = plan->Aextra.p;
+    ga.vec_ok = (n % 4 == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0;
+    ga.vidx = plan->live_vox.p; ga.nlive = plan->live_counts.p; ga.mask = ones; ga.effbits = plan->effbits.p;
+    ga.out0 = nullptr; ga.out1 = out; ga.nvox = n;
+    ga.K = plan->gK; ga.Kpad = plan->Kpad; ga.M = plan->gM; ga.nrow0 = 0; ga.ntile_m = plan->ntile_m;
+    ga.scale_frame = -1; ga.scale_coef = 0.0f; ga.stride = n; ga.has_ineff = 0;
+    const unsigned grid = (unsigned)(fib::cdiv(n, WG_VOX) * plan->ntile_m);
+    fib::ProfScope prof("matrix_gemm", st);
+#define FIB_GEMM_CASE(MBV, NXV) if (plan->MB == MBV && plan->NX == NXV) { launch_gemm<MBV, NXV>(ga, grid, st); launched = true; }
+    bool launched = false;
+    FIB_GEMM_CASE(5, 0) FIB_GEMM_CASE(5, 1) FIB_GEMM_CASE(5, 2) FIB_GEMM_CASE(5, 4)
+    FIB_GEMM_CASE(6, 0) FIB_GEMM_CASE(7, 0) FIB_GEMM_CASE(8, 0) FIB_GEMM_CASE(9, 0) FIB_GEMM_CASE(10, 0) FIB_GEMM_CASE(11, 0)
+    FIB_GEMM_CASE(6, 1) FIB_GEMM_CASE(7, 1) FIB_GEMM_CASE(8, 1) FIB_GEMM_CASE(9, 1) FIB_GEMM_CASE(10, 1)
+    FIB_GEMM_CASE(6, 2) FIB_GEMM_CASE(7, 2) FIB_GEMM_CASE(8, 2) FIB_GEMM_CASE(9, 2) FIB_GEMM_CASE(10, 2)
+    FIB_GEMM_CASE(6, 4) FIB_GEMM_CASE(7, 4) FIB_GEMM_CASE(8, 4) FIB_GEMM_CASE(9, 4) FIB_GEMM_CASE(10, 4)
+#undef FIB_GEMM_CASE
+    if (!launched) return fib::fail(FIB_ERR_INVALID, "internal: no GEMM variant for MB=%d NX=%d", plan->MB, plan->NX);
+    FIB_HIP(hipGetLastError());
     return FIB_OK;
 }
 

@@ -145,6 +145,37 @@ int fibd_find_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox,
                     int32_t *isort_top, int32_t *nvalid, void *stream);
 
 /* ------------------------------------------------------------------------------------ */
+/* RUMBA-SD (rusd.jl), SURVEY.md row N4                                                   */
+/* ------------------------------------------------------------------------------------ */
+typedef struct fib_rumba_plan fib_rumba_plan;   /* kernel of the multi-tensor model + the two contraction plans */
+
+/* rumba_rec's set-up (rusd.jl:449, 466-521, 529-531): ib0 = (bval .== minimum(bval)); the kernel K [ndir x (nvert+2)]
+ * (ndir = 1 + number of non-low-b frames; one prolate tensor per half-sphere vertex, isotropic CSF and GM columns),
+ * the angular peak neighbourhoods (12.5 deg for sphere_642/724, 16 deg for sphere_362) and the uniform initial fODF.
+ * verts [nverts x 3] column-major as for the GQI plan.  Reference defaults: lam_para 1.7e-3, lam_perp 0.2e-3,
+ * lam_csf 3.0e-3, lam_gm 0.8e-4. */
+int fib_rumba_plan_create(int device, const float *bval, const float *bvec, int nvol, const float *verts, int nverts,
+                          float lam_para, float lam_perp, float lam_csf, float lam_gm, fib_rumba_plan **plan);
+void fib_rumba_plan_destroy(fib_rumba_plan *plan);
+/* host copy of the kernel, column-major [ndir x ncomp]; K == NULL queries the sizes only */
+int fib_rumba_plan_kernel(const fib_rumba_plan *plan, float *K, int *ndir, int *ncomp);
+
+/* outputs of rumba_rec (the RUMBASD struct, rusd.jl:11-20): fodf planar [nvert][nvox]; fgm, fcsf, gfa, var [nvox];
+ * peak[k] planar [3][nvox], k = 0..4 */
+typedef struct {
+    float *fodf, *fgm, *fcsf, *gfa, *var;
+    float *peak[5];
+} fib_rumba_out;
+
+/* rumba_rec(dwi, mask, odf_dirs, niter, ...) (rusd.jl:419-636) on device-resident volumes: dwi planar [nvol][nvox],
+ * mask uint8 [nvox] (already `> 0`-tested).  niter: Richardson-Lucy iterations (reference default 600); ncoils /
+ * sos_grappa: coil_combine == "SoS-GRAPPA" uses n_order = ncoils, "SMF-SENSE" n_order = 1; ipat_factor >= 1; use_tv:
+ * total-variation prior.  snr_mean / snr_std: host scalars (may be NULL).  Blocking. */
+int fibd_rumba_rec(const fib_rumba_plan *plan, const float *dwi, const uint8_t *mask, int nx, int ny, int nz,
+                   int niter, int ncoils, int sos_grappa, int ipat_factor, int use_tv,
+                   const fib_rumba_out *out, float *snr_mean, float *snr_std, void *stream);
+
+/* ------------------------------------------------------------------------------------ */
 /* Streamlines                                                                            */
 /* ------------------------------------------------------------------------------------ */
 typedef struct {
@@ -232,6 +263,13 @@ int fib_dsi_rec(int device, const float *dwi, int nx, int ny, int nz, int nvol,
                 const void *mask, int mask_dtype, const float *bval, const float *bvec,
                 const float *verts, int nverts, const int32_t *faces, int nfaces, int hann_width,
                 float *pdf, float *odf, float *const peak[3], float *const qa[3]);
+
+/* rumba_rec(dwi, mask, odf_dirs, niter, lam_para, lam_perp, lam_csf, lam_gm, ncoils, coil_combine, ipat_factor, use_tv)
+ * ::RUMBASD (rusd.jl:419); host buffers, outputs caller-allocated like the other fits. */
+int fib_rumba_rec(int device, const float *dwi, int nx, int ny, int nz, int nvol, const void *mask, int mask_dtype,
+                  const float *bval, const float *bvec, const float *verts, int nverts, int niter,
+                  float lam_para, float lam_perp, float lam_csf, float lam_gm, int ncoils, int sos_grappa, int ipat_factor,
+                  int use_tv, const fib_rumba_out *out, float *snr_mean, float *snr_std);
 
 /* find_peaks!(W) (gqi.jl:180-201) for nvox ODFs in host memory.  odf [nvox x nvert] planar (row v = the nvox
  * amplitudes of half-sphere vertex v, like MRI.vol[:,:,:,v]); isort_top [3 x nvox] planar: the first three entries

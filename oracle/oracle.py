@@ -420,3 +420,194 @@ def stream(ovec, sublist, f=None, f_thresh=0.03, fa=None, fa_thresh=0.1, mask=No
 def split_lines(res):
     off = np.concatenate([[0], np.cumsum(res["npts"])])
     return [res["xyz"][off[i]:off[i + 1]] for i in range(len(res["npts"]))]
+
+
+# ---------------------------------------------------------------------------------------------
+# RUMBA-SD (rusd.jl) -- row N4.  NumPy float32 restatement; every step cites the reference line.
+# ---------------------------------------------------------------------------------------------
+def _ang2rot(phi, theta):
+    """util.jl:85-100"""
+    c, s_, ct, st = np.cos(phi), np.sin(phi), np.cos(theta), np.sin(theta)
+    Rz = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], np.float64)
+    Ry = np.array([[ct, 0, st], [0, 1, 0], [-st, 0, ct]], np.float64)
+    return Rz @ Ry
+
+
+def rumba_kernel(bval, bvec, vertices, lam_para=1.7e-3, lam_perp=0.2e-3, lam_csf=3.0e-3, lam_gm=0.8e-4):
+    """reconstruction kernel of the multi-tensor model (rusd.jl:141-153, 466-469, 495-521): [ndir, nvert+2] float32,
+    rows = (mean low-b, then the DWIs in acquisition order), columns = half-sphere vertices, CSF, GM.
+    Built in float64 and rounded once (the reference computes it in Float32: differences at the 1e-7 level)."""
+    bval = np.asarray(bval, np.float64)
+    bvec = np.asarray(bvec, np.float64).reshape(-1, 3)
+    ib0 = bval == bval.min()                                                # rusd.jl:449
+    gd = bvec[~ib0]
+    g = np.vstack([np.zeros((1, 3)), gd / np.sqrt((gd ** 2).sum(1, keepdims=True))])   # :466-467
+    b = np.concatenate([[0.0], bval[~ib0]])                                 # :468
+    V = np.asarray(vertices, np.float64)
+    nvert = V.shape[0] // 2
+    x, y, z = V[nvert:, 0], V[nvert:, 1], V[nvert:, 2]                      # second half (:502-504)
+    hxy = np.hypot(x, y)
+    theta = -np.arctan2(z, hxy)                                             # cart2sph, then θ .= -θ (:505)
+    phi = np.arctan2(y, x)
+    K = np.empty((len(b), nvert + 2), np.float64)
+    for i in range(nvert):
+        R = _ang2rot(phi[i], theta[i])
+        D = R @ np.diag([lam_para, lam_perp, lam_perp]) @ R.T
+        K[:, i] = np.exp(-b * np.einsum("ij,jk,ik->i", g, D, g))            # tensor_model, :150
+    K[:, nvert] = np.exp(-b * lam_csf * (g ** 2).sum(1))                    # isotropic CSF (:515)
+    K[:, nvert + 1] = np.exp(-b * lam_gm * (g ** 2).sum(1))                 # isotropic GM (:518)
+    return K.astype(np.float32), ib0
+
+
+def rumba_signal(dwi, mask, ib0):
+    """signal matrix [ndir, nmask] (rusd.jl:444-464)"""
+    dwi = np.asarray(dwi, np.float32)
+    nxyz = int(np.prod(dwi.shape[:3]))
+    ind = np.flatnonzero(np.asarray(mask).reshape(-1, order="F") > 0)       # :446
+    vol = np.maximum(dwi, f32(0)).reshape(nxyz, -1, order="F")
+    s0 = vol[:, ib0].mean(axis=1, dtype=np.float32)[ind]                    # :456-457 (mean in Float32)
+    sig = np.empty((int((~ib0).sum()) + 1, ind.size), np.float32)
+    sig[0] = s0
+    with np.errstate(all="ignore"):
+        sig[1:] = (vol[:, ~ib0][ind].T / s0[None, :]).astype(np.float32)    # :458-461
+    sig[np.isnan(sig)] = 0                                                  # :462
+    sig[0] = (sig[0] > 0).astype(np.float32)                                # :463
+    sig[sig > 1] = 1                                                        # :464
+    return sig, ind
+
+
+def _besseli_ratio(nu, z):
+    """Perron's continued fraction (rusd.jl:170-177), Float32"""
+    nu = f32(nu)
+    two = f32(2)
+    with np.errstate(all="ignore"):
+        return z / ((two * nu + z) - ((two * nu + 1) * z / (two * z + (two * nu + 1) -
+                    ((two * nu + 3) * z / ((two * nu + 2) + two * z - ((two * nu + 5) * z / ((two * nu + 3) + two * z)))))))
+
+
+def _rumba_tv(vol, lam):
+    """rumba_tv! (rusd.jl:216-235) with sd_grad!/sd_div! (:183-207); vol, lam [nx,ny,nz] float32"""
+    eps = np.finfo(np.float32).eps
+    gx = np.concatenate([vol[1:], vol[-1:]], 0) - vol
+    gy = np.concatenate([vol[:, 1:], vol[:, -1:]], 1) - vol
+    gz = np.concatenate([vol[:, :, 1:], vol[:, :, -1:]], 2) - vol
+    nrm = np.sqrt(gx ** 2 + gy ** 2 + gz ** 2 + eps)
+    gx, gy, gz = gx / nrm, gy / nrm, gz / nrm
+    div = np.zeros_like(vol)
+    div[1:-1] = gx[1:-1] - gx[:-2]; div[0] = gx[0]; div[-1] = -gx[-2]
+    t = np.zeros_like(vol); t[:, 1:-1] = gy[:, 1:-1] - gy[:, :-2]; t[:, 0] = gy[:, 0]; t[:, -1] = -gy[:, -2]; div += t
+    t = np.zeros_like(vol); t[:, :, 1:-1] = gz[:, :, 1:-1] - gz[:, :, :-2]; t[:, :, 0] = gz[:, :, 0]; t[:, :, -1] = -gz[:, :, -2]; div += t
+    return (f32(1) / (np.abs(f32(1) - lam * div) + eps)).astype(np.float32)
+
+
+def rumba_neighbours(vertices):
+    """idx_neig (rusd.jl:475-493): half-sphere vertices within ang_neig of each vertex (antipodally folded)"""
+    V = np.asarray(vertices, np.float32)
+    nvert = V.shape[0] // 2
+    ang_neig = {362: 12.5, 321: 12.5, 181: 16.0}[nvert]
+    H = V[:nvert]
+    c = np.clip(H @ H.T, -1, 1)
+    ang = np.degrees(np.arccos(c.astype(np.float64)))
+    ang = np.minimum(ang, 180 - ang)
+    isn = ang < ang_neig
+    np.fill_diagonal(isn, False)
+    return [np.flatnonzero(isn[i]) for i in range(nvert)]
+
+
+def rumba_rec(dwi, mask, bval, bvec, vertices, niter=600, lam_para=1.7e-3, lam_perp=0.2e-3, lam_csf=3.0e-3, lam_gm=0.8e-4,
+              ncoils=1, coil_combine="SMF-SENSE", ipat_factor=1, use_tv=True):
+    """rumba_rec (rusd.jl:419-636).  Returns dict(fodf [nx,ny,nz,nvert], fgm, fcsf, peak[5] [nx,ny,nz,3], gfa, var,
+    snr_mean, snr_std)."""
+    n_order = 1
+    if coil_combine == "SoS-GRAPPA":
+        n_order = ncoils
+    elif coil_combine != "SMF-SENSE":
+        raise ValueError("Unknown coil combine mode " + coil_combine)
+    if ipat_factor < 1:
+        raise ValueError("iPAT factor must be a positive integer")
+    dwi = np.asarray(dwi, np.float32)
+    nx, ny, nz = dwi.shape[:3]
+    nxyz = nx * ny * nz
+    K, ib0 = rumba_kernel(bval, bvec, vertices, lam_para, lam_perp, lam_csf, lam_gm)
+    sig, ind = rumba_signal(dwi, mask, ib0)
+    ndir, ncomp = K.shape
+    nvert = ncomp - 2
+    nmask = ind.size
+    eps = np.finfo(np.float32).eps
+    fodf0 = np.ones(ncomp, np.float32) / f32(2 * nvert + 2)                 # :529-531
+    fodf0 = fodf0 / fodf0.sum(dtype=np.float32)
+    fodf = np.tile(fodf0[:, None], (1, nmask)).astype(np.float32)           # rumba_sd_initialize!, :241-259
+    dodf = np.tile((K @ fodf0)[:, None], (1, nmask)).astype(np.float32)
+    lam0 = f32(1 / 15) ** 2
+    lam = np.full((nx, ny, nz), lam0, np.float32, order="F")
+    s2 = np.full(nmask, lam0, np.float32)
+    dsig = (sig * dodf) / s2[None, :]
+    tv = np.ones((ncomp, nmask), np.float32)
+    snr = np.zeros(nmask, np.float32)
+    for _ in range(niter):                                                   # rumba_sd_iterate!, :266-345
+        ir = _besseli_ratio(n_order, dsig)
+        rl = K.T @ (sig * ir)
+        rl2 = K.T @ dodf + eps
+        rl = rl / rl2
+        if use_tv:
+            for ic in range(ncomp):
+                vol = np.zeros(nxyz, np.float32)
+                vol[ind] = fodf[ic]
+                tv[ic] = _rumba_tv(vol.reshape(nx, ny, nz, order="F"), lam).reshape(-1, order="F")[ind]
+        fodf = np.maximum(fodf * rl * tv, f32(0))
+        dodf = (K @ fodf).astype(np.float32)
+        dsig = (sig * dodf) / s2[None, :]
+        ir = (sig ** 2 + dodf ** 2) / f32(2) - (s2[None, :] * dsig) * ir
+        s2 = ir.sum(axis=0, dtype=np.float32) / f32(n_order * ndir)
+        s2 = np.clip(s2, f32((1 / 80) ** 2), f32((1 / 8) ** 2))
+        snr = f32(1) / np.sqrt(s2)
+        if use_tv:
+            if ipat_factor == 1:
+                lam[...] = max(s2.mean(dtype=np.float32), f32((1 / 30) ** 2))
+            else:
+                lam[...] = 0
+                lamv = lam.reshape(-1, order="F")                           # a view: lam is Fortran-contiguous
+                assert np.shares_memory(lamv, lam)
+                lamv[ind] = s2
+    snr_mean = float(snr.mean(dtype=np.float32)) if niter > 0 else 0.0
+    snr_std = float(np.sqrt(((snr - f32(snr_mean)) ** 2).sum(dtype=np.float32) / f32(max(nmask - 1, 1)))) if niter > 0 else 0.0
+    fodf = fodf / (fodf.sum(axis=0, dtype=np.float32) + eps)                # :553
+    out_fodf = np.zeros((nxyz, nvert), np.float32)
+    out_fodf[ind] = fodf[:nvert].T
+    fcsf = np.zeros(nxyz, np.float32); fcsf[ind] = fodf[nvert]
+    fgm = np.zeros(nxyz, np.float32); fgm[ind] = fodf[nvert + 1]
+    var = np.zeros(nxyz, np.float32); var[ind] = s2
+    fiso = fgm + fcsf
+    out_fodf = out_fodf + fiso[:, None]                                     # :578
+    with np.errstate(all="ignore"):
+        out_fodf = out_fodf / out_fodf.sum(axis=1, dtype=np.float32, keepdims=True)
+    out_fodf[np.isnan(out_fodf)] = 0
+    with np.errstate(all="ignore"):
+        m = out_fodf.mean(axis=1, dtype=np.float32, keepdims=True)
+        sd = np.sqrt(((out_fodf - m) ** 2).sum(axis=1, dtype=np.float32) / f32(nvert - 1))
+        gfa = sd / np.sqrt((out_fodf ** 2).mean(axis=1, dtype=np.float32))  # :589
+    gfa[np.isnan(gfa)] = 0
+    neig = rumba_neighbours(vertices)
+    H = np.asarray(vertices, np.float32)[:nvert]
+    peaks = np.zeros((5, nxyz, 3), np.float32)
+    mflat = np.asarray(mask).reshape(-1, order="F")
+    for v in np.flatnonzero(mflat != 0):                                     # :605-631
+        o = out_fodf[v]
+        with np.errstate(all="ignore"):
+            thr_abs = (f32(0.1) / (f32(1) - fiso[v])) * o.max()
+        pk = o.copy()
+        for iv in range(nvert):
+            if o[iv] < thr_abs or o[iv] <= o[neig[iv]].max():
+                pk[iv] = 0
+        isort = np.argsort(-pk, kind="stable")
+        nvalid = int((pk > 0).sum())
+        n = min(nvalid, 5)
+        with np.errstate(all="ignore"):
+            fnorm = (f32(1) - fiso[v]) / o[isort[:n]].sum(dtype=np.float32)
+        for k in range(n):
+            peaks[k, v] = H[isort[k]] * (o[isort[k]] * fnorm)
+    shp = (nx, ny, nz)
+    return dict(fodf=out_fodf.reshape(shp + (nvert,), order="F"), fgm=fgm.reshape(shp, order="F"),
+                fcsf=fcsf.reshape(shp, order="F"), gfa=gfa.reshape(shp, order="F"), var=var.reshape(shp, order="F"),
+                peak=[peaks[k].reshape(shp + (3,), order="F") for k in range(5)], snr_mean=snr_mean, snr_std=snr_std,
+                kernel=K)

@@ -219,3 +219,32 @@ def test_micro_regime_uniform_field_known_path():
     i10 = [i for i in range(len(xyz)) if tuple(xyz[i]) == (10.0, 10.0, 10.0)]
     assert len(i10) == 2                                       # the seed point opens both directions
     assert xyz[i10[0] - 1][2] < 10.0                           # first forward move drops in z (smallest z wins the tie)
+
+
+def test_rumba_oracle_pieces():
+    """RUMBA-SD oracle (rusd.jl): Perron's continued fraction vs the Bessel functions it approximates; the kernel's
+    columns against the closed-form single-tensor signal; the TV term of a constant volume is 1; single-fibre recovery"""
+    from scipy.special import ive
+    from oracle import oracle as orc
+    from fibers_jl_amd import phantom, sphere_724
+    z = np.geomspace(1e-3, 200.0, 200).astype(np.float32)
+    approx = orc._besseli_ratio(1, z)
+    exact = ive(1, z.astype(np.float64)) / ive(0, z.astype(np.float64))
+    assert np.abs(approx - exact).max() < 1e-2                   # the reference's 4-term truncation (rusd.jl:170-177) is this coarse (8.5e-3 near z ~ 1)
+    bval, bvec = phantom.scheme_gqi(2, 40, (1500.0, 3000.0), 7)
+    K, ib0 = orc.rumba_kernel(bval, bvec, sphere_724.vertices)
+    assert K.shape == (int((~ib0).sum()) + 1, 362 + 2) and np.all(K[0] == 1.0)
+    g = bvec[~ib0] / np.linalg.norm(bvec[~ib0], axis=1, keepdims=True)
+    u = sphere_724.vertices[362 + 17].astype(np.float64)          # second-half vertex of column 17 (rusd.jl:502-504)
+    want = np.exp(-bval[~ib0] * (0.2e-3 + (1.7e-3 - 0.2e-3) * (g @ u) ** 2))
+    np.testing.assert_allclose(K[1:, 17], want, rtol=2e-5)
+    np.testing.assert_allclose(K[1:, 362], np.exp(-bval[~ib0] * 3.0e-3), rtol=2e-6)
+    tv = orc._rumba_tv(np.full((4, 5, 6), 0.3, np.float32), np.full((4, 5, 6), 0.01, np.float32))
+    np.testing.assert_allclose(tv, 1.0, rtol=1e-6)
+    ax = np.array([0.6, -0.48, 0.64])
+    sig = (800.0 * np.exp(-bval * (0.2e-3 + 1.5e-3 * ((bvec / np.maximum(np.linalg.norm(bvec, axis=1, keepdims=True), 1e-12)) @ ax) ** 2)))
+    dwi = np.asfortranarray(np.tile(sig.astype(np.float32), (2, 2, 2, 1)))
+    r = orc.rumba_rec(dwi, np.ones((2, 2, 2), np.uint8), bval, bvec, sphere_724.vertices, niter=150, use_tv=False)
+    pk = r["peak"][0][0, 0, 0]
+    assert abs(pk @ ax) / np.linalg.norm(pk) > 0.985              # nearest vertex of a 362-point half sphere
+    assert abs(r["fodf"][0, 0, 0].sum() - 1.0) < 1e-5
