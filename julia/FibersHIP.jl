@@ -105,6 +105,36 @@ function dsi_rec(dwi::MRI, mask::MRI, odf_dirs::ODF=sphere_642, hann_width::Int=
   return DSI(pdf, odf, peak, qa)
 end
 
+struct FibRumbaOut
+  fodf::Ptr{Float32}; fgm::Ptr{Float32}; fcsf::Ptr{Float32}; gfa::Ptr{Float32}; var::Ptr{Float32}
+  peak::NTuple{5, Ptr{Float32}}
+end
+
+"rumba_rec(dwi, mask, odf_dirs, niter, ...) — replaces rusd.jl:419-636"
+function rumba_rec(dwi::MRI, mask::MRI, odf_dirs::ODF=sphere_724, niter::Integer=600, λ_para::Float32=Float32(1.7e-3),
+                   λ_perp::Float32=Float32(0.2e-3), λ_csf::Float32=Float32(3.0e-3), λ_gm::Float32=Float32(0.8e-4),
+                   ncoils::Integer=1, coil_combine::String="SMF-SENSE", ipat_factor::Integer=1, use_tv::Bool=true;
+                   device::Integer=0)
+  isempty(dwi.bval) && error("Missing b-value table from input DWI structure")
+  isempty(dwi.bvec) && error("Missing gradient table from input DWI structure")
+  sos = coil_combine == "SoS-GRAPPA" ? 1 : (coil_combine == "SMF-SENSE" ? 0 : error("Unknown coil combine mode " * coil_combine))
+  ipat_factor < 1 && error("iPAT factor must be a positive integer")
+  nx, ny, nz, nvol = size(dwi.vol)
+  nvert = div(size(odf_dirs.vertices, 1), 2)
+  fodf = MRI(mask, nvert, Float32); fgm = MRI(mask, 1, Float32); fcsf = MRI(mask, 1, Float32)
+  gfa = MRI(mask, 1, Float32); var = MRI(mask, 1, Float32); peak = [MRI(mask, 3, Float32) for _ in 1:5]
+  verts = odf_dirs.vertices; vol = dwi.vol::Array{Float32,4}; m = mask.vol
+  snr = Ref{Float32}(0); snrsd = Ref{Float32}(0)
+  out = Ref(FibRumbaOut(pointer(fodf.vol), pointer(fgm.vol), pointer(fcsf.vol), pointer(gfa.vol), pointer(var.vol),
+                        ntuple(i -> pointer(peak[i].vol), 5)))
+  GC.@preserve vol m fodf fgm fcsf gfa var peak verts fib_check(ccall((:fib_rumba_rec, libfibers), Cint,
+      (Cint, Ptr{Float32}, Cint, Cint, Cint, Cint, Ptr{Cvoid}, Cint, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Cint, Cint,
+       Cfloat, Cfloat, Cfloat, Cfloat, Cint, Cint, Cint, Cint, Ref{FibRumbaOut}, Ref{Float32}, Ref{Float32}),
+      device, vol, nx, ny, nz, nvol, m, FIB_DTYPE[eltype(m)], dwi.bval, dwi.bvec, verts, size(verts, 1), niter,
+      λ_para, λ_perp, λ_csf, λ_gm, ncoils, sos, ipat_factor, use_tv ? 1 : 0, out, snr, snrsd))
+  return RUMBASD(fodf, fgm, fcsf, peak, gfa, var, snr[], snrsd[])
+end
+
 struct FibStreamParams
   nx::Int32; ny::Int32; nz::Int32; nvec::Int32; len_min::Int32; len_max::Int32
   cosang_thresh::Float32; step_size::Float32; smooth_coeff::Float32
