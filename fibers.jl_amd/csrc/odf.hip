@@ -45,7 +45,6 @@ struct GemmArgs {
     unsigned long long *dbg;      // timing experiments only (FIBERS_GEMM3_STAMP): 6 words per workgroup
     const float *Aextra;          // split-bf16 kernel: f32 coefficients of the NX extra rows [ntile_m][Kpad/16][NX][16]
     int vec_ok;                   // split-bf16 kernel: output rows are 16-byte aligned (dwordx4 stores allowed)
-    int stagger;                  // split-bf16 kernel: largest start delay of a workgroup, in units of 1024 cycles
     const int32_t *rowA, *rowB;   // optional output-row map for rows < nrow0: row r goes to frames rowA[r] and rowB[r] (>= 0)
 };
 
@@ -484,10 +483,6 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
     };
     Work cur = work_at(0);
     if (!cur.valid) return;
-    if (a.stagger > 0) {                                 // spread the workgroups' phases so that their store bursts do not coincide
-        const int n = (int)((((blockIdx.x * 2654435761u) >> 20) & 0xfffu) * (unsigned)a.stagger >> 12);
-        for (int k = 0; k < n; k++) __builtin_amdgcn_s_sleep(16);   // 1024 cycles each
-    }
     int32_t vraw = vidx_at(cur);
     Work nxt = work_at(1);
     int32_t vraw_nxt = nxt.valid ? vidx_at(nxt) : 0;
@@ -1538,8 +1533,6 @@ void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
         GemmArgs g2 = ga;
-        static const int stagger = getenv("FIBERS_GEMM3_STAGGER") ? atoi(getenv("FIBERS_GEMM3_STAGGER")) : 0;
-        g2.stagger = stagger;
         const int nw = 8;
         const int64_t items = fib::cdiv(ga.nvox, nw * 32) * ga.ntile_m;
         unsigned pg = (unsigned)std::min<int64_t>((int64_t)ncu * (8 / nw), items);

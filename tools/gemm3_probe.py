@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Timing experiments on odf_gemm3_kernel: sweeps FIBERS_GEMM3_WAVES / _STAGGER / _STAMP (each in a child process).
-usage: gemm3_probe.py [kind] ["W=4,S=0,T=0" ...]"""
+"""Per-kernel timing of one ODF reconstruction step (each configuration in a child process).
+usage: gemm3_probe.py [gqi|dsi] ["T=1" (in-kernel stamps) | "G=f32" (f32-MFMA kernel) ...]"""
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -37,10 +37,9 @@ else:
     kind = "gqi"
     if args and args[0] in ("gqi", "dsi"):
         kind = args.pop(0)
-    for cfg in (args or ["A=1", "A=0", "A=1,T=1"]):
+    for cfg in (args or ["T=0", "T=1", "G=f32"]):
         kv = dict(x.split("=") for x in cfg.split(","))
         env = dict(os.environ)
-        env["FIBERS_GEMM3_STAGGER"] = kv.get("S", "0"); env["FIBERS_GEMM3_STAMP"] = kv.get("T", "0")
+        env["FIBERS_GEMM3_STAMP"] = kv.get("T", "0")
         if "G" in kv: env["FIBERS_ODF_GEMM"] = kv["G"]
-        env["FIBERS_GEMM3_ANTIPHASE"] = kv.get("A", "1")
         subprocess.call([sys.executable, os.path.abspath(__file__), "child", kind, cfg], env=env)
