@@ -1227,6 +1227,215 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
     }
 }
 
+// ---- v4 (default tessellation only): candidates go to per-voxel lists, two barriers per tile ---------------------------
+// Same tile and scan as the S642 variant above; what changes is everything after the scan.  A wave no longer keeps a top-3
+// per voxel that two merge levels (three barriers, most waves idle) fold together: every candidate (a voxel has a handful)
+// is appended to its voxel's list in LDS through an LDS atomic counter, wave 0 then picks the top three of each list and
+// wave 1 folds the 16 partial sums / minima, WHILE the other waves already write the next tile into LDS (the keys carry
+// the amplitudes, so the finished tile is not needed any more), and the 12 output rows of a tile are written while the
+// scan of the next one runs.  A voxel of finite data has at most 107 candidates (no two of the 640 folded triangles'
+// vertices are both maxima: sum of degrees <= 640); the list holds 112.  Only a NaN-poisoned voxel can overflow it: the
+// tile is then finished before the next one is stored and wave 0 re-derives that voxel's candidates from the tile.
+constexpr int PQ_CAP = 112;
+__device__ const short fib_s642_nbr_dev[FIB_S642_NVERT][FIB_S642_DEG] = {
+#define FIB_S642_ROW(a, b, c, d, e, f) {a, b, c, d, e, f},
+    FIB_S642_TABLE(FIB_S642_ROW)
+#undef FIB_S642_ROW
+};
+__device__ __forceinline__ float peak_key_value(unsigned hi) {    // inverse of peak_key's float image (NaN canonical)
+    return hi == 0xffffffffu ? __builtin_nanf("") : __uint_as_float((hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi);
+}
+
+__global__ __launch_bounds__(P64_T) void odf_peaks642_kernel(const PeakArgs a, int64_t ntiles) {
+    constexpr int NV = FIB_S642_NVERT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *o = smem;                                              // [NV + 1][64]; row NV = NaN sentinel
+    unsigned long long *list = reinterpret_cast<unsigned long long *>(o + (NV + 1) * 64);   // [PQ_CAP][64] keys, slot-major
+    int *cnt = reinterpret_cast<int *>(list + PQ_CAP * 64);       // [64] candidates appended per voxel; [64] = overflow flag
+    float *pmin = reinterpret_cast<float *>(cnt + 128);           // [16][64]
+    float *psum = pmin + P64_W * 64;                              // [16][64]
+    float *fin = psum + P64_W * 64;                               // [2][8][64]: keys (lo,hi) x 3, npos, vmin
+    float *vl = fin + 2 * 8 * 64;                                 // [NV][3] vertex coordinates
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nq = NV * 16;
+    if (tid < 64) { o[NV * 64 + tid] = __builtin_nanf(""); cnt[tid] = 0; cnt[64 + tid] = 0; }
+    for (int i = tid; i < NV * 3; i += P64_T) vl[i] = a.verts[i];
+    float4 s0, s1, s2, s3, s4, s5;
+    s0 = s1 = s2 = s3 = s4 = s5 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto is_fast = [&](int64_t tile) { return a.vec_ok && tile * 64 + 64 <= a.nvox; };
+    const int rbase = tid >> 4;
+    const int64_t nlist = a.tiles ? (int64_t)a.ntl[0] : ntiles;
+    if (a.tiles && a.maxenc && blockIdx.x == 0 && tid == 0 && nlist < ntiles) atomicMax(&a.maxenc[0], enc_ordered(0.0f));
+    auto tile_at = [&](int64_t k) -> int64_t { return k < nlist ? (a.tiles ? (int64_t)a.tiles[k] : k) : -1; };
+    auto put_tile = [&](int64_t tile, bool fast) {                // staging registers (or memory) -> o
+        if (fast) {
+            FIB_P64_PUT(0, s0); FIB_P64_PUT(1, s1); FIB_P64_PUT(2, s2);
+            FIB_P64_PUT(3, s3); FIB_P64_PUT(4, s4); FIB_P64_PUT(5, s5);
+        } else {
+            for (int e = tid; e < NV * 64; e += P64_T) {
+                const int row = e >> 6, c = e & 63;
+                const int64_t vx = tile * 64 + c;
+                o[e] = vx < a.nvox ? a.odf[(int64_t)row * a.stride + vx] : 0.0f;
+            }
+        }
+    };
+    int64_t slot = blockIdx.x;
+    int64_t tile = tile_at(slot);
+    if (tile < 0) return;
+    int64_t next = tile_at(slot + gridDim.x);
+    bool fast = is_fast(tile);
+    if (fast) FIB_P64_FETCH(tile);
+    put_tile(tile, fast);
+    __syncthreads();
+    int par = 0;
+    const float *ob = o + lane, *ob1 = o + FIB_S642_BASE1 * 64 + lane;
+    for (;;) {
+        slot += gridDim.x;
+        const int64_t next2 = tile_at(slot + gridDim.x);
+        const bool fast_n = next >= 0 && is_fast(next);
+        if (fast_n) FIB_P64_FETCH(next);                          // in flight during the scan
+        // ---- scan (as odf_peaks64_kernel<.., S642>) ------------------------------------------------------------------
+        float vmin = INFINITY, vsum = 0.0f;
+        unsigned bits = 0;
+        int nscan = 0;
+#define FIB_RD(B, R) (((B) == 0 || ((B) == 2 && (R) <= 255)) ? ob[(R) * 64] : ob1[((R) - FIB_S642_BASE1) * 64])
+#define FIB_SCAN_ONE(V, B, A0, A1, A2, A3, A4, A5)                                                          \
+        if ((V) < FIB_S642_NVERT) {                                                                         \
+            const float x = FIB_RD(B, V);                                                                   \
+            const float mx = max6_0_f32(FIB_RD(B, A0), FIB_RD(B, A1), FIB_RD(B, A2), FIB_RD(B, A3), FIB_RD(B, A4), FIB_RD(B, A5)); \
+            asm("v_cmp_nge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(mx), "v"(x) : "vcc"); \
+            asm("v_min_f32 %0, %0, %1" : "+v"(vmin) : "v"(x));                                              \
+            vsum += x;                                                                                      \
+            nscan++;                                                                                        \
+        }
+#define FIB_SCAN_G(V0, B0, a0, a1, a2, a3, a4, a5, V1, B1, b0, b1, b2, b3, b4, b5, V2, B2, c0, c1, c2, c3, c4, c5, V3, B3, d0, d1, d2, d3, d4, d5) \
+        FIB_SCAN_ONE(V0, B0, a0, a1, a2, a3, a4, a5) FIB_SCAN_ONE(V1, B1, b0, b1, b2, b3, b4, b5)           \
+        FIB_SCAN_ONE(V2, B2, c0, c1, c2, c3, c4, c5) FIB_SCAN_ONE(V3, B3, d0, d1, d2, d3, d4, d5)
+        switch (wave) {
+            case 0: FIB_S642_WAVE0(FIB_SCAN_G) break;
+            case 1: FIB_S642_WAVE1(FIB_SCAN_G) break;
+            case 2: FIB_S642_WAVE2(FIB_SCAN_G) break;
+            case 3: FIB_S642_WAVE3(FIB_SCAN_G) break;
+            case 4: FIB_S642_WAVE4(FIB_SCAN_G) break;
+            case 5: FIB_S642_WAVE5(FIB_SCAN_G) break;
+            case 6: FIB_S642_WAVE6(FIB_SCAN_G) break;
+            case 7: FIB_S642_WAVE7(FIB_SCAN_G) break;
+            case 8: FIB_S642_WAVE8(FIB_SCAN_G) break;
+            case 9: FIB_S642_WAVE9(FIB_SCAN_G) break;
+            case 10: FIB_S642_WAVE10(FIB_SCAN_G) break;
+            case 11: FIB_S642_WAVE11(FIB_SCAN_G) break;
+            case 12: FIB_S642_WAVE12(FIB_SCAN_G) break;
+            case 13: FIB_S642_WAVE13(FIB_SCAN_G) break;
+            case 14: FIB_S642_WAVE14(FIB_SCAN_G) break;
+            default: FIB_S642_WAVE15(FIB_SCAN_G) break;
+        }
+#undef FIB_SCAN_G
+#undef FIB_SCAN_ONE
+#undef FIB_RD
+        // candidates -> the voxel's list (bit b of `bits` = vertex wave + 16*(nscan-1-b))
+        while (__any(bits != 0u)) {
+            if (bits != 0u) {
+                const int b = __ffs((int)bits) - 1;
+                bits &= bits - 1u;
+                const int v = wave + P64_W * (nscan - 1 - b);
+                const int sl = atomicAdd(&cnt[lane], 1);
+                if (sl < PQ_CAP) list[sl * 64 + lane] = peak_key(ob[v * 64], v);
+                else cnt[64] = 1;                                 // overflow: NaN-poisoned voxel
+            }
+        }
+        pmin[wave * 64 + lane] = vmin;
+        psum[wave * 64 + lane] = vsum;
+        __syncthreads();                                          // B2: lists and partials complete
+        const bool ovf = cnt[64] != 0;
+        const int64_t vox = tile * 64 + lane;
+        const bool inb = vox < a.nvox;
+        float *fn = fin + par * 8 * 64;
+        auto finalize = [&]() {
+            if (wave == 0) {                                      // top three of the voxel's candidates, npos (gqi.jl:198-200)
+                Top3 t;
+                top3_clear(t);
+                int npos = 0;
+                const int n = cnt[lane];
+                if (n <= PQ_CAP) {
+                    for (int i = 0; i < n; i++) {
+                        const unsigned long long k = list[i * 64 + lane];
+                        npos += (unsigned)(k >> 32) != 0xffffffffu;        // candidates are > 0 or NaN
+                        top3_insert_key(t, k);
+                    }
+                } else {                                          // more candidates than the list holds: rescan this voxel
+                    for (int v = 0; v < NV; v++) {
+                        const float x = ob[v * 64];
+                        bool killed = false;
+                        for (int d = 0; d < FIB_S642_DEG; d++) { const int u = fib_s642_nbr_dev[v][d]; if (u < NV) killed |= ob[u * 64] >= x; }
+                        const float pk = killed ? 0.0f : x;
+                        if (pk > 0.0f) npos++;
+                        if (!(pk <= 0.0f)) top3_insert(t, pk, v);
+                    }
+                }
+                cnt[lane] = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { fn[(2 * k) * 64 + lane] = __uint_as_float((unsigned)t.k[k]); fn[(2 * k + 1) * 64 + lane] = __uint_as_float((unsigned)(t.k[k] >> 32)); }
+                fn[6 * 64 + lane] = __int_as_float(npos);
+            } else if (wave == 1) {                               // partial sums / minima, folded in the order of the two-level merge
+                float s[4], m = INFINITY;
+                bool hasnan = false;                              // a NaN amplitude makes its wave's partial sum NaN
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    s[w] = psum[w * 64 + lane];
+                    hasnan |= s[w] != s[w];
+#pragma unroll
+                    for (int g = 1; g < 4; g++) { const float q = psum[(w + 4 * g) * 64 + lane]; hasnan |= q != q; s[w] += q; }
+                }
+#pragma unroll
+                for (int w = 0; w < P64_W; w++) m = fminf(m, pmin[w * 64 + lane]);
+                const float vs = ((s[0] + s[1]) + s[2]) + s[3];
+                if (hasnan) m = NAN;                              // minimum() propagates NaN (gqi.jl:147)
+                fn[7 * 64 + lane] = m;
+                const float mean = vs * (1.0f / (float)NV);       // mean(odf, dims=4), gqi.jl:164
+                const bool mean_nan = mean != mean;
+                if (a.maxenc) {
+                    unsigned e = inb && !mean_nan ? enc_ordered(mean) : 0u;
+                    const unsigned long long nanb = __ballot(inb && mean_nan);
+                    for (int off = 32; off >= 1; off >>= 1) { const unsigned oth = (unsigned)__shfl_xor((int)e, off); e = oth > e ? oth : e; }
+                    if (lane == 0) {
+                        if (e) atomicMax(&a.maxenc[0], e);
+                        if (nanb) atomicOr(&a.maxenc[1], 1u);
+                    }
+                }
+            }
+        };
+        if (ovf) {                                                // rare: the tile must survive until wave 0 is done
+            finalize();
+            __syncthreads();
+            if (tid == 0) cnt[64] = 0;
+            if (next >= 0) put_tile(next, fast_n);
+        } else {
+            if (wave < 2) finalize();
+            if (next >= 0) put_tile(next, fast_n);
+        }
+        __syncthreads();                                          // B3: records of this tile and the next tile in LDS are complete
+        // ---- outputs of this tile: one wave per output row; the other waves are already scanning the next tile ---------
+        if (wave < 12 && inb) {
+            const int npos = __float_as_int(fn[6 * 64 + lane]);
+            const int k = wave < 9 ? wave / 3 : wave - 9;
+            const bool have = k < (npos < 3 ? npos : 3);          // gqi.jl:151
+            const unsigned klo = __float_as_uint(fn[(2 * k) * 64 + lane]), khi = __float_as_uint(fn[(2 * k + 1) * 64 + lane]);
+            const int iv = (int)~klo;
+            if (wave < 9) {
+                const int c = wave - 3 * k;
+                a.peak[k][(int64_t)c * a.stride + vox] = have ? vl[3 * iv + c] : 0.0f;      // gqi.jl:154-155
+            } else {
+                a.qa[k][vox] = have ? peak_key_value(khi) - fn[7 * 64 + lane] : 0.0f;       // gqi.jl:157-158
+            }
+        }
+        if (next < 0) break;
+        tile = next;
+        next = next2;
+        par ^= 1;
+    }
+}
+
 __global__ void odfmax_finalize_kernel(const unsigned *enc, float *out) {
     const bool nan = enc[1] != 0;
     const float m = enc[0] ? dec_ordered(enc[0]) : -INFINITY;
@@ -1612,6 +1821,14 @@ int launch_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox, int64
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, plan->device);
         const int64_t ntiles = fib::cdiv(nvox, 64);
         const unsigned g64 = (unsigned)std::min<int64_t>(ntiles, ncu);
+        if (plan->is_s642 && !exact && !getenv("FIBERS_PEAKS_V3")) {
+            const size_t smem642 = ((size_t)(FIB_S642_NVERT + 1) * 64 + (size_t)PQ_CAP * 64 * 2 + 128 + 2 * P64_W * 64 + 2 * 8 * 64 +
+                                    (size_t)FIB_S642_NVERT * 3) * sizeof(float);
+            FIB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(odf_peaks642_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem642));
+            hipLaunchKernelGGL(odf_peaks642_kernel, dim3(g64), dim3(P64_T), smem642, st, pa, ntiles);
+            FIB_HIP(hipGetLastError());
+            return FIB_OK;
+        }
         if (plan->is_s642 && !exact) return launch_peaks64_t<6, false, true>(pa, smem64, ntiles, g64, st);
         switch (plan->deg_pad) {
             case 6:  return exact ? launch_peaks64_t<6, true>(pa, smem64, ntiles, g64, st) : launch_peaks64_t<6, false>(pa, smem64, ntiles, g64, st);

@@ -286,3 +286,40 @@ def test_find_peaks_host_entry(fj, orc):
                 isort, nv, _ = orc.find_peaks(odf[i, j], faces0)
                 assert nv == nvalid[i, j]
                 assert list(isort[:3]) == list(top[i, j])
+
+
+def test_peak_kernels_agree_incl_nan_poisoned_voxels(fj, monkeypatch):
+    """the list-based sphere_642 peak kernel (v4), the register top-3 kernel (v3) and the generic-table kernel give
+    identical peaks / qa / odfmax, also when NaN samples poison whole voxels (321 candidates: more than the 112 a
+    voxel's candidate list holds, which takes the kernel's overflow path)"""
+    import torch
+    from fibers_jl_amd import phantom
+    dev = torch.device("cuda", 0)
+    shape = (32, 24, 20)
+    nvox = shape[0] * shape[1] * shape[2]
+    bval, bvec = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3)
+    dwi, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=6, device=dev)
+    rng = np.random.default_rng(4)
+    bad = torch.from_numpy(rng.choice(nvox, 60, replace=False)).to(dev)
+    dwi[5, bad] = float("nan")
+    mask = torch.ones(nvox, dtype=torch.uint8, device=dev)
+    plan = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642)
+    res = {}
+    for name, env in (("v4", {}), ("v3", {"FIBERS_PEAKS_V3": "1"}), ("generic", {"FIBERS_PEAKS_V3": "1", "FIBERS_PEAKS_GENERIC": "1"})):
+        for k in ("FIBERS_PEAKS_V3", "FIBERS_PEAKS_GENERIC"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        p = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642) if name == "generic" else plan
+        o = fj.odf_rec_device(p, dwi, mask, normalize=False)
+        torch.cuda.synchronize()
+        res[name] = dict(peak=[t.clone() for t in o["peak"]], qa=[t.clone() for t in o["qa"]], odfmax=o["odfmax"].clone(),
+                         odf=o["odf"].clone())
+    assert bool(torch.isnan(res["v4"]["odf"][:, bad]).all())
+    assert float(res["v4"]["odfmax"][1]) == 1.0                  # NaN flag of the global maximum (gqi.jl:164)
+    for other in ("v3", "generic"):
+        for k in range(3):
+            assert torch.equal(res["v4"]["peak"][k], res[other]["peak"][k]), (other, k)
+            assert torch.equal(torch.nan_to_num(res["v4"]["qa"][k], nan=-7.0), torch.nan_to_num(res[other]["qa"][k], nan=-7.0)), (other, k)
+        assert torch.equal(torch.nan_to_num(res["v4"]["odfmax"], nan=-7.0), torch.nan_to_num(res[other]["odfmax"], nan=-7.0))
+    assert float(res["v4"]["peak"][0][:, bad].abs().max()) == 0.0   # nvalid = 0 for an all-NaN ODF: no peaks (gqi.jl:151,200)
