@@ -82,6 +82,8 @@ struct TraceArgs {
     const float4 *search;       // half of the search cube's cells with rho < 1, column-major order: {unit vector, bits of (kx | ky<<8 | kz<<16)} (0-based cell)
     int nsearch, search_dist;
     float search_cosang;
+    const int32_t *cell_start;  // [G^3 + 1]: the table is sorted by direction cell (x fastest); entries of cell i = [cell_start[i], cell_start[i+1])
+    int G;                      // direction grid: cell (floor((v + 1) / h)) per axis, h = 2 / G
 };
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -281,9 +283,12 @@ __device__ __forceinline__ unsigned long long micro_key(float c, unsigned lin) {
 }
 
 __global__ __launch_bounds__(1024) void stream_trace_micro_kernel(const TraceArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float4 stab[];  // [nsearch]
+    extern __shared__ __attribute__((aligned(16))) float4 stab[];  // [nsearch] entries, then [G^3 + 1] cell offsets
+    int32_t *cst = reinterpret_cast<int32_t *>(stab + a.nsearch);
     for (int i = threadIdx.x; i < a.nsearch; i += blockDim.x) stab[i] = a.search[i];
+    for (int i = threadIdx.x; i <= a.G * a.G * a.G; i += blockDim.x) cst[i] = a.cell_start[i];
     __syncthreads();
+    const float gh = 2.0f / (float)a.G;
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -318,23 +323,43 @@ __global__ __launch_bounds__(1024) void stream_trace_micro_kernel(const TraceArg
                 if (fc.w == 0.0f) break;                                                              // :569
                 unsigned long long best = 0ull;                  // 0 = nothing found (every real key has |c| bits or ~lin != 0)
                 if (lane == 0) best = micro_key(dot3(vx, vy, vz, fc.x, fc.y, fc.z), lin_centre);     // the centre cell
-                for (int e = lane; e < a.nsearch; e += 64) {
+                // Entries that can pass dot(u, v) > c lie within |v - u/|u|| < sqrt(2 - 2c/|u|) of the (normalised) direction:
+                // only the direction cells that box touches are visited (the test itself stays exact); sg = 1 visits the
+                // antipodes (dot(u, -v) > c  <=>  v near -u).  A degenerate direction falls back to the whole table.
+                const float un = sqrtf(dot3(vx, vy, vz, vx, vy, vz));
+                const float r2 = 2.0f - 2.0f * a.search_cosang / un;
+                const bool boxed = un > 0.0f && r2 < 1.0f;           // NaN / zero / very short vectors: everything
+                const float rr = boxed ? sqrtf(r2 > 0.0f ? r2 : 0.0f) + 2e-3f : 3.0f;
+                auto test_entry = [&](int e, int sg) {
                     const float4 t = stab[e];
                     const float sdot = dot3(vx, vy, vz, t.x, t.y, t.z);
+                    const float dv = sg ? -sdot : sdot;
+                    if (dv <= a.search_cosang) return;                                                // :597-598
                     const unsigned cell = __float_as_uint(t.w);
                     const int kx = (int)(cell & 255u), ky = (int)((cell >> 8) & 255u), kz = (int)(cell >> 16);
-#pragma unroll
-                    for (int sg = 0; sg < 2; sg++) {             // the cell and its antipode
-                        const float dv = sg ? -sdot : sdot;
-                        if (dv <= a.search_cosang) continue;                                          // :597-598
-                        const int ox = sg ? d - kx : kx - d, oy = sg ? d - ky : ky - d, oz = sg ? d - kz : kz - d;
-                        const int ix = cx + ox, iy = cy + oy, iz = cz + oz;
-                        if (ix < 0 || ix >= a.nx || iy < 0 || iy >= a.ny || iz < 0 || iz >= a.nz) continue;   // :586-588
-                        const float4 f = a.field[((int64_t)ix + a.nx * ((int64_t)iy + (int64_t)a.ny * iz)) * a.nvec];
-                        if (f.w == 0.0f) continue;                                                    // :596
-                        const unsigned l0 = (unsigned)(kx + S * (ky + S * kz));
-                        const unsigned long long k = micro_key(dot3(vx, vy, vz, f.x, f.y, f.z), sg ? lin_last - l0 : l0);   // :600-601
-                        best = k > best ? k : best;
+                    const int ox = sg ? d - kx : kx - d, oy = sg ? d - ky : ky - d, oz = sg ? d - kz : kz - d;
+                    const int ix = cx + ox, iy = cy + oy, iz = cz + oz;
+                    if (ix < 0 || ix >= a.nx || iy < 0 || iy >= a.ny || iz < 0 || iz >= a.nz) return;   // :586-588
+                    const float4 f = a.field[((int64_t)ix + a.nx * ((int64_t)iy + (int64_t)a.ny * iz)) * a.nvec];
+                    if (f.w == 0.0f) return;                                                          // :596
+                    const unsigned l0 = (unsigned)(kx + S * (ky + S * kz));
+                    const unsigned long long k = micro_key(dot3(vx, vy, vz, f.x, f.y, f.z), sg ? lin_last - l0 : l0);   // :600-601
+                    best = k > best ? k : best;
+                };
+                if (!boxed) {
+                    for (int e = lane; e < a.nsearch; e += 64) { test_entry(e, 0); test_entry(e, 1); }
+                } else {
+#pragma unroll 1
+                    for (int sg = 0; sg < 2; sg++) {
+                        const float qx = (sg ? -vx : vx) / un, qy = (sg ? -vy : vy) / un, qz = (sg ? -vz : vz) / un;
+                        auto cl = [&](float x) { int c = (int)floorf((x + 1.0f) / gh); return c < 0 ? 0 : (c >= a.G ? a.G - 1 : c); };
+                        const int x0 = cl(qx - rr), x1 = cl(qx + rr), y0 = cl(qy - rr), y1 = cl(qy + rr), z0 = cl(qz - rr), z1 = cl(qz + rr);
+                        for (int gz = z0; gz <= z1; gz++)
+                            for (int gy = y0; gy <= y1; gy++) {
+                                const int rowc = a.G * (gy + a.G * gz);
+                                const int e0 = cst[rowc + x0], e1 = cst[rowc + x1 + 1];   // cells x0..x1 of this row are contiguous
+                                for (int e = e0 + lane; e < e1; e += 64) test_entry(e, sg);
+                            }
                     }
                 }
 #pragma unroll
@@ -693,6 +718,7 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
     ta.cosang = prm->cosang_thresh; ta.step = prm->step_size; ta.smooth = prm->smooth_coeff;
     const unsigned grid = (unsigned)fib::cdiv(nl, 256);
     fib::DevBuf<float4> d_search;
+    fib::DevBuf<int32_t> d_cell;
     fib::DevBuf<float> d_lcm;
     if (prm->search_dist > 0) {
         // search_area (stream.jl:255-277), Float32 arithmetic like the reference's T; one entry per antipodal pair
@@ -711,13 +737,29 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
             float w; memcpy(&w, &cell, 4);
             tab.push_back(make_float4(rx / r, ry / r, rz / r, w));
         }
-        const size_t smem = tab.size() * sizeof(float4);
+        // direction grid: cell size a little above the chord of the search cone, so a query box spans <= 3 cells per axis
+        const float chord = std::sqrt(std::max(0.0f, 2.0f - 2.0f * prm->search_cosang));
+        int G = (int)std::floor(2.0f / std::max(chord * 1.05f + 4e-3f, 0.1f));
+        G = std::max(1, std::min(G, 24));
+        const float gh = 2.0f / (float)G;
+        auto cell_of = [&](const float4 &t) {
+            auto cl = [&](float x) { int c = (int)std::floor((x + 1.0f) / gh); return c < 0 ? 0 : (c >= G ? G - 1 : c); };
+            return cl(t.x) + G * (cl(t.y) + G * cl(t.z));
+        };
+        std::stable_sort(tab.begin(), tab.end(), [&](const float4 &p, const float4 &q) { return cell_of(p) < cell_of(q); });
+        std::vector<int32_t> cstart((size_t)G * G * G + 1, 0);
+        for (const float4 &t : tab) cstart[(size_t)cell_of(t) + 1]++;
+        for (size_t i = 1; i < cstart.size(); i++) cstart[i] += cstart[i - 1];
+        const size_t smem = tab.size() * sizeof(float4) + cstart.size() * sizeof(int32_t);
         if (smem > 150 * 1024) return bail(fib::fail(FIB_ERR_UNSUPPORTED, "search_dist %d needs %zu bytes of LDS for the search table (max 150 KiB)", d, smem));
         if ((rc = d_search.alloc(tab.size())) != FIB_OK) return bail(rc);
-        hipError_t ec = hipMemcpyAsync(d_search.p, tab.data(), smem, hipMemcpyHostToDevice, st);
-        if (ec == hipSuccess) ec = hipStreamSynchronize(st);     // (the table is a local: it must outlive the copy)
+        if ((rc = d_cell.alloc(cstart.size())) != FIB_OK) return bail(rc);
+        hipError_t ec = hipMemcpyAsync(d_search.p, tab.data(), tab.size() * sizeof(float4), hipMemcpyHostToDevice, st);
+        if (ec == hipSuccess) ec = hipMemcpyAsync(d_cell.p, cstart.data(), cstart.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+        if (ec == hipSuccess) ec = hipStreamSynchronize(st);     // (the tables are locals: they must outlive the copies)
         if (ec != hipSuccess) return bail(fib::fail(FIB_ERR_HIP, "search table upload failed: %s", hipGetErrorString(ec)));
         ta.search = d_search.p; ta.nsearch = (int)tab.size(); ta.search_dist = d; ta.search_cosang = prm->search_cosang;
+        ta.cell_start = d_cell.p; ta.G = G;
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
         const unsigned mg = (unsigned)std::min<int64_t>(ncu, fib::cdiv(nl, 16));
