@@ -47,37 +47,31 @@ __global__ __launch_bounds__(256) void rumba_signal_kernel(const float *__restri
     }
 }
 
-// rumba_sd_initialize! (rusd.jl:241-259)
-__global__ __launch_bounds__(256) void rumba_init_kernel(RumbaDims d, const float *__restrict__ fodf0, const float *__restrict__ dodf0, float lam0,
-                                                        const float *__restrict__ sig, float *__restrict__ fodf, float *__restrict__ dodf,
-                                                        float *__restrict__ dsig, float *__restrict__ tv, float *__restrict__ s2) {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d.npad) return;
-    const bool live = c < d.nmask;
-    for (int k = 0; k < d.ncomp; k++) { fodf[(int64_t)k * d.npad + c] = live ? fodf0[k] : 0.0f; tv[(int64_t)k * d.npad + c] = 1.0f; }
-    for (int r = 0; r < d.ndir; r++) {
-        const float dd = live ? dodf0[r] : 0.0f;
-        dodf[(int64_t)r * d.npad + c] = dd;
-        dsig[(int64_t)r * d.npad + c] = (sig[(int64_t)r * d.npad + c] * dd) / lam0;
-    }
-    s2[c] = lam0;
-}
-
 // besseli_ratio (rusd.jl:170-177), Float32 like the reference
 __device__ __forceinline__ float besseli_ratio(float nu, float z) {
     const float a = 2.0f * nu;
     return z / ((a + z) - ((a + 1.0f) * z / (2.0f * z + (a + 1.0f) - ((a + 3.0f) * z / ((a + 2.0f) + 2.0f * z - ((a + 5.0f) * z / ((a + 3.0f) + 2.0f * z)))))));
 }
 
-// Iratio = besseli_ratio.(n, dodf_sig); x = signal .* Iratio  (the operand of the first contraction)
-__global__ __launch_bounds__(256) void rumba_iratio_kernel(int64_t n, float nu, const float *__restrict__ sig, const float *__restrict__ dsig,
-                                                          float *__restrict__ ir, float *__restrict__ x) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float r = besseli_ratio(nu, dsig[i]);
-    ir[i] = r;
-    float p = sig[i] * r;
-    x[i] = p;                                                     // (0 * NaN = NaN reaches the contraction like in the reference)
+// rumba_sd_initialize! (rusd.jl:241-259).  dodf_sig = signal .* dodf ./ sigma2 only ever feeds the Bessel ratio of the next
+// iteration (rusd.jl:275), so it is not stored: Iratio and the first contraction's operand x = signal .* Iratio are
+// produced right where dodf_sig is known (here and in rumba_noise_kernel).
+__global__ __launch_bounds__(256) void rumba_init_kernel(RumbaDims d, float nu, const float *__restrict__ fodf0, const float *__restrict__ dodf0, float lam0,
+                                                        const float *__restrict__ sig, float *__restrict__ fodf, float *__restrict__ dodf,
+                                                        float *__restrict__ ir, float *__restrict__ x, float *__restrict__ tv, float *__restrict__ s2) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.npad) return;
+    const bool live = c < d.nmask;
+    for (int k = 0; k < d.ncomp; k++) { fodf[(int64_t)k * d.npad + c] = live ? fodf0[k] : 0.0f; if (tv) tv[(int64_t)k * d.npad + c] = 1.0f; }
+    for (int r = 0; r < d.ndir; r++) {
+        const int64_t i = (int64_t)r * d.npad + c;
+        const float dd = live ? dodf0[r] : 0.0f;
+        dodf[i] = dd;
+        const float q = besseli_ratio(nu, (sig[i] * dd) / lam0);
+        ir[i] = q;
+        x[i] = sig[i] * q;                                        // (0 * NaN = NaN reaches the contraction like in the reference)
+    }
+    s2[c] = lam0;
 }
 
 // TV term of one compartment block (rumba_tv!, sd_grad!, sd_div!: rusd.jl:183-235), straight from the masked matrix:
@@ -86,6 +80,9 @@ __global__ __launch_bounds__(256) void rumba_iratio_kernel(int64_t n, float nu, 
 struct TvArgs {
     const float *fodf; float *tv; const int32_t *ind; const int32_t *col_of; const float *lam;   // lam: [npad] per column
     RumbaDims d;
+    // fused update (rusd.jl:281, 301): fodf_new = max(fodf .* (rl ./ (rl2 + eps)) .* tv, 0) -- the TV term is consumed where it is
+    // produced and never stored; fodf is double buffered because neighbouring lanes still read the old values
+    const float *rl, *rl2; float *fodf_new;
 };
 __device__ __forceinline__ int32_t rumba_col(const TvArgs &a, int x, int y, int z) {
     if (x < 0 || y < 0 || z < 0 || x >= a.d.nx || y >= a.d.ny || z >= a.d.nz) return -2;   // outside the volume
@@ -125,7 +122,11 @@ __global__ __launch_bounds__(256) void rumba_tv_kernel(const TvArgs a) {
         const float dy = a.d.ny == 1 ? g[0][1] : (y == 0 ? g[0][1] : (y == a.d.ny - 1 ? -g[2][1] : g[0][1] - g[2][1]));
         const float dz = a.d.nz == 1 ? g[0][2] : (z == 0 ? g[0][2] : (z == a.d.nz - 1 ? -g[3][2] : g[0][2] - g[3][2]));
         const float div = (dx + dy) + dz;
-        a.tv[(int64_t)k * a.d.npad + c] = 1.0f / (fabsf(1.0f - lam * div) + EPS32);
+        const float tvv = 1.0f / (fabsf(1.0f - lam * div) + EPS32);
+        const int64_t i = (int64_t)k * a.d.npad + c;
+        const float r = a.rl[i] / (a.rl2[i] + EPS32);
+        const float fo = (f[c] * r) * tvv;
+        a.fodf_new[i] = fo > 0.0f ? fo : (fo != fo ? fo : 0.0f);   // max.(x, 0): NaN stays NaN
     }
 }
 
@@ -142,38 +143,46 @@ __global__ __launch_bounds__(256) void rumba_update_kernel(int64_t n, const floa
 // dodf_sig = signal .* dodf ./ sigma2;  sigma2 <- clamp(sum((signal^2 + dodf^2)/2 - sigma2 .* dodf_sig .* Iratio) / (n ndir))
 // (rusd.jl:313-326); one lane per column, rows walked in order (the reference's column sum)
 __global__ __launch_bounds__(256) void rumba_noise_kernel(RumbaDims d, float n_order, const float *__restrict__ sig, const float *__restrict__ dodf,
-                                                         const float *__restrict__ ir, float *__restrict__ dsig, float *__restrict__ s2,
-                                                         float *__restrict__ snr) {
+                                                         float *__restrict__ ir, float *__restrict__ x, float *__restrict__ s2,
+                                                         float *__restrict__ snr, double *__restrict__ s2sum) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d.npad) return;
+    float sn = 0.0f;
+    if (c < d.npad) {
     const float so = s2[c];
     float acc = 0.0f;
     for (int r = 0; r < d.ndir; r++) {
         const int64_t i = (int64_t)r * d.npad + c;
         const float s = sig[i], dd = dodf[i];
-        const float ds = (s * dd) / so;
-        dsig[i] = ds;
+        const float ds = (s * dd) / so;                           // dodf_sig with the OLD sigma2 (rusd.jl:314)
         acc += (s * s + dd * dd) / 2.0f - (so * ds) * ir[i];
+        const float q = besseli_ratio(n_order, ds);               // next iteration's Iratio (rusd.jl:275) and contraction operand
+        ir[i] = q;
+        x[i] = s * q;
     }
-    float sn = acc / (n_order * (float)d.ndir);
+    sn = acc / (n_order * (float)d.ndir);
     const float lo = (float)((1.0 / 80.0) * (1.0 / 80.0)), hi = (float)((1.0 / 8.0) * (1.0 / 8.0));
     sn = sn < lo ? lo : (sn > hi ? hi : sn);                      // clamp! (NaN stays NaN)
     s2[c] = sn;
     snr[c] = 1.0f / sqrtf(sn);
+    }
+    // sum of sigma2 over the masked columns for mean(W.sigma2_vec) (rusd.jl:334): wave reduction + one double atomic per wave
+    double part = (c < d.nmask) ? (double)sn : 0.0;
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+    if ((threadIdx.x & 63) == 0 && s2sum) atomicAdd(s2sum, part);
 }
 
 // sum / sum of squares of v[0..n) in double (mean(sigma2), mean / std of the SNR): one block
 __global__ __launch_bounds__(1024) void rumba_stats_kernel(const float *__restrict__ v, int64_t n, double *__restrict__ out) {
     __shared__ double s1[1024], s2[1024];
     double a = 0.0, b = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) { const double x = v[i]; a += x; b += x * x; }
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 1024) { const double x = v[i]; a += x; b += x * x; }
     s1[threadIdx.x] = a; s2[threadIdx.x] = b;
     __syncthreads();
     for (int off = 512; off >= 1; off >>= 1) {
         if ((int)threadIdx.x < off) { s1[threadIdx.x] += s1[threadIdx.x + off]; s2[threadIdx.x] += s2[threadIdx.x + off]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out[0] = s1[0]; out[1] = s2[0]; }
+    if (threadIdx.x == 0) { atomicAdd(&out[0], s1[0]); atomicAdd(&out[1], s2[0]); }     // out zeroed by the caller
 }
 // lambda (rusd.jl:331-345): ipat == 1: max(mean(sigma2), (1/30)^2) everywhere; ipat > 1: sigma2 of the voxel
 __global__ __launch_bounds__(256) void rumba_lambda_kernel(int64_t nmask, int ipat, const double *__restrict__ stats, const float *__restrict__ s2,
@@ -419,14 +428,15 @@ extern "C" int fibd_rumba_rec(const fib_rumba_plan *plan, const float *dwi, cons
     RumbaDims d{plan->ndir, plan->ncomp, plan->nvert, nmask, (nmask + 255) / 256 * 256, nx, ny, nz};
     const int64_t nD = (int64_t)d.ndir * d.npad, nC = (int64_t)d.ncomp * d.npad;
     fib::DevBuf<int32_t> d_ind, d_col;
-    fib::DevBuf<float> sig, dodf, dsig, ir, x, fodf, rl, rl2, tv, s2, snr, lam;
+    fib::DevBuf<float> sig, dodf, ir, x, fodf, fodf2, rl, rl2, tv, s2, snr, lam;
     fib::DevBuf<uint8_t> ones;
     fib::DevBuf<double> stats;
     int rc;
     if ((rc = d_ind.alloc((size_t)nmask)) != FIB_OK || (rc = d_col.alloc((size_t)nvox)) != FIB_OK ||
-        (rc = sig.alloc((size_t)nD)) != FIB_OK || (rc = dodf.alloc((size_t)nD)) != FIB_OK || (rc = dsig.alloc((size_t)nD)) != FIB_OK ||
+        (rc = sig.alloc((size_t)nD)) != FIB_OK || (rc = dodf.alloc((size_t)nD)) != FIB_OK ||
         (rc = ir.alloc((size_t)nD)) != FIB_OK || (rc = x.alloc((size_t)nD)) != FIB_OK || (rc = fodf.alloc((size_t)nC)) != FIB_OK ||
-        (rc = rl.alloc((size_t)nC)) != FIB_OK || (rc = rl2.alloc((size_t)nC)) != FIB_OK || (rc = tv.alloc((size_t)nC)) != FIB_OK ||
+        (rc = fodf2.alloc((size_t)nC)) != FIB_OK || (rc = rl.alloc((size_t)nC)) != FIB_OK || (rc = rl2.alloc((size_t)nC)) != FIB_OK ||
+        (rc = tv.alloc((size_t)(use_tv ? 1 : nC))) != FIB_OK ||
         (rc = s2.alloc((size_t)d.npad)) != FIB_OK || (rc = snr.alloc((size_t)d.npad)) != FIB_OK || (rc = lam.alloc((size_t)d.npad)) != FIB_OK ||
         (rc = ones.alloc((size_t)d.npad)) != FIB_OK || (rc = stats.alloc(2)) != FIB_OK) return rc;
     FIB_HIP(hipMemcpyAsync(d_ind.p, ind.data(), sizeof(int32_t) * nmask, hipMemcpyHostToDevice, st));
@@ -436,8 +446,10 @@ extern "C" int fibd_rumba_rec(const fib_rumba_plan *plan, const float *dwi, cons
     hipLaunchKernelGGL(rumba_signal_kernel, dim3(gcol), dim3(256), 0, st, dwi, nvox, d_ind.p, plan->d_b0.p, (int)plan->b0_frames.size(),
                        plan->d_dw.p, d, sig.p);
     const float lam0 = (1.0f / 15.0f) * (1.0f / 15.0f);                                                               // sigma0^2, rusd.jl:537-538
-    hipLaunchKernelGGL(rumba_init_kernel, dim3(gcol), dim3(256), 0, st, d, plan->d_fodf0.p, plan->d_dodf0.p, lam0, sig.p, fodf.p, dodf.p,
-                       dsig.p, tv.p, s2.p);
+    float *f_cur = fodf.p, *f_new = fodf2.p;
+    FIB_HIP(hipMemsetAsync(fodf2.p, 0, sizeof(float) * nC, st));   // (its padding columns are never written again)
+    hipLaunchKernelGGL(rumba_init_kernel, dim3(gcol), dim3(256), 0, st, d, n_order, plan->d_fodf0.p, plan->d_dodf0.p, lam0, sig.p, f_cur, dodf.p,
+                       ir.p, x.p, use_tv ? (float *)nullptr : tv.p, s2.p);          // without TV the term stays 1
     {   // lambda = lambda0 everywhere
         std::vector<float> l0((size_t)d.npad, lam0);
         FIB_HIP(hipMemcpyAsync(lam.p, l0.data(), sizeof(float) * d.npad, hipMemcpyHostToDevice, st));
@@ -445,28 +457,30 @@ extern "C" int fibd_rumba_rec(const fib_rumba_plan *plan, const float *dwi, cons
     }
     FIB_HIP(hipGetLastError());
     for (int it = 0; it < niter; it++) {                          // rumba_sd_iterate!, rusd.jl:266-345
-        { fib::ProfScope prof("rumba_elementwise", st);
-        hipLaunchKernelGGL(rumba_iratio_kernel, dim3((unsigned)fib::cdiv(nD, 256)), dim3(256), 0, st, nD, n_order, sig.p, dsig.p, ir.p, x.p); }
         if ((rc = fib::matrix_plan_run(plan->pT, x.p, ones.p, d.npad, rl.p, it == 0, st)) != FIB_OK) return rc;        // K' (signal .* Iratio)
         if ((rc = fib::matrix_plan_run(plan->pT, dodf.p, ones.p, d.npad, rl2.p, false, st)) != FIB_OK) return rc;     // K' dodf
-        if (use_tv) {
+        if (use_tv) {                                             // TV term + multiplicative update in one pass
             fib::ProfScope prof("rumba_tv", st);
-            TvArgs ta{fodf.p, tv.p, d_ind.p, d_col.p, lam.p, d};
+            TvArgs ta{f_cur, nullptr, d_ind.p, d_col.p, lam.p, d, rl.p, rl2.p, f_new};
             hipLaunchKernelGGL(rumba_tv_kernel, dim3(gmask), dim3(256), 0, st, ta);
+            std::swap(f_cur, f_new);
+        } else {
+            fib::ProfScope prof("rumba_elementwise", st);
+            hipLaunchKernelGGL(rumba_update_kernel, dim3((unsigned)fib::cdiv(nC, 256)), dim3(256), 0, st, nC, rl.p, rl2.p, tv.p, f_cur);
         }
+        if ((rc = fib::matrix_plan_run(plan->pK, f_cur, ones.p, d.npad, dodf.p, it == 0, st)) != FIB_OK) return rc;    // K fodf
         { fib::ProfScope prof("rumba_elementwise", st);
-        hipLaunchKernelGGL(rumba_update_kernel, dim3((unsigned)fib::cdiv(nC, 256)), dim3(256), 0, st, nC, rl.p, rl2.p, tv.p, fodf.p); }
-        if ((rc = fib::matrix_plan_run(plan->pK, fodf.p, ones.p, d.npad, dodf.p, it == 0, st)) != FIB_OK) return rc;   // K fodf
-        { fib::ProfScope prof("rumba_elementwise", st);
-        hipLaunchKernelGGL(rumba_noise_kernel, dim3(gcol), dim3(256), 0, st, d, n_order, sig.p, dodf.p, ir.p, dsig.p, s2.p, snr.p);
-        if (use_tv) {
-            if (ipat_factor == 1) hipLaunchKernelGGL(rumba_stats_kernel, dim3(1), dim3(1024), 0, st, s2.p, nmask, stats.p);
-            hipLaunchKernelGGL(rumba_lambda_kernel, dim3(gmask), dim3(256), 0, st, nmask, ipat_factor, stats.p, s2.p, lam.p);
-        } }
+        const bool need_mean = use_tv && ipat_factor == 1;
+        if (need_mean) FIB_HIP(hipMemsetAsync(stats.p, 0, 2 * sizeof(double), st));
+        hipLaunchKernelGGL(rumba_noise_kernel, dim3(gcol), dim3(256), 0, st, d, n_order, sig.p, dodf.p, ir.p, x.p, s2.p, snr.p,
+                           need_mean ? stats.p : (double *)nullptr);
+        if (use_tv) hipLaunchKernelGGL(rumba_lambda_kernel, dim3(gmask), dim3(256), 0, st, nmask, ipat_factor, stats.p, s2.p, lam.p); }
         FIB_HIP(hipGetLastError());
     }
+    float *fodf_final = f_cur;
     if (niter > 0 && (snr_mean || snr_std)) {                     // mean / std (corrected) of the SNR estimates, rusd.jl:546-547
-        hipLaunchKernelGGL(rumba_stats_kernel, dim3(1), dim3(1024), 0, st, snr.p, nmask, stats.p);
+        FIB_HIP(hipMemsetAsync(stats.p, 0, 2 * sizeof(double), st));
+        hipLaunchKernelGGL(rumba_stats_kernel, dim3(64), dim3(1024), 0, st, snr.p, nmask, stats.p);
         double hs[2];
         FIB_HIP(hipMemcpyAsync(hs, stats.p, sizeof hs, hipMemcpyDeviceToHost, st));
         FIB_HIP(hipStreamSynchronize(st));
@@ -475,7 +489,7 @@ extern "C" int fibd_rumba_rec(const fib_rumba_plan *plan, const float *dwi, cons
         if (snr_mean) *snr_mean = (float)m;
         if (snr_std) *snr_std = (float)std::sqrt(var);
     }
-    PostArgs pa{fodf.p, s2.p, d_ind.p, d, nvox, out->fodf, out->fgm, out->fcsf, out->gfa, out->var};
+    PostArgs pa{fodf_final, s2.p, d_ind.p, d, nvox, out->fodf, out->fgm, out->fcsf, out->gfa, out->var};
     hipLaunchKernelGGL(rumba_post_kernel, dim3(gmask), dim3(256), 0, st, pa);
     PeakArgs5 pk{};
     pk.fodf = out->fodf; pk.fgm = out->fgm; pk.fcsf = out->fcsf; pk.ind = d_ind.p; pk.nb_off = plan->d_nb_off.p; pk.nb_idx = plan->d_nb_idx.p;
