@@ -103,7 +103,60 @@ def stream_case(name, n, seed):
          **{"kw_" + k: v for k, v in kw.items()})
 
 
+def micro_case(name, n, seed):
+    """microscopy regime (stream.jl:547-619): smooth random unit field, mask holes, thresholded vectors"""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    g = rng.normal(size=(n, n, n, 3))
+    for c in range(3):
+        g[..., c] = gaussian_filter(g[..., c], 2.0)
+    g[..., 0] += 0.15
+    g /= np.linalg.norm(g, axis=3, keepdims=True)
+    ov = np.asfortranarray(g.astype(np.float32))
+    mask = (rng.random((n, n, n)) < 0.93).astype(np.uint8)
+    f = np.asfortranarray(rng.random((n, n, n)).astype(np.float32))
+    seed_vol = np.zeros((n, n, n), np.uint8)
+    seed_vol[2::5, 3::4, 1::6] = 1
+    sub = np.zeros((1, 3), np.float32)
+    kw = dict(f_thresh=0.05, ang_thresh=20, step_size=1.0, smooth_coeff=0.0, search_dist=4, search_ang=15.0, len_max=50)
+    r = orc.stream(ov, sub, f=f, mask=mask, seed=seed_vol, nthreads=2, **kw)
+    save(name, ovec=ov, f=f, mask=mask, seed=seed_vol, sublist=sub, npts=r["npts"], seed_index=r["seed_index"], xyz=r["xyz"],
+         **{"kw_" + k: v for k, v in kw.items()})
+
+
+def lcm_case(name, n, seed):
+    """LCM-guided tracking (stream.jl:380-495) on 2-D in-plane data, uniforms from the ABI's counter-based stream"""
+    rng = np.random.default_rng(seed)
+    ovs = []
+    for k in range(2):
+        a = rng.uniform(-0.5, 0.5, (n, n, 1)) + k * np.pi / 2
+        ov = np.zeros((n, n, 1, 3), np.float32, order="F")
+        ov[..., 0], ov[..., 1] = np.cos(a), np.sin(a)
+        ovs.append(ov)
+    mask = (rng.random((n, n, 1)) < 0.95).astype(np.uint8)
+    lcms = np.asfortranarray(rng.random((n, n, 1, 10)).astype(np.float32))
+    lcms[rng.random((n, n, 1)) < 0.05] = 0.0
+    sub = np.array([[0.1, -0.2, 0.0], [0.3, 0.25, 0.0]], np.float32)
+    r = orc.stream(ovs, sub, mask=mask, lcms=lcms, lcm_thresh=0.15, rng_seed=20251003, len_max=40, nthreads=2)
+    save(name, ovec=np.stack(ovs), mask=mask, lcms=lcms, sublist=sub, lcm_thresh=0.15, rng_seed=20251003, len_max=40,
+         npts=r["npts"], seed_index=r["seed_index"], xyz=r["xyz"], flags=r["flags"],
+         uniforms=np.array([[orc.lib().orc_uniform(__import__("ctypes").c_uint64(20251003), __import__("ctypes").c_uint64(line),
+                                                   __import__("ctypes").c_uint32(k)) for k in range(4)] for line in range(4)], np.float32))
+
+
+def rumba_case(name, shape, seed, niter):
+    bval, bvec = phantom.scheme_gqi(3, 30, (1000.0, 2500.0), seed)
+    dwi, _, _ = phantom.make_volume(shape, bval, bvec, seed, noise_frac=0.03, crossing=True)
+    mask = (np.random.default_rng(seed + 1).random(shape) < 0.85).astype(np.uint8)
+    r = orc.rumba_rec(dwi, mask, bval, bvec, fj.sphere_724.vertices, niter=niter)
+    save(name, dwi=dwi, mask=mask, bval=bval, bvec=bvec, niter=niter, fodf=r["fodf"], fgm=r["fgm"], fcsf=r["fcsf"], gfa=r["gfa"],
+         var=r["var"], peak=np.stack(r["peak"]), snr_mean=r["snr_mean"], snr_std=r["snr_std"])
+
+
 if __name__ == "__main__":
+    micro_case("stream_micro_14", 14, seed=21)
+    lcm_case("stream_lcm_20", 20, seed=22)
+    rumba_case("rumba_5x4x4x63_sphere724", (5, 4, 4), seed=23, niter=20)
     dti_case("dti_8x8x8x7", (8, 8, 8), 6, 1, seed=1, nonpos=0.0)
     dti_case("dti_6x5x4x33_nonpositive", (6, 5, 4), 30, 3, seed=7, nonpos=0.03)
     gqi_case("gqi_6x6x6x63_sphere642", (6, 6, 6), "sphere_642", seed=3)
