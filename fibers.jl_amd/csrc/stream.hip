@@ -65,11 +65,15 @@ __global__ __launch_bounds__(256) void stream_field_kernel(const FieldArgs a) {
     if (a.mask_out) a.mask_out[i] = m ? 1 : 0;
 }
 
+struct Pair { int64_t pts, lines; };
+constexpr int SCR_TILE = 16;         // lines per tile of the point scratch
+constexpr int TRACE_SCAN_B = 2048;   // = SCAN_B (lines per block of the scan)
 struct TraceArgs {
     const float4 *field;        // [nvox][nvec]
     const int64_t *seeds;       // [nseed] 0-based linear voxel index
     const float *sublist;       // [nsub][3]
-    float *scratch;             // [2*stride slots][nlines][3]: forward step i -> slot i, backward step j -> slot stride+j
+    float *scratch;             // [nlines/16 tiles][2*stride slots][16 lines][3]: forward step i -> slot i, backward step j -> slot stride+j
+                                // (a tile is one contiguous run that the pack kernel streams; a wave of the trace kernel writes 4 x 192 B per step)
     int32_t *npts, *nfwd;       // [nlines]
     int64_t line0, nlines;      // this batch covers global lines [line0, line0+nlines)
     int nx, ny, nz, nvec, nsub, len_max, stride;
@@ -84,6 +88,13 @@ struct TraceArgs {
     float search_cosang;
     const int32_t *cell_start;  // [G^3 + 1]: the table is sorted by direction cell (x fastest); entries of cell i = [cell_start[i], cell_start[i+1])
     int G;                      // direction grid: cell (floor((v + 1) / h)) per axis, h = 2 / G
+    // second pass of the two-pass scheme (MODE 2): the lines are traced again and written where they belong
+    const Pair *excl, *block_off;   // exclusive scan of the kept lines / points (scan_block_kernel, scan_totals_kernel)
+    int32_t *out_npts;
+    int64_t *out_seed;
+    float *out_xyz;
+    int len_min, trk;
+    float vs[3];
 };
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -124,10 +135,31 @@ __device__ __forceinline__ int lcm_match_edge(int dx, int dy, int dz, int sd0, i
     return 0;
 }
 
-template <int NVEC, bool LCM = false>   // NVEC > 0: compile-time vector count; 0: runtime
+// MODE 0: points into the slot-major scratch + counts (packed later by stream_pack_kernel);  MODE 1: counts only;
+// MODE 2: the counts and their scan are known: trace again, every point goes straight to its place in the packed output
+// (forward points descending from nf-1, backward points ascending from nf: stream.jl:652), no scratch at all.
+template <int NVEC, bool LCM = false, int MODE = 0>   // NVEC > 0: compile-time vector count; 0: runtime
 __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= a.nlines) return;
+    float *ofw = nullptr, *obw = nullptr;
+    if (MODE == 2) {
+        const int n = a.npts[li];
+        if (n < a.len_min) return;                                // stream.jl:769
+        const int nf0 = a.nfwd[li];
+        const Pair e = a.excl[li], bo = a.block_off[li / TRACE_SCAN_B];
+        const int64_t pt = e.pts + bo.pts, l0 = e.lines + bo.lines;
+        int64_t p0;
+        if (a.trk) {
+            reinterpret_cast<int32_t *>(a.out_xyz)[l0 + 3 * pt] = n;                  // write(io, Int32(npts)), trk.jl:472
+            p0 = pt * 3 + l0 + 1;
+        } else {
+            a.out_npts[l0] = n; a.out_seed[l0] = a.line0 + li;
+            p0 = pt * 3;
+        }
+        ofw = a.out_xyz + p0 + (int64_t)(nf0 - 1) * 3;
+        obw = a.out_xyz + p0 + (int64_t)nf0 * 3;
+    }
     const int nvec = NVEC > 0 ? NVEC : a.nvec;
     const int64_t line = a.line0 + li;
     const int64_t iseed = line / a.nsub;
@@ -137,8 +169,8 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
     const float p0x = (float)(sx + 1) + a.sublist[3 * isub];      // pos_now .= seed_vox .+ sub_vox, stream.jl:649
     const float p0y = (float)(sy + 1) + a.sublist[3 * isub + 1];
     const float p0z = (float)(sz + 1) + a.sublist[3 * isub + 2];
-    const int64_t slot_floats = a.nlines * 3;
-    float *dfw = a.scratch + li * 3;                            // next forward slot of this line (advanced per point)
+    constexpr int64_t slot_floats = SCR_TILE * 3;
+    float *dfw = a.scratch + (li / SCR_TILE) * ((int64_t)2 * a.stride * slot_floats) + (li % SCR_TILE) * 3;   // next forward slot of this line
     float *dbw = dfw + (int64_t)a.stride * slot_floats;         // next backward slot
     const char *fbase = reinterpret_cast<const char *>(a.field);   // wave-uniform base; per-lane offsets are 32-bit
     const float fnx = (float)a.nx, fny = (float)a.ny, fnz = (float)a.nz;
@@ -233,7 +265,14 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
                 }
                 isdiff = ivec != ivec_ang;                        // :538
             }
-            {   // push!/prepend! of pos_now (stream.jl:660): slot = step index within this pass
+            if (MODE == 2) {
+                float *d = pass == 0 ? ofw : obw;
+                if (a.trk) {                                      // T.((xyz .+ .5) .* voxel_size), Float64 arithmetic (trk.jl:475-476)
+                    d[0] = (float)(((double)px + 0.5) * (double)a.vs[0]); d[1] = (float)(((double)py + 0.5) * (double)a.vs[1]);
+                    d[2] = (float)(((double)pz + 0.5) * (double)a.vs[2]);
+                } else { d[0] = px; d[1] = py; d[2] = pz; }
+                if (pass == 0) ofw -= 3; else obw += 3;
+            } else if (MODE == 0) {   // push!/prepend! of pos_now (stream.jl:660): slot = step index within this pass
                 float *d = pass == 0 ? dfw : dbw;
                 // LCM runs: the method-difference flag of the point (stream.jl:666) rides in the sign bit of x (x > 0)
                 d[0] = (LCM && isdiff) ? -px : px; d[1] = py; d[2] = pz;
@@ -263,8 +302,7 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
             vx = wx; vy = wy; vz = wz;
         }
     }
-    a.npts[li] = npts;
-    a.nfwd[li] = nf;
+    if (MODE != 2) { a.npts[li] = npts; a.nfwd[li] = nf; }
 }
 
 // ---- microscopy regime: stream_micro_new_point! (stream.jl:547-619) -------------------------------------------
@@ -294,7 +332,7 @@ __global__ __launch_bounds__(1024) void stream_trace_micro_kernel(const TraceArg
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int d = a.search_dist, S = 2 * d + 1;
     const unsigned lin_centre = (unsigned)(d + S * (d + S * d)), lin_last = (unsigned)(S * S * S - 1);
-    const int64_t slot_floats = a.nlines * 3;
+    constexpr int64_t slot_floats = SCR_TILE * 3;
     const float fnx = (float)a.nx, fny = (float)a.ny, fnz = (float)a.nz;
     const float omc = 1.0f - a.smooth;
     for (int64_t li = wave0; li < a.nlines; li += nwaves) {
@@ -306,7 +344,7 @@ __global__ __launch_bounds__(1024) void stream_trace_micro_kernel(const TraceArg
         const float p0x = (float)(sx + 1) + a.sublist[3 * isub];
         const float p0y = (float)(sy + 1) + a.sublist[3 * isub + 1];
         const float p0z = (float)(sz + 1) + a.sublist[3 * isub + 2];
-        float *dfw = a.scratch + li * 3;
+        float *dfw = a.scratch + (li / SCR_TILE) * ((int64_t)2 * a.stride * slot_floats) + (li % SCR_TILE) * 3;
         float *dbw = dfw + (int64_t)a.stride * slot_floats;
         int npts = 0, nf = 0;
         for (int pass = 0; pass < 2; pass++) {
@@ -410,8 +448,8 @@ __global__ __launch_bounds__(1024) void stream_trace_micro_kernel(const TraceArg
 }
 
 // ---- exclusive scan of (kept ? npts : 0, kept ? 1 : 0) over the lines, int64 pairs --------------------
-struct Pair { int64_t pts, lines; };
 constexpr int SCAN_T = 256, SCAN_E = 8, SCAN_B = SCAN_T * SCAN_E;
+static_assert(SCAN_B == TRACE_SCAN_B, "scan block size");
 
 __global__ __launch_bounds__(SCAN_T) void scan_block_kernel(const int32_t *npts, int64_t n, int len_min,
                                                             Pair *excl, Pair *block_tot) {
@@ -482,24 +520,25 @@ struct PackArgs {
     float vs[3];
 };
 
-// 64 lines per workgroup; 16-slot x 64-line blocks of the slot-major scratch are read coalesced into LDS and
-// written out line by line: thread (line tl, quarter q) emits PK_PER consecutive points (96 contiguous bytes).
-// Forward slots are reversed on the way out, backward slots follow (stream.jl:652).
-constexpr int PK_LINES = 64, PK_SLOTS = 16, PK_ROW = PK_LINES * 3 + 1;
-__global__ __launch_bounds__(256) void stream_pack_kernel(const PackArgs a) {
-    __shared__ float tile[2][PK_SLOTS * PK_ROW];
-    __shared__ int smax[2];
-    __shared__ int lcnt[2][PK_LINES];                           // per line: forward / backward point counts (0 if dropped)
-    __shared__ int64_t lpt0[PK_LINES];                          // per line: float index of its first output coordinate
-    const int tid = threadIdx.x;
-    const int64_t line0 = (int64_t)blockIdx.x * PK_LINES;
-    if (tid < 2) smax[tid] = 0;
-    __syncthreads();
-    if (tid < PK_LINES) {
-        const int64_t li = line0 + tid;
-        int nf = 0, nb = 0;
-        int64_t p0 = 0;
-        if (li < a.nlines) {
+// One wave per scratch tile (16 lines), four independent waves per workgroup: no workgroup barriers.  A chunk = 16 slots of
+// the tile = 3 KiB of contiguous scratch: three 16-byte loads per lane, parked in a wave-private LDS tile (rows padded
+// to 52 dwords), then written out line by line: 16 lanes per line, one point each -> a wave instruction emits 4 runs
+// of 192 contiguous bytes.  The next chunk's loads fly during the write-out.  Forward slots are reversed on the way out,
+// backward slots follow (stream.jl:652).
+constexpr int PK_LINES = SCR_TILE, PK_SLOTS = 16, PK_ROW = 52, PK_WAVES = 4;
+static_assert(PK_LINES == 16, "the pack kernel maps 16 lanes to the 16 lines of a tile");
+__global__ __launch_bounds__(PK_WAVES * 64) void stream_pack_kernel(const PackArgs a) {
+    __shared__ __attribute__((aligned(16))) float tile[PK_WAVES][2][PK_SLOTS * PK_ROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tix = (int64_t)blockIdx.x * PK_WAVES + wave;   // scratch tile of this wave
+    const int64_t line0 = tix * PK_LINES;
+    if (line0 >= a.nlines) return;
+    // lanes 0..15: the tile's lines
+    int nf = 0, nb = 0;
+    int64_t p0 = 0;
+    {
+        const int64_t li = line0 + (lane & 15);
+        if (lane < PK_LINES && li < a.nlines) {
             const int n = a.npts[li];
             if (n >= a.len_min) {                               // stream.jl:769
                 nf = a.nfwd[li]; nb = n - nf;
@@ -512,48 +551,56 @@ __global__ __launch_bounds__(256) void stream_pack_kernel(const PackArgs a) {
                     a.out_npts[l0] = n; a.out_seed[l0] = a.line0 + li;
                     p0 = pt * 3;
                 }
-                atomicMax(&smax[0], nf); atomicMax(&smax[1], nb);
             }
         }
-        lcnt[0][tid] = nf; lcnt[1][tid] = nb; lpt0[tid] = p0;
     }
-    __syncthreads();
-    const int lines_here = (int)((a.nlines - line0) < PK_LINES ? (a.nlines - line0) : PK_LINES);
-    const bool colok = tid < lines_here * 3;                    // threads 0..191 own one float column of the 64-line row
-    const int my0 = tid < PK_LINES * 3 ? lcnt[0][tid / 3] : 0, my1 = tid < PK_LINES * 3 ? lcnt[1][tid / 3] : 0;
-    const int cnt0 = smax[0], cnt1 = smax[1];
+    int cnt0 = nf, cnt1 = nb;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { cnt0 = max(cnt0, __shfl_xor(cnt0, o)); cnt1 = max(cnt1, __shfl_xor(cnt1, o)); }
+    cnt0 = __builtin_amdgcn_readfirstlane(cnt0); cnt1 = __builtin_amdgcn_readfirstlane(cnt1);
     const int nch0 = (cnt0 + PK_SLOTS - 1) / PK_SLOTS, nch = nch0 + (cnt1 + PK_SLOTS - 1) / PK_SLOTS;
-    // write-out mapping: 16 lanes per line, one point each -> a wave-instruction emits 4 runs of 192 contiguous bytes
-    const int lg = tid >> 4, pt = tid & 15;
-    float v[PK_SLOTS];
-    auto fetch = [&](int c) {                                   // 16 independent coalesced loads per thread
+    // write-out mapping: lane = (line group lg, point pt); line tl = lg + 4 j
+    const int lg = lane >> 4, pt = lane & 15;
+    int wnf[4], wnb[4];
+    int64_t wp0[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        wnf[j] = __shfl(nf, lg + 4 * j); wnb[j] = __shfl(nb, lg + 4 * j);
+        wp0[j] = ((int64_t)__shfl((int)(p0 >> 32), lg + 4 * j) << 32) | (uint32_t)__shfl((int)(uint32_t)p0, lg + 4 * j);
+    }
+    const float4 *tbase = reinterpret_cast<const float4 *>(a.scratch + tix * ((int64_t)2 * a.stride * PK_LINES * 3));
+    float4 v[3];
+    auto fetch = [&](int c) {                                   // 3 KiB of contiguous scratch
         const int region = c < nch0 ? 0 : 1;
         const int s0 = (region == 0 ? c : c - nch0) * PK_SLOTS;
-        const float *src = a.scratch + (((int64_t)(region == 0 ? 0 : a.stride) + s0) * a.nlines + line0) * 3 + tid;
+        const float4 *src = tbase + ((int64_t)(region == 0 ? 0 : a.stride) + s0) * (PK_LINES * 3 / 4) + lane;
+        const int live = (region == 0 ? cnt0 : cnt1) - s0;     // live slots of the chunk (the scratch ends with the last slot)
 #pragma unroll
-        for (int sl = 0; sl < PK_SLOTS; sl++)                   // only live slots of this column's line
-            v[sl] = (colok && s0 + sl < (region == 0 ? my0 : my1)) ? src[(int64_t)sl * a.nlines * 3] : 0.0f;
-    };
-    if (nch > 0 && tid < PK_LINES * 3) fetch(0);
-    for (int c = 0; c < nch; c++) {
-        float *T = tile[c & 1];
-        if (tid < PK_LINES * 3) {
-#pragma unroll
-            for (int sl = 0; sl < PK_SLOTS; sl++) T[sl * PK_ROW + tid] = v[sl];
+        for (int i = 0; i < 3; i++) {
+            const int f = lane + 64 * i;                        // float4 index within the chunk: slot f / 12
+            v[i] = (f < live * 12) ? src[64 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        __syncthreads();                                        // one barrier per chunk (double-buffered tile)
-        if (c + 1 < nch && tid < PK_LINES * 3) fetch(c + 1);    // next chunk's loads fly during the write-out
+    };
+    if (nch > 0) fetch(0);
+    for (int c = 0; c < nch; c++) {
+        float *T = tile[wave][c & 1];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int f = lane + 64 * i;
+            *reinterpret_cast<float4 *>(T + (f / 12) * PK_ROW + (f % 12) * 4) = v[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (c + 1 < nch) fetch(c + 1);                          // next chunk's loads fly during the write-out
         const int region = c < nch0 ? 0 : 1;
         const int sidx = (region == 0 ? c : c - nch0) * PK_SLOTS + pt;
 #pragma unroll
-        for (int j = 0; j < PK_LINES / 16; j++) {
-            const int tl = lg + 16 * j;
-            const int nf = lcnt[0][tl];
-            if (sidx < (region == 0 ? nf : lcnt[1][tl])) {
-                const int64_t p = region == 0 ? (int64_t)(nf - 1 - sidx) : (int64_t)nf + sidx;
+        for (int j = 0; j < 4; j++) {
+            const int tl = lg + 4 * j;
+            if (sidx < (region == 0 ? wnf[j] : wnb[j])) {
+                const int64_t p = region == 0 ? (int64_t)(wnf[j] - 1 - sidx) : (int64_t)wnf[j] + sidx;
                 struct P3 { float x, y, z; };
                 const float *t = T + pt * PK_ROW + tl * 3;
-                float *d = a.out_xyz + lpt0[tl] + p * 3;
+                float *d = a.out_xyz + wp0[j] + p * 3;
                 if (a.trk)                                      // T.((xyz .+ .5) .* voxel_size), Float64 arithmetic (trk.jl:475-476)
                     *reinterpret_cast<P3 *>(d) =
                         P3{(float)(((double)t[0] + 0.5) * (double)a.vs[0]), (float)(((double)t[1] + 0.5) * (double)a.vs[1]),
@@ -561,6 +608,97 @@ __global__ __launch_bounds__(256) void stream_pack_kernel(const PackArgs a) {
                 else
                     *reinterpret_cast<P3 *>(d) = P3{t[0], t[1], t[2]};
             }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Default pack kernel: one workgroup per scratch tile.  The kept lines of a tile occupy ONE contiguous range of the packed
+// output (or of the .trk body), so the workgroup assembles that whole range in LDS -- thread = (slot, line) reads its
+// 12-byte point from the contiguous tile (coalesced) and drops it at its final position -- and then streams the range
+// out with 16-byte stores aligned to the output address (fill-like: 12-byte stores in 192-byte runs reached 2.7 TB/s,
+// aligned 16-byte stores of whole lines reach twice that).  LDS = 16 (len_max + 2) points; longer lines than the LDS
+// holds go through stream_pack_kernel above.
+__global__ __launch_bounds__(256) void stream_pack_tile_kernel(const PackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float obuf[];
+    __shared__ int s_nf[PK_LINES], s_nb[PK_LINES], s_o[PK_LINES];   // per line: forward / backward counts (0 if dropped), offset in obuf
+    __shared__ int s_cnt[4];                                        // max forward, max backward, range length (floats), misalignment
+    __shared__ int64_t s_g0;                                        // first float of the range in out_xyz
+    const int tid = threadIdx.x;
+    const int64_t line0 = (int64_t)blockIdx.x * PK_LINES;
+    if (tid < 64) {
+        const int64_t li = line0 + tid;
+        int nf = 0, nb = 0, n = 0;
+        int64_t p0 = 0, gs = INT64_MAX, ge = -1;
+        if (tid < PK_LINES && li < a.nlines) {
+            n = a.npts[li];
+            if (n >= a.len_min) {                               // stream.jl:769
+                nf = a.nfwd[li]; nb = n - nf;
+                const Pair e = a.excl[li], bo = a.block_off[li / SCAN_B];
+                const int64_t pt = a.out_pt0 + e.pts + bo.pts, l0 = a.out_line0 + e.lines + bo.lines;
+                if (a.trk) { p0 = pt * 3 + l0 + 1; gs = p0 - 1; }   // the Int32 point count precedes the points (trk.jl:472)
+                else { a.out_npts[l0] = n; a.out_seed[l0] = a.line0 + li; p0 = pt * 3; gs = p0; }
+                ge = p0 + (int64_t)n * 3;
+            } else n = 0;
+        }
+        int mf = nf, mb = nb;
+        int64_t g0 = gs, g1 = ge;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            mf = max(mf, __shfl_xor(mf, o)); mb = max(mb, __shfl_xor(mb, o));
+            const int64_t og0 = ((int64_t)__shfl_xor((int)(g0 >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)g0, o);
+            const int64_t og1 = ((int64_t)__shfl_xor((int)(g1 >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)g1, o);
+            g0 = og0 < g0 ? og0 : g0; g1 = og1 > g1 ? og1 : g1;
+        }
+        const int mis = g1 >= 0 ? (int)((reinterpret_cast<uintptr_t>(a.out_xyz + g0) >> 2) & 3) : 0;
+        if (tid < PK_LINES) {
+            s_nf[tid] = nf; s_nb[tid] = nb; s_o[tid] = n > 0 ? (int)(p0 - g0) + mis : 0;
+            if (a.trk && n > 0) obuf[(int)(p0 - g0) + mis - 1] = __int_as_float(n);
+        }
+        if (tid == 0) { s_cnt[0] = mf; s_cnt[1] = mb; s_cnt[2] = g1 >= 0 ? (int)(g1 - g0) : 0; s_cnt[3] = mis; s_g0 = g0; }
+    }
+    __syncthreads();
+    const int cnt0 = s_cnt[0], cnt1 = s_cnt[1], len = s_cnt[2], mis = s_cnt[3];
+    if (len == 0) return;
+    const int nch0 = (cnt0 + 15) >> 4, nch = nch0 + ((cnt1 + 15) >> 4);
+    const int l = tid & 15, sl = tid >> 4;                      // thread = (line, slot within the 16-slot chunk)
+    const int nf = s_nf[l], nb = s_nb[l], o = s_o[l];
+    struct P3 { float x, y, z; };
+    const P3 *tbase = reinterpret_cast<const P3 *>(a.scratch + (int64_t)blockIdx.x * ((int64_t)2 * a.stride * PK_LINES * 3)) + tid;
+    for (int c0 = 0; c0 < nch; c0 += 4) {
+        P3 v[4];
+        int pos[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int c = c0 + i;
+            const int region = c < nch0 ? 0 : 1;
+            const int s = ((region == 0 ? c : c - nch0) << 4) + sl;
+            const bool ok = c < nch && s < (region == 0 ? nf : nb);
+            pos[i] = ok ? (region == 0 ? nf - 1 - s : nf + s) : -1;
+            if (ok) v[i] = tbase[((int64_t)(region == 0 ? 0 : a.stride) + s - sl) * PK_LINES];
+            else v[i] = P3{0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (pos[i] < 0) continue;
+            float *d = obuf + o + pos[i] * 3;
+            if (a.trk) {                                        // T.((xyz .+ .5) .* voxel_size), Float64 arithmetic (trk.jl:475-476)
+                d[0] = (float)(((double)v[i].x + 0.5) * (double)a.vs[0]); d[1] = (float)(((double)v[i].y + 0.5) * (double)a.vs[1]);
+                d[2] = (float)(((double)v[i].z + 0.5) * (double)a.vs[2]);
+            } else { d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; }
+        }
+    }
+    __syncthreads();
+    // obuf[mis .. mis + len) -> out_xyz[g0 .. g0 + len): obuf[4k..4k+3] lands on a 16-byte aligned address
+    float *gbase = a.out_xyz + s_g0 - mis;
+    const int nq = (mis + len + 3) >> 2;
+    for (int k = tid; k < nq; k += 256) {
+        const float4 q = reinterpret_cast<const float4 *>(obuf)[k];
+        if (4 * k >= mis && 4 * k + 4 <= mis + len) *reinterpret_cast<float4 *>(gbase + 4 * k) = q;
+        else {
+            const float e[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (4 * k + j >= mis && 4 * k + j < mis + len) gbase[4 * k + j] = e[j];
         }
     }
 }
@@ -593,6 +731,8 @@ struct fib_stream_job {
     struct ViewP { Pair *p = nullptr; } excl, block_tot, total;
     int64_t kept_lines = 0, kept_pts = 0;
     bool lcm = false;               // LCM run: the method-difference flag rides in the sign bit of x until unpacked
+    bool two_pass = false;          // no point scratch: the pack call traces the kept lines again, straight into the output
+    TraceArgs ta{};                 // (two_pass) the arguments of the first pass
 };
 
 extern "C" void fib_stream_job_destroy(fib_stream_job *job) {
@@ -679,7 +819,11 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
     auto bail = [&](int code) { fib_stream_job_destroy(job); return code; };
     const int nblocks = (int)fib::cdiv(nl, SCAN_B);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t b_scratch = up((size_t)nl * job->stride * 2 * 3 * sizeof(float));
+    {
+        const char *e = getenv("FIBERS_STREAM_TWOPASS");
+        job->two_pass = prm->search_dist == 0 && !lin.lcms && e && e[0] == '1';
+    }
+    const size_t b_scratch = job->two_pass ? 0 : up((size_t)fib::cdiv(nl, SCR_TILE) * SCR_TILE * job->stride * 2 * 3 * sizeof(float));
     const size_t b_i32 = up((size_t)nl * sizeof(int32_t)), b_excl = up((size_t)nl * sizeof(Pair));
     const size_t b_btot = up((size_t)nblocks * sizeof(Pair)), b_tot = 256;
     const size_t sbytes = b_scratch + 2 * b_i32 + b_excl + b_btot + b_tot;
@@ -778,6 +922,13 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
         else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, true>), dim3(grid), dim3(256), 0, st, ta);
         else                     hipLaunchKernelGGL((stream_trace_kernel<0, true>), dim3(grid), dim3(256), 0, st, ta);
     } else
+    if (job->two_pass) {
+        fib::ProfScope prof("stream_count", st);
+        if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1, false, 1>), dim3(grid), dim3(256), 0, st, ta);
+        else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, false, 1>), dim3(grid), dim3(256), 0, st, ta);
+        else                     hipLaunchKernelGGL((stream_trace_kernel<0, false, 1>), dim3(grid), dim3(256), 0, st, ta);
+        job->ta = ta;
+    } else
     { fib::ProfScope prof("stream_trace", st);
     if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1>), dim3(grid), dim3(256), 0, st, ta);
     else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3>), dim3(grid), dim3(256), 0, st, ta);
@@ -810,6 +961,36 @@ __global__ __launch_bounds__(256) void stream_unpack_flags_kernel(float *xyz, ui
 
 static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, void *stream);
 
+// whole-tile kernel while 16 (len_max + 2) points (+ the .trk headers and the alignment slack) fit in LDS
+static int launch_pack(fib_stream_job *job, const PackArgs &pa, hipStream_t st) {
+    const size_t smem = ((size_t)PK_LINES * job->stride * 3 + PK_LINES + 8) * sizeof(float);
+    const char *e = getenv("FIBERS_PACK_KERNEL");
+    if (smem <= 120 * 1024 && !(e && e[0] == 'w')) {
+        if (smem > 48 * 1024)
+            FIB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stream_pack_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(stream_pack_tile_kernel, dim3((unsigned)fib::cdiv(job->nlines, PK_LINES)), dim3(256), smem, st, pa);
+    } else
+        hipLaunchKernelGGL(stream_pack_kernel, dim3((unsigned)fib::cdiv(job->nlines, PK_LINES * PK_WAVES)), dim3(PK_WAVES * 64), 0, st, pa);
+    FIB_HIP(hipGetLastError());
+    return FIB_OK;
+}
+
+// second pass of a two-pass job: the same trace, every kept line written straight to its place (packed arrays or .trk body)
+static int retrace(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, const float *voxel_size, void *stream) {
+    TraceArgs ta = job->ta;
+    ta.excl = job->excl.p; ta.block_off = job->block_tot.p;
+    ta.out_npts = npts; ta.out_seed = seed_index; ta.out_xyz = xyz; ta.len_min = job->prm.len_min;
+    if (voxel_size) { ta.trk = 1; ta.vs[0] = voxel_size[0]; ta.vs[1] = voxel_size[1]; ta.vs[2] = voxel_size[2]; }
+    const unsigned grid = (unsigned)fib::cdiv(job->nlines, 256);
+    hipStream_t st = (hipStream_t)stream;
+    fib::ProfScope prof(voxel_size ? "stream_write_trk" : "stream_write", st);
+    if (ta.nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1, false, 2>), dim3(grid), dim3(256), 0, st, ta);
+    else if (ta.nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, false, 2>), dim3(grid), dim3(256), 0, st, ta);
+    else                   hipLaunchKernelGGL((stream_trace_kernel<0, false, 2>), dim3(grid), dim3(256), 0, st, ta);
+    FIB_HIP(hipGetLastError());
+    return FIB_OK;
+}
+
 extern "C" int fibd_stream_pack_flags(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, uint8_t *flags, void *stream) {
     int rc = pack_plain(job, npts, seed_index, xyz, stream);
     if (rc != FIB_OK || job->kept_pts == 0) return rc;
@@ -831,6 +1012,7 @@ static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, f
     FIB_CHECK(npts && seed_index && xyz, FIB_ERR_INVALID, "NULL output buffer");
     fib::DeviceGuard guard;
     FIB_HIP(hipSetDevice(job->device));
+    if (job->two_pass) return retrace(job, npts, seed_index, xyz, nullptr, stream);
     PackArgs pa{};
     pa.scratch = job->scratch; pa.npts = job->npts.p; pa.nfwd = job->nfwd.p;
     pa.excl = job->excl.p; pa.block_off = job->block_tot.p;
@@ -838,7 +1020,7 @@ static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, f
     pa.nlines = job->nlines; pa.line0 = 0; pa.out_line0 = 0; pa.out_pt0 = 0;
     pa.stride = job->stride; pa.len_min = job->prm.len_min;
     fib::ProfScope prof("stream_pack", (hipStream_t)stream);
-    hipLaunchKernelGGL(stream_pack_kernel, dim3((unsigned)fib::cdiv(job->nlines, PK_LINES)), dim3(256), 0, (hipStream_t)stream, pa);
+    { const int rcl = launch_pack(job, pa, (hipStream_t)stream); if (rcl != FIB_OK) return rcl; }
     FIB_HIP(hipGetLastError());
     return FIB_OK;                                      // (LCM jobs: x still carries the flag bit; the caller strips it)
 }
@@ -850,6 +1032,7 @@ extern "C" int fibd_stream_pack_trk(fib_stream_job *job, const float voxel_size[
     FIB_CHECK(body != nullptr, FIB_ERR_INVALID, "NULL output buffer");
     fib::DeviceGuard guard;
     FIB_HIP(hipSetDevice(job->device));
+    if (job->two_pass) return retrace(job, nullptr, nullptr, reinterpret_cast<float *>(body), voxel_size, stream);
     PackArgs pa{};
     pa.scratch = job->scratch; pa.npts = job->npts.p; pa.nfwd = job->nfwd.p;
     pa.excl = job->excl.p; pa.block_off = job->block_tot.p;
@@ -858,7 +1041,7 @@ extern "C" int fibd_stream_pack_trk(fib_stream_job *job, const float voxel_size[
     pa.stride = job->stride; pa.len_min = job->prm.len_min;
     pa.trk = 1; pa.vs[0] = voxel_size[0]; pa.vs[1] = voxel_size[1]; pa.vs[2] = voxel_size[2];
     fib::ProfScope prof("stream_pack_trk", (hipStream_t)stream);
-    hipLaunchKernelGGL(stream_pack_kernel, dim3((unsigned)fib::cdiv(job->nlines, PK_LINES)), dim3(256), 0, (hipStream_t)stream, pa);
+    { const int rcl = launch_pack(job, pa, (hipStream_t)stream); if (rcl != FIB_OK) return rcl; }
     FIB_HIP(hipGetLastError());
     return FIB_OK;
 }

@@ -191,14 +191,15 @@ def stream_field_device(ovec: List, f: Optional[List] = None, f_thresh: float = 
 
 def stream_device(field, shape, seeds, sublist, len_min=3, len_max=None, ang_thresh=45, step_size=0.5,
                   smooth_coeff=0.2, stream=None, want_all_npts=False, search_dist=0, search_ang=10,
-                  lcms=None, lcm_thresh=0.099, strdims=(0, 1), rng_seed=0):
+                  lcms=None, lcm_thresh=0.099, strdims=(0, 1), rng_seed=0, xyz_out=None):
     """Trace + pack on the GPU.  field: [nvox, nvec, 4] from stream_field_device; seeds: int64 CUDA tensor of
     0-based column-major voxel indices (findall order); sublist: float32 CUDA [nsub, 3].
     search_dist > 0: microscopy regime (stream.jl:547-619; reference defaults there: search_dist 15, search_ang 10,
     ang_thresh 20, step_size 1, smooth_coeff 0, one zero sub-voxel offset).
     lcms (float32 CUDA [10, nvox], planar like MRI.vol[nx,ny,nz,10]): LCM-guided tracking (stream.jl:380-495) over the
     in-plane dimensions `strdims`, uniforms from the ABI's counter-based stream (`rng_seed`); adds `flags` uint8 [npoints].
-    Returns dict(npts int32 [nlines], seed_index int64 [nlines], xyz float32 [npoints, 3])."""
+    xyz_out: optional callable npoints -> float32 CUDA tensor of at least 3 * npoints elements to pack the points into (any
+    4-byte alignment).  Returns dict(npts int32 [nlines], seed_index int64 [nlines], xyz float32 [npoints, 3])."""
     import torch
     _chk_dev(field, torch.float32, "field")
     _chk_dev(seeds, torch.int64, "seeds")
@@ -221,7 +222,8 @@ def stream_device(field, shape, seeds, sublist, len_min=3, len_max=None, ang_thr
         dev = field.device
         out = dict(npts=torch.empty(nl.value, dtype=torch.int32, device=dev),
                    seed_index=torch.empty(nl.value, dtype=torch.int64, device=dev),
-                   xyz=torch.empty((npnt.value, 3), dtype=torch.float32, device=dev))
+                   xyz=torch.empty((npnt.value, 3), dtype=torch.float32, device=dev) if xyz_out is None
+                   else xyz_out(npnt.value)[:3 * npnt.value].view(npnt.value, 3))
         if lcms is None:
             _lib.check(L.fibd_stream_pack(job, out["npts"].data_ptr(), out["seed_index"].data_ptr(), out["xyz"].data_ptr(), sp))
         else:

@@ -105,6 +105,41 @@ def test_stream_device_tier(fj, orc):
     assert np.array_equal(out["all_npts"].cpu().numpy(), ref["all_npts"])
 
 
+@pytest.mark.parametrize("len_max,nvec", [(None, 1), (40, 3), (3000, 1)])
+def test_stream_pack_paths_agree(fj, orc, monkeypatch, len_max, nvec):
+    """The three ways the points reach the packed arrays -- whole-tile LDS pack (default), wave pack (long lines), second
+    trace straight into the output (no point scratch) -- give the same bytes, at every 4-byte alignment of xyz."""
+    import torch
+    n = 22
+    F = _fields(n, 11)
+    ovs = [F["circ"], F["wavy"], F["noisy"]][:nvec]
+    mask = (np.random.default_rng(3).random((n, n, n)) < 0.97).astype(np.uint8)
+    sub = np.array([[0.0, 0.0, 0.0], [0.3, -0.3, 0.2], [-0.2, 0.1, 0.4]], np.float32)
+    nvox = n ** 3
+    o = [torch.from_numpy(np.ascontiguousarray(ov.reshape(nvox, 3, order="F").T)).cuda() for ov in ovs]
+    m = torch.from_numpy(mask.reshape(-1, order="F").copy()).cuda()
+    field, mout = fj.stream_field_device(o, mask=m)
+    seeds = torch.nonzero(mout).flatten()
+    subd = torch.from_numpy(sub).cuda()
+    kw = dict(len_max=len_max, ang_thresh=60 if len_max == 3000 else 45)
+    ref = orc.stream(ovs if nvec > 1 else ovs[0], sub, mask=mask, nthreads=4, **kw)
+    res = []
+    for env in ({}, {"FIBERS_PACK_KERNEL": "w"}, {"FIBERS_STREAM_TWOPASS": "1"}):
+        for k in ("FIBERS_PACK_KERNEL", "FIBERS_STREAM_TWOPASS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for shift in range(4):
+            out = fj.stream_device(field, (n, n, n), seeds, subd, xyz_out=lambda npnt: torch.full((3 * npnt + 8,), -7.0, device="cuda")[shift:], **kw)
+            torch.cuda.synchronize()
+            assert np.array_equal(out["npts"].cpu().numpy(), ref["npts"]), (env, shift)
+            assert np.array_equal(out["seed_index"].cpu().numpy(), ref["seed_index"]), (env, shift)
+            assert np.array_equal(out["xyz"].cpu().numpy(), ref["xyz"]), (env, shift)
+            base = out["xyz"].untyped_storage()
+            full = torch.empty(0, dtype=torch.float32, device="cuda").set_(base)
+            assert float(full[:shift].sum()) == -7.0 * shift and bool((full[shift + out["xyz"].numel():] == -7.0).all()), "wrote outside the range"
+
+
 def _micro_case(n, seed):
     rng = np.random.default_rng(seed)
     # smooth random unit field + holes in the mask + a few zero vectors
