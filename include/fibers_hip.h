@@ -206,7 +206,9 @@ int fibd_stream_field(int32_t nvec, int64_t nvox, const float *const *ovec, cons
  * picking, non-LCM, macro scale).  seeds: int64 [nseed] 0-based column-major linear voxel indices
  * in the reference's findall order; sublist [nsub*3] (xyz per offset; caller-generated, stream.jl:176-181).
  * Traces into library-owned scratch, applies len_min (stream.jl:769) and computes output offsets.
- * Synchronises `stream`; returns the number of kept lines and their total point count. */
+ * Synchronises `stream`; returns the number of kept lines and their total point count.
+ * field4, seeds and sublist must stay valid and unchanged until the job has been packed (the low-memory
+ * mode FIBERS_STREAM_TWOPASS=1 keeps no point scratch: the pack call traces the kept lines again). */
 int fibd_stream_trace(const fib_stream_params *prm, const float *field4, const int64_t *seeds, int64_t nseed,
                       const float *sublist, int32_t nsub, void *stream,
                       fib_stream_job **job, int64_t *nlines, int64_t *npoints);
