@@ -45,7 +45,10 @@ struct GemmArgs {
     unsigned long long *dbg;      // timing experiments only (FIBERS_GEMM3_STAMP): 6 words per workgroup
     const float *Aextra;          // split-bf16 kernel: f32 coefficients of the NX extra rows [ntile_m][Kpad/16][NX][16]
     int vec_ok;                   // split-bf16 kernel: output rows are 16-byte aligned (dwordx4 stores allowed)
-    const int32_t *rowA, *rowB;   // optional output-row map for rows < nrow0: row r goes to frames rowA[r] and rowB[r] (>= 0)
+    const int32_t *rowA, *rowB;   // optional output-row map for rows < nrow0: row r goes to frames rowA[r] and rowB[r] (>= 0)    // split-bf16 kernel, unscaled outputs (GQI): voxels holding a +Inf sample are listed and recomputed by odf_inf_fix_kernel
+    // (Inf has no three-piece split: Inf - Inf = NaN; the reference's A*s gives +-Inf rows there)
+    int32_t *fix_count, *fix_list;
+    int fix_cap;
 };
 
 // scheduling hint: spread one k-step's fragment reads (ds_read2_b32 = 2 fragments) between the previous
@@ -64,6 +67,14 @@ __device__ __forceinline__ void interleave_ds_mfma() {
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// s[s .< 0] .= 0 (gqi.jl:140) / max.(X, 0) (dsi.jl:209): a NaN sample stays NaN, -Inf becomes 0.  v_max_f32 would
+// return 0 for NaN; gfx950's v_maximum3_f32 is the NaN-propagating IEEE-754-2019 maximum.
+__device__ __forceinline__ float clamp_sample(float x) {
+    float c;
+    asm("v_maximum3_f32 %0, %1, 0, 0" : "=v"(c) : "v"(x));
+    return c;
+}
 
 // On gfx950 the f32-input MFMA runs on the same FMA lanes as the vector ALU: every VALU instruction a wave
 // issues costs the SIMD ~4 cycles of MFMA time whether it sits between MFMAs or after them (measured with
@@ -89,7 +100,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[M
     // ---- epilogue: the two k-halves of a voxel live in lanes l and l^32 -----------------------------------
     float pm = fmaxf(vmax, __shfl_xor(vmax, 32));
     float pn = vnf + __shfl_xor(vnf, 32);
-    const bool nonfinite = pn != pn;                    // a NaN sample makes every output NaN (NaN * A[v,i] for all v)
+    const bool nonfinite = pn != pn;                    // the voxel holds a NaN or +Inf sample (after the clamp)
     const bool valid = lv && (pm > 0.0f || nonfinite);
     const bool do_scale = a.scale_frame >= 0;
     float scale = 1.0f;
@@ -97,7 +108,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, f32x16 (&acc)[M
         const float s = sraw < 0.0f ? 0.0f : sraw;
         scale = 1.0f / (a.scale_coef * s);              // p ./ sum(p), dsi.jl:225 (0 -> Inf/NaN like the reference)
     }
-    if (nonfinite) scale = __builtin_nanf("");
+    // DSI: the reference's FFT smears a NaN / +Inf sample over the whole voxel and p ./ sum(p) makes it NaN everywhere.
+    // GQI: o = A*s propagates on its own (NaN * a = NaN, Inf * a = +-Inf, Inf * 0 = NaN) exactly as the reference's mul!.
+    if (nonfinite && do_scale) scale = __builtin_nanf("");
     const bool plain = __all(valid && !nonfinite) && !do_scale;   // wave-uniform: store the accumulators as they are
     const float mulv = valid ? scale : 0.0f;
 #pragma unroll
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
 #pragma unroll
     for (int x = 0; x < NX; x++) xacc[x] = 0.0f;
     float vmax = 0.0f;                                  // running max of the samples  -> "any sample > 0"
-    float vnf = 0.0f;                                   // becomes NaN once a sample is NaN or +-Inf
+    float vnf = 0.0f;                                   // becomes NaN once a clamped sample is NaN or +Inf
 
     load_B(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): a builtin, so that hipcc's own wait-count bookkeeping sees it
@@ -244,18 +257,18 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
 #pragma unroll
             for (int kk = 0; kk < KT / 2; kk++) {
                 const float s = braw[kk];
-                bcur[kk] = fmaxf(s, 0.0f);
+                bcur[kk] = clamp_sample(s);
                 vmax = fmaxf(vmax, ((eff >> (2 * kk)) & 1u) ? s : 0.0f);
-                vnf = __builtin_fmaf(s, 0.0f, vnf);
+                vnf = __builtin_fmaf(bcur[kk], 0.0f, vnf);
             }
         } else {
 #pragma unroll
             for (int kk = 0; kk < KT / 2; kk++) {
                 const float s = braw[kk];
                 // raw v_max_f32: fmaxf() would add a canonicalising v_max(s,s) per sample
-                asm("v_max_f32 %0, 0, %1" : "=v"(bcur[kk]) : "v"(s));
+                bcur[kk] = clamp_sample(s);
                 asm("v_max_f32 %0, %1, %2" : "=v"(vmax) : "v"(vmax), "v"(s));
-                vnf = __builtin_fmaf(s, 0.0f, vnf);
+                vnf = __builtin_fmaf(bcur[kk], 0.0f, vnf);
             }
         }
         if (t + 1 < ntiles) {
@@ -305,7 +318,7 @@ __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[
     const int col = lane & 31, kh = lane >> 5;
     float pm = fmaxf(vmax, __shfl_xor(vmax, 32));
     float pn = vnf + __shfl_xor(vnf, 32);
-    const bool nonfinite = pn != pn;                    // a NaN sample makes every output NaN (NaN * A[v,i] for all v)
+    const bool nonfinite = pn != pn;                    // the voxel holds a NaN or +Inf sample (after the clamp)
     const bool valid = lv && (pm > 0.0f || nonfinite);
     const bool do_scale = a.scale_frame >= 0;
     float scale = 1.0f;
@@ -313,7 +326,14 @@ __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[
         const float s = sraw < 0.0f ? 0.0f : sraw;
         scale = 1.0f / (a.scale_coef * s);              // p ./ sum(p), dsi.jl:225 (0 -> Inf/NaN like the reference)
     }
-    if (nonfinite) scale = __builtin_nanf("");
+    // DSI: the reference's FFT smears a NaN / +Inf sample over the whole voxel and p ./ sum(p) makes it NaN everywhere.
+    // GQI: a NaN sample gives NaN pieces and a NaN column on its own; a +Inf sample too (Inf - Inf = NaN in the split), but
+    // the reference's A*s has +-Inf rows there: the voxel is listed and odf_inf_fix_kernel recomputes its column.
+    if (nonfinite && do_scale) scale = __builtin_nanf("");
+    if (!do_scale && a.fix_list != nullptr && tile_m == 0 && kh == 0 && lv && pm == INFINITY) {
+        const int slot = atomicAdd(a.fix_count, 1);
+        if (slot < a.fix_cap) a.fix_list[slot] = (int32_t)vox;
+    }
     const bool plain = __all(valid && !nonfinite) && !do_scale;   // wave-uniform: store the accumulators as they are
     const float mulv = valid ? scale : 0.0f;
 #pragma unroll
@@ -538,11 +558,11 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
         for (int jj = 0; jj < 4; jj++) {
             const float x0 = braw[2 * jj], x1 = braw[2 * jj + 1];
             float c0, c1;
-            asm("v_max_f32 %0, 0, %1" : "=v"(c0) : "v"(x0));
-            asm("v_max_f32 %0, 0, %1" : "=v"(c1) : "v"(x1));
+            c0 = clamp_sample(x0);
+            c1 = clamp_sample(x1);
             asm("v_max3_f32 %0, %1, %2, %3" : "=v"(vmax) : "v"(vmax), "v"(x0), "v"(x1));
-            vnf = __builtin_fmaf(x0, 0.0f, vnf);
-            vnf = __builtin_fmaf(x1, 0.0f, vnf);
+            vnf = __builtin_fmaf(c0, 0.0f, vnf);
+            vnf = __builtin_fmaf(c1, 0.0f, vnf);
             const uint32_t h = cvt_pk_bf16(c0, c1);
             const float r0 = c0 - __uint_as_float(h << 16), r1 = c1 - __uint_as_float(h & 0xffff0000u);      // exact
             const uint32_t m = cvt_pk_bf16(r0, r1);
@@ -677,7 +697,7 @@ __global__ __launch_bounds__(1024) void mask_scan_kernel(int2 *__restrict__ bloc
     }
     int2 run = tid ? part[tid - 1] : make_int2(0, 0);
     for (int i = lo; i < hi; i++) { const int2 c = blockcnt[i]; blockcnt[i] = run; run.x += c.x; run.y += c.y; }
-    if (tid == 1023) { totals[0] = part[1023].x; totals[1] = part[1023].y; }
+    if (tid == 1023) { totals[0] = part[1023].x; totals[1] = part[1023].y; totals[2] = 0; }   // [2]: length of the +Inf voxel list
 }
 __global__ __launch_bounds__(256) void mask_write_kernel(const uint8_t *__restrict__ mask, int64_t nvox, const int2 *__restrict__ blockoff,
                                                         int32_t *__restrict__ vidx, int32_t *__restrict__ tiles) {
@@ -711,7 +731,6 @@ __global__ __launch_bounds__(256) void zero_dead_kernel(const ZeroArgs z) {
     // ms on the ball mask, i.e. half the fill rate).
     if (z.nlive[0] == z.nvox) return;                       // nothing outside the mask
     const int64_t v0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (v0 >= z.nvox) return;
     const int nr = z.n0 + z.n1 + 12;
     const int per = (nr + ZROWS - 1) / ZROWS;
     const int r0 = blockIdx.y * per, r1 = r0 + per < nr ? r0 + per : nr;
@@ -734,12 +753,12 @@ __global__ __launch_bounds__(256) void zero_dead_kernel(const ZeroArgs z) {
             for (; q + 768 < nq; q += nb * 1024) { d[q] = zero4; d[q + 256] = zero4; d[q + 512] = zero4; d[q + 768] = zero4; }
             for (int i = 0; i < 4; i++) if (q + 256 * i < nq) d[q + 256 * i] = zero4;
         };
-        if (blockIdx.x * 1024ll >= z.nvox) return;
         clear(z.out0, (int64_t)z.n0 * z.nvox);
         clear(z.out1, (int64_t)z.n1 * z.nvox);
         for (int k = 0; k < 3; k++) { clear(z.peak[k], 3 * z.nvox); clear(z.qa[k], z.nvox); }
         return;
     }
+    if (v0 >= z.nvox) return;
     bool dead[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) dead[i] = v0 + i < z.nvox && (everything || z.mask[v0 + i] == 0);
@@ -753,6 +772,21 @@ __global__ __launch_bounds__(256) void zero_dead_kernel(const ZeroArgs z) {
         if (all && (reinterpret_cast<uintptr_t>(row) & 15) == 0) { *reinterpret_cast<float4 *>(row + v0) = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
 #pragma unroll
         for (int i = 0; i < 4; i++) if (dead[i]) row[v0 + i] = 0.0f;
+    }
+}
+
+// Columns of voxels with a +Inf sample, recomputed as a plain f32 fma chain over the frames (the reference's mul!(o, A, s):
+// Inf * a = +-Inf, Inf * 0 = NaN, +Inf - Inf = NaN).  G is column-major [M x K].  Almost always an empty list.
+struct InfFixArgs { const float *G, *S; float *out; const int32_t *count, *list; int cap, M, K; int64_t stride; };
+__global__ __launch_bounds__(256) void odf_inf_fix_kernel(const InfFixArgs f) {
+    const int n = f.count[0] < f.cap ? f.count[0] : f.cap;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int64_t vox = f.list[i];
+        for (int row = threadIdx.x; row < f.M; row += 256) {
+            float o = 0.0f;
+            for (int k = 0; k < f.K; k++) o = __builtin_fmaf(f.G[row + (size_t)f.M * k], clamp_sample(f.S[(int64_t)k * f.stride + vox]), o);
+            f.out[(int64_t)row * f.stride + vox] = o;
+        }
     }
 }
 
@@ -1508,6 +1542,7 @@ __global__ __launch_bounds__(256) void qa_normalize_kernel(float *q0, float *q1,
 // ------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------
+constexpr int INF_FIX_CAP = 1 << 16;   // voxels with a +Inf sample that one call repairs (more: their columns stay NaN)
 struct fib_odf_plan {
     int device = 0;
     int nvol = 0, nvert = 0, nrows = 0, nrow0 = 0;   // nrow0 = rows that go to the pdf output (DSI), else 0
@@ -1525,13 +1560,15 @@ struct fib_odf_plan {
     fib::DevBuf<float> At, verts;
     fib::DevBuf<uint16_t> At3;                       // split-bf16 image of G (odf_gemm3_kernel), empty in f32-MFMA mode
     fib::DevBuf<float> Aextra;                       // f32 coefficients of the NX extra rows [ntile_m][NX][Kpad]
+    fib::DevBuf<float> Gdev;                         // G, column-major [gM x gK] (odf_inf_fix_kernel)
+    fib::DevBuf<int32_t> inf_list;                   // voxels with a +Inf sample (GQI, split-bf16 kernel)
     bool split_bf16 = false;
     fib::DevBuf<uint32_t> effbits;
     fib::DevBuf<int32_t> nbr, nbr64; // [nvert_even][deg_pad] LDS row of each neighbour (sentinel-padded)
     int deg_pad = 6, rows_pad = 0;
     bool is_s642 = false;                            // neighbour table == the compiled-in sphere_642 table (specialised scan)
     mutable fib::DevBuf<unsigned> maxenc;
-    mutable fib::DevBuf<int32_t> live_vox, live_tiles, live_counts;   // mask compaction scratch (grow-only), counts = {voxels, tiles}
+    mutable fib::DevBuf<int32_t> live_vox, live_tiles, live_counts;   // mask compaction scratch (grow-only), counts = {voxels, tiles, +Inf voxels}
     mutable fib::DevBuf<int2> live_blocks;
     mutable fib::DevBuf<float> odfmax;
 };
@@ -1616,6 +1653,10 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
         }
         int rc3 = p->At3.alloc(A3.size());
         if (rc3 != FIB_OK) return rc3;
+        if (p->gRow0 == 0 && p->scale_frame < 0 && faces) {     // GQI: +Inf samples are repaired after the GEMM
+            if ((rc3 = p->Gdev.alloc(p->G.size())) != FIB_OK || (rc3 = p->inf_list.alloc(INF_FIX_CAP)) != FIB_OK) return rc3;
+            FIB_HIP(hipMemcpy(p->Gdev.p, p->G.data(), p->G.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         if ((rc3 = p->Aextra.alloc(AX.size())) != FIB_OK) return rc3;
         FIB_HIP(hipMemcpy(p->At3.p, A3.data(), A3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         FIB_HIP(hipMemcpy(p->Aextra.p, AX.data(), AX.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1661,7 +1702,7 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
     if ((rc = p->verts.alloc(v3.size())) != FIB_OK) return rc;
     if ((rc = p->nbr.alloc(nbr.size())) != FIB_OK) return rc;
     if ((rc = p->maxenc.alloc(2)) != FIB_OK) return rc;
-    if ((rc = p->live_counts.alloc(2)) != FIB_OK) return rc;
+    if ((rc = p->live_counts.alloc(3)) != FIB_OK) return rc;
     if ((rc = p->odfmax.alloc(2)) != FIB_OK) return rc;
     FIB_HIP(hipMemcpy(p->At.p, At.data(), At.size() * sizeof(float), hipMemcpyHostToDevice));
     FIB_HIP(hipMemcpy(p->effbits.p, effbits.data(), effbits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1924,6 +1965,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
     ga.Aextra = plan->Aextra.p;
     ga.vec_ok = (nvox % 4 == 0 && ((uintptr_t)odf & 15) == 0 && (pdf == nullptr || ((uintptr_t)pdf & 15) == 0)) ? 1 : 0; ga.vidx = plan->live_vox.p; ga.nlive = plan->live_counts.p; ga.mask = mask; ga.effbits = plan->effbits.p;
     ga.out0 = pdf; ga.out1 = odf; ga.nvox = nvox;
+    if (ga.At3 && plan->inf_list.p) { ga.fix_count = plan->live_counts.p + 2; ga.fix_list = plan->inf_list.p; ga.fix_cap = INF_FIX_CAP; }
     ga.K = plan->gK; ga.Kpad = plan->Kpad; ga.M = plan->gM; ga.nrow0 = plan->gRow0; ga.ntile_m = plan->ntile_m;
     if (plan->folded) {
         int rcf = plan->folded_dwi.ensure((size_t)plan->gK * nvox);
@@ -1971,6 +2013,10 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
     }
     int rc = run_gemm(ga, st);
     if (rc != FIB_OK) return rc;
+    if (ga.fix_list) {
+        InfFixArgs fx{plan->Gdev.p, dwi, odf, ga.fix_count, ga.fix_list, INF_FIX_CAP, plan->gM, plan->gK, nvox};
+        hipLaunchKernelGGL(odf_inf_fix_kernel, dim3(64), dim3(256), 0, st, fx);
+    }
     rc = launch_peaks(plan, odf, nvox, nvox, peak, qa, nullptr, nullptr, true, st, false, plan->live_tiles.p, plan->live_counts.p + 1);
     if (rc != FIB_OK) return rc;
     float *om = odfmax_dev ? odfmax_dev : plan->odfmax.p;

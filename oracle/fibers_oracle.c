@@ -432,9 +432,9 @@ float orc_gqi_rec(const float *dwi, const uint8_t *mask, int nx, int ny, int nz,
                 float x = dwi[(int64_t)i * nvox + vox];
                 if (x < 0.0f) x = 0.0f;
                 s[i] = x;
-                if (x > smax) smax = x;
+                if (x != x || (smax == smax && x > smax)) smax = x;   /* Base.maximum propagates NaN */
             }
-            if (smax == 0.0f) continue;                         /* gqi.jl:142 */
+            if (smax == 0.0f) continue;                         /* gqi.jl:142 (NaN == 0 is false: not skipped) */
             for (int v = 0; v < nvert; v++) o[v] = 0.0f;        /* sgemv, gqi.jl:144 */
             for (int i = 0; i < nvol; i++) {
                 const float *col = A + (int64_t)i * nvert;
@@ -543,9 +543,9 @@ float orc_dsi_rec(const float *dwi, const uint8_t *mask, int nx, int ny, int nz,
             if (mask[vox] == 0) continue;                       /* dsi.jl:200 */
             for (int i = 0; i < nvol; i++) X[iq_ind[i]] = dwi[(int64_t)i * nvox + vox];   /* :205 */
             float xmax = X[0];
-            for (int i = 1; i < 4096; i++) if (X[i] > xmax) xmax = X[i];
+            for (int i = 1; i < 4096; i++) if (X[i] != X[i] || (xmax == xmax && X[i] > xmax)) xmax = X[i];   /* maximum propagates NaN */
             if (xmax == 0.0f) continue;                         /* dsi.jl:207 */
-            for (int i = 0; i < 4096; i++) { float t = X[i] > 0.0f ? X[i] : 0.0f; X[i] = t * H[i]; }  /* :209-212 */
+            for (int i = 0; i < 4096; i++) { float t = X[i] > 0.0f ? X[i] : (X[i] != X[i] ? X[i] : 0.0f); X[i] = t * H[i]; }   /* max(NaN, 0) is NaN in Julia */  /* :209-212 */
             /* circshift!(x, X, (8,8,8)); xtmp = F*x; circshift!(x, xtmp, (8,8,8))   dsi.jl:218-220 */
             for (int k = 0; k < 16; k++) for (int j = 0; j < 16; j++) for (int i = 0; i < 16; i++) {
                 int src = i + 16 * j + 256 * k;

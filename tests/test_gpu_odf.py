@@ -323,3 +323,112 @@ def test_peak_kernels_agree_incl_nan_poisoned_voxels(fj, monkeypatch):
             assert torch.equal(torch.nan_to_num(res["v4"]["qa"][k], nan=-7.0), torch.nan_to_num(res[other]["qa"][k], nan=-7.0)), (other, k)
         assert torch.equal(torch.nan_to_num(res["v4"]["odfmax"], nan=-7.0), torch.nan_to_num(res[other]["odfmax"], nan=-7.0))
     assert float(res["v4"]["peak"][0][:, bad].abs().max()) == 0.0   # nvalid = 0 for an all-NaN ODF: no peaks (gqi.jl:151,200)
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_gqi_nonfinite_samples_propagate_like_the_reference(fj, orc, mode, monkeypatch):
+    """gqi.jl:139-144 on samples that are not finite: `s[s .< 0] .= 0` turns -Inf into 0 and keeps NaN; `maximum(s) == 0`
+    does not skip a voxel with a NaN; mul!(o, A, s) makes a NaN sample a NaN column and a +Inf sample +-Inf rows (NaN where
+    the coefficient is 0 or where both signs meet).  Nothing is trapped."""
+    monkeypatch.setenv("FIBERS_ODF_GEMM", mode)
+    from fibers_jl_amd import phantom
+    shape = (8, 6, 5)
+    bval, bvec = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3)
+    dwi, _, _ = phantom.make_volume(shape, bval, bvec, seed=23, noise_frac=0.02, crossing=True)
+    mask = np.ones(shape, np.uint8)
+    mask[0, 0, 1] = 0
+    dwi[1, 0, 0, 7] = np.inf                                   # +Inf: +-Inf rows
+    dwi[2, 0, 0, 9] = -np.inf                                  # -Inf: clamped to 0, finite column
+    dwi[3, 0, 0, 11] = np.nan                                  # NaN: NaN column
+    dwi[4, 0, 0, 5] = np.inf; dwi[4, 0, 0, 40] = np.inf        # two +Inf samples: NaN where their coefficients disagree in sign
+    dwi[5, 0, 0, :] = -1.0; dwi[5, 0, 0, 3] = np.nan           # all samples <= 0 and one NaN: not skipped, NaN column
+    dwi[6, 0, 0, :] = -np.inf                                  # everything clamps to 0: skipped, zeros
+    dwi[0, 0, 1, 2] = np.inf                                   # outside the mask: zeros
+    sph = fj.sphere_642
+    with np.errstate(all="ignore"):
+        ref = orc.gqi_rec(dwi, mask, bval, bvec, sph.vertices, sph.faces, 1.25, nthreads=2)
+        got = fj.gqi_rec(fj.MRI(dwi, bval, bvec), fj.MRI(mask), sph)
+    ro, go = ref["odf"], got.odf.vol
+    special = np.zeros(shape, bool)
+    special[1:7, 0, 0] = True
+    assert np.array_equal(np.isnan(go), np.isnan(ro))
+    assert np.array_equal(np.isposinf(go), np.isposinf(ro)) and np.array_equal(np.isneginf(go), np.isneginf(ro))
+    assert np.isinf(ro[1, 0, 0]).sum() > 300 and np.isfinite(ro[2, 0, 0]).all() and np.isnan(ro[3, 0, 0]).all() and np.isnan(ro[5, 0, 0]).all()
+    assert (go[6, 0, 0] == 0).all() and (go[0, 0, 1] == 0).all()
+    fin = np.isfinite(ro)
+    scale = np.abs(np.where(fin, ro, 0.0)).max(axis=3, keepdims=True) + 1e-30
+    with np.errstate(all="ignore"):
+        assert (np.abs(np.where(fin, go - ro, 0.0)) / scale).max() < 2e-5
+    # the global odfmax is NaN (maximum of means, gqi.jl:164) -> every qa is NaN after the normalisation, peaks as the oracle's
+    for k in range(3):
+        assert np.array_equal(np.isnan(got.qa[k].vol[..., 0]), np.isnan(ref["qa"][k]))
+        same = np.all(ref["peak"][k] == got.peak[k].vol, axis=3)
+        assert same[special].all(), (mode, k)
+        assert (~same).sum() <= 2
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_dsi_nonfinite_samples_propagate_like_the_reference(fj, orc, mode, monkeypatch):
+    """dsi.jl:205-225 on samples that are not finite: max.(X, 0) turns -Inf into 0 and keeps NaN; the FFT smears a NaN or
+    +Inf sample over the whole grid and p ./ sum(p) leaves NaN everywhere in that voxel's pdf and odf."""
+    monkeypatch.setenv("FIBERS_ODF_GEMM", mode)
+    dwi, mask, bval, bvec = _dsi_case((5, 4, 3), seed=6)
+    mask[:, 0, 0] = 1
+    dwi[0, 0, 0, 100] = np.inf
+    dwi[1, 0, 0, 200] = -np.inf
+    dwi[2, 0, 0, 300] = np.nan
+    dwi[3, 0, 0, :] = -2.0; dwi[3, 0, 0, 17] = np.nan            # maximum(X) is NaN, not 0: the voxel is not skipped
+    sph = fj.sphere_642
+    with np.errstate(all="ignore"):
+        ref = orc.dsi_rec(dwi, mask, bval, bvec, sph.vertices, sph.faces, 32, nthreads=4)
+        got = fj.dsi_rec(fj.MRI(dwi, bval, bvec), fj.MRI(mask), sph, 32)
+    for name, g, r in (("pdf", got.pdf.vol, ref["pdf"]), ("odf", got.odf.vol, ref["odf"])):
+        assert np.isnan(r[0, 0, 0]).all() and np.isnan(r[2, 0, 0]).all() and np.isnan(r[3, 0, 0]).all() and np.isfinite(r[1, 0, 0]).all(), name
+        assert np.array_equal(np.isnan(g), np.isnan(r)), name
+        fin = np.isfinite(r)
+        assert np.isfinite(g[fin]).all(), name
+        scale = np.abs(np.where(fin, r, 0.0)).max(axis=3, keepdims=True) + 1e-30
+        with np.errstate(all="ignore"):
+            assert (np.abs(np.where(fin, g - r, 0.0)) / scale).max() < 1e-4, name
+
+
+@pytest.mark.parametrize("kind", ["gqi", "dsi"])
+@pytest.mark.parametrize("shape,live", [((11, 9, 7), 0.9), ((11, 9, 7), 0.3), ((40, 40, 26), 0.5), ((40, 40, 26), 0.97), ((12, 12, 12), 0.0)])
+def test_outputs_outside_the_mask_are_cleared_whatever_they_held(fj, kind, shape, live):
+    """The reference's output volumes start zero-filled (mri.jl:251-255); the library writes into caller-owned memory, so every
+    voxel outside the mask must be cleared whatever the buffers held: both clearing strategies (selective below a quarter
+    of the volume outside the mask, everything above), voxel counts that are not multiples of 4 / 1024."""
+    import torch
+    from fibers_jl_amd import phantom
+    dev = torch.device("cuda", 0)
+    nvox = int(np.prod(shape))
+    bval, bvec = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3) if kind == "gqi" else phantom.scheme_dsi()
+    dwi, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=8, device=dev)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    mask = (torch.rand(nvox, device=dev, generator=g) < live).to(torch.uint8)
+    plan = fj.OdfPlan(kind, bval, bvec, fj.sphere_642)
+
+    def run(fill):
+        out = dict(odf=torch.full((plan.nvert, nvox), fill, dtype=torch.float32, device=dev),
+                   peak=[torch.full((3, nvox), fill, dtype=torch.float32, device=dev) for _ in range(3)],
+                   qa=[torch.full((nvox,), fill, dtype=torch.float32, device=dev) for _ in range(3)],
+                   odfmax=torch.empty(2, dtype=torch.float32, device=dev))
+        if kind == "dsi":
+            out["pdf"] = torch.full((plan.nvol, nvox), fill, dtype=torch.float32, device=dev)
+        fj.odf_rec_device(plan, dwi, mask, out=out)
+        torch.cuda.synchronize()
+        return out
+
+    a, b = run(0.0), run(float("nan"))
+    dead = mask == 0
+    for key in ("odf", "pdf") if kind == "dsi" else ("odf",):
+        assert torch.equal(a[key], b[key]), key
+        assert (b[key][:, dead] == 0).all(), key
+    for k in range(3):
+        assert torch.equal(a["peak"][k], b["peak"][k]) and torch.equal(a["qa"][k].nan_to_num(nan=-7.0), b["qa"][k].nan_to_num(nan=-7.0))
+        assert (b["peak"][k][:, dead] == 0).all()
+        if live > 0:
+            assert (b["qa"][k][dead] == 0).all()
+        else:                                                # odfmax = 0: qa ./ odfmax is 0/0 everywhere (gqi.jl:166-168), not trapped
+            assert torch.isnan(b["qa"][k]).all()
+    plan.close()
