@@ -71,3 +71,33 @@ def test_dti_device_tier_and_errors(fj, orc):
         fj.dti_fit(fj.MRI(dwi), fj.MRI(mask))
     with pytest.raises(RuntimeError, match="Missing gradient table"):
         fj.dti_fit(fj.MRI(dwi, bval), fj.MRI(mask))
+
+
+def test_dti_nonfinite_samples(fj, orc):
+    """dti.jl:291-303 on samples that are not finite: `s .> 0` is false for NaN and -Inf (they drop out like any
+    non-positive sample: the row-subset fit, a finite tensor), true for +Inf (log(Inf) = Inf reaches the fit: nothing
+    finite comes out and nothing is trapped)."""
+    dwi, mask, bval, bvec = _case(fj, (8, 8, 6), 30, 3, seed=11)
+    mask[:4, 0, 0] = 1
+    dwi[0, 0, 0, 9] = np.nan
+    dwi[1, 0, 0, 12] = -np.inf
+    dwi[2, 0, 0, 15] = np.inf
+    dwi[3, 0, 0, :] = np.nan                  # nothing positive: zeros
+    with np.errstate(all="ignore"):
+        ref = orc.dti_fit(dwi, mask, bval, bvec, nthreads=2)
+        got = fj.dti_fit(fj.MRI(dwi, bval, bvec), fj.MRI(mask))
+    g = {k: getattr(got, k).vol for k in fj.dti.DTI_FIELDS}
+    for k in ("s0", "fa", "md", "eigval1"):
+        assert np.isfinite(ref[k][:2, 0, 0]).all() and np.isfinite(g[k][:2, 0, 0]).all(), k
+        assert g[k][3, 0, 0] == 0 and ref[k][3, 0, 0] == 0, k
+    # d = pA * log.(s) has +-Inf entries: S0 = exp(d7) is 0 or Inf, the tensor's eigen-decomposition is not finite
+    assert np.array_equal(np.ravel(g["s0"][2, 0, 0]), np.ravel(ref["s0"][2, 0, 0]))
+    for k in ("fa", "md", "eigval1"):
+        assert not np.isfinite(g[k][2, 0, 0]).any() and not np.isfinite(ref[k][2, 0, 0]).any(), k
+    ok = mask.astype(bool).copy()
+    ok[2, 0, 0] = False                        # (+Inf voxel: NaN / Inf pattern of the eigen-solver, not compared)
+    m2 = mask * ok
+    for k in g:
+        g[k] = np.where(ok[..., None] if g[k].ndim == 4 else ok, g[k], 0)
+        ref[k] = np.where(ok[..., None] if np.ndim(ref[k]) == 4 else ok, ref[k], 0) if k in ref and hasattr(ref[k], "ndim") else ref[k]
+    assert_dti_close(g, ref, m2, label="nonfinite", s0_rtol=2e-3, ev_rtol=5e-3, ev_atol=2e-6, fa_atol=5e-3, vec_tol=1e-3, gap=0.2)
