@@ -49,6 +49,7 @@ struct GemmArgs {
     // (Inf has no three-piece split: Inf - Inf = NaN; the reference's A*s gives +-Inf rows there)
     int32_t *fix_count, *fix_list;
     int fix_cap;
+    int fold;                     // split-bf16 kernel, FOLD variant: S holds the raw frames; sample J of the contraction is max(S[rowA[J]],0) + max(S[rowB[J]],0)
 };
 
 // scheduling hint: spread one k-step's fragment reads (ds_read2_b32 = 2 fragments) between the previous
@@ -461,15 +462,25 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {      // ro
     return r;
 }
 
-template <int MB, int NX, int NW, bool STAMP = false>
+// FOLD (DSI with an antipodally symmetric lattice, see dsi_fold_kernel): the kernel reads the RAW frames and forms the folded
+// sample t[J] = max(s[q_J],0) + max(s[-q_J],0) itself: 16 instead of 8 loads per lane and stage, but no 2.8-GB folded copy
+// of the volume written and read back (the separate pre-pass ran at the HBM roofline and still cost 1.65 of 7.7 ms).
+// The two lane halves of a load need different frames; their byte offsets come from an LDS table (relative to the
+// lowest frame that the stage touches on that side: one buffer resource per stage and side).
+constexpr int FKMAX = 512, FSMAX = FKMAX / KT;
+template <int MB, int NX, int NW, bool STAMP = false, bool FOLD = false>
 __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a) {
     constexpr int NPIECE = 3 * MB;                      // 1-KiB pieces per stage
     constexpr int TILEB = NPIECE * 1024;                // bytes per stage
     constexpr int NA = (NPIECE + NW - 1) / NW;          // direct-to-LDS loads per wave and stage (a surplus load repeats the last piece)
     constexpr int WGV = NW * 32;                        // voxels per work item
     constexpr int NXA = NX > 0 ? NX : 1;
-    constexpr int XTAB = NX > 0 ? 4096 : 0;             // coefficients of the extra rows, all stages of all M tiles: [ntile_m][NX][Kpad] f32
-    __shared__ __attribute__((aligned(16))) char lds[2 * TILEB + NW * 2048 + XTAB];
+    constexpr int XTAB = NX > 0 ? 8192 : 0;             // coefficients of the extra rows, all stages of all M tiles: [ntile_m][NX][Kpad] f32
+    constexpr int FTAB = FOLD ? 2 * FKMAX * 4 + 4 * FSMAX * 4 : 0;
+    __shared__ __attribute__((aligned(16))) char lds[2 * TILEB + NW * 2048 + XTAB + FTAB];
+    uint32_t *f_off = reinterpret_cast<uint32_t *>(lds + 2 * TILEB + NW * 2048 + XTAB);   // [2][FKMAX] byte offset of sample J's frame, side a / b
+    int32_t *f_base = reinterpret_cast<int32_t *>(f_off + 2 * FKMAX);                      // [2][FSMAX] lowest frame of the stage
+    int32_t *f_span = f_base + 2 * FSMAX;                                                  // [2][FSMAX] frames spanned (0: none)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, kh = lane >> 5;
@@ -481,6 +492,28 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
     }
     const char *Sbase = reinterpret_cast<const char *>(a.S);
     const uint32_t row_bytes = (uint32_t)(a.stride * 4);
+    if (FOLD) {
+        for (int i = tid; i < 2 * ntiles; i += NW * 64) {
+            const int side = i / ntiles, t = i - side * ntiles;
+            const int32_t *fr = side ? a.rowB : a.rowA;
+            int lo = 0x7fffffff, hi = -1;
+            for (int j = 0; j < KT; j++) {
+                const int J = t * KT + j;
+                const int f = J < a.K ? fr[J] : -1;
+                if (f >= 0) { lo = f < lo ? f : lo; hi = f > hi ? f : hi; }
+            }
+            f_base[side * FSMAX + t] = hi >= 0 ? lo : 0;
+            f_span[side * FSMAX + t] = hi >= 0 ? hi - lo + 1 : 0;
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * a.Kpad; i += NW * 64) {
+            const int side = i / a.Kpad, J = i - side * a.Kpad;
+            const int f = J < a.K ? (side ? a.rowB : a.rowA)[J] : -1;
+            // (the host checked that a stage's span times the frame size stays below 0xE0000000; 0xF0000000 + 4 vox is past every span)
+            f_off[side * FKMAX + J] = f >= 0 ? (uint32_t)(f - f_base[side * FSMAX + J / KT]) * row_bytes : 0xF0000000u;
+        }
+        __syncthreads();
+    }
     unsigned long long st0 = 0, rt1 = 0, acc_epi = 0;
     if (STAMP) { st0 = __builtin_amdgcn_s_memtime(); rt1 = __builtin_amdgcn_s_memrealtime(); }
 
@@ -518,11 +551,25 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
                                              (__attribute__((address_space(3))) void *)(l + p * 1024), 16, 0, 0);
         }
     };
-    float braw[8];
+    float braw[8], brawb[FOLD ? 8 : 1];
     // sample j of the lane = frame t*16 + 8h + j.  One buffer resource per stage, based at frame t*16 and ending with the
     // frame list: loads past it return 0.0 without a memory access (the padded columns of A are zero).  The frame
     // offsets j*row_bytes go in as scalar offsets, the lane's (voxel + 8h rows) as the 32-bit vector offset.
     auto load_B = [&](int t, uint32_t s_off, bool live) {
+        if constexpr (FOLD) {
+            const int ba = __builtin_amdgcn_readfirstlane(f_base[t]), bb = __builtin_amdgcn_readfirstlane(f_base[FSMAX + t]);
+            const int sa = live ? __builtin_amdgcn_readfirstlane(f_span[t]) : 0, sb = live ? __builtin_amdgcn_readfirstlane(f_span[FSMAX + t]) : 0;
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(Sbase + (int64_t)ba * row_bytes), 0, (int)((uint32_t)sa * row_bytes), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(Sbase + (int64_t)bb * row_bytes), 0, (int)((uint32_t)sb * row_bytes), 0x00020000);
+            const u32x4_t *pa = reinterpret_cast<const u32x4_t *>(f_off + t * KT + 8 * kh), *pb = reinterpret_cast<const u32x4_t *>(f_off + FKMAX + t * KT + 8 * kh);
+            const u32x4_t oa0 = pa[0], oa1 = pa[1], ob0 = pb[0], ob1 = pb[1];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                braw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, (int)(s_off + (j < 4 ? oa0[j & 3] : oa1[j & 3])), 0, 0));
+                brawb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (int)(s_off + (j < 4 ? ob0[j & 3] : ob1[j & 3])), 0, 0));
+            }
+            return;
+        }
         const int rem = live ? a.K - t * KT : 0;        // frames from this stage's first to the end of the list
         const uint64_t span = (uint64_t)(rem > 0 ? rem : 0) * row_bytes;
         const uint32_t nrec = span > 0xffffffffull ? 0xffffffffu : (uint32_t)span;
@@ -534,7 +581,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
     auto lane_state = [&](const Work &w, int32_t vr, bool &inb, int64_t &vox, uint32_t &s_off) {
         inb = (int64_t)w.tile_n * WGV + wave * 32 + col < nlive;
         vox = inb ? vr : 0;
-        s_off = (uint32_t)((vox + (int64_t)8 * kh * a.stride) * 4);       // frame 8h of a stage, this voxel (nvox <= 2^26)
+        s_off = (uint32_t)((vox + (FOLD ? (int64_t)0 : (int64_t)8 * kh * a.stride)) * 4);   // frame 8h of a stage (FOLD: the table's frame), this voxel (nvox <= 2^26)
     };
 
     f32x16 acc[MB];
@@ -556,10 +603,14 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
     auto split = [&](int tile_m, int t) {
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
-            const float x0 = braw[2 * jj], x1 = braw[2 * jj + 1];
+            float x0 = braw[2 * jj], x1 = braw[2 * jj + 1];
+            if (FOLD) {                                 // t[J] = max(s[q],0) + max(s[-q],0) (dsi.jl:209; an absent partner loads 0)
+                x0 = clamp_sample(x0) + clamp_sample(brawb[2 * jj]);
+                x1 = clamp_sample(x1) + clamp_sample(brawb[2 * jj + 1]);
+            }
             float c0, c1;
-            c0 = clamp_sample(x0);
-            c1 = clamp_sample(x1);
+            c0 = FOLD ? x0 : clamp_sample(x0);
+            c1 = FOLD ? x1 : clamp_sample(x1);
             asm("v_max3_f32 %0, %1, %2, %3" : "=v"(vmax) : "v"(vmax), "v"(x0), "v"(x1));
             vnf = __builtin_fmaf(c0, 0.0f, vnf);
             vnf = __builtin_fmaf(c1, 0.0f, vnf);
@@ -1554,6 +1605,7 @@ struct fib_odf_plan {
     int gM = 0, gK = 0, gRow0 = 0;
     std::vector<float> G;
     bool folded = false;
+    int fold_span_max = 0, scale_frame_raw = -1;     // fused fold: most frames a 16-sample stage spans on one side; raw frame of sum(p)
     fib::DevBuf<int32_t> foldA, foldB;               // [gK] frames summed into folded sample J; [gRow0] == same tables map pdf rows
     mutable fib::DevBuf<float> folded_dwi;           // [gK x nvox] scratch of the fold pre-pass (grow-only)
     std::vector<float> A;                            // host copy [nrows x nvol] column-major
@@ -1615,7 +1667,7 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
     // MB <= 10 (LDS: two workgroups per CU), and the extra rows' coefficient table within its 4-KiB LDS slot
     bool any_ineff = false;
     for (int k = 0; k < K; k++) if (frame_eff[k] == 0.0f) any_ineff = true;
-    if (p->split_bf16 && (any_ineff || p->Kpad / KT < 2 || p->MB > 10 || (size_t)p->ntile_m * p->NX * p->Kpad > 1024)) p->split_bf16 = false;
+    if (p->split_bf16 && (any_ineff || p->Kpad / KT < 2 || p->MB > 10 || (size_t)p->ntile_m * p->NX * p->Kpad > 2048)) p->split_bf16 = false;
     if (p->split_bf16) {
         const int npiece = 3 * p->MB, nst = p->Kpad / KT;
         std::vector<uint16_t> A3((size_t)p->ntile_m * nst * npiece * 512, 0);
@@ -1789,7 +1841,13 @@ extern "C" int fib_dsi_plan_create(int device, const float *bval, const float *b
                 for (int v = 0; v < p->nvert; v++) p->G[nrep + v + (size_t)p->gM * c] = col[nvol + v];
                 if (fa[c] == p->scale_frame) p->scale_frame = -1000 - c;          // re-index below
             }
-            if (p->scale_frame <= -1000) p->scale_frame = -(p->scale_frame + 1000);
+            if (p->scale_frame <= -1000) { p->scale_frame = -(p->scale_frame + 1000); p->scale_frame_raw = fa[p->scale_frame]; }
+            for (int t0 = 0; t0 < nrep; t0 += KT)
+                for (const std::vector<int32_t> *side : {&fa, &fb}) {
+                    int lo = 1 << 30, hi = -1;
+                    for (int j = t0; j < std::min(nrep, t0 + KT); j++) if ((*side)[j] >= 0) { lo = std::min(lo, (*side)[j]); hi = std::max(hi, (*side)[j]); }
+                    if (hi >= 0) p->fold_span_max = std::max(p->fold_span_max, hi - lo + 1);
+                }
             if ((rc = p->foldA.alloc(nrep)) != FIB_OK || (rc = p->foldB.alloc(nrep)) != FIB_OK) { delete p; return rc; }
             (void)hipMemcpy(p->foldA.p, fa.data(), nrep * sizeof(int32_t), hipMemcpyHostToDevice);
             (void)hipMemcpy(p->foldB.p, fb.data(), nrep * sizeof(int32_t), hipMemcpyHostToDevice);
@@ -1823,6 +1881,7 @@ extern "C" int fib_odf_plan_matrix(const fib_odf_plan *plan, float *A, int *nrow
 // ------------------------------------------------------------------------------------------
 namespace {
 
+constexpr int FOLD_MB_MAX = 10;   // M tiles that the fused-fold variant is built for (room for 16 raw samples per lane and stage)
 template <int MB, int NX>
 void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
     if (ga.At3) {
@@ -1860,6 +1919,10 @@ void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
                 fprintf(stderr, "gemm3 stamps over %zu workgroups: clock %.0f MHz; cycles per work item %.0f (%.1f per MFMA), of which epilogue %.0f\n",
                         clk.size(), med(clk), med(item), med(item) / (17.0 * 60.0), med(epi));
             }
+            return;
+        }
+        if (ga.fold) {
+            if constexpr (MB <= FOLD_MB_MAX) hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 8, false, true>), dim3(pg), dim3(512), 0, st, g2);
             return;
         }
         hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 8>), dim3(pg), dim3(512), 0, st, g2);
@@ -1967,7 +2030,12 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
     ga.out0 = pdf; ga.out1 = odf; ga.nvox = nvox;
     if (ga.At3 && plan->inf_list.p) { ga.fix_count = plan->live_counts.p + 2; ga.fix_list = plan->inf_list.p; ga.fix_cap = INF_FIX_CAP; }
     ga.K = plan->gK; ga.Kpad = plan->Kpad; ga.M = plan->gM; ga.nrow0 = plan->gRow0; ga.ntile_m = plan->ntile_m;
-    if (plan->folded) {
+    const bool fuse_fold = plan->folded && ga.At3 != nullptr && plan->MB <= FOLD_MB_MAX && plan->Kpad <= FKMAX && plan->scale_frame_raw >= 0 &&
+                           (int64_t)plan->fold_span_max * nvox * 4 < (int64_t)0xE0000000ll && !getenv("FIBERS_DSI_UNFUSED");
+    if (fuse_fold) {
+        ga.fold = 1;
+        ga.rowA = plan->foldA.p; ga.rowB = plan->foldB.p;
+    } else if (plan->folded) {
         int rcf = plan->folded_dwi.ensure((size_t)plan->gK * nvox);
         if (rcf != FIB_OK) return rcf;
         fib::ProfScope prof("dsi_fold", st);
@@ -1980,7 +2048,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         ga.S = plan->folded_dwi.p;
         ga.rowA = plan->foldA.p; ga.rowB = plan->foldB.p;
     }
-    ga.scale_frame = plan->nrow0 > 0 ? plan->scale_frame : -1;
+    ga.scale_frame = plan->nrow0 > 0 ? (fuse_fold ? plan->scale_frame_raw : plan->scale_frame) : -1;
     ga.scale_coef = plan->scale_coef;
     ga.stride = nvox;
     ga.has_ineff = plan->has_ineff ? 1 : 0;

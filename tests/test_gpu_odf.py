@@ -432,3 +432,37 @@ def test_outputs_outside_the_mask_are_cleared_whatever_they_held(fj, kind, shape
         else:                                                # odfmax = 0: qa ./ odfmax is 0/0 everywhere (gqi.jl:166-168), not trapped
             assert torch.isnan(b["qa"][k]).all()
     plan.close()
+
+
+def test_dsi_fused_fold_is_bit_identical_to_the_prepass(fj, monkeypatch):
+    """The split-bf16 kernel folding the antipodal pairs itself (default) and the separate fold pre-pass feed the same
+    numbers to the same contraction: identical pdf / odf / peaks, with a mask, a ragged voxel count and non-finite samples."""
+    import torch
+    from fibers_jl_amd import phantom
+    dev = torch.device("cuda", 0)
+    shape = (23, 21, 10)
+    nvox = int(np.prod(shape))
+    bval, bvec = phantom.scheme_dsi()
+    dwi, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=12, device=dev)
+    dwi[100, 7] = float("nan"); dwi[400, 8] = float("inf"); dwi[33, 9] = -float("inf"); dwi[:, 10] = -1.0
+    g = torch.Generator(device=dev); g.manual_seed(2)
+    res = {}
+    for mname, mask in (("ones", torch.ones(nvox, dtype=torch.uint8, device=dev)),
+                        ("sparse", (torch.rand(nvox, device=dev, generator=g) < 0.6).to(torch.uint8))):
+        for mode in ("fused", "prepass"):
+            if mode == "prepass":
+                monkeypatch.setenv("FIBERS_DSI_UNFUSED", "1")
+            else:
+                monkeypatch.delenv("FIBERS_DSI_UNFUSED", raising=False)
+            plan = fj.OdfPlan("dsi", bval, bvec, fj.sphere_642, hann_width=32)
+            o = fj.odf_rec_device(plan, dwi, mask)
+            torch.cuda.synchronize()
+            res[mode] = {k: (v.clone() if torch.is_tensor(v) else [t.clone() for t in v]) for k, v in o.items()}
+            plan.close()
+        for k in ("pdf", "odf"):
+            assert torch.equal(res["fused"][k].nan_to_num(nan=-7.0, posinf=-8.0, neginf=-9.0), res["prepass"][k].nan_to_num(nan=-7.0, posinf=-8.0, neginf=-9.0)), (mname, k)
+        for i in range(3):
+            assert torch.equal(res["fused"]["peak"][i], res["prepass"]["peak"][i]), (mname, i)
+            assert torch.equal(res["fused"]["qa"][i].nan_to_num(nan=-7.0), res["prepass"]["qa"][i].nan_to_num(nan=-7.0)), (mname, i)
+        assert bool(torch.isnan(res["fused"]["odf"][:, 7]).all()) and bool(torch.isnan(res["fused"]["odf"][:, 8]).all()) or mname == "sparse"
+        assert bool((res["fused"]["odf"][:, 10] == 0).all())
