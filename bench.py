@@ -338,7 +338,7 @@ def main():
         f_ms, f_n = prof_get(L, "dsi_fold")
         extra["dsi_rec_140x515"] = dict(mvoxels_per_s=nvox / t_dsi / 1e6, ms_per_step=t_dsi * 1e3,
                                         gemm_kernel_ms=g_ms / max(g_n, 1), fold_kernel_ms=f_ms / max(f_n, 1),
-                                        note="antipodal folding: 258 folded samples x (258 pdf + 321 odf) rows")
+                                        note="antipodal folding inside the contraction kernel: 258 folded samples x (258 pdf + 321 odf) rows")
         # ---- C5 tracking: 3 peaks per voxel (f = qa, f_thresh = .03), ball mask, nsub = 10 -> ~10 M lines -------------
         del d5
         bm = phantom.ball_mask_torch(SHAPE, dev)
