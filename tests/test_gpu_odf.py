@@ -466,3 +466,32 @@ def test_dsi_fused_fold_is_bit_identical_to_the_prepass(fj, monkeypatch):
             assert torch.equal(res["fused"]["qa"][i].nan_to_num(nan=-7.0), res["prepass"]["qa"][i].nan_to_num(nan=-7.0)), (mname, i)
         assert bool(torch.isnan(res["fused"]["odf"][:, 7]).all()) and bool(torch.isnan(res["fused"]["odf"][:, 8]).all()) or mname == "sparse"
         assert bool((res["fused"]["odf"][:, 10] == 0).all())
+
+
+@pytest.mark.parametrize("sphere", ["sphere_362", "sphere_642", "sphere_724"])
+def test_find_peaks_randomised_against_the_oracle(fj, orc, sphere):
+    """find_peaks! (gqi.jl:180-201) on adversarial ODFs: heavy ties (values on a coarse grid), plateaus, negative values,
+    all-equal columns, +-0, NaN and +-Inf entries.  sortperm(rev=true) order (ties: lower index first, NaN first) and the
+    count of positive survivors must match the oracle exactly for every column."""
+    sph = getattr(fj, sphere)
+    rng = np.random.default_rng(31)
+    n = 400
+    odf = rng.random((n, sph.nvert)).astype(np.float32)
+    odf[0:60] = np.round(odf[0:60] * 3) / 3                       # three levels: ties everywhere
+    odf[60:90] = np.round(odf[60:90] * 16) / 16 - 0.5             # ties and negatives
+    odf[90] = 0.25                                                # all equal: nobody is strictly greater
+    odf[91] = 0.0; odf[92] = -0.0
+    for i in range(100, 140):
+        odf[i, rng.integers(0, sph.nvert, 3)] = np.nan
+    for i in range(140, 160):
+        odf[i, rng.integers(0, sph.nvert, 2)] = np.inf
+        odf[i, rng.integers(0, sph.nvert, 2)] = -np.inf
+    odf[160:170] = np.nan
+    odf[170:200] = (odf[170:200] > 0.97).astype(np.float32)       # isolated spikes on a plateau of zeros
+    top, nvalid = fj.find_peaks(odf.reshape(n, 1, sph.nvert), sph)
+    faces0 = orc.fold_faces(sph.faces, sph.nvert)
+    for i in range(n):
+        with np.errstate(all="ignore"):
+            isort, nv, _ = orc.find_peaks(odf[i], faces0)
+        assert nv == nvalid[i, 0], (i, nv, nvalid[i, 0])
+        assert list(isort[:3]) == list(top[i, 0]), (i, isort[:3], top[i, 0])

@@ -234,3 +234,47 @@ def test_lcm_uniform_stream_contract(orc):
     assert u.min() >= 0.0 and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.02
     assert len(np.unique(u)) > 4000
     assert np.all(u * 16777216.0 == np.round(u * 16777216.0))
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_stream_randomised_configurations_exact(fj, orc, case):
+    """Seeded random draws over everything `stream` takes (stream.jl:730-790): volume shape, 1-4 orientation volumes that
+    are not unit length, amplitude / FA thresholds, masks of several dtypes, seed masks, step, angle, smoothing, length
+    limits, sub-voxel offsets, vectors with zeros / NaN / Inf components.  Lines must agree exactly."""
+    rng = np.random.default_rng(1000 + case)
+    shape = tuple(int(x) for x in rng.integers(5, 15, 3))
+    nvec = int(rng.integers(1, 5))
+    x, y, z = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+    ovs = []
+    for k in range(nvec):
+        a, b, c = rng.uniform(0.05, 0.5, 3)
+        ph = rng.uniform(0, 6.28, 3)
+        v = np.stack([np.cos(a * x + ph[0]) + 0.2 * rng.normal(size=shape), np.sin(b * y + ph[1]) + 0.2 * rng.normal(size=shape),
+                      np.cos(c * z + ph[2]) * 0.7 + 0.2 * rng.normal(size=shape)], -1)
+        if rng.random() < 0.6:
+            v /= np.linalg.norm(v, axis=-1, keepdims=True)
+        v = v.astype(np.float32)
+        v[rng.random(shape) < 0.03] = 0                              # zero vectors (stream.jl:353-354)
+        if case % 6 == 5:                                            # non-finite components reach argmax / isfinite (stream.jl:361-363)
+            v[rng.random(shape) < 0.01, int(rng.integers(0, 3))] = [np.nan, np.inf, -np.inf][k % 3]
+        ovs.append(np.asfortranarray(v))
+    kw = dict(step_size=float(rng.choice([0.25, 0.5, 0.75, 1.0, 1.3])), ang_thresh=float(rng.choice([20, 45, 60, 89])),
+              smooth_coeff=float(rng.choice([0.0, 0.2, 0.5, 0.9])), len_min=int(rng.integers(1, 6)),
+              len_max=int(rng.choice([3, 10, 40, max(shape)])))
+    f = fa = seed = None
+    if rng.random() < 0.5:
+        f = [np.asfortranarray(rng.uniform(0, 0.2, shape).astype(np.float32)) for _ in range(nvec)]
+        kw["f_thresh"] = float(rng.uniform(0.0, 0.1))
+    if rng.random() < 0.5:
+        fa = np.asfortranarray(rng.uniform(0, 1, shape).astype(np.float32))
+        kw["fa_thresh"] = float(rng.uniform(0.0, 0.4))
+    mask = (rng.random(shape) < rng.uniform(0.6, 1.0)).astype(rng.choice([np.uint8, np.int16, np.float32]))
+    if rng.random() < 0.5:
+        seed = (rng.random(shape) < 0.4).astype(np.uint8)
+    sub = fj.make_sublist(int(rng.integers(1, 4)), rng=case)
+    with np.errstate(all="ignore"):
+        ref = orc.stream(ovs if nvec > 1 else ovs[0], sub, f=f, fa=fa, mask=mask, seed=seed, nthreads=3, **kw)
+    tr = fj.stream([fj.MRI(o) for o in ovs] if nvec > 1 else fj.MRI(ovs[0]), f=None if f is None else [fj.MRI(q) for q in f],
+                   fa=None if fa is None else fj.MRI(fa), mask=fj.MRI(mask), seed=None if seed is None else fj.MRI(seed), sublist=sub, **kw)
+    assert tr.nstr == len(ref["npts"]) and np.array_equal(tr.npts, ref["npts"]) and np.array_equal(tr.seed_index, ref["seed_index"])
+    assert np.array_equal(tr.xyz, ref["xyz"], equal_nan=True)
