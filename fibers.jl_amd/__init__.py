@@ -11,6 +11,7 @@ from .dti import DTI, DtiPlan, adc_fit, adc_fit_device, dti_fit, dti_fit_device 
 from .gqi import (DSI, GQI, OdfPlan, dsi_rec, find_peaks, find_peaks_device, gqi_rec, odf_rec_device,  # noqa: F401
                   qa_normalize_device)
 from .rumba import RUMBASD, RumbaPlan, rumba_rec, rumba_rec_device  # noqa: F401
+from .structens import st_eigen, st_eigen_device  # noqa: F401
 from .tract import Tract  # noqa: F401
 from .stream import make_sublist, stream, stream_device, stream_field_device  # noqa: F401
 from .nifti import (dsi_write, dti_write, gqi_write, load_nifti, mri_read, mri_read_bfiles, mri_write,  # noqa: F401

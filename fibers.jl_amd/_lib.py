@@ -61,6 +61,8 @@ _PROTOS = {
     "fib_odf_plan_matrix": (i32, [vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "fibd_dti_fit": (i32, [vp, vp, vp, i64, C.POINTER(DtiOut), vp]),
     "fibd_adc_fit": (i32, [vp, vp, vp, i64, vp, vp, vp]),
+    "fibd_st_eigen": (i32, [vp, i64, vp, vp, vp]),
+    "fib_st_eigen": (i32, [i32, vp, i64, vp, vp]),
     "fibd_dti_last_partial_count": (i32, [vp, vp, C.POINTER(i64)]),
     "fibd_odf_rec": (i32, [vp, vp, vp, i64, vp, vp, P3, P3, vp, i32, vp]),
     "fibd_qa_normalize": (i32, [P3, i64, f32, vp]),

@@ -88,6 +88,24 @@ extern "C" int fib_dti_fit(int device, const float *dwi, int nx, int ny, int nz,
     return FIB_OK;
 }
 
+extern "C" int fib_st_eigen(int device, const float *const S[6], int64_t nvox, float *eigvec, float *eigval) {
+    FIB_CHECK(S && eigvec && eigval, FIB_ERR_INVALID, "NULL argument");
+    FIB_CHECK(nvox > 0, FIB_ERR_INVALID, "nvox must be positive");
+    for (int k = 0; k < 6; k++) FIB_CHECK(S[k] != nullptr, FIB_ERR_INVALID, "NULL structure tensor volume %d", k);
+    fib::DeviceGuard guard;
+    RC(fib::use_device(device));
+    fib::DevBuf<float> d_in, d_out;
+    RC(d_in.alloc((size_t)nvox * 6));
+    RC(d_out.alloc((size_t)nvox * 12));
+    const float *dS[6];
+    for (int k = 0; k < 6; k++) { dS[k] = d_in.p + (size_t)k * nvox; RC(h2d(d_in.p + (size_t)k * nvox, S[k], sizeof(float) * nvox)); }
+    RC(fibd_st_eigen(dS, nvox, d_out.p, d_out.p + (size_t)9 * nvox, nullptr));
+    FIB_HIP(hipDeviceSynchronize());
+    RC(d2h(eigvec, d_out.p, sizeof(float) * nvox * 9));
+    RC(d2h(eigval, d_out.p + (size_t)9 * nvox, sizeof(float) * nvox * 3));
+    return FIB_OK;
+}
+
 extern "C" int fib_adc_fit(int device, const float *dwi, int nx, int ny, int nz, int nvol,
                            const void *mask, int mask_dtype, const float *bval, float *adc, float *s0) {
     FIB_CHECK(bval != nullptr && nvol > 0, FIB_ERR_MISSING_BVAL, "Missing b-value table from input DWI structure");

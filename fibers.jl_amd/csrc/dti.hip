@@ -551,6 +551,36 @@ extern "C" int fibd_adc_fit(const fib_dti_plan *plan, const float *dwi, const ui
     return launch_fit<2>(plan, dwi, mask, nvox, o, adc, (hipStream_t)stream);
 }
 
+// st_eigen (structens.jl:13-37): eigen(Symmetric(S, :L)) of the structure tensor of every voxel, the same closed form as
+// the diffusion tensor's (dti.jl:311).  eigval [nvox*3] ascending, eigvec [nvox*9]: component i of eigenvector j at
+// (i + 3 j) * nvox + vox -- the column-major image of the reference's eigvec[ix, iy, iz, i, j].  HBM-bound: 24 B in, 48 B out.
+namespace {
+struct StIn { const float *s[6]; };
+__global__ __launch_bounds__(256) void st_eigen_kernel(const StIn in, int64_t nvox, float *__restrict__ eigvec, float *__restrict__ eigval) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvox) return;
+    float w[3], ev[3][3];
+    sym3_eigen(in.s[0][i], in.s[1][i], in.s[2][i], in.s[3][i], in.s[4][i], in.s[5][i], w, ev);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        eigval[(int64_t)j * nvox + i] = w[j];
+#pragma unroll
+        for (int c = 0; c < 3; c++) eigvec[(int64_t)(c + 3 * j) * nvox + i] = ev[j][c];
+    }
+}
+}  // namespace
+
+extern "C" int fibd_st_eigen(const float *const S[6], int64_t nvox, float *eigvec, float *eigval, void *stream) {
+    FIB_CHECK(S && eigvec && eigval, FIB_ERR_INVALID, "NULL argument");
+    FIB_CHECK(nvox > 0, FIB_ERR_INVALID, "nvox must be positive");
+    StIn in{};
+    for (int k = 0; k < 6; k++) { FIB_CHECK(S[k] != nullptr, FIB_ERR_INVALID, "NULL structure tensor volume %d", k); in.s[k] = S[k]; }
+    fib::ProfScope prof("st_eigen", (hipStream_t)stream);
+    hipLaunchKernelGGL(st_eigen_kernel, dim3((unsigned)fib::cdiv(nvox, 256)), dim3(256), 0, (hipStream_t)stream, in, nvox, eigvec, eigval);
+    FIB_HIP(hipGetLastError());
+    return FIB_OK;
+}
+
 extern "C" int fibd_dti_last_partial_count(const fib_dti_plan *plan, void *stream, int64_t *count) {
     FIB_CHECK(plan && count, FIB_ERR_INVALID, "NULL argument");
     fib::DeviceGuard guard;

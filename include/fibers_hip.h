@@ -114,6 +114,10 @@ int fibd_dti_fit(const fib_dti_plan *plan, const float *dwi, const uint8_t *mask
 /* adc_fit (dti.jl:164-213) */
 int fibd_adc_fit(const fib_dti_plan *plan, const float *dwi, const uint8_t *mask, int64_t nvox,
                  float *adc, float *s0, void *stream);
+/* st_eigen (structens.jl:13-37): eigen(Symmetric(S, :L)) per voxel with the diffusion tensor's 3x3 solver.
+ * S = {Sxx, Sxy, Sxz, Syy, Syz, Szz}, each [nvox]; eigval [nvox*3] ascending (eigval[ix,iy,iz,k]);
+ * eigvec [nvox*9], component i of eigenvector j at (i + 3*j)*nvox + vox (eigvec[ix,iy,iz,i,j]). */
+int fibd_st_eigen(const float *const S[6], int64_t nvox, float *eigvec, float *eigval, void *stream);
 /* number of voxels the last fibd_dti_fit/fibd_adc_fit call on this plan sent through the
  * per-voxel pinv branch (dti.jl:297-298, 206-207); synchronises `stream`. */
 int fibd_dti_last_partial_count(const fib_dti_plan *plan, void *stream, int64_t *count);
@@ -253,6 +257,8 @@ int fib_dti_fit(int device, const float *dwi, int nx, int ny, int nz, int nvol,
                 const void *mask, int mask_dtype, const float *bval, const float *bvec,
                 const fib_dti_out *out);
 /* adc_fit(dwi::MRI, mask::MRI) (dti.jl:164) */
+/* host-buffer form of fibd_st_eigen (structens.jl:13-37) */
+int fib_st_eigen(int device, const float *const S[6], int64_t nvox, float *eigvec, float *eigval);
 int fib_adc_fit(int device, const float *dwi, int nx, int ny, int nz, int nvol,
                 const void *mask, int mask_dtype, const float *bval, float *adc, float *s0);
 /* gqi_rec(dwi, mask, odf_dirs, sigma)::GQI (gqi.jl:109) */

@@ -110,6 +110,17 @@ struct FibRumbaOut
   peak::NTuple{5, Ptr{Float32}}
 end
 
+"st_eigen(Sxx, Sxy, Sxz, Syy, Syz, Szz) — replaces structens.jl:13-37"
+function st_eigen(Sxx::Array{Float32,3}, Sxy::Array{Float32,3}, Sxz::Array{Float32,3},
+                  Syy::Array{Float32,3}, Syz::Array{Float32,3}, Szz::Array{Float32,3})
+  eigvec = Array{Float32,5}(undef, size(Sxx)..., 3, 3)
+  eigval = Array{Float32,4}(undef, size(Sxx)..., 3)
+  S = [pointer(Sxx), pointer(Sxy), pointer(Sxz), pointer(Syy), pointer(Syz), pointer(Szz)]
+  GC.@preserve Sxx Sxy Sxz Syy Syz Szz S eigvec eigval fib_check(ccall((:fib_st_eigen, libfibers), Cint,
+      (Cint, Ptr{Ptr{Cfloat}}, Int64, Ptr{Cfloat}, Ptr{Cfloat}), DEVICE[], S, length(Sxx), eigvec, eigval))
+  return eigvec, eigval
+end
+
 "rumba_rec(dwi, mask, odf_dirs, niter, ...) — replaces rusd.jl:419-636"
 function rumba_rec(dwi::MRI, mask::MRI, odf_dirs::ODF=sphere_724, niter::Integer=600, λ_para::Float32=Float32(1.7e-3),
                    λ_perp::Float32=Float32(0.2e-3), λ_csf::Float32=Float32(3.0e-3), λ_gm::Float32=Float32(0.8e-4),

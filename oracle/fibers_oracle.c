@@ -182,6 +182,21 @@ static void dti_maps(float e1, float e2, float e3, float *rd, float *md, float *
     *rd = r; *md = m;
 }
 
+/* st_eigen (structens.jl:13-37): eigen(Symmetric(S, :L)) per voxel; eigvec[vox + nvox*(i + 3 j)] = component i of
+ * eigenvector j (ascending eigenvalues), eigval[vox + nvox*k]. */
+void orc_st_eigen(const float *sxx, const float *sxy, const float *sxz, const float *syy, const float *syz, const float *szz,
+                  int64_t nvox, float *eigvec, float *eigval)
+{
+    for (int64_t vox = 0; vox < nvox; vox++) {
+        float w[3], v[3][3];
+        orc_sym3_eigen(sxx[vox], sxy[vox], sxz[vox], syy[vox], syz[vox], szz[vox], w, v);
+        for (int j = 0; j < 3; j++) {
+            eigval[(int64_t)j * nvox + vox] = w[j];
+            for (int c = 0; c < 3; c++) eigvec[(int64_t)(c + 3 * j) * nvox + vox] = v[j][c];
+        }
+    }
+}
+
 /* Per-voxel tail shared by the full and partial branches: d[7] -> 16 outputs (dti.jl:305-315). */
 void orc_dti_from_d(const float d[7], float out[16])
 {

@@ -129,6 +129,20 @@ def sym3_eigen(a11, a12, a13, a22, a23, a33):
     return w, v.T.copy()      # columns = eigenvectors, ascending eigenvalues
 
 
+def st_eigen(sxx, sxy, sxz, syy, syz, szz):
+    """st_eigen (structens.jl:13-37) -> (eigvec [nx,ny,nz,3,3], eigval [nx,ny,nz,3]), Fortran order."""
+    vols = [np.asfortranarray(v, dtype=np.float32) for v in (sxx, sxy, sxz, syy, syz, szz)]
+    shape = vols[0].shape
+    nvox = int(np.prod(shape))
+    eigvec = np.zeros(shape + (3, 3), np.float32, order="F")
+    eigval = np.zeros(shape + (3,), np.float32, order="F")
+    L = lib()
+    L.orc_st_eigen.argtypes = [C.c_void_p] * 6 + [C.c_int64, C.c_void_p, C.c_void_p]
+    L.orc_st_eigen.restype = None
+    L.orc_st_eigen(*[_p(v) for v in vols], nvox, _p(eigvec), _p(eigval))
+    return eigvec, eigval
+
+
 def dti_fit(dwi, mask, bval, bvec, nthreads=1):
     """dti_fit(dwi::MRI, mask::MRI) (dti.jl:221) -> dict of the 10 DTI volumes."""
     if bval is None or len(bval) == 0:

@@ -101,3 +101,38 @@ def test_dti_nonfinite_samples(fj, orc):
         g[k] = np.where(ok[..., None] if g[k].ndim == 4 else ok, g[k], 0)
         ref[k] = np.where(ok[..., None] if np.ndim(ref[k]) == 4 else ok, ref[k], 0) if k in ref and hasattr(ref[k], "ndim") else ref[k]
     assert_dti_close(g, ref, m2, label="nonfinite", s0_rtol=2e-3, ev_rtol=5e-3, ev_atol=2e-6, fa_atol=5e-3, vec_tol=1e-3, gap=0.2)
+
+
+def test_st_eigen_matches_oracle(fj, orc):
+    """st_eigen (structens.jl:13-37): eigen(Symmetric(S,:L)) of every voxel's structure tensor -- ascending eigenvalues,
+    eigenvectors as columns -- against the oracle's StaticArrays closed form, host and device tier."""
+    import torch
+    rng = np.random.default_rng(41)
+    shape = (9, 7, 5)
+    g = rng.normal(size=shape + (3,)).astype(np.float32)
+    sm = [g[..., i] * g[..., j] for i, j in ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))]     # rank-1 tensors (as st_recon without smoothing)
+    sm = [np.asfortranarray(v + 0.05 * rng.normal(size=shape).astype(np.float32) * (k in (0, 3, 5))) for k, v in enumerate(sm)]
+    sm[0][0, 0, 0] = sm[3][0, 0, 0] = sm[5][0, 0, 0] = 2.0; sm[1][0, 0, 0] = sm[2][0, 0, 0] = sm[4][0, 0, 0] = 0.0   # isotropic: degenerate
+    for v in sm: v[1, 0, 0] = 0.0                                                                                      # zero tensor
+    rvec, rval = orc.st_eigen(*sm)
+    gvec, gval = fj.st_eigen(*sm)
+    assert gvec.shape == shape + (3, 3) and gval.shape == shape + (3,)
+    np.testing.assert_allclose(gval, rval, rtol=2e-5, atol=2e-6)
+    assert (np.diff(gval, axis=3) >= 0).all()
+    gap = np.minimum(np.abs(rval[..., 1] - rval[..., 0]), np.abs(rval[..., 2] - rval[..., 1])) / (np.abs(rval).max(axis=3) + 1e-30)
+    well = gap > 1e-2
+    for j in range(3):
+        dots = np.abs((gvec[..., :, j] * rvec[..., :, j]).sum(axis=3))
+        assert dots[well].min() > 1 - 1e-4, j
+        np.testing.assert_allclose(np.linalg.norm(gvec[..., :, j], axis=3)[well], 1.0, atol=1e-5)
+    # A v = lambda v where the spectrum is well separated
+    A = np.zeros(shape + (3, 3), np.float64)
+    for (i, j), v in zip(((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)), sm):
+        A[..., i, j] = v; A[..., j, i] = v
+    for j in range(3):
+        res = np.einsum("...ik,...k->...i", A, gvec[..., :, j].astype(np.float64)) - gval[..., j:j + 1] * gvec[..., :, j]
+        assert np.abs(res)[well].max() < 5e-5 * max(1.0, np.abs(A).max())
+    dvec, dval = fj.st_eigen_device([torch.from_numpy(v.reshape(-1, order="F").copy()).cuda() for v in sm])
+    torch.cuda.synchronize()
+    assert np.array_equal(dval.cpu().numpy().reshape((3,) + shape[::-1]).transpose(3, 2, 1, 0), gval)
+    assert np.array_equal(dvec.cpu().numpy().reshape((3, 3) + shape[::-1]).transpose(4, 3, 2, 1, 0), gvec, equal_nan=True)
