@@ -112,12 +112,12 @@ end
 
 "st_eigen(Sxx, Sxy, Sxz, Syy, Syz, Szz) — replaces structens.jl:13-37"
 function st_eigen(Sxx::Array{Float32,3}, Sxy::Array{Float32,3}, Sxz::Array{Float32,3},
-                  Syy::Array{Float32,3}, Syz::Array{Float32,3}, Szz::Array{Float32,3})
+                  Syy::Array{Float32,3}, Syz::Array{Float32,3}, Szz::Array{Float32,3}; device::Integer=0)
   eigvec = Array{Float32,5}(undef, size(Sxx)..., 3, 3)
   eigval = Array{Float32,4}(undef, size(Sxx)..., 3)
   S = [pointer(Sxx), pointer(Sxy), pointer(Sxz), pointer(Syy), pointer(Syz), pointer(Szz)]
   GC.@preserve Sxx Sxy Sxz Syy Syz Szz S eigvec eigval fib_check(ccall((:fib_st_eigen, libfibers), Cint,
-      (Cint, Ptr{Ptr{Cfloat}}, Int64, Ptr{Cfloat}, Ptr{Cfloat}), DEVICE[], S, length(Sxx), eigvec, eigval))
+      (Cint, Ptr{Ptr{Cfloat}}, Int64, Ptr{Cfloat}, Ptr{Cfloat}), device, S, length(Sxx), eigvec, eigval))
   return eigvec, eigval
 end
 
