@@ -14,6 +14,6 @@ from .rumba import RUMBASD, RumbaPlan, rumba_rec, rumba_rec_device  # noqa: F401
 from .structens import st_eigen, st_eigen_device  # noqa: F401
 from .tract import Tract  # noqa: F401
 from .stream import make_sublist, stream, stream_device, stream_field_device  # noqa: F401
-from .nifti import (dsi_write, dti_write, gqi_write, load_nifti, mri_read, mri_read_bfiles, mri_write,  # noqa: F401
+from .nifti import (dsi_write, dti_write, gqi_write, load_nifti, mri_read, mri_read_bfiles, mri_write, rumba_write,  # noqa: F401
                     read_struct)
 from .trk import str_add, stream_to_trk, tract_header, trk_read, trk_write  # noqa: F401

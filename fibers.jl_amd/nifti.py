@@ -248,6 +248,17 @@ def write_struct(obj, basename):
 dti_write = gqi_write = dsi_write = write_struct
 
 
+def rumba_write(rumba, basename):
+    """rumba_write (rusd.jl:645-663): the MRI fields like the other writers, every other field (snr_mean, snr_std) as
+    `<base>_<field>.txt` (writedlm of one Float32: its shortest decimal form and a newline)."""
+    write_struct(rumba, basename)
+    for name, val in vars(rumba).items():
+        if isinstance(val, MRI) or (isinstance(val, (list, tuple)) and val and all(isinstance(v, MRI) for v in val)):
+            continue
+        with open("%s_%s.txt" % (basename, name), "w") as f:
+            f.write(" ".join(str(np.float32(x)) for x in np.atleast_1d(val)) + "\n")
+
+
 def read_struct(inbase, cls):
     """mri_read(inbase, type) (mri.jl:2276-2311): reload a DTI / GQI / DSI result from its files"""
     import dataclasses

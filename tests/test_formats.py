@@ -91,6 +91,20 @@ def test_result_struct_write_and_reload(fj, tmp_path):
     assert np.array_equal(back.odf.vol, gqi.odf.vol) and all(np.array_equal(a.vol, b.vol) for a, b in zip(back.peak, gqi.peak))
 
 
+def test_rumba_write_files(fj, tmp_path):
+    """rumba_write (rusd.jl:645-663): <base>_<field>.nii.gz per volume, <base>_peak<k>.nii.gz, scalars as one-line .txt"""
+    rng = np.random.default_rng(3)
+    mk = lambda n: fj.MRI(np.asfortranarray(rng.normal(size=(3, 2, 2, n)).astype(np.float32)), volres=(2, 2, 2), vox2ras=_affine())
+    r = fj.RUMBASD(fodf=mk(6), fgm=mk(1), fcsf=mk(1), peak=[mk(3) for _ in range(5)], gfa=mk(1), var=mk(1), snr_mean=12.539062, snr_std=0.1)
+    base = str(tmp_path / "s")
+    fj.rumba_write(r, base)
+    names = sorted(os.listdir(tmp_path))
+    assert names == sorted(["s_%s.nii.gz" % k for k in ("fodf", "fgm", "fcsf", "gfa", "var")] + ["s_peak%d.nii.gz" % k for k in range(1, 6)] +
+                           ["s_snr_mean.txt", "s_snr_std.txt"])
+    assert open(base + "_snr_mean.txt").read() == "12.539062\n" and open(base + "_snr_std.txt").read() == "0.1\n"
+    assert np.array_equal(fj.mri_read(base + "_peak4.nii.gz").vol, r.peak[3].vol)
+
+
 def test_trk_header_body_and_roundtrip(fj, tmp_path):
     ref = fj.MRI(np.zeros((10, 12, 14), np.uint8), volres=(1.5, 1.5, 2.0), vox2ras=_affine())
     rng = np.random.default_rng(2)
