@@ -106,6 +106,9 @@ def main():
     out = fj.odf_rec_device(plan, dwi, mask, normalize=False)
 
     def gqi_step():
+        if world == 1:                                                     # one volume, one GPU: qa ./= odfmax inside the library call
+            fj.odf_rec_device(plan, dwi, mask, out=out, normalize=True)
+            return
         fj.odf_rec_device(plan, dwi, mask, out=out, normalize=False)
         if world > 1:
             dist.all_reduce(out["odfmax"][:1], op=dist.ReduceOp.MAX)      # gqi.jl:164 across ranks

@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256) void mask_count_kernel(const uint8_t *__restri
     if (tid == 0) blockcnt[blockIdx.x] = make_int2(cv[0] + cv[1] + cv[2] + cv[3], ct[0] + ct[1] + ct[2] + ct[3]);
 }
 // in-place exclusive scan of blockcnt[nb]; totals -> {nlive, ntiles_live}
-__global__ __launch_bounds__(1024) void mask_scan_kernel(int2 *__restrict__ blockcnt, int nb, int32_t *__restrict__ totals) {
+__global__ __launch_bounds__(1024) void mask_scan_kernel(int2 *__restrict__ blockcnt, int nb, int32_t *__restrict__ totals, unsigned *__restrict__ maxenc) {
     __shared__ int2 part[1024];
     const int tid = threadIdx.x;
     const int per = (nb + 1023) / 1024;
@@ -749,6 +749,7 @@ __global__ __launch_bounds__(1024) void mask_scan_kernel(int2 *__restrict__ bloc
     int2 run = tid ? part[tid - 1] : make_int2(0, 0);
     for (int i = lo; i < hi; i++) { const int2 c = blockcnt[i]; blockcnt[i] = run; run.x += c.x; run.y += c.y; }
     if (tid == 1023) { totals[0] = part[1023].x; totals[1] = part[1023].y; totals[2] = 0; }   // [2]: length of the +Inf voxel list
+    if (tid < 2 && maxenc) maxenc[tid] = 0u;                // (the peak finder's running odfmax: one memset launch less)
 }
 __global__ __launch_bounds__(256) void mask_write_kernel(const uint8_t *__restrict__ mask, int64_t nvox, const int2 *__restrict__ blockoff,
                                                         int32_t *__restrict__ vidx, int32_t *__restrict__ tiles) {
@@ -2020,7 +2021,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         if ((rcc = plan->live_blocks.ensure((size_t)nb)) != FIB_OK) return rcc;
         fib::ProfScope prof("mask_compact", st);
         hipLaunchKernelGGL(mask_count_kernel, dim3(nb), dim3(256), 0, st, mask, nvox, plan->live_blocks.p);
-        hipLaunchKernelGGL(mask_scan_kernel, dim3(1), dim3(1024), 0, st, plan->live_blocks.p, nb, plan->live_counts.p);
+        hipLaunchKernelGGL(mask_scan_kernel, dim3(1), dim3(1024), 0, st, plan->live_blocks.p, nb, plan->live_counts.p, plan->maxenc.p);
         hipLaunchKernelGGL(mask_write_kernel, dim3(nb), dim3(256), 0, st, mask, nvox, plan->live_blocks.p, plan->live_vox.p, plan->live_tiles.p);
         FIB_HIP(hipGetLastError());
     }
@@ -2053,7 +2054,6 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
     ga.stride = nvox;
     ga.has_ineff = plan->has_ineff ? 1 : 0;
     FIB_CHECK(fib::cdiv(nvox, WG_VOX) * plan->ntile_m < ((int64_t)1 << 31), FIB_ERR_UNSUPPORTED, "volume too large for one launch");
-    FIB_HIP(hipMemsetAsync(plan->maxenc.p, 0, 2 * sizeof(unsigned), st));
 
     auto run_gemm = [&](GemmArgs g, hipStream_t s) -> int {
         const unsigned grid = (unsigned)(fib::cdiv(g.nvox, WG_VOX) * plan->ntile_m);
@@ -2127,7 +2127,7 @@ int fib::matrix_plan_run(const fib_odf_plan *plan, const float *S, const uint8_t
         if ((rcc = plan->live_tiles.ensure((size_t)fib::cdiv(n, 64))) != FIB_OK) return rcc;
         if ((rcc = plan->live_blocks.ensure((size_t)nb)) != FIB_OK) return rcc;
         hipLaunchKernelGGL(mask_count_kernel, dim3(nb), dim3(256), 0, st, ones, n, plan->live_blocks.p);
-        hipLaunchKernelGGL(mask_scan_kernel, dim3(1), dim3(1024), 0, st, plan->live_blocks.p, nb, plan->live_counts.p);
+        hipLaunchKernelGGL(mask_scan_kernel, dim3(1), dim3(1024), 0, st, plan->live_blocks.p, nb, plan->live_counts.p, (unsigned *)nullptr);
         hipLaunchKernelGGL(mask_write_kernel, dim3(nb), dim3(256), 0, st, ones, n, plan->live_blocks.p, plan->live_vox.p, plan->live_tiles.p);
     }
     GemmArgs ga{};
