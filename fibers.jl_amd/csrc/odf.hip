@@ -1,18 +1,25 @@
 // odf.hip — K2..K5: GQI / DSI ODF reconstruction, ODF peak finder, global QA normalisation (gfx950).
 //
-//   K2/K5  odf_gemm_kernel   O[M x Nvox] = A[M x K] * clamp(S[K x Nvox])   on v_mfma_f32_32x32x2_f32
+//   K2/K5  odf_gemm3_kernel  O[M x Nvox] = A[M x K] * clamp(S[K x Nvox]) as an exact f32 contraction on the bf16 matrix
+//                            cores (three bf16 pieces per operand, v_mfma_f32_32x32x16_bf16; default), with the DSI
+//                            antipodal fold fused into the sample load (FOLD)
+//          odf_gemm_kernel   the same contraction on v_mfma_f32_32x32x2_f32 (FIBERS_ODF_GEMM=f32 and every plan the
+//                            split kernel does not take)
 //                            (gqi.jl:139-145 `mul!(o, A, s)`; dsi.jl:204-246 recast as two dense maps)
-//   K3     odf_peaks_kernel  find_peaks! + peak/qa extraction (gqi.jl:147-159,180-201; dsi.jl:244-258)
+//          mask_*_kernel, zero_dead_kernel, odf_inf_fix_kernel: voxel-list compaction, outputs outside the mask,
+//                            columns of voxels with a +Inf sample
+//   K3     odf_peaks642_kernel (sphere_642, specialised scan + candidate lists), odf_peaks64_kernel (any tessellation),
+//          odf_peaks_kernel (32-voxel tiles): find_peaks! + peak/qa extraction (gqi.jl:147-159,180-201; dsi.jl:244-258)
 //   K4     max-of-means reduction + qa ./= odfmax (gqi.jl:164-168; dsi.jl:263-267)
 //
-// GEMM design.  M (ODF vertices, 321 for sphere_642) is small, K (frames, 270) is small, N (voxels,
+// GEMM design (both kernels).  M (ODF vertices, 321 for sphere_642) is small, K (frames, 270) is small, N (voxels,
 // 2.7 M) is huge and contiguous in memory for both S (planar frames) and O (planar vertices).  So the
 // voxel index sits on the MFMA lane (N = column): a wave owns 32 voxels and ALL rows of its M tile;
 // accumulators stay in registers for the whole K loop (MB blocks of 32x32 = 16*MB VGPRs), S is read
 // exactly once straight into VGPRs as the B operand (two 128-B segments per wave load), and the only
 // shared operand, the matrix A (347 KB: larger than LDS), is streamed K-tile by K-tile through a
-// double-buffered LDS ring with direct-to-LDS loads (global_load_lds), laid out K-major so that the
-// A-fragment ds_read_b32 is bank-conflict free.  f32-input MFMA is exact f32 (k-ordered fma chain):
+// double-buffered LDS ring with direct-to-LDS loads (global_load_lds), laid out so that the A-fragment
+// reads are bank-conflict free.  Both kernels are exact f32 (a k-ordered fma chain / exact piece products):
 // the ODF matches a CPU sgemv to rounding, which the strict-inequality peak finder needs.
 #include <algorithm>
 #include <cmath>
