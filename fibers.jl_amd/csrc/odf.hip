@@ -521,7 +521,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
         }
         __syncthreads();
     }
-    unsigned long long st0 = 0, rt1 = 0, acc_epi = 0;
+    unsigned long long st0 = 0, rt1 = 0, acc_epi = 0, ph_split = 0, ph_issue = 0, ph_mfma = 0, ph_bar = 0;
     if (STAMP) { st0 = __builtin_amdgcn_s_memtime(); rt1 = __builtin_amdgcn_s_memrealtime(); }
 
     // ---- work list of this workgroup ---------------------------------------------------------------------------
@@ -656,12 +656,16 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
         for (int t = 0; t < ntiles; t++, g++) {
             const int cb = g & 1;
             const char *L = lds + cb * TILEB;
+            unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+            if (STAMP) q0 = __builtin_amdgcn_s_memtime();
             split(cur.tile_m, t);
+            if (STAMP) { __builtin_amdgcn_sched_barrier(0); q1 = __builtin_amdgcn_s_memtime(); }
             // the next stage (it may open the next work item): pieces into the other buffer, samples into braw
             const bool w1 = t + 1 < ntiles;
             stage_A(w1 ? cur.tile_m : (nxt.valid ? nxt.tile_m : cur.tile_m), w1 ? t + 1 : 0, cb ^ 1);
             load_B(w1 ? t + 1 : 0, w1 ? s_off : s_off_n, w1 || nxt.valid);
             __builtin_amdgcn_sched_barrier(0);          // the requests go out before the MFMA block, not after it
+            if (STAMP) q2 = __builtin_amdgcn_s_memtime();
             const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, bp[0]), b1 = __builtin_bit_cast(bf16x8_t, bp[1]), b2 = __builtin_bit_cast(bf16x8_t, bp[2]);
             const bf16x8_t *LA = reinterpret_cast<const bf16x8_t *>(L) + lane;
             // The fragment reads are pinned (sched_barrier) 2-5 MFMAs ahead of their first use, each into the registers
@@ -686,8 +690,10 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
                 __builtin_amdgcn_sched_barrier(0);
                 a2 = n2; a1 = n1; a0 = n0;
             }
+            if (STAMP) { __builtin_amdgcn_sched_barrier(0); q3 = __builtin_amdgcn_s_memtime(); }
             __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): the next stage's pieces and samples have landed
             __syncthreads();
+            if (STAMP) { const unsigned long long q4 = __builtin_amdgcn_s_memtime(); ph_split += q1 - q0; ph_issue += q2 - q1; ph_mfma += q3 - q2; ph_bar += q4 - q3; }
         }
         unsigned long long te = 0;
         if (STAMP) te = __builtin_amdgcn_s_memtime();
@@ -703,7 +709,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
         const unsigned long long st2 = __builtin_amdgcn_s_memtime(), rt2 = __builtin_amdgcn_s_memrealtime();
         if (tid == 0 && a.dbg) {
             unsigned long long *d = a.dbg + (size_t)blockIdx.x * 8;
-            d[0] = st2 - st0; d[1] = acc_epi; d[2] = 0; d[3] = (unsigned long long)(g / ntiles); d[4] = rt2 - rt1; d[5] = 0; d[6] = 0; d[7] = 0;
+            d[0] = st2 - st0; d[1] = acc_epi; d[2] = ph_split; d[3] = (unsigned long long)(g / ntiles); d[4] = rt2 - rt1; d[5] = ph_issue; d[6] = ph_mfma; d[7] = ph_bar;
         }
     }
 }
@@ -1915,17 +1921,19 @@ void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
                 (void)hipStreamSynchronize(st);
                 std::vector<unsigned long long> h((size_t)pg * 8);
                 (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
-                std::vector<double> clk, item, epi;
+                std::vector<double> clk, item, epi, psp, pis, pmf, pba;
                 for (unsigned b = 0; b < pg; b++) {
                     const unsigned long long *d = &h[(size_t)b * 8];
                     if (d[4] == 0 || d[3] == 0) continue;
                     const double n = (double)d[3];
                     clk.push_back((double)d[0] / (double)d[4] * 100.0);
                     item.push_back((double)d[0] / n); epi.push_back((double)d[1] / n);
+                    psp.push_back((double)d[2] / n); pis.push_back((double)d[5] / n); pmf.push_back((double)d[6] / n); pba.push_back((double)d[7] / n);
                 }
                 auto med = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
                 fprintf(stderr, "gemm3 stamps over %zu workgroups: clock %.0f MHz; cycles per work item %.0f (%.1f per MFMA), of which epilogue %.0f\n",
                         clk.size(), med(clk), med(item), med(item) / (17.0 * 60.0), med(epi));
+                fprintf(stderr, "  wave 0, per work item: split %.0f, request issue %.0f, MFMA block %.0f, wait + barrier %.0f cycles\n", med(psp), med(pis), med(pmf), med(pba));
             }
             return;
         }
