@@ -110,22 +110,39 @@ __global__ __launch_bounds__(256) void rumba_tv_kernel(const TvArgs a) {
     // against the real-number result as the reference's sqrt-then-divide (two roundings), at a third of the instructions.
     // Components that div(p) never uses (y, z of the -x point, ...) are not formed.
     const bool in1 = cc[1][0] != -2, in2 = cc[2][0] != -2, in3 = cc[3][0] != -2;
+    // 13 distinct values enter div(p); six of them are what the neighbouring LANE holds when the masked columns run along x
+    // (lane+1 = voxel x+1, lane-1 = voxel x-1): they come over by wave shuffles, not as further L2 reads (the sweep moved
+    // 23 GB between L2 and the CUs for 5.8 GB of HBM traffic).  Lanes at a wave edge or a mask edge load them as before.
+    const int lane = threadIdx.x & 63;
+    const bool up = lane < 63 && cc[0][1] == (int32_t)c + 1;      // lane+1 holds (x+1, y, z)
+    const bool dn = lane > 0 && cc[1][0] == (int32_t)c - 1;       // lane-1 holds (x-1, y, z)
     for (int k = 0; k < a.d.ncomp; k++) {
         const float *f = a.fodf + (int64_t)k * a.d.npad;
         auto at = [&](int32_t col) { return col >= 0 ? f[col] : 0.0f; };
         auto inv_norm = [&](float gx, float gy, float gz) {       // 1 ./ sqrt.(Gx.^2 .+ Gy.^2 .+ Gz.^2 .+ eps(T))
             return __builtin_amdgcn_rsqf(((gx * gx + gy * gy) + gz * gz) + EPS32);
         };
-        const float fc = f[c];                                    // cc[0][0] == c
+        const float fc = f[c];                                    // cc[0][0] == c (and cc[1][1], cc[2][2], cc[3][3] when those points exist)
+        const float fB = at(cc[0][2]), fC = at(cc[0][3]);         // p+y, p+z
+        const float fD = at(cc[2][0]), fE = at(cc[3][0]);         // p-y, p-z
+        const float fF = at(cc[2][3]), fG = at(cc[3][2]);         // p-y+z, p-z+y
+        const float sA_up = __shfl_down(fc, 1), sD_up = __shfl_down(fD, 1), sE_up = __shfl_down(fE, 1);
+        const float sA_dn = __shfl_up(fc, 1), sB_dn = __shfl_up(fB, 1), sC_dn = __shfl_up(fC, 1);
+        const float fX1 = up ? sA_up : at(cc[0][1]);              // p+x
+        const float fD1 = up ? sD_up : at(cc[2][1]);              // p-y+x
+        const float fE1 = up ? sE_up : at(cc[3][1]);              // p-z+x
+        const float fM1 = dn ? sA_dn : at(cc[1][0]);              // p-x
+        const float fM1y = dn ? sB_dn : at(cc[1][2]);             // p-x+y
+        const float fM1z = dn ? sC_dn : at(cc[1][3]);             // p-x+z
         float g0x, g0y, g0z, g1x = 0.0f, g2y = 0.0f, g3z = 0.0f;
         {
-            const float gx = at(cc[0][1]) - fc, gy = at(cc[0][2]) - fc, gz = at(cc[0][3]) - fc;
+            const float gx = fX1 - fc, gy = fB - fc, gz = fC - fc;
             const float iv = inv_norm(gx, gy, gz);
             g0x = gx * iv; g0y = gy * iv; g0z = gz * iv;
         }
-        if (in1) { const float f0 = at(cc[1][0]); const float gx = at(cc[1][1]) - f0, gy = at(cc[1][2]) - f0, gz = at(cc[1][3]) - f0; g1x = gx * inv_norm(gx, gy, gz); }
-        if (in2) { const float f0 = at(cc[2][0]); const float gx = at(cc[2][1]) - f0, gy = at(cc[2][2]) - f0, gz = at(cc[2][3]) - f0; g2y = gy * inv_norm(gx, gy, gz); }
-        if (in3) { const float f0 = at(cc[3][0]); const float gx = at(cc[3][1]) - f0, gy = at(cc[3][2]) - f0, gz = at(cc[3][3]) - f0; g3z = gz * inv_norm(gx, gy, gz); }
+        if (in1) { const float gx = fc - fM1, gy = fM1y - fM1, gz = fM1z - fM1; g1x = gx * inv_norm(gx, gy, gz); }
+        if (in2) { const float gx = fD1 - fD, gy = fc - fD, gz = fF - fD; g2y = gy * inv_norm(gx, gy, gz); }
+        if (in3) { const float gx = fE1 - fE, gy = fG - fE, gz = fc - fE; g3z = gz * inv_norm(gx, gy, gz); }
         // sd_div!: interior G[i] - G[i-1]; first G[1]; last -G[end-1]
         const float dx = a.d.nx == 1 ? g0x : (x == 0 ? g0x : (x == a.d.nx - 1 ? -g1x : g0x - g1x));
         const float dy = a.d.ny == 1 ? g0y : (y == 0 ? g0y : (y == a.d.ny - 1 ? -g2y : g0y - g2y));
