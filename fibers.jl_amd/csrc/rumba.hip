@@ -311,6 +311,9 @@ struct fib_rumba_plan {
     fib_odf_plan *pT = nullptr, *pK = nullptr;                    // contractions with K' and with K
     fib::DevBuf<int32_t> d_b0, d_dw, d_nb_off, d_nb_idx;
     fib::DevBuf<float> d_verts, d_fodf0, d_dodf0;
+    // work arrays of a call (grow-only, kept for the next call on this plan: ten fresh GB cost ~0.3 s of hipMalloc per call;
+    // a plan serves one call at a time)
+    mutable fib::DevBuf<float> w_sig, w_dodf, w_ir, w_x, w_fodf, w_fodf2, w_rl, w_rl2;
 };
 
 extern "C" void fib_rumba_plan_destroy(fib_rumba_plan *p) {
@@ -454,14 +457,16 @@ extern "C" int fibd_rumba_rec(const fib_rumba_plan *plan, const float *dwi, cons
     RumbaDims d{plan->ndir, plan->ncomp, plan->nvert, nmask, (nmask + 255) / 256 * 256, nx, ny, nz};
     const int64_t nD = (int64_t)d.ndir * d.npad, nC = (int64_t)d.ncomp * d.npad;
     fib::DevBuf<int32_t> d_ind, d_col;
-    fib::DevBuf<float> sig, dodf, ir, x, fodf, fodf2, rl, rl2, tv, s2, snr, lam;
+    fib::DevBuf<float> tv, s2, snr, lam;
+    fib::DevBuf<float> &sig = plan->w_sig, &dodf = plan->w_dodf, &ir = plan->w_ir, &x = plan->w_x, &fodf = plan->w_fodf, &fodf2 = plan->w_fodf2,
+                       &rl = plan->w_rl, &rl2 = plan->w_rl2;
     fib::DevBuf<uint8_t> ones;
     fib::DevBuf<double> stats;
     int rc;
     if ((rc = d_ind.alloc((size_t)nmask)) != FIB_OK || (rc = d_col.alloc((size_t)nvox)) != FIB_OK ||
-        (rc = sig.alloc((size_t)nD)) != FIB_OK || (rc = dodf.alloc((size_t)nD)) != FIB_OK ||
-        (rc = ir.alloc((size_t)nD)) != FIB_OK || (rc = x.alloc((size_t)nD)) != FIB_OK || (rc = fodf.alloc((size_t)nC)) != FIB_OK ||
-        (rc = fodf2.alloc((size_t)nC)) != FIB_OK || (rc = rl.alloc((size_t)nC)) != FIB_OK || (rc = rl2.alloc((size_t)nC)) != FIB_OK ||
+        (rc = sig.ensure((size_t)nD)) != FIB_OK || (rc = dodf.ensure((size_t)nD)) != FIB_OK ||
+        (rc = ir.ensure((size_t)nD)) != FIB_OK || (rc = x.ensure((size_t)nD)) != FIB_OK || (rc = fodf.ensure((size_t)nC)) != FIB_OK ||
+        (rc = fodf2.ensure((size_t)nC)) != FIB_OK || (rc = rl.ensure((size_t)nC)) != FIB_OK || (rc = rl2.ensure((size_t)nC)) != FIB_OK ||
         (rc = tv.alloc((size_t)(use_tv ? 1 : nC))) != FIB_OK ||
         (rc = s2.alloc((size_t)d.npad)) != FIB_OK || (rc = snr.alloc((size_t)d.npad)) != FIB_OK || (rc = lam.alloc((size_t)d.npad)) != FIB_OK ||
         (rc = ones.alloc((size_t)d.npad)) != FIB_OK || (rc = stats.alloc(2)) != FIB_OK) return rc;

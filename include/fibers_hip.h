@@ -174,7 +174,8 @@ typedef struct {
 /* rumba_rec(dwi, mask, odf_dirs, niter, ...) (rusd.jl:419-636) on device-resident volumes: dwi planar [nvol][nvox],
  * mask uint8 [nvox] (already `> 0`-tested).  niter: Richardson-Lucy iterations (reference default 600); ncoils /
  * sos_grappa: coil_combine == "SoS-GRAPPA" uses n_order = ncoils, "SMF-SENSE" n_order = 1; ipat_factor >= 1; use_tv:
- * total-variation prior.  snr_mean / snr_std: host scalars (may be NULL).  Blocking. */
+ * total-variation prior.  snr_mean / snr_std: host scalars (may be NULL).  Blocking.  The plan keeps the call's work arrays
+ * (8 x [ndir or ncomp][masked voxels] floats) for the next call: one call at a time per plan; destroy the plan to release them. */
 int fibd_rumba_rec(const fib_rumba_plan *plan, const float *dwi, const uint8_t *mask, int nx, int ny, int nz,
                    int niter, int ncoils, int sos_grappa, int ipat_factor, int use_tv,
                    const fib_rumba_out *out, float *snr_mean, float *snr_std, void *stream);
