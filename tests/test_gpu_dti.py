@@ -136,3 +136,29 @@ def test_st_eigen_matches_oracle(fj, orc):
     torch.cuda.synchronize()
     assert np.array_equal(dval.cpu().numpy().reshape((3,) + shape[::-1]).transpose(3, 2, 1, 0), gval)
     assert np.array_equal(dvec.cpu().numpy().reshape((3, 3) + shape[::-1]).transpose(4, 3, 2, 1, 0), gvec, equal_nan=True)
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_dti_and_adc_randomised_configurations(fj, orc, case):
+    """Seeded random draws: volume shape (odd sizes), 6-48 directions, 1-5 b0 frames in random positions, b-values, mask
+    density and dtype, fraction of non-positive samples (row-subset fits and zero voxels), noise level."""
+    from fibers_jl_amd import phantom
+    rng = np.random.default_rng(500 + case)
+    shape = tuple(int(x) for x in rng.integers(3, 13, 3))
+    ndir, nb0 = int(rng.integers(6, 49)), int(rng.integers(1, 6))
+    bval, bvec = phantom.scheme_dti(ndir, nb0, float(rng.choice([700.0, 1000.0, 2500.0])), 500 + case)
+    perm = rng.permutation(len(bval))                              # b0 frames anywhere in the table
+    bval, bvec = np.ascontiguousarray(bval[perm]), np.ascontiguousarray(bvec[perm])
+    nonpos = float(rng.choice([0.0, 0.0, 0.01, 0.05]))
+    dwi, _, _ = phantom.make_volume(shape, bval, bvec, 500 + case, noise_frac=float(rng.choice([0.0, 0.02, 0.08])), nonpositive_frac=nonpos)
+    mask = (rng.random(shape) < rng.uniform(0.4, 1.0)).astype(rng.choice([np.uint8, np.int16, np.float32]))
+    with np.errstate(all="ignore"):
+        ref = orc.dti_fit(dwi, mask, bval, bvec, nthreads=3)
+        got = fj.dti_fit(fj.MRI(dwi, bval, bvec), fj.MRI(mask))
+    g = {k: getattr(got, k).vol for k in fj.dti.DTI_FIELDS}
+    loose = dict(s0_rtol=2e-3, ev_rtol=5e-3, ev_atol=2e-6, fa_atol=5e-3, vec_tol=1e-3, gap=0.2) if nonpos > 0 else {}
+    assert_dti_close(g, ref, (mask != 0).astype(np.uint8), label="case %d %s" % (case, shape), **loose)
+    radc, rs0 = orc.adc_fit(dwi, mask, bval, nthreads=3)
+    adc, s0 = fj.adc_fit(fj.MRI(dwi, bval, bvec), fj.MRI(mask))
+    np.testing.assert_allclose(adc.vol[..., 0], radc, rtol=3e-3, atol=2e-7)
+    np.testing.assert_allclose(s0.vol[..., 0], rs0, rtol=3e-3)

@@ -495,3 +495,39 @@ def test_find_peaks_randomised_against_the_oracle(fj, orc, sphere):
             isort, nv, _ = orc.find_peaks(odf[i], faces0)
         assert nv == nvalid[i, 0], (i, nv, nvalid[i, 0])
         assert list(isort[:3]) == list(top[i, 0]), (i, isort[:3], top[i, 0])
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_gqi_and_dsi_randomised_configurations(fj, orc, case, monkeypatch):
+    """Seeded random draws over what gqi_rec / dsi_rec take: tessellation, sigma, shell layout and frame order, Hanning
+    width, lattice radius (257 / 389 / 515 frames, shuffled so that antipodal partners sit anywhere), mask density, fraction of
+    non-positive samples, and which contraction kernel runs."""
+    from fibers_jl_amd import phantom
+    rng = np.random.default_rng(900 + case)
+    monkeypatch.setenv("FIBERS_ODF_GEMM", "f32" if case % 4 == 3 else "bf16x3")
+    sph = getattr(fj, ["sphere_642", "sphere_362", "sphere_724"][case % 3])
+    shape = tuple(int(x) for x in rng.integers(3, 9, 3))
+    mask = (rng.random(shape) < rng.uniform(0.5, 1.0)).astype(np.uint8)
+    # ---- GQI
+    nb0, ndir = int(rng.integers(1, 5)), int(rng.integers(12, 40))
+    shells = tuple(sorted(rng.choice([700.0, 1000.0, 1500.0, 2000.0, 3000.0, 5000.0], size=int(rng.integers(1, 4)), replace=False)))
+    bval, bvec = phantom.scheme_gqi(nb0, ndir, shells, 900 + case)
+    perm = rng.permutation(len(bval))
+    bval, bvec = np.ascontiguousarray(bval[perm]), np.ascontiguousarray(bvec[perm])
+    dwi, _, _ = phantom.make_volume(shape, bval, bvec, 900 + case, noise_frac=0.03, nonpositive_frac=float(rng.choice([0.0, 0.03])), crossing=True)
+    sigma = float(rng.choice([1.0, 1.25, 1.6]))
+    ref = orc.gqi_rec(dwi, mask, bval, bvec, sph.vertices, sph.faces, sigma, nthreads=3)
+    got = fj.gqi_rec(fj.MRI(dwi, bval, bvec), fj.MRI(mask), sph, sigma)
+    _check_odf_rec(got.odf.vol, [p.vol for p in got.peak], [q.vol[..., 0] for q in got.qa], ref, mask, label="gqi case %d" % case)
+    # ---- DSI
+    bval, bvec = phantom.scheme_dsi(bmax=float(rng.choice([5000.0, 7000.0])), r2max=int(rng.choice([16, 20, 25])))
+    perm = rng.permutation(len(bval))
+    bval, bvec = np.ascontiguousarray(bval[perm]), np.ascontiguousarray(bvec[perm])
+    dwi, _, _ = phantom.make_volume(shape, bval, bvec, 950 + case, noise_frac=0.01, crossing=True)
+    hw = int(rng.choice([16, 32, 48]))
+    ref = orc.dsi_rec(dwi, mask, bval, bvec, sph.vertices, sph.faces, hw, nthreads=3)
+    got = fj.dsi_rec(fj.MRI(dwi, bval, bvec), fj.MRI(mask), sph, hw)
+    scale = np.abs(ref["pdf"]).max(axis=3, keepdims=True) + 1e-30
+    assert (np.abs(got.pdf.vol - ref["pdf"]) / scale).max() < 5e-5, "dsi pdf case %d" % case
+    _check_odf_rec(got.odf.vol, [p.vol for p in got.peak], [q.vol[..., 0] for q in got.qa], ref, mask, odf_rtol=1e-4, qa_atol=1e-4,
+                   label="dsi case %d" % case)
