@@ -112,10 +112,7 @@ def main():
         fj.odf_rec_device(plan, dwi, mask, out=out, normalize=False)
         if world > 1:
             dist.all_reduce(out["odfmax"][:1], op=dist.ReduceOp.MAX)      # gqi.jl:164 across ranks
-        # qa ./= odfmax with the (all-reduced) device scalar; no host round trip
-        torch.div(out["qa"][0], out["odfmax"][0], out=out["qa"][0])
-        torch.div(out["qa"][1], out["odfmax"][0], out=out["qa"][1])
-        torch.div(out["qa"][2], out["odfmax"][0], out=out["qa"][2])
+        fj.qa_normalize_device(out["qa"], out["odfmax"])                   # qa ./= the all-reduced odfmax, read on the device
 
     def sync():
         torch.cuda.synchronize()

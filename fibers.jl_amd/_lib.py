@@ -66,6 +66,7 @@ _PROTOS = {
     "fibd_dti_last_partial_count": (i32, [vp, vp, C.POINTER(i64)]),
     "fibd_odf_rec": (i32, [vp, vp, vp, i64, vp, vp, P3, P3, vp, i32, vp]),
     "fibd_qa_normalize": (i32, [P3, i64, f32, vp]),
+    "fibd_qa_normalize_dev": (i32, [P3, i64, vp, vp]),
     "fibd_find_peaks": (i32, [vp, vp, i64, vp, vp, vp]),
     "fibd_stream_field": (i32, [i32, i64, vp, vp, f32, vp, f32, vp, vp, vp, vp]),
     "fibd_stream_trace": (i32, [C.POINTER(StreamParams), vp, vp, i64, vp, i32, vp,

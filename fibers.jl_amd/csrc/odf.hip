@@ -2176,6 +2176,13 @@ extern "C" int fibd_qa_normalize(float *const qa[3], int64_t nvox, float odfmax,
     return FIB_OK;
 }
 
+extern "C" int fibd_qa_normalize_dev(float *const qa[3], int64_t nvox, const float *odfmax_dev, void *stream) {
+    FIB_CHECK(qa && qa[0] && qa[1] && qa[2] && odfmax_dev && nvox > 0, FIB_ERR_INVALID, "NULL argument");
+    hipLaunchKernelGGL(qa_normalize_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, qa[0], qa[1], qa[2], nvox, odfmax_dev, 0.0f);
+    FIB_HIP(hipGetLastError());
+    return FIB_OK;
+}
+
 extern "C" int fibd_find_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox,
                                int32_t *isort_top, int32_t *nvalid, void *stream) {
     FIB_CHECK(plan && odf && isort_top && nvalid && nvox > 0, FIB_ERR_INVALID, "NULL argument");

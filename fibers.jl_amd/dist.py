@@ -102,8 +102,7 @@ def odf_rec_sharded(plan, dwi_local, mask_local, group=None, stream=None):
     import torch
     out = odf_rec_device(plan, dwi_local, mask_local, normalize=False, stream=stream)
     allreduce_odfmax(out["odfmax"], group)
-    torch.cuda.current_stream().synchronize()
-    qa_normalize_device(out["qa"], float(out["odfmax"][0]), stream=stream)
+    qa_normalize_device(out["qa"], out["odfmax"], stream=stream)     # the divisor is read on the device: no host round trip
     return out
 
 

@@ -165,9 +165,14 @@ def odf_rec_device(plan: OdfPlan, dwi, mask, out: Optional[dict] = None, normali
     return out
 
 
-def qa_normalize_device(qa, odfmax: float, stream=None):
+def qa_normalize_device(qa, odfmax, stream=None):
+    """qa[k] ./= odfmax (gqi.jl:166-168).  odfmax: a float, or a float32 CUDA tensor whose first element is the divisor (e.g.
+    the all-reduced `out["odfmax"]`: it never leaves the device)."""
     nvox = qa[0].numel()
-    _lib.check(_lib.lib().fibd_qa_normalize(_lib.P3(*[t.data_ptr() for t in qa]), nvox, float(odfmax), _stream_ptr(stream)))
+    if hasattr(odfmax, "data_ptr"):
+        _lib.check(_lib.lib().fibd_qa_normalize_dev(_lib.P3(*[t.data_ptr() for t in qa]), nvox, odfmax.data_ptr(), _stream_ptr(stream)))
+    else:
+        _lib.check(_lib.lib().fibd_qa_normalize(_lib.P3(*[t.data_ptr() for t in qa]), nvox, float(odfmax), _stream_ptr(stream)))
 
 
 def find_peaks_device(plan: OdfPlan, odf, stream=None):

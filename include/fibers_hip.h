@@ -141,6 +141,8 @@ int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const uint8_t *mask
                  float *odfmax_dev, int flags, void *stream);
 /* qa[k] ./= odfmax for all voxels (gqi.jl:166-168) */
 int fibd_qa_normalize(float *const qa[3], int64_t nvox, float odfmax, void *stream);
+/* same with the divisor read from device memory (the all-reduced odfmax stays on the device: no host round trip) */
+int fibd_qa_normalize_dev(float *const qa[3], int64_t nvox, const float *odfmax_dev, void *stream);
 
 /* find_peaks!(W) (gqi.jl:180-201) on a planar ODF volume [nvox*nvert]: for every voxel the
  * indices (0-based, first-half vertex rows) of the first 3 entries of `isort` and `nvalid`.

@@ -531,3 +531,19 @@ def test_gqi_and_dsi_randomised_configurations(fj, orc, case, monkeypatch):
     assert (np.abs(got.pdf.vol - ref["pdf"]) / scale).max() < 5e-5, "dsi pdf case %d" % case
     _check_odf_rec(got.odf.vol, [p.vol for p in got.peak], [q.vol[..., 0] for q in got.qa], ref, mask, odf_rtol=1e-4, qa_atol=1e-4,
                    label="dsi case %d" % case)
+
+
+def test_qa_normalize_with_device_scalar(fj):
+    """fibd_qa_normalize_dev: the divisor comes from device memory (the all-reduced odfmax of the multi-GPU flow)"""
+    import torch
+    g = torch.Generator(device="cuda"); g.manual_seed(4)
+    qa = [torch.rand(1000, device="cuda", generator=g) for _ in range(3)]
+    om = torch.tensor([3.5, 0.0], dtype=torch.float32, device="cuda")
+    ref = [torch.div(q, om[0]) for q in qa]                       # (tensor divisor: a Python scalar makes torch multiply by 1/x)
+    fj.qa_normalize_device(qa, om)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(qa, ref))
+    fj.qa_normalize_device(qa, 2.0)
+    torch.cuda.synchronize()
+    two = torch.tensor(2.0, device="cuda")
+    assert all(torch.equal(a, torch.div(b, two)) for a, b in zip(qa, ref))
