@@ -68,6 +68,8 @@ int fib_profile_get(const char *kernel, double *total_ms, int64_t *count);
 /* ------------------------------------------------------------------------------------ */
 /* Plans = the reference's pre-computed work structs, resident on one device             */
 /* ------------------------------------------------------------------------------------ */
+/* A plan also owns the scratch of the calls made on it (voxel lists, counters, work arrays: the reference's per-thread
+ * work structs): use one plan per concurrent call / stream; plans themselves are independent of each other. */
 typedef struct fib_dti_plan fib_dti_plan;   /* DTIwork / ADCwork  (dti.jl:39-84, 101-155) */
 typedef struct fib_odf_plan fib_odf_plan;   /* GQIwork (gqi.jl:32-82) or DSIwork (dsi.jl:41-143) */
 
