@@ -57,6 +57,14 @@ struct GemmArgs {
     int32_t *fix_count, *fix_list;
     int fix_cap;
     int fold;                     // split-bf16 kernel, FOLD variant: S holds the raw frames; sample J of the contraction is max(S[rowA[J]],0) + max(S[rowB[J]],0)
+    // FUSE variant (sphere_642, GQI): find_peaks! + peak / qa extraction run on the accumulators (gemm3_epilogue_fused)
+    float *peak[3], *qa[3];       // outputs as PeakArgs
+    const float *verts;           // [nvert][3]
+    unsigned *maxenc;             // [4]: {exact max of means (ordered uint), NaN flag, lower bound of the max from the approximate means, -}
+    float *mean_hi;               // [nvox] upper bound of each listed voxel's mean (NaN: the voxel is on the redo list)
+    int32_t *redo_count, *redo_list;   // voxels the register scan could not finish (NaN / Inf columns, candidate-list overflow)
+    int redo_cap;
+    int fuse_skip;                // timing experiments only (FIBERS_FUSE_SKIP bit mask: 1 scan, 2 statistics, 4 top-3 + outputs, 8 atomics, 16 ODF rows)
 };
 
 // scheduling hint: spread one k-step's fragment reads (ds_read2_b32 = 2 fragments) between the previous
@@ -83,6 +91,67 @@ __device__ __forceinline__ float clamp_sample(float x) {
     asm("v_maximum3_f32 %0, %1, 0, 0" : "=v"(c) : "v"(x));
     return c;
 }
+
+// sortperm!(odf_peak, rev=true) (gqi.jl:198) orders by descending value with Base.isless semantics (NaN above
+// everything, +0.0 above -0.0) and keeps ascending index among equals.  Both are captured by one 64-bit key:
+// high word = order-preserving uint image of the float (NaN canonicalised to the top), low word = ~index.
+// A larger key sorts earlier; key 0 = empty slot.  Keeping the best three is then a branch-free 3-element
+// insertion (3 compares + selects) instead of a comparison-function call per candidate.
+__device__ __forceinline__ unsigned long long peak_key(float x, int idx) {
+    const unsigned b = __float_as_uint(x);
+    unsigned hi = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    if (x != x) hi = 0xffffffffu;
+    return ((unsigned long long)hi << 32) | (unsigned)(~idx);
+}
+struct Top3 { unsigned long long k[3]; };
+__device__ __forceinline__ void top3_clear(Top3 &t) { t.k[0] = t.k[1] = t.k[2] = 0ull; }
+__device__ __forceinline__ void top3_insert_key(Top3 &t, unsigned long long k) {
+    const bool g0 = k > t.k[0], g1 = k > t.k[1], g2 = k > t.k[2];
+    t.k[2] = g1 ? t.k[1] : (g2 ? k : t.k[2]);
+    t.k[1] = g0 ? t.k[0] : (g1 ? k : t.k[1]);
+    t.k[0] = g0 ? k : t.k[0];
+}
+__device__ __forceinline__ void top3_insert(Top3 &t, float x, int idx) { top3_insert_key(t, peak_key(x, idx)); }
+__device__ __forceinline__ int top3_index(const Top3 &t, int k) { return t.k[k] ? (int)~(unsigned)t.k[k] : -1; }
+
+__device__ __forceinline__ unsigned enc_ordered(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float dec_ordered(unsigned e) {
+    return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
+}
+
+// maximum(mean(odf, dims=4)) (gqi.jl:164) in two steps.  The reference's per-voxel sum runs sequentially over the vertices
+// (Base mapreducedim! over dim 4) and is divided by n; a kernel that sums in another order can only bound that mean:
+// |its sum - the sequential sum| <= 2 (n-1) 2^-24 sum|o|, and |o| <= o - 2 min(vmin, 0).  Every peak kernel therefore
+// records mean_hi[vox] >= the voxel's mean and raises maxenc[2] to a lower bound of the maximum; odfmax_refine_kernel then
+// recomputes, with the sequential sum, the few voxels whose upper bound reaches it.  NaN means set the NaN flag (maximum()
+// propagates NaN), infinite means are order-independent and go straight to the exact maximum maxenc[0].
+// Called by all 64 lanes of a wave; `active` lanes contribute voxel `vox`.
+__device__ __forceinline__ void odfmax_contribute(unsigned *maxenc, float *mean_hi, int64_t vox, bool active, float mean, float vmin, int nvert) {
+    const bool isnan_ = mean != mean, isinf_ = fabsf(mean) == INFINITY;
+    const float eps = (2.1f * 5.9604645e-8f) * (float)nvert * (fabsf(mean) + 2.0f * fabsf(fminf(vmin, 0.0f)));
+    if (active && mean_hi) mean_hi[vox] = (isnan_ || isinf_) ? __builtin_nanf("") : mean + eps;
+    unsigned e = active && !isnan_ && !isinf_ ? enc_ordered(mean - eps) : 0u;
+    unsigned ex = active && isinf_ ? enc_ordered(mean) : 0u;
+    const unsigned long long nanb = __ballot(active && isnan_);
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned oth = (unsigned)__shfl_xor((int)e, off), othx = (unsigned)__shfl_xor((int)ex, off);
+        e = oth > e ? oth : e;
+        ex = othx > ex ? othx : ex;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (e) atomicMax(&maxenc[2], e);
+        if (ex) atomicMax(&maxenc[0], ex);
+        if (nanb) atomicOr(&maxenc[1], 1u);
+    }
+}
+
+__device__ __forceinline__ float peak_key_value(unsigned hi) {    // inverse of peak_key's float image (NaN canonical)
+    return hi == 0xffffffffu ? __builtin_nanf("") : __uint_as_float((hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi);
+}
+
 
 // On gfx950 the f32-input MFMA runs on the same FMA lanes as the vector ALU: every VALU instruction a wave
 // issues costs the SIMD ~4 cycles of MFMA time whether it sits between MFMAs or after them (measured with
@@ -439,6 +508,198 @@ __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[
     }
 }
 
+// ---- fused epilogue (sphere_642, GQI): ODF rows out + find_peaks! on the accumulators -------------------------------
+// The reference finds the peaks on the thread-local ODF right after mul! (gqi.jl:144-159); a separate peak kernel re-reads
+// 3.5 GB of ODF.  Here the wave that holds 32 voxels x 321 rows in registers tests every vertex against its <= 6 folded-face
+// neighbours in registers (layout and program: sphere642_fused.inc / tools/gen_s642_fused.py), appends the few candidates
+// (amplitude, slot) to a per-lane list in LDS, picks the top three by the sortperm key, merges the two lane halves and
+// writes peak / qa.  Not handled here, listed for odf_redo_kernel instead: voxels whose column holds a NaN / Inf and
+// voxels with more candidates in a lane half than the list holds.  The per-voxel mean is only bounded here (order of the
+// f32 sum differs from the reference's): mean_hi[vox] >= mean(odf[vox,:]) and maxenc[2] <= max of the means;
+// odfmax_refine_kernel recomputes the few voxels in between with the reference's sequential sum.
+#include "sphere642_fused.inc"
+__device__ const short fib_f642_pos_vertex_dev[321] = {
+#define FIB_F642_COPY(...) __VA_ARGS__
+    FIB_F642_POS_LIST(FIB_F642_COPY)
+};
+__device__ const short fib_f642_slot_vertex_dev[2 * 161] = {
+    FIB_F642_SLOT_LIST(FIB_F642_COPY)
+#undef FIB_F642_COPY
+};
+constexpr int FQ_CAP = 12;                       // candidates per lane half that the list holds
+constexpr int FQ_LIST = FQ_CAP * 512;            // bytes per wave: [FQ_CAP][2][64] dwords
+constexpr int FQ_NPOS = 320, FQ_NSLOT = 2 * 161, FQ_NV = 321;
+constexpr int FQ_TABB = (2 * FQ_NPOS + FQ_NSLOT + 3 * FQ_NV) * 4 + 12;   // byte offset of each position's output row, vertex-of-slot, vertex coordinates (16-byte multiple)
+static_assert(FQ_TABB % 16 == 0, "table block keeps the LDS carve-up 16-byte aligned");
+
+// (plain fmaxf / fminf chains: hipcc folds them into v_max3_f32 / v_min3_f32 and knows MFMA results are canonical; inline asm
+// would cost an s_nop per statement)
+__device__ __forceinline__ float fq_max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ float fq_max3z(float a, float b) { return __builtin_fmaxf(__builtin_fmaxf(a, b), 0.0f); }
+__device__ __forceinline__ float fq_min3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+__device__ __forceinline__ float fq_max2(float a, float b) { return __builtin_fmaxf(a, b); }
+
+template <int NW>
+__device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (&acc)[10], float xrow, float vmax, float vnf, bool inb, bool lv,
+                                                     int64_t vox, int lane, char *tr, char *lst, const uint64_t *posoff, const int *slotv, const float *vl) {
+    const int col = lane & 31, kh = lane >> 5;
+    const float pm = fmaxf(vmax, __shfl_xor(vmax, 32));
+    const float pn = vnf + __shfl_xor(vnf, 32);
+    const bool nonfinite = pn != pn;                    // the voxel holds a NaN or +Inf sample (after the clamp)
+    const bool valid = lv && (pm > 0.0f || nonfinite);  // gqi.jl:142
+    if (a.fix_list != nullptr && kh == 0 && lv && pm == INFINITY) {      // +Inf sample: column recomputed by odf_inf_fix_kernel
+        const int slot = atomicAdd(a.fix_count, 1);
+        if (slot < a.fix_cap) a.fix_list[slot] = (int32_t)vox;
+    }
+    xrow += __shfl_xor(xrow, 32);
+    if (!__all(valid && !nonfinite)) {                  // wave-uniform, rare: skipped voxels and voxels outside the mask read 0
+#pragma unroll
+        for (int m = 0; m < 10; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][r] = valid ? acc[m][r] : 0.0f;
+        xrow = valid ? xrow : 0.0f;
+    }
+    // ---- pass 1, branch-free: candidate flag of every slot = vertex above all its neighbours and above 0 (gqi.jl:185-196, 200),
+    // shifted into five 32-bit strings per lane (slot 32w + i -> bit 31 - i of word w) --------------------------------------
+    unsigned cw0 = 0, cw1 = 0, cw2 = 0, cw3 = 0, cw4 = 0;
+    bool cpole = false;
+    if (!(a.fuse_skip & 1)) {
+#define O(m, r) acc[m][r]
+#define F(i) ff##i
+#define X(j) fx##j
+#define Z 0.0f
+#define FQ_FLAG(sid, t_, x_) asm("v_cmp_nge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"((sid) < 32 ? cw0 : (sid) < 64 ? cw1 : (sid) < 96 ? cw2 : (sid) < 128 ? cw3 : cw4) : "v"(t_), "v"(x_) : "vcc");
+#define FQ_FDEF(i, m, r) const float ff##i = __shfl_xor(acc[m][r], 32);
+#define FQ_SLOT(sid, m, r, n0, n1, n2, n3, n4, n5) { const float t_ = fq_max3z(fq_max3(fq_max3(n0, n1, n2), n3, n4), n5); FQ_FLAG(sid, t_, acc[m][r]) }
+#define FQ_XDEF(ja, jb, m, r) const float fo##ja = __shfl_xor(acc[m][r], 32); const float fx##ja = kh ? fo##ja : acc[m][r], fx##jb = kh ? acc[m][r] : fo##ja;
+#define FQ_FMAX(o0, o1, o2, x0, x1, x2, out) float out; { float p_ = fq_max3(o0, o1, o2); p_ = fq_max2(p_, __shfl_xor(p_, 32)); out = fq_max3z(fq_max3(p_, x0, x1), x2); }
+#define FQ_FTEST2(sid, ja, oa0, oa1, oa2, xa0, xa1, xa2, jb, ob0, ob1, ob2, xb0, xb1, xb2) { FQ_FMAX(oa0, oa1, oa2, xa0, xa1, xa2, ta_) FQ_FMAX(ob0, ob1, ob2, xb0, xb1, xb2, tb_) \
+        const float t_ = kh ? tb_ : ta_, x_ = kh ? fx##jb : fx##ja; FQ_FLAG(sid, t_, x_) }
+#define FQ_FPOLE(j, o0, o1, o2, x0, x1, x2) { FQ_FMAX(o0, o1, o2, x0, x1, x2, t_) cpole = kh == 0 && !(t_ >= fx##j); }
+        const float fx16 = xrow;
+        FIB_F642_XDEFS(FQ_XDEF)
+        FIB_F642_PAIRS(FQ_FDEF, FQ_SLOT)
+        FIB_F642_FTESTS(FQ_FTEST2, FQ_FPOLE)
+#undef O
+#undef F
+#undef X
+#undef Z
+#undef FQ_FLAG
+#undef FQ_FDEF
+#undef FQ_SLOT
+#undef FQ_XDEF
+#undef FQ_FMAX
+#undef FQ_FTEST2
+#undef FQ_FPOLE
+    }
+    // ---- ODF rows + pass 2.  Each half block (8 registers of both lane halves = 16 rows x 32 voxels) goes through one of the
+    // wave's two LDS tiles and leaves as 2 stores of 8 rows x 128 B (row = vertex of the position).  While a half block is
+    // in the tile, a lane that flagged one of its 8 slots reads the amplitude back by its dynamic index (registers cannot
+    // be indexed per lane) and appends (amplitude, slot) to its candidate list. ----------------------------------------------
+    uint32_t *lw = reinterpret_cast<uint32_t *>(lst) + lane;      // entry k of this lane: amplitude at lw[k*128], slot at lw[k*128 + 64]
+    int cnt = 0;
+    {
+        const int qsrc = 4 * (lane & 7);
+        const int32_t qvox = __shfl((int)vox, qsrc);
+        const bool qinb = __shfl((int)inb, qsrc) != 0;
+        const int P = lane >> 3;
+        const int lrow = ((P >> 1) & 3) | ((P & 1) << 2);
+        char *obase = reinterpret_cast<char *>(a.out1) + (uint32_t)qvox * 4u;
+        auto rows_out = [&](auto guard) {
+#pragma unroll
+            for (int m = 0; m < 10; m++) {
+#pragma unroll
+                for (int hb = 0; hb < 2; hb++) {
+                    float *tw = reinterpret_cast<float *>(tr + hb * 2048) + kh * 32 + col;
+                    const float4 *trd = reinterpret_cast<const float4 *>(tr + hb * 2048) + lane;
+#pragma unroll
+                    for (int r = 8 * hb; r < 8 * hb + 8; r++) tw[(8 * ((r >> 2) & 1) + 2 * (r & 3)) * 32] = acc[m][r];
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        const float4 v4 = trd[j * 64];
+                        char *dst = obase + posoff[m * 32 + 16 * hb + 8 * j + lrow];
+                        if (!decltype(guard)::value || qinb) *reinterpret_cast<float4 *>(dst) = v4;
+                    }
+                    const unsigned cw = m < 2 ? cw0 : m < 4 ? cw1 : m < 6 ? cw2 : m < 8 ? cw3 : cw4;
+                    unsigned byte = (cw >> (8 * (3 - (2 * (m & 1) + hb)))) & 0xffu;      // bit 7 - j: slot 16 m + 8 hb + j
+                    if (__any(byte != 0u)) {
+                        while (byte != 0u) {
+                            const int b = 31 - __clz((int)byte);
+                            byte &= ~(1u << b);
+                            const int j = 7 - b;
+                            const float x = tw[(8 * (j >> 2) + 2 * (j & 3)) * 32];
+                            if (cnt < FQ_CAP) { lw[cnt * 128] = __float_as_uint(x); lw[cnt * 128 + 64] = (uint32_t)(16 * m + 8 * hb + j); }
+                            cnt++;
+                        }
+                    }
+                }
+            }
+        };
+        if (a.fuse_skip & 16) {} else
+        if (__all(qinb)) rows_out(std::false_type{}); else rows_out(std::true_type{});   // (the guarded copy: ragged end of the voxel list)
+        if (inb && kh == 0) a.out1[(int64_t)FIB_F642_POLE * a.stride + vox] = xrow;
+        if (cpole) { if (cnt < FQ_CAP) { lw[cnt * 128] = __float_as_uint(xrow); lw[cnt * 128 + 64] = 160u; } cnt++; }
+    }
+    // ---- minimum (gqi.jl:147), bounds of the mean (gqi.jl:164) over this half's 160 rows ---------------------------------
+    float vmin = INFINITY;
+    f32x2 vs2 = {0.0f, 0.0f};
+    if (!(a.fuse_skip & 2))
+#pragma unroll
+    for (int m = 0; m < 10; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            vmin = fq_min3(vmin, acc[m][r], acc[m][r + 1]);
+            const f32x2 pr = {acc[m][r], acc[m][r + 1]};
+            vs2 += pr;                                  // v_pk_add_f32
+        }
+    const float vsum = vs2[0] + vs2[1];
+    // ---- top three of this half's candidates in the order of sortperm!(odf_peak, rev=true) (gqi.jl:198) -------------------
+    Top3 t;
+    top3_clear(t);
+    const int nl = cnt < FQ_CAP ? cnt : FQ_CAP;
+    for (int i = 0; __any(i < nl); i++)
+        if (i < nl) top3_insert(t, __uint_as_float(lw[i * 128]), slotv[kh * 161 + (int)lw[i * 128 + 64]]);
+    // ---- merge the two lane halves of a voxel ---------------------------------------------------------------------------
+    unsigned long long ok[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)t.k[k], 32), hi = (unsigned)__shfl_xor((int)(unsigned)(t.k[k] >> 32), 32);
+        ok[k] = ((unsigned long long)hi << 32) | lo;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) top3_insert_key(t, ok[k]);
+    const int cnt_o = __shfl_xor(cnt, 32);
+    const int npos = cnt + cnt_o;                       // candidates are > 0: count(odf_peak .> 0), gqi.jl:200
+    const float vmin_t = fq_min3(vmin, __shfl_xor(vmin, 32), xrow);
+    const float vsum_t = (vsum + __shfl_xor(vsum, 32)) + xrow;
+    const bool finite = fabsf(vsum_t) < INFINITY;       // false for NaN / Inf columns
+    const bool redo = inb && (!finite || cnt > FQ_CAP || cnt_o > FQ_CAP);
+    const float mean = vsum_t / (float)FQ_NV;
+    const float eps = (2.1f * 5.9604645e-8f) * (float)FQ_NV * (fabsf(mean) + 2.0f * fabsf(fminf(vmin_t, 0.0f)));   // see odfmax_contribute
+    if (kh == 0 && inb && !(a.fuse_skip & 4)) {
+        if (redo) {
+            const int slot = atomicAdd(a.redo_count, 1);
+            if (slot < a.redo_cap) a.redo_list[slot] = (int32_t)vox;
+        }
+        a.mean_hi[vox] = redo ? __builtin_nanf("") : mean + eps;
+        const int n = npos < 3 ? npos : 3;              // gqi.jl:151
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float px = 0.0f, py = 0.0f, pz = 0.0f, q = 0.0f;
+            if (k < n && !redo) {
+                const int iv = top3_index(t, k);
+                px = vl[3 * iv]; py = vl[3 * iv + 1]; pz = vl[3 * iv + 2];          // gqi.jl:154-155
+                q = peak_key_value((unsigned)(t.k[k] >> 32)) - vmin_t;              // gqi.jl:157-158
+            }
+            a.peak[k][vox] = px; a.peak[k][a.stride + vox] = py; a.peak[k][2 * a.stride + vox] = pz;
+            a.qa[k][vox] = q;
+        }
+    }
+    unsigned e = (kh == 0 && inb && !redo) ? enc_ordered(mean - eps) : 0u;
+    for (int off = 16; off >= 1; off >>= 1) { const unsigned oth = (unsigned)__shfl_xor((int)e, off); e = oth > e ? oth : e; }
+    if (lane == 0 && e && !(a.fuse_skip & 8)) atomicMax(&a.maxenc[2], e);
+}
+
 // ---- K2/K5, second form: the same f32 contraction on the bf16 matrix cores (16x the f32 MFMA rate) ----------
 // An f32 number is EXACTLY the sum of three bf16 numbers (3 x 8 significant bits, round-to-nearest pieces):
 //   a = a1 + a2 + a3 (split once on the host),   s = s1 + s2 + s3 (split in registers as the samples arrive),
@@ -475,17 +736,23 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {      // ro
 // The two lane halves of a load need different frames; their byte offsets come from an LDS table (relative to the
 // lowest frame that the stage touches on that side: one buffer resource per stage and side).
 constexpr int FKMAX = 512, FSMAX = FKMAX / KT;
-template <int MB, int NX, int NW, bool STAMP = false, bool FOLD = false>
+template <int MB, int NX, int NW, bool STAMP = false, bool FOLD = false, bool FUSE = false>
 __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a) {
+    static_assert(!FUSE || (MB == 10 && NX == 1 && !FOLD), "the fused peak scan is generated for 10 blocks + 1 extra row");
     constexpr int NPIECE = 3 * MB;                      // 1-KiB pieces per stage
     constexpr int TILEB = NPIECE * 1024;                // bytes per stage
     constexpr int NA = (NPIECE + NW - 1) / NW;          // direct-to-LDS loads per wave and stage (a surplus load repeats the last piece)
     constexpr int WGV = NW * 32;                        // voxels per work item
     constexpr int NXA = NX > 0 ? NX : 1;
-    constexpr int XTAB = NX > 0 ? 8192 : 0;             // coefficients of the extra rows, all stages of all M tiles: [ntile_m][NX][Kpad] f32
+    constexpr int XTAB = NX > 0 ? (FUSE ? 2048 : 8192) : 0;   // coefficients of the extra rows, all stages of all M tiles: [ntile_m][NX][Kpad] f32
     constexpr int FTAB = FOLD ? 2 * FKMAX * 4 + 4 * FSMAX * 4 : 0;
-    __shared__ __attribute__((aligned(16))) char lds[2 * TILEB + NW * 2048 + XTAB + FTAB];
-    uint32_t *f_off = reinterpret_cast<uint32_t *>(lds + 2 * TILEB + NW * 2048 + XTAB);   // [2][FKMAX] byte offset of sample J's frame, side a / b
+    constexpr int QTAB = FUSE ? NW * FQ_LIST + FQ_TABB : 0;   // fused peak scan: candidate lists + lookup tables
+    constexpr int TRB = FUSE ? 4096 : 2048;                   // per-wave transposition tile(s) of the epilogue
+    __shared__ __attribute__((aligned(16))) char lds[2 * TILEB + NW * TRB + XTAB + FTAB + QTAB];
+    uint64_t *q_posoff = reinterpret_cast<uint64_t *>(lds + 2 * TILEB + NW * TRB + XTAB + FTAB + (FUSE ? NW * FQ_LIST : 0));   // [320] matrix row -> byte offset of its output row
+    int *q_slotv = reinterpret_cast<int *>(q_posoff + FQ_NPOS);                                                                               // [2][161] (half, slot) -> vertex
+    float *q_vl = reinterpret_cast<float *>(q_slotv + FQ_NSLOT);                                                   // [321][3]
+    uint32_t *f_off = reinterpret_cast<uint32_t *>(lds + 2 * TILEB + NW * TRB + XTAB);   // [2][FKMAX] byte offset of sample J's frame, side a / b
     int32_t *f_base = reinterpret_cast<int32_t *>(f_off + 2 * FKMAX);                      // [2][FSMAX] lowest frame of the stage
     int32_t *f_span = f_base + 2 * FSMAX;                                                  // [2][FSMAX] frames spanned (0: none)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -494,8 +761,13 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
     const int ntiles = a.Kpad / KT;
     const uint32_t a_off = (uint32_t)lane * 16;
     if (NX > 0) {
-        float *xt = reinterpret_cast<float *>(lds + 2 * TILEB + NW * 2048);
+        float *xt = reinterpret_cast<float *>(lds + 2 * TILEB + NW * TRB);
         for (int i = tid; i < a.ntile_m * NX * a.Kpad; i += NW * 64) xt[i] = a.Aextra[i];
+    }
+    if constexpr (FUSE) {
+        for (int i = tid; i < FQ_NPOS; i += NW * 64) q_posoff[i] = (uint64_t)fib_f642_pos_vertex_dev[i] * (uint64_t)a.stride * 4u;
+        for (int i = tid; i < FQ_NSLOT; i += NW * 64) q_slotv[i] = fib_f642_slot_vertex_dev[i];
+        for (int i = tid; i < 3 * FQ_NV; i += NW * 64) q_vl[i] = a.verts[i];
     }
     const char *Sbase = reinterpret_cast<const char *>(a.S);
     const uint32_t row_bytes = (uint32_t)(a.stride * 4);
@@ -628,7 +900,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
             const uint32_t l = cvt_pk_bf16(q0, q1);                                                           // exact
             bp[0][jj] = h; bp[1][jj] = m; bp[2][jj] = l;
             if (NX > 0) {                               // extra rows: f32 fma, coefficients from the LDS table (frames 8h + 2jj, +1)
-                const f32x2 *ex = reinterpret_cast<const f32x2 *>(lds + 2 * TILEB + NW * 2048) + ((tile_m * NX) * a.Kpad + t * KT + 8 * kh) / 2 + jj;
+                const f32x2 *ex = reinterpret_cast<const f32x2 *>(lds + 2 * TILEB + NW * TRB) + ((tile_m * NX) * a.Kpad + t * KT + 8 * kh) / 2 + jj;
 #pragma unroll
                 for (int x = 0; x < NX; x++) {
                     const f32x2 e = ex[x * (a.Kpad / 2)];
@@ -697,7 +969,11 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
         }
         unsigned long long te = 0;
         if (STAMP) te = __builtin_amdgcn_s_memtime();
-        gemm3_epilogue<MB, NX>(a, acc, xacc, vmax, vnf, inb, lv, vox, lane, cur.tile_m, sraw, lds + 2 * TILEB + wave * 2048);
+        if constexpr (FUSE)
+            gemm3_epilogue_fused<NW>(a, acc, xacc[0], vmax, vnf, inb, lv, vox, lane, lds + 2 * TILEB + wave * TRB,
+                                     lds + 2 * TILEB + NW * TRB + XTAB + FTAB + wave * FQ_LIST, q_posoff, q_slotv, q_vl);
+        else
+            gemm3_epilogue<MB, NX>(a, acc, xacc, vmax, vnf, inb, lv, vox, lane, cur.tile_m, sraw, lds + 2 * TILEB + wave * TRB);
         if (STAMP) acc_epi += __builtin_amdgcn_s_memtime() - te;
         if (!nxt.valid) break;
         cur = nxt; inb = inb_n; vox = vox_n; s_off = s_off_n;
@@ -761,8 +1037,8 @@ __global__ __launch_bounds__(1024) void mask_scan_kernel(int2 *__restrict__ bloc
     }
     int2 run = tid ? part[tid - 1] : make_int2(0, 0);
     for (int i = lo; i < hi; i++) { const int2 c = blockcnt[i]; blockcnt[i] = run; run.x += c.x; run.y += c.y; }
-    if (tid == 1023) { totals[0] = part[1023].x; totals[1] = part[1023].y; totals[2] = 0; }   // [2]: length of the +Inf voxel list
-    if (tid < 2 && maxenc) maxenc[tid] = 0u;                // (the peak finder's running odfmax: one memset launch less)
+    if (tid == 1023) { totals[0] = part[1023].x; totals[1] = part[1023].y; totals[2] = 0; totals[3] = 0; }   // [2]: length of the +Inf voxel list, [3]: of the redo list
+    if (tid < 4 && maxenc) maxenc[tid] = 0u;                // (the peak finder's running odfmax: one memset launch less)
 }
 __global__ __launch_bounds__(256) void mask_write_kernel(const uint8_t *__restrict__ mask, int64_t nvox, const int2 *__restrict__ blockoff,
                                                         int32_t *__restrict__ vidx, int32_t *__restrict__ tiles) {
@@ -913,28 +1189,6 @@ constexpr int PW = 4;         // waves per workgroup
 constexpr int PG = 2 * PW;    // vertex groups (wave, half)
 constexpr int PREC = 10;      // floats per merge record
 
-// sortperm!(odf_peak, rev=true) (gqi.jl:198) orders by descending value with Base.isless semantics (NaN above
-// everything, +0.0 above -0.0) and keeps ascending index among equals.  Both are captured by one 64-bit key:
-// high word = order-preserving uint image of the float (NaN canonicalised to the top), low word = ~index.
-// A larger key sorts earlier; key 0 = empty slot.  Keeping the best three is then a branch-free 3-element
-// insertion (3 compares + selects) instead of a comparison-function call per candidate.
-__device__ __forceinline__ unsigned long long peak_key(float x, int idx) {
-    const unsigned b = __float_as_uint(x);
-    unsigned hi = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-    if (x != x) hi = 0xffffffffu;
-    return ((unsigned long long)hi << 32) | (unsigned)(~idx);
-}
-struct Top3 { unsigned long long k[3]; };
-__device__ __forceinline__ void top3_clear(Top3 &t) { t.k[0] = t.k[1] = t.k[2] = 0ull; }
-__device__ __forceinline__ void top3_insert_key(Top3 &t, unsigned long long k) {
-    const bool g0 = k > t.k[0], g1 = k > t.k[1], g2 = k > t.k[2];
-    t.k[2] = g1 ? t.k[1] : (g2 ? k : t.k[2]);
-    t.k[1] = g0 ? t.k[0] : (g1 ? k : t.k[1]);
-    t.k[0] = g0 ? k : t.k[0];
-}
-__device__ __forceinline__ void top3_insert(Top3 &t, float x, int idx) { top3_insert_key(t, peak_key(x, idx)); }
-__device__ __forceinline__ int top3_index(const Top3 &t, int k) { return t.k[k] ? (int)~(unsigned)t.k[k] : -1; }
-
 struct PeakArgs {
     const float *odf;         // [nvert][nvox]
     const int32_t *nbr;       // [nvert_even][DEG]: row index of each neighbour, unused slots = sentinel row (32-voxel tiles)
@@ -944,7 +1198,8 @@ struct PeakArgs {
     float *qa[3];             // [nvox] each
     int32_t *isort_top;       // [3][nvox] (find-peaks mode) or NULL
     int32_t *nvalid;          // [nvox]    (find-peaks mode) or NULL
-    unsigned *maxenc;         // [2]: ordered-uint max of per-voxel means, NaN flag (may be NULL)
+    unsigned *maxenc;         // [4]: see odfmax_contribute (may be NULL)
+    float *mean_hi;           // [nvox] upper bounds of the means (with maxenc)
     int64_t nvox;             // voxels in this launch
     int64_t stride;           // row stride of odf / component stride of the outputs
     int nvert, rows_pad;      // rows_pad = nvert rounded up to 8; sentinel row index = rows_pad
@@ -952,14 +1207,6 @@ struct PeakArgs {
     const int32_t *tiles;     // optional: ascending list of the 64-voxel tiles to scan (mask compaction) and its
     const int32_t *ntl;       // device-side length; tiles not listed keep the zeros zero_dead_kernel wrote
 };
-
-__device__ __forceinline__ unsigned enc_ordered(float f) {
-    const unsigned b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float dec_ordered(unsigned e) {
-    return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
-}
 
 // DEG = padded neighbour count per vertex; EXACT: keep the full sortperm order (find_peaks! API) instead of
 // only the entries gqi_rec/dsi_rec can use (positive or NaN survivors)
@@ -1048,7 +1295,7 @@ __global__ __launch_bounds__(PW * 64) void odf_peaks_kernel(const PeakArgs a) {
             hasnan |= r[9] != 0.0f;
         }
         if (hasnan) vmin = NAN;                                 // minimum() propagates NaN (gqi.jl:147)
-        mean = vsum * (1.0f / (float)a.nvert);                  // mean(odf, dims=4), gqi.jl:164
+        mean = vsum / (float)a.nvert;                           // mean(odf, dims=4) = sum ./ n, gqi.jl:164
         mean_nan = mean != mean;
         if (inb) {
             if (a.isort_top) {
@@ -1071,16 +1318,7 @@ __global__ __launch_bounds__(PW * 64) void odf_peaks_kernel(const PeakArgs a) {
             }
         }
     }
-    if (a.maxenc) {
-        const bool mine = owner && inb;
-        unsigned e = mine && !mean_nan ? enc_ordered(mean) : 0u;
-        const unsigned long long nanb = __ballot(mine && mean_nan);
-        for (int off = 32; off >= 1; off >>= 1) { const unsigned oth = (unsigned)__shfl_xor((int)e, off); e = oth > e ? oth : e; }
-        if (tid == 0) {
-            if (e) atomicMax(&a.maxenc[0], e);
-            if (nanb) atomicOr(&a.maxenc[1], 1u);
-        }
-    }
+    if (a.maxenc) odfmax_contribute(a.maxenc, a.mean_hi, vox, owner && inb, mean, vmin, a.nvert);
 }
 
 #include "sphere642_scan.inc"
@@ -1120,10 +1358,7 @@ __device__ __forceinline__ void p64_merge(Peak64Partial &p, const float *r) {
     p.hasnan |= r[9] != 0.0f;
 }
 
-// S642: the tessellation is the default sphere_642 -> the scan is straight-line code generated from its neighbour table
-// (sphere642_scan.inc): vertex and neighbour rows are immediate LDS offsets, no table reads, no address arithmetic;
-// "some neighbour >= x" is one compare against the largest neighbour.
-template <int DEG, bool EXACT, bool S642 = false>
+template <int DEG, bool EXACT>
 __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, int64_t ntiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *o = smem;                                            // [nvert + 1][64]; row nvert = NaN sentinel
@@ -1162,7 +1397,6 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
 
     const int64_t nlist = a.tiles ? (int64_t)a.ntl[0] : ntiles;
     // voxels of unlisted tiles have an all-zero ODF: their mean (0) takes part in odfmax (gqi.jl:164-166)
-    if (a.tiles && a.maxenc && blockIdx.x == 0 && tid == 0 && nlist < ntiles) atomicMax(&a.maxenc[0], enc_ordered(0.0f));
     auto tile_at = [&](int64_t k) -> int64_t { return k < nlist ? (a.tiles ? (int64_t)a.tiles[k] : k) : -1; };
     int64_t slot = blockIdx.x;
     int64_t tile = tile_at(slot);
@@ -1193,60 +1427,6 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
         Peak64Partial p;
         top3_clear(p.t);
         p.npos = 0; p.vmin = INFINITY; p.vsum = 0.0f; p.hasnan = false;
-        if constexpr (S642) {
-            // Candidate = vertex above all its neighbours and above 0 (or NaN): !(max(neighbours, 0) >= x).  The flag of
-            // each scanned vertex is shifted into a per-lane bit string with one add-with-carry; the few candidates of a
-            // lane (a voxel has a handful of peaks among 321 vertices) are inserted afterwards, one bit per iteration.
-            static_assert(!EXACT, "the specialised scan keeps candidates only");
-            const float *ob = o + lane, *ob1 = o + FIB_S642_BASE1 * 64 + lane;   // two bases: every row within 255 rows of one
-            unsigned bits = 0;
-            int nscan = 0;
-#define FIB_RD(B, R) (((B) == 0 || ((B) == 2 && (R) <= 255)) ? ob[(R) * 64] : ob1[((R) - FIB_S642_BASE1) * 64])
-#define FIB_SCAN_ONE(V, B, A0, A1, A2, A3, A4, A5)                                                          \
-            if ((V) < FIB_S642_NVERT) {                                                                     \
-                const float x = FIB_RD(B, V);                                                               \
-                const float mx = max6_0_f32(FIB_RD(B, A0), FIB_RD(B, A1), FIB_RD(B, A2), FIB_RD(B, A3), FIB_RD(B, A4), FIB_RD(B, A5)); \
-                asm("v_cmp_nge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(mx), "v"(x) : "vcc"); \
-                asm("v_min_f32 %0, %0, %1" : "+v"(p.vmin) : "v"(x));      /* NaN-ignoring; NaN is recovered from vsum */ \
-                p.vsum += x;                                                                                \
-                nscan++;                                                                                    \
-            }
-#define FIB_SCAN_G(V0, B0, a0, a1, a2, a3, a4, a5, V1, B1, b0, b1, b2, b3, b4, b5, V2, B2, c0, c1, c2, c3, c4, c5, V3, B3, d0, d1, d2, d3, d4, d5) \
-            FIB_SCAN_ONE(V0, B0, a0, a1, a2, a3, a4, a5) FIB_SCAN_ONE(V1, B1, b0, b1, b2, b3, b4, b5)       \
-            FIB_SCAN_ONE(V2, B2, c0, c1, c2, c3, c4, c5) FIB_SCAN_ONE(V3, B3, d0, d1, d2, d3, d4, d5)
-            switch (wave) {
-                case 0: FIB_S642_WAVE0(FIB_SCAN_G) break;
-                case 1: FIB_S642_WAVE1(FIB_SCAN_G) break;
-                case 2: FIB_S642_WAVE2(FIB_SCAN_G) break;
-                case 3: FIB_S642_WAVE3(FIB_SCAN_G) break;
-                case 4: FIB_S642_WAVE4(FIB_SCAN_G) break;
-                case 5: FIB_S642_WAVE5(FIB_SCAN_G) break;
-                case 6: FIB_S642_WAVE6(FIB_SCAN_G) break;
-                case 7: FIB_S642_WAVE7(FIB_SCAN_G) break;
-                case 8: FIB_S642_WAVE8(FIB_SCAN_G) break;
-                case 9: FIB_S642_WAVE9(FIB_SCAN_G) break;
-                case 10: FIB_S642_WAVE10(FIB_SCAN_G) break;
-                case 11: FIB_S642_WAVE11(FIB_SCAN_G) break;
-                case 12: FIB_S642_WAVE12(FIB_SCAN_G) break;
-                case 13: FIB_S642_WAVE13(FIB_SCAN_G) break;
-                case 14: FIB_S642_WAVE14(FIB_SCAN_G) break;
-                default: FIB_S642_WAVE15(FIB_SCAN_G) break;
-            }
-#undef FIB_SCAN_G
-#undef FIB_SCAN_ONE
-#undef FIB_RD
-            // bit b of `bits` = the (nscan-1-b)-th vertex this wave scanned = vertex wave + 16*(nscan-1-b)
-            while (__any(bits != 0u)) {
-                if (bits != 0u) {
-                    const int b = __ffs((int)bits) - 1;
-                    bits &= bits - 1u;
-                    const int v = wave + P64_W * (nscan - 1 - b);
-                    const float x = ob[v * 64];
-                    if (x > 0.0f) p.npos++;                                     // gqi.jl:200
-                    top3_insert(p.t, x, v);
-                }
-            }
-        } else {
         // UNR vertices per iteration: their neighbour-table reads and ODF reads are all issued before the
         // first compare, so each wave keeps ~(1+DEG)*UNR LDS reads in flight instead of a dependent chain
         constexpr int UNR = 4;
@@ -1321,7 +1501,6 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
                 }
             }
         }
-        }
         p.hasnan = p.vsum != p.vsum;                            // a NaN amplitude makes the sum NaN
         p64_store(mrg + (size_t)(wave * 64 + lane) * PREC, p);
         __syncthreads();
@@ -1336,18 +1515,9 @@ __global__ __launch_bounds__(P64_T) void odf_peaks64_kernel(const PeakArgs a, in
         if (wave == 0) {
             for (int g = 1; g < 4; g++) p64_merge(p, mrg + (size_t)(g * 64 + lane) * PREC);
             if (p.hasnan) p.vmin = NAN;                         // minimum() propagates NaN (gqi.jl:147)
-            const float mean = p.vsum * (1.0f / (float)a.nvert);   // mean(odf, dims=4), gqi.jl:164
-            const bool mean_nan = mean != mean;
+            const float mean = p.vsum / (float)a.nvert;   // mean(odf, dims=4) = sum ./ n, gqi.jl:164
             p64_store(mrg + (size_t)lane * PREC, p);            // final record of this voxel for the writer waves
-            if (a.maxenc) {
-                unsigned e = inb && !mean_nan ? enc_ordered(mean) : 0u;
-                const unsigned long long nanb = __ballot(inb && mean_nan);
-                for (int off = 32; off >= 1; off >>= 1) { const unsigned oth = (unsigned)__shfl_xor((int)e, off); e = oth > e ? oth : e; }
-                if (lane == 0) {
-                    if (e) atomicMax(&a.maxenc[0], e);
-                    if (nanb) atomicOr(&a.maxenc[1], 1u);
-                }
-            }
+            if (a.maxenc) odfmax_contribute(a.maxenc, a.mean_hi, vox, inb, mean, p.vmin, a.nvert);
         }
         __syncthreads();
         // ---- outputs: one wave per output row (9 peak components + 3 qa, or 3 indices + nvalid) -------------
@@ -1391,10 +1561,6 @@ __device__ const short fib_s642_nbr_dev[FIB_S642_NVERT][FIB_S642_DEG] = {
     FIB_S642_TABLE(FIB_S642_ROW)
 #undef FIB_S642_ROW
 };
-__device__ __forceinline__ float peak_key_value(unsigned hi) {    // inverse of peak_key's float image (NaN canonical)
-    return hi == 0xffffffffu ? __builtin_nanf("") : __uint_as_float((hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi);
-}
-
 __global__ __launch_bounds__(P64_T) void odf_peaks642_kernel(const PeakArgs a, int64_t ntiles) {
     constexpr int NV = FIB_S642_NVERT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1415,7 +1581,6 @@ __global__ __launch_bounds__(P64_T) void odf_peaks642_kernel(const PeakArgs a, i
     auto is_fast = [&](int64_t tile) { return a.vec_ok && tile * 64 + 64 <= a.nvox; };
     const int rbase = tid >> 4;
     const int64_t nlist = a.tiles ? (int64_t)a.ntl[0] : ntiles;
-    if (a.tiles && a.maxenc && blockIdx.x == 0 && tid == 0 && nlist < ntiles) atomicMax(&a.maxenc[0], enc_ordered(0.0f));
     auto tile_at = [&](int64_t k) -> int64_t { return k < nlist ? (a.tiles ? (int64_t)a.tiles[k] : k) : -1; };
     auto put_tile = [&](int64_t tile, bool fast) {                // staging registers (or memory) -> o
         if (fast) {
@@ -1541,17 +1706,8 @@ __global__ __launch_bounds__(P64_T) void odf_peaks642_kernel(const PeakArgs a, i
                 const float vs = ((s[0] + s[1]) + s[2]) + s[3];
                 if (hasnan) m = NAN;                              // minimum() propagates NaN (gqi.jl:147)
                 fn[7 * 64 + lane] = m;
-                const float mean = vs * (1.0f / (float)NV);       // mean(odf, dims=4), gqi.jl:164
-                const bool mean_nan = mean != mean;
-                if (a.maxenc) {
-                    unsigned e = inb && !mean_nan ? enc_ordered(mean) : 0u;
-                    const unsigned long long nanb = __ballot(inb && mean_nan);
-                    for (int off = 32; off >= 1; off >>= 1) { const unsigned oth = (unsigned)__shfl_xor((int)e, off); e = oth > e ? oth : e; }
-                    if (lane == 0) {
-                        if (e) atomicMax(&a.maxenc[0], e);
-                        if (nanb) atomicOr(&a.maxenc[1], 1u);
-                    }
-                }
+                const float mean = vs / (float)NV;                // mean(odf, dims=4) = sum ./ n, gqi.jl:164
+                if (a.maxenc) odfmax_contribute(a.maxenc, a.mean_hi, vox, inb, mean, m, NV);
             }
         };
         if (ovf) {                                                // rare: the tile must survive until wave 0 is done
@@ -1585,6 +1741,108 @@ __global__ __launch_bounds__(P64_T) void odf_peaks642_kernel(const PeakArgs a, i
     }
 }
 
+// ---- companions of the fused epilogue (gemm3_epilogue_fused) ------------------------------------------------------------
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)k, off), hi = (unsigned)__shfl_xor((int)(unsigned)(k >> 32), off);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        k = o > k ? o : k;
+    }
+    return k;
+}
+// Voxels the register scan left alone (NaN / Inf columns, candidate-list overflow): one wave per listed voxel reads the
+// stored column and runs find_peaks! + peak / qa extraction with the generic semantics of odf_peaks_kernel (NaN
+// amplitudes lead the sort order, `NaN >= x` kills nothing), and the reference's sequential mean (gqi.jl:164).
+struct RedoArgs { const float *odf; int64_t stride; const int32_t *count, *list; int cap; const float *verts; float *peak[3], *qa[3]; unsigned *maxenc; };
+__global__ __launch_bounds__(64) void odf_redo_kernel(const RedoArgs a) {
+    constexpr int NV = FIB_S642_NVERT;
+    __shared__ float o[NV + 1];
+    const int lane = threadIdx.x;
+    const int n = a.count[0] < a.cap ? a.count[0] : a.cap;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int64_t vox = a.list[i];
+        __syncthreads();
+        for (int v = lane; v < NV; v += 64) o[v] = a.odf[(int64_t)v * a.stride + vox];
+        if (lane == 0) o[NV] = __builtin_nanf("");      // unused neighbour slots
+        __syncthreads();
+        Top3 t;
+        top3_clear(t);
+        int npos = 0;
+        float vmin = INFINITY;
+        bool hasnan = false;
+        for (int v = lane; v < NV; v += 64) {
+            const float x = o[v];
+            bool killed = false;
+#pragma unroll
+            for (int d = 0; d < FIB_S642_DEG; d++) killed |= o[fib_s642_nbr_dev[v][d]] >= x;   // gqi.jl:185-196
+            const float pk = killed ? 0.0f : x;
+            if (pk > 0.0f) npos++;                      // gqi.jl:200
+            if (!(pk <= 0.0f)) top3_insert(t, pk, v);
+            hasnan |= x != x;
+            vmin = x < vmin ? x : vmin;
+        }
+        Top3 best;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {                   // keys are unique (vertex index in the low word): one lane pops per round
+            const unsigned long long m = wave_max_u64(t.k[0]);
+            best.k[k] = m;
+            if (m != 0ull && t.k[0] == m) { t.k[0] = t.k[1]; t.k[1] = t.k[2]; t.k[2] = 0ull; }
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            npos += __shfl_xor(npos, off);
+            const float om = __shfl_xor(vmin, off);
+            vmin = om < vmin ? om : vmin;
+        }
+        if (__any(hasnan)) vmin = __builtin_nanf("");   // minimum() propagates NaN (gqi.jl:147)
+        if (lane == 0) {
+            float sum = 0.0f;
+            for (int v = 0; v < NV; v++) sum += o[v];   // mean(odf, dims=4): sequential over the vertices, then ./ n (gqi.jl:164)
+            const float mean = sum / (float)NV;
+            if (mean != mean) atomicOr(&a.maxenc[1], 1u); else atomicMax(&a.maxenc[0], enc_ordered(mean));
+            const int n3 = npos < 3 ? npos : 3;         // gqi.jl:151
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float px = 0.0f, py = 0.0f, pz = 0.0f, q = 0.0f;
+                if (k < n3) {
+                    const int iv = top3_index(best, k);
+                    px = a.verts[3 * iv]; py = a.verts[3 * iv + 1]; pz = a.verts[3 * iv + 2];
+                    q = o[iv] - vmin;
+                }
+                a.peak[k][vox] = px; a.peak[k][a.stride + vox] = py; a.peak[k][2 * a.stride + vox] = pz;
+                a.qa[k][vox] = q;
+            }
+        }
+    }
+}
+// maximum(mean(odf, dims=4)) (gqi.jl:164) with the reference's arithmetic: the fused epilogue only bounds each voxel's mean
+// (mean_hi) and the maximum (maxenc[2]); every listed voxel whose upper bound reaches the lower bound of the maximum gets
+// the sequential f32 sum over its stored column here (a handful of voxels unless many voxels hold the same ODF).
+struct RefineArgs { const float *odf; int64_t stride, nvox; int nvert; const int32_t *vidx, *nlive; const float *mean_hi; unsigned *maxenc; };
+__global__ __launch_bounds__(256) void odfmax_refine_kernel(const RefineArgs a) {
+    const int nlive = a.nlive[0];
+    // voxels of quads that are not listed have an all-zero ODF: their mean (0) takes part in the maximum
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nlive < a.nvox) atomicMax(&a.maxenc[0], enc_ordered(0.0f));
+    const unsigned lo_e = a.maxenc[2];
+    const float m_lo = lo_e ? dec_ordered(lo_e) : -INFINITY;
+    const int64_t nround = ((int64_t)nlive + 63) / 64 * 64;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nround; i += (int64_t)gridDim.x * 256) {
+        int64_t vox = 0;
+        bool sel = false;
+        if (i < nlive) { vox = a.vidx[i]; sel = a.mean_hi[vox] >= m_lo; }
+        unsigned e = 0u;
+        if (sel) {
+            float sum = 0.0f;
+#pragma unroll 8
+            for (int r = 0; r < a.nvert; r++) sum += a.odf[(int64_t)r * a.stride + vox];
+            e = enc_ordered(sum / (float)a.nvert);      // finite columns only (the others are on the redo list)
+        }
+        if (__any(sel)) {
+            for (int off = 32; off >= 1; off >>= 1) { const unsigned oth = (unsigned)__shfl_xor((int)e, off); e = oth > e ? oth : e; }
+            if ((threadIdx.x & 63) == 0 && e) atomicMax(&a.maxenc[0], e);
+        }
+    }
+}
+
 __global__ void odfmax_finalize_kernel(const unsigned *enc, float *out) {
     const bool nan = enc[1] != 0;
     const float m = enc[0] ? dec_ordered(enc[0]) : -INFINITY;
@@ -1607,7 +1865,6 @@ __global__ __launch_bounds__(256) void qa_normalize_kernel(float *q0, float *q1,
 // ------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------
-constexpr int INF_FIX_CAP = 1 << 16;   // voxels with a +Inf sample that one call repairs (more: their columns stay NaN)
 struct fib_odf_plan {
     int device = 0;
     int nvol = 0, nvert = 0, nrows = 0, nrow0 = 0;   // nrow0 = rows that go to the pdf output (DSI), else 0
@@ -1627,8 +1884,14 @@ struct fib_odf_plan {
     fib::DevBuf<uint16_t> At3;                       // split-bf16 image of G (odf_gemm3_kernel), empty in f32-MFMA mode
     fib::DevBuf<float> Aextra;                       // f32 coefficients of the NX extra rows [ntile_m][NX][Kpad]
     fib::DevBuf<float> Gdev;                         // G, column-major [gM x gK] (odf_inf_fix_kernel)
-    fib::DevBuf<int32_t> inf_list;                   // voxels with a +Inf sample (GQI, split-bf16 kernel)
+    mutable fib::DevBuf<int32_t> inf_list;           // [nvox] voxels with a +Inf sample (GQI, split-bf16 kernel; grow-only)
     bool split_bf16 = false;
+    bool fused_shape = false;                        // (GQI, 10 blocks + 1 extra row: the shape the fused scan is generated for)
+    bool fused = false;                              // sphere_642 GQI plan: the contraction kernel finds the peaks on its accumulators
+    fib::DevBuf<uint16_t> At3f;                      // split-bf16 image with the rows in the order of sphere642_fused.inc
+    fib::DevBuf<float> Aextraf;                      // its extra row (the pole of the layout's rotation)
+    mutable fib::DevBuf<float> mean_hi;              // [nvox] per-voxel upper bound of the mean (fused path)
+    mutable fib::DevBuf<int32_t> redo_list;          // [nvox] voxels left to odf_redo_kernel
     fib::DevBuf<uint32_t> effbits;
     fib::DevBuf<int32_t> nbr, nbr64; // [nvert_even][deg_pad] LDS row of each neighbour (sentinel-padded)
     int deg_pad = 6, rows_pad = 0;
@@ -1654,7 +1917,7 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
     }
     // pick (MB, NX) minimising the per-k-step issue cost ntile*(64*MB + 4*NX) cycles (MFMA block = 64, v_fmac = 4)
     int best_cost = INT32_MAX;
-    const int nxs[] = {0, 1, 2, 4};
+    const int nxs[] = {0, 1};                            // (tiles with 2 or 4 VALU rows never won for a shape in use: 13 variants instead of 25)
     for (int mb = p->split_bf16 ? 10 : 11; mb >= 5; mb--)
         for (int nx : nxs) {
             if (nx > 0 && mb > 10) continue;            // register budget
@@ -1665,7 +1928,7 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
         }
     if (const char *e = getenv("FIBERS_GEMM_TILE")) {        // tuning hook: "<MB>x<NX>"
         int mb = 0, nx = 0;
-        if (sscanf(e, "%dx%d", &mb, &nx) == 2 && mb >= 5 && mb <= 11 && (nx == 0 || nx == 1 || nx == 2 || nx == 4) && !(nx > 0 && mb > 10)) {
+        if (sscanf(e, "%dx%d", &mb, &nx) == 2 && mb >= 5 && mb <= 11 && (nx == 0 || nx == 1) && !(nx > 0 && mb > 10)) {
             p->MB = mb; p->NX = nx; p->ntile_m = (M + mb * 32 + nx - 1) / (mb * 32 + nx);
         }
     }
@@ -1684,8 +1947,6 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
     if (p->split_bf16 && (any_ineff || p->Kpad / KT < 2 || p->MB > 10 || (size_t)p->ntile_m * p->NX * p->Kpad > 2048)) p->split_bf16 = false;
     if (p->split_bf16) {
         const int npiece = 3 * p->MB, nst = p->Kpad / KT;
-        std::vector<uint16_t> A3((size_t)p->ntile_m * nst * npiece * 512, 0);
-        std::vector<float> AX((size_t)std::max(1, p->ntile_m * p->NX * p->Kpad), 0.0f);
         auto bf16_rn = [](float f) -> uint16_t {
             uint32_t u; memcpy(&u, &f, 4);
             if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
@@ -1693,39 +1954,54 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
             return (uint16_t)(u >> 16);
         };
         auto bf16_f = [](uint16_t h) -> float { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
-        for (int tm = 0; tm < p->ntile_m; tm++) {
-            for (int t = 0; t < nst; t++) {
-                uint16_t *st = A3.data() + ((size_t)tm * nst + t) * npiece * 512;
-                for (int m = 0; m < p->MB; m++)
-                    for (int l = 0; l < 64; l++)
-                        for (int j = 0; j < 8; j++) {
-                            const int row = tm * ROWS + m * 32 + (l & 31), k = t * KT + 8 * (l >> 5) + j;
-                            if (row >= M || k >= K) continue;
-                            const float v = p->G[row + (size_t)M * k];
-                            const uint16_t h1 = bf16_rn(v);
-                            const float r1 = v - bf16_f(h1);
-                            const uint16_t h2 = bf16_rn(r1);
-                            const float r2 = r1 - bf16_f(h2);
-                            const uint16_t h3 = bf16_rn(r2);
-                            const uint16_t hs[3] = {h1, h2, h3};
-                            for (int pc = 0; pc < 3; pc++) st[((size_t)(pc * p->MB + m) * 64 + l) * 8 + j] = hs[pc];
-                        }
-            }
-            for (int x = 0; x < p->NX; x++)
-                for (int k = 0; k < K; k++) {
-                    const int row = tm * ROWS + p->MB * 32 + x;
-                    if (row < M) AX[((size_t)tm * p->NX + x) * p->Kpad + k] = p->G[row + (size_t)M * k];
+        // image row `row` of the kernel holds row rowmap[row] of G (identity, or the layout of the fused peak scan)
+        auto build = [&](const short *rowmap, std::vector<uint16_t> &A3, std::vector<float> &AX) {
+            A3.assign((size_t)p->ntile_m * nst * npiece * 512, 0);
+            AX.assign((size_t)std::max(1, p->ntile_m * p->NX * p->Kpad), 0.0f);
+            for (int tm = 0; tm < p->ntile_m; tm++) {
+                for (int t = 0; t < nst; t++) {
+                    uint16_t *st = A3.data() + ((size_t)tm * nst + t) * npiece * 512;
+                    for (int m = 0; m < p->MB; m++)
+                        for (int l = 0; l < 64; l++)
+                            for (int j = 0; j < 8; j++) {
+                                const int row = tm * ROWS + m * 32 + (l & 31), k = t * KT + 8 * (l >> 5) + j;
+                                if (row >= M || k >= K) continue;
+                                const float v = p->G[(rowmap ? rowmap[row] : row) + (size_t)M * k];
+                                const uint16_t h1 = bf16_rn(v);
+                                const float r1 = v - bf16_f(h1);
+                                const uint16_t h2 = bf16_rn(r1);
+                                const float r2 = r1 - bf16_f(h2);
+                                const uint16_t h3 = bf16_rn(r2);
+                                const uint16_t hs[3] = {h1, h2, h3};
+                                for (int pc = 0; pc < 3; pc++) st[((size_t)(pc * p->MB + m) * 64 + l) * 8 + j] = hs[pc];
+                            }
                 }
-        }
+                for (int x = 0; x < p->NX; x++)
+                    for (int k = 0; k < K; k++) {
+                        const int row = tm * ROWS + p->MB * 32 + x;
+                        if (row < M) AX[((size_t)tm * p->NX + x) * p->Kpad + k] = p->G[(rowmap ? rowmap[row] : row) + (size_t)M * k];
+                    }
+            }
+        };
+        std::vector<uint16_t> A3;
+        std::vector<float> AX;
+        build(nullptr, A3, AX);
         int rc3 = p->At3.alloc(A3.size());
         if (rc3 != FIB_OK) return rc3;
         if (p->gRow0 == 0 && p->scale_frame < 0 && faces) {     // GQI: +Inf samples are repaired after the GEMM
-            if ((rc3 = p->Gdev.alloc(p->G.size())) != FIB_OK || (rc3 = p->inf_list.alloc(INF_FIX_CAP)) != FIB_OK) return rc3;
+            if ((rc3 = p->Gdev.alloc(p->G.size())) != FIB_OK) return rc3;
             FIB_HIP(hipMemcpy(p->Gdev.p, p->G.data(), p->G.size() * sizeof(float), hipMemcpyHostToDevice));
         }
         if ((rc3 = p->Aextra.alloc(AX.size())) != FIB_OK) return rc3;
         FIB_HIP(hipMemcpy(p->At3.p, A3.data(), A3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         FIB_HIP(hipMemcpy(p->Aextra.p, AX.data(), AX.size() * sizeof(float), hipMemcpyHostToDevice));
+        p->fused_shape = faces && p->gRow0 == 0 && p->scale_frame < 0 && M == FQ_NV && p->MB == 10 && p->NX == 1 && p->ntile_m == 1 && p->Kpad <= 512;
+        if (p->fused_shape) {                                   // second image in the row order of sphere642_fused.inc
+            build(fib_f642_pos_vertex, A3, AX);
+            if ((rc3 = p->At3f.alloc(A3.size())) != FIB_OK || (rc3 = p->Aextraf.alloc(AX.size())) != FIB_OK) return rc3;
+            FIB_HIP(hipMemcpy(p->At3f.p, A3.data(), A3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            FIB_HIP(hipMemcpy(p->Aextraf.p, AX.data(), AX.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
     std::vector<int32_t> nbr32;
     int rc = FIB_OK;
@@ -1753,6 +2029,7 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
         std::sort(mine.begin(), mine.end());
         if (mine != ref) p->is_s642 = false;
     }
+    p->fused = p->fused_shape && p->is_s642 && p->At3f.p != nullptr;
     std::vector<int32_t> nbr64(nbr);
     for (auto &u : nbr64) if (u == p->rows_pad) u = p->nvert;
     if ((rc = p->nbr64.alloc(nbr64.size())) != FIB_OK) return rc;
@@ -1767,8 +2044,8 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
     if ((rc = p->effbits.alloc(effbits.size())) != FIB_OK) return rc;
     if ((rc = p->verts.alloc(v3.size())) != FIB_OK) return rc;
     if ((rc = p->nbr.alloc(nbr.size())) != FIB_OK) return rc;
-    if ((rc = p->maxenc.alloc(2)) != FIB_OK) return rc;
-    if ((rc = p->live_counts.alloc(3)) != FIB_OK) return rc;
+    if ((rc = p->maxenc.alloc(4)) != FIB_OK) return rc;
+    if ((rc = p->live_counts.alloc(4)) != FIB_OK) return rc;
     if ((rc = p->odfmax.alloc(2)) != FIB_OK) return rc;
     FIB_HIP(hipMemcpy(p->At.p, At.data(), At.size() * sizeof(float), hipMemcpyHostToDevice));
     FIB_HIP(hipMemcpy(p->effbits.p, effbits.data(), effbits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1910,7 +2187,7 @@ void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
         const int64_t items = fib::cdiv(ga.nvox, nw * 32) * ga.ntile_m;
         unsigned pg = (unsigned)std::min<int64_t>((int64_t)ncu * (8 / nw), items);
         pg = (pg + 7) / 8 * 8;
-        if (stamp && MB == 10 && NX == 1) {              // timing experiment: in-kernel clock and epilogue share (stderr, 12th call)
+        if (stamp && MB == 10 && NX == 1 && !ga.mean_hi) {              // timing experiment: in-kernel clock and epilogue share (stderr, 12th call)
             static unsigned long long *dbg = nullptr;
             static int calls = 0;
             if (!dbg) (void)hipMalloc((void **)&dbg, (size_t)4096 * 8 * 8);
@@ -1941,6 +2218,9 @@ void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
             if constexpr (MB <= FOLD_MB_MAX) hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 8, false, true>), dim3(pg), dim3(512), 0, st, g2);
             return;
         }
+        if constexpr (MB == 10 && NX == 1) {
+            if (ga.mean_hi) { hipLaunchKernelGGL((odf_gemm3_kernel<10, 1, 8, false, false, true>), dim3(pg), dim3(512), 0, st, g2); return; }
+        }
         hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 8>), dim3(pg), dim3(512), 0, st, g2);
     }
     else hipLaunchKernelGGL((odf_gemm_kernel<MB, NX>), dim3(grid), dim3(256), 0, st, ga);
@@ -1959,11 +2239,11 @@ int launch_peaks_t(const PeakArgs &pa, size_t smem, unsigned grid, hipStream_t s
     return FIB_OK;
 }
 
-template <int DEG, bool EXACT, bool S642 = false>
+template <int DEG, bool EXACT>
 int launch_peaks64_t(const PeakArgs &pa, size_t smem, int64_t ntiles, unsigned grid, hipStream_t st) {
-    FIB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(odf_peaks64_kernel<DEG, EXACT, S642>),
+    FIB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(odf_peaks64_kernel<DEG, EXACT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL((odf_peaks64_kernel<DEG, EXACT, S642>), dim3(grid), dim3(P64_T), smem, st, pa, ntiles);
+    hipLaunchKernelGGL((odf_peaks64_kernel<DEG, EXACT>), dim3(grid), dim3(P64_T), smem, st, pa, ntiles);
     FIB_HIP(hipGetLastError());
     return FIB_OK;
 }
@@ -1977,6 +2257,7 @@ int launch_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox, int64
     for (int k = 0; k < 3; k++) { pa.peak[k] = peak ? peak[k] : nullptr; pa.qa[k] = qa ? qa[k] : nullptr; }
     pa.isort_top = isort_top; pa.nvalid = nvalid;
     pa.maxenc = reduce ? plan->maxenc.p : nullptr;
+    pa.mean_hi = reduce ? plan->mean_hi.p : nullptr;
     pa.nvox = nvox; pa.stride = stride; pa.nvert = plan->nvert; pa.rows_pad = plan->rows_pad;
     pa.vec_ok = (stride % 4 == 0 && ((uintptr_t)odf & 15) == 0) ? 1 : 0;
     const size_t smem = peaks_smem(plan);
@@ -1985,13 +2266,12 @@ int launch_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox, int64
     const bool exact = isort_top != nullptr;
     fib::ProfScope prof("odf_peaks", st);
     const size_t smem64 = ((size_t)(plan->nvert + 1) * 64 + (size_t)P64_W * 64 * PREC + (size_t)plan->nvert * (plan->deg_pad + 3)) * sizeof(float);
-    const char *force32 = getenv("FIBERS_PEAKS_V2");
-    if (!small_tiles && plan->nvert * 16 <= P64_NI * P64_T && smem64 <= 160 * 1024 && !(force32 && atoi(force32))) {
+    if (!small_tiles && plan->nvert * 16 <= P64_NI * P64_T && smem64 <= 160 * 1024) {
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, plan->device);
         const int64_t ntiles = fib::cdiv(nvox, 64);
         const unsigned g64 = (unsigned)std::min<int64_t>(ntiles, ncu);
-        if (plan->is_s642 && !exact && !getenv("FIBERS_PEAKS_V3")) {
+        if (plan->is_s642 && !exact) {
             const size_t smem642 = ((size_t)(FIB_S642_NVERT + 1) * 64 + (size_t)PQ_CAP * 64 * 2 + 128 + 2 * P64_W * 64 + 2 * 8 * 64 +
                                     (size_t)FIB_S642_NVERT * 3) * sizeof(float);
             FIB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(odf_peaks642_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem642));
@@ -1999,7 +2279,6 @@ int launch_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox, int64
             FIB_HIP(hipGetLastError());
             return FIB_OK;
         }
-        if (plan->is_s642 && !exact) return launch_peaks64_t<6, false, true>(pa, smem64, ntiles, g64, st);
         switch (plan->deg_pad) {
             case 6:  return exact ? launch_peaks64_t<6, true>(pa, smem64, ntiles, g64, st) : launch_peaks64_t<6, false>(pa, smem64, ntiles, g64, st);
             case 8:  return exact ? launch_peaks64_t<8, true>(pa, smem64, ntiles, g64, st) : launch_peaks64_t<8, false>(pa, smem64, ntiles, g64, st);
@@ -2044,7 +2323,26 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
     ga.Aextra = plan->Aextra.p;
     ga.vec_ok = (nvox % 4 == 0 && ((uintptr_t)odf & 15) == 0 && (pdf == nullptr || ((uintptr_t)pdf & 15) == 0)) ? 1 : 0; ga.vidx = plan->live_vox.p; ga.nlive = plan->live_counts.p; ga.mask = mask; ga.effbits = plan->effbits.p;
     ga.out0 = pdf; ga.out1 = odf; ga.nvox = nvox;
-    if (ga.At3 && plan->inf_list.p) { ga.fix_count = plan->live_counts.p + 2; ga.fix_list = plan->inf_list.p; ga.fix_cap = INF_FIX_CAP; }
+    if (ga.At3 && plan->Gdev.p) {                        // GQI: voxels with a +Inf sample are listed and recomputed (no cap: the list holds every voxel)
+        int rci = plan->inf_list.ensure((size_t)nvox);
+        if (rci != FIB_OK) return rci;
+        ga.fix_count = plan->live_counts.p + 2; ga.fix_list = plan->inf_list.p; ga.fix_cap = (int)std::min<int64_t>(nvox, INT32_MAX);
+    }
+    // sphere_642 GQI plans: find_peaks! runs on the contraction kernel's accumulators (gemm3_epilogue_fused)
+    const bool fuse = plan->fused && ga.At3 != nullptr && ga.vec_ok && !getenv("FIBERS_ODF_UNFUSED");
+    {
+        int rcm = plan->mean_hi.ensure((size_t)nvox);
+        if (rcm != FIB_OK) return rcm;
+    }
+    if (fuse) {
+        int rcf = plan->redo_list.ensure((size_t)nvox);
+        if (rcf != FIB_OK) return rcf;
+        ga.At3 = plan->At3f.p; ga.Aextra = plan->Aextraf.p;
+        for (int k = 0; k < 3; k++) { ga.peak[k] = peak[k]; ga.qa[k] = qa[k]; }
+        ga.verts = plan->verts.p; ga.maxenc = plan->maxenc.p; ga.mean_hi = plan->mean_hi.p;
+        ga.redo_count = plan->live_counts.p + 3; ga.redo_list = plan->redo_list.p; ga.redo_cap = (int)std::min<int64_t>(nvox, INT32_MAX);
+        if (const char *e = getenv("FIBERS_FUSE_SKIP")) ga.fuse_skip = atoi(e);
+    }
     ga.K = plan->gK; ga.Kpad = plan->Kpad; ga.M = plan->gM; ga.nrow0 = plan->gRow0; ga.ntile_m = plan->ntile_m;
     const bool fuse_fold = plan->folded && ga.At3 != nullptr && plan->MB <= FOLD_MB_MAX && plan->Kpad <= FKMAX && plan->scale_frame_raw >= 0 &&
                            (int64_t)plan->fold_span_max * nvox * 4 < (int64_t)0xE0000000ll && !getenv("FIBERS_DSI_UNFUSED");
@@ -2075,11 +2373,8 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         fib::ProfScope prof("odf_gemm", s);
 #define FIB_GEMM_CASE(MBV, NXV) if (plan->MB == MBV && plan->NX == NXV) { launch_gemm<MBV, NXV>(g, grid, s); launched = true; }
         bool launched = false;
-        FIB_GEMM_CASE(5, 0) FIB_GEMM_CASE(5, 1) FIB_GEMM_CASE(5, 2) FIB_GEMM_CASE(5, 4)
-        FIB_GEMM_CASE(6, 0) FIB_GEMM_CASE(7, 0) FIB_GEMM_CASE(8, 0) FIB_GEMM_CASE(9, 0) FIB_GEMM_CASE(10, 0) FIB_GEMM_CASE(11, 0)
-        FIB_GEMM_CASE(6, 1) FIB_GEMM_CASE(7, 1) FIB_GEMM_CASE(8, 1) FIB_GEMM_CASE(9, 1) FIB_GEMM_CASE(10, 1)
-        FIB_GEMM_CASE(6, 2) FIB_GEMM_CASE(7, 2) FIB_GEMM_CASE(8, 2) FIB_GEMM_CASE(9, 2) FIB_GEMM_CASE(10, 2)
-        FIB_GEMM_CASE(6, 4) FIB_GEMM_CASE(7, 4) FIB_GEMM_CASE(8, 4) FIB_GEMM_CASE(9, 4) FIB_GEMM_CASE(10, 4)
+        FIB_GEMM_CASE(5, 0) FIB_GEMM_CASE(6, 0) FIB_GEMM_CASE(7, 0) FIB_GEMM_CASE(8, 0) FIB_GEMM_CASE(9, 0) FIB_GEMM_CASE(10, 0) FIB_GEMM_CASE(11, 0)
+        FIB_GEMM_CASE(5, 1) FIB_GEMM_CASE(6, 1) FIB_GEMM_CASE(7, 1) FIB_GEMM_CASE(8, 1) FIB_GEMM_CASE(9, 1) FIB_GEMM_CASE(10, 1)
 #undef FIB_GEMM_CASE
         if (!launched) return fib::fail(FIB_ERR_INVALID, "internal: no GEMM variant for MB=%d NX=%d", plan->MB, plan->NX);
         FIB_HIP(hipGetLastError());
@@ -2097,11 +2392,24 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
     int rc = run_gemm(ga, st);
     if (rc != FIB_OK) return rc;
     if (ga.fix_list) {
-        InfFixArgs fx{plan->Gdev.p, dwi, odf, ga.fix_count, ga.fix_list, INF_FIX_CAP, plan->gM, plan->gK, nvox};
+        InfFixArgs fx{plan->Gdev.p, dwi, odf, ga.fix_count, ga.fix_list, ga.fix_cap, plan->gM, plan->gK, nvox};
         hipLaunchKernelGGL(odf_inf_fix_kernel, dim3(64), dim3(256), 0, st, fx);
     }
-    rc = launch_peaks(plan, odf, nvox, nvox, peak, qa, nullptr, nullptr, true, st, false, plan->live_tiles.p, plan->live_counts.p + 1);
-    if (rc != FIB_OK) return rc;
+    if (fuse) {
+        fib::ProfScope prof("odf_peaks", st);           // what is left of the peak finder: the redo list and the exact odfmax
+        RedoArgs ra{odf, nvox, ga.redo_count, ga.redo_list, ga.redo_cap, plan->verts.p, {peak[0], peak[1], peak[2]}, {qa[0], qa[1], qa[2]}, plan->maxenc.p};
+        hipLaunchKernelGGL(odf_redo_kernel, dim3(256), dim3(64), 0, st, ra);
+        FIB_HIP(hipGetLastError());
+    } else {
+        rc = launch_peaks(plan, odf, nvox, nvox, peak, qa, nullptr, nullptr, true, st, false, plan->live_tiles.p, plan->live_counts.p + 1);
+        if (rc != FIB_OK) return rc;
+    }
+    {
+        fib::ProfScope prof("odfmax_refine", st);
+        RefineArgs rf{odf, nvox, nvox, plan->nvert, plan->live_vox.p, plan->live_counts.p, plan->mean_hi.p, plan->maxenc.p};
+        hipLaunchKernelGGL(odfmax_refine_kernel, dim3(1024), dim3(256), 0, st, rf);
+        FIB_HIP(hipGetLastError());
+    }
     float *om = odfmax_dev ? odfmax_dev : plan->odfmax.p;
     hipLaunchKernelGGL(odfmax_finalize_kernel, dim3(1), dim3(1), 0, st, plan->maxenc.p, om);
     FIB_HIP(hipGetLastError());
@@ -2157,11 +2465,8 @@ int fib::matrix_plan_run(const fib_odf_plan *plan, const float *S, const uint8_t
     fib::ProfScope prof("matrix_gemm", st);
 #define FIB_GEMM_CASE(MBV, NXV) if (plan->MB == MBV && plan->NX == NXV) { launch_gemm<MBV, NXV>(ga, grid, st); launched = true; }
     bool launched = false;
-    FIB_GEMM_CASE(5, 0) FIB_GEMM_CASE(5, 1) FIB_GEMM_CASE(5, 2) FIB_GEMM_CASE(5, 4)
-    FIB_GEMM_CASE(6, 0) FIB_GEMM_CASE(7, 0) FIB_GEMM_CASE(8, 0) FIB_GEMM_CASE(9, 0) FIB_GEMM_CASE(10, 0) FIB_GEMM_CASE(11, 0)
-    FIB_GEMM_CASE(6, 1) FIB_GEMM_CASE(7, 1) FIB_GEMM_CASE(8, 1) FIB_GEMM_CASE(9, 1) FIB_GEMM_CASE(10, 1)
-    FIB_GEMM_CASE(6, 2) FIB_GEMM_CASE(7, 2) FIB_GEMM_CASE(8, 2) FIB_GEMM_CASE(9, 2) FIB_GEMM_CASE(10, 2)
-    FIB_GEMM_CASE(6, 4) FIB_GEMM_CASE(7, 4) FIB_GEMM_CASE(8, 4) FIB_GEMM_CASE(9, 4) FIB_GEMM_CASE(10, 4)
+    FIB_GEMM_CASE(5, 0) FIB_GEMM_CASE(6, 0) FIB_GEMM_CASE(7, 0) FIB_GEMM_CASE(8, 0) FIB_GEMM_CASE(9, 0) FIB_GEMM_CASE(10, 0) FIB_GEMM_CASE(11, 0)
+    FIB_GEMM_CASE(5, 1) FIB_GEMM_CASE(6, 1) FIB_GEMM_CASE(7, 1) FIB_GEMM_CASE(8, 1) FIB_GEMM_CASE(9, 1) FIB_GEMM_CASE(10, 1)
 #undef FIB_GEMM_CASE
     if (!launched) return fib::fail(FIB_ERR_INVALID, "internal: no GEMM variant for MB=%d NX=%d", plan->MB, plan->NX);
     FIB_HIP(hipGetLastError());

@@ -400,7 +400,7 @@ static float odf_max_of_means(const float *odf, int64_t nvox, int nvert, int nth
     for (int64_t vox = 0; vox < nvox; vox++) {
         float sum = 0.0f;
         for (int v = 0; v < nvert; v++) sum += odf[(int64_t)v * nvox + vox];
-        float m = sum * (1.0f / (float)nvert);
+        float m = sum / (float)nvert;   /* Statistics.mean: sum(A, dims=4) ./ n; the sum runs sequentially over dim 4 (Base mapreducedim!) */
         if (isnan(m)) anynan = 1;
         else if (m > best) best = m;
     }
