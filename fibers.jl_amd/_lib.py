@@ -27,7 +27,7 @@ class StreamParams(C.Structure):
     _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("nvec", C.c_int32),
                 ("len_min", C.c_int32), ("len_max", C.c_int32),
                 ("cosang_thresh", C.c_float), ("step_size", C.c_float), ("smooth_coeff", C.c_float),
-                ("search_dist", C.c_int32), ("search_cosang", C.c_float)]
+                ("search_dist", C.c_int32), ("search_cosang", C.c_float), ("ws", C.c_void_p)]
 
 
 class RumbaOut(C.Structure):
@@ -71,6 +71,8 @@ _PROTOS = {
     "fibd_stream_field": (i32, [i32, i64, vp, vp, f32, vp, f32, vp, vp, vp, vp]),
     "fibd_stream_trace": (i32, [C.POINTER(StreamParams), vp, vp, i64, vp, i32, vp,
                                 C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]),
+    "fibd_stream_ws_create": (i32, [i32, C.POINTER(vp)]),
+    "fibd_stream_ws_destroy": (None, [vp]),
     "fibd_stream_pack": (i32, [vp, vp, vp, vp, vp]),
     "fibd_stream_pack_trk": (i32, [vp, C.POINTER(C.c_float * 3), vp, vp]),
     "fibd_stream_trace_lcm": (i32, [C.POINTER(StreamParams), vp, vp, f32, i32, i32, C.c_uint64, vp, i64, vp, i32, vp,
@@ -78,6 +80,8 @@ _PROTOS = {
     "fibd_stream_pack_flags": (i32, [vp, vp, vp, vp, vp, vp]),
     "fibd_stream_all_npts": (i32, [vp, vp, vp]),
     "fib_stream_job_destroy": (None, [vp]),
+    "fib_init": (i32, [i32, vp]),
+    "fib_shutdown": (None, []),
     "fib_dti_fit": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, C.POINTER(DtiOut)]),
     "fib_adc_fit": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp]),
     "fib_gqi_rec": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, f32, vp, P3, P3]),
@@ -126,6 +130,21 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+DEVICE_ALL = -1     # FIB_DEVICE_ALL: the device set declared with init()
+
+
+def init(devices=None):
+    """fib_init: the device set that `device=DEVICE_ALL` shards over (None / empty: every visible device; an index may
+    repeat: two pipelines on one GPU)."""
+    devs = [] if devices is None else [int(d) for d in devices]
+    arr = (C.c_int * max(1, len(devs)))(*devs)
+    check(lib().fib_init(len(devs), arr))
+
+
+def shutdown():
+    lib().fib_shutdown()
 
 
 def check(rc):

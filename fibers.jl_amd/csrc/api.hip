@@ -1,11 +1,29 @@
-// api.hip — host-buffer ("drop-in") entry points: stage caller-owned host arrays through HBM,
-// run the device-resident path (fibd_*), copy results back.  These are the functions the Julia
-// wrapper ccalls in place of the bodies of dti_fit / adc_fit / gqi_rec / dsi_rec / stream.
+// api.hip — host-buffer ("drop-in") entry points: the functions the Julia wrapper ccalls in place of the bodies of
+// dti_fit / adc_fit / gqi_rec / dsi_rec / stream.  Caller-owned host arrays in, caller-owned host arrays out.
+//
+// The reference threads its volume loops over z-slices (dti.jl:258, gqi.jl:132, dsi.jl:197) and its seed list over
+// contiguous chunks (stream.jl:757-761).  Here the same decomposition feeds GPUs:
+//   * a device set (fib_init; default: device 0) — the voxel range is cut into contiguous slabs, one per device, each
+//     driven by its own host thread; seeds shard round-robin;
+//   * per device a three-stage pipeline over voxel chunks: gather rows of the planar host arrays into a pinned ring
+//     (threaded memcpy) -> H2D on one stream || the device-resident path (fibd_*) on a second || D2H on a third ->
+//     scatter rows back.  PCIe runs in both directions at once; the kernels hide completely behind the link;
+//   * the only exchange step of the fits, odfmax = maximum(mean(odf, dims=4)) (gqi.jl:164, dsi.jl:263), is one float per
+//     chunk: reduced on the host, then qa ./= odfmax runs on every device before the qa volumes are copied out;
+//   * plans (the reference's work structs) are cached per device, keyed by the tables they were built from.
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
 
 #include "common.h"
 
 namespace {
+
+#define RC(x) do { int _rc = (x); if (_rc != FIB_OK) return _rc; } while (0)
 
 // mask.vol[...] == 0 && continue (dti.jl:261, gqi.jl:135, dsi.jl:200)  -> nonzero test
 // mask.vol .> 0 (stream.jl:102), seed.vol .> 0 (stream.jl:751)         -> positive test
@@ -14,27 +32,35 @@ void mask_convert_t(const T *m, int64_t n, bool positive, uint8_t *out) {
     if (positive) for (int64_t i = 0; i < n; i++) out[i] = m[i] > (T)0 ? 1 : 0;
     else          for (int64_t i = 0; i < n; i++) out[i] = m[i] != (T)0 ? 1 : 0;
 }
-
-int mask_convert(const void *m, int dtype, int64_t n, bool positive, std::vector<uint8_t> &out) {
-    out.resize((size_t)n);
+int dtype_size(int dtype) {
     switch (dtype) {
-        case FIB_U8: case FIB_BOOL: mask_convert_t((const uint8_t *)m, n, positive, out.data()); break;
-        case FIB_I8:  mask_convert_t((const int8_t *)m, n, positive, out.data()); break;
-        case FIB_I16: mask_convert_t((const int16_t *)m, n, positive, out.data()); break;
-        case FIB_U16: mask_convert_t((const uint16_t *)m, n, positive, out.data()); break;
-        case FIB_I32: mask_convert_t((const int32_t *)m, n, positive, out.data()); break;
-        case FIB_U32: mask_convert_t((const uint32_t *)m, n, positive, out.data()); break;
-        case FIB_I64: mask_convert_t((const int64_t *)m, n, positive, out.data()); break;
-        case FIB_F32: mask_convert_t((const float *)m, n, positive, out.data()); break;
-        case FIB_F64: mask_convert_t((const double *)m, n, positive, out.data()); break;
+        case FIB_U8: case FIB_BOOL: case FIB_I8: return 1;
+        case FIB_I16: case FIB_U16: return 2;
+        case FIB_I32: case FIB_U32: case FIB_F32: return 4;
+        case FIB_I64: case FIB_F64: return 8;
+        default: return 0;
+    }
+}
+// elements [i0, i0 + n) of a mask / seed volume of any numeric type -> bytes
+int mask_convert_range(const void *m, int dtype, int64_t i0, int64_t n, bool positive, uint8_t *out) {
+    switch (dtype) {
+        case FIB_U8: case FIB_BOOL: mask_convert_t((const uint8_t *)m + i0, n, positive, out); break;
+        case FIB_I8:  mask_convert_t((const int8_t *)m + i0, n, positive, out); break;
+        case FIB_I16: mask_convert_t((const int16_t *)m + i0, n, positive, out); break;
+        case FIB_U16: mask_convert_t((const uint16_t *)m + i0, n, positive, out); break;
+        case FIB_I32: mask_convert_t((const int32_t *)m + i0, n, positive, out); break;
+        case FIB_U32: mask_convert_t((const uint32_t *)m + i0, n, positive, out); break;
+        case FIB_I64: mask_convert_t((const int64_t *)m + i0, n, positive, out); break;
+        case FIB_F32: mask_convert_t((const float *)m + i0, n, positive, out); break;
+        case FIB_F64: mask_convert_t((const double *)m + i0, n, positive, out); break;
         default: return fib::fail(FIB_ERR_INVALID, "unknown mask dtype %d", dtype);
     }
     return FIB_OK;
 }
-
-struct PlanDeleter { void operator()(fib_dti_plan *p) const { fib_dti_plan_destroy(p); } };
-
-#define RC(x) do { int _rc = (x); if (_rc != FIB_OK) return _rc; } while (0)
+int mask_convert(const void *m, int dtype, int64_t n, bool positive, std::vector<uint8_t> &out) {
+    out.resize((size_t)n);
+    return mask_convert_range(m, dtype, 0, n, positive, out.data());
+}
 
 int h2d(void *dst, const void *src, size_t bytes) {
     FIB_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
@@ -45,50 +71,392 @@ int d2h(void *dst, const void *src, size_t bytes) {
     return FIB_OK;
 }
 
+// ---- a small pool for the row copies between the caller's arrays and the pinned ring --------------------------------------
+class CopyPool {
+  public:
+    explicit CopyPool(int nthreads) {
+        for (int i = 0; i < nthreads; i++) th_.emplace_back([this] { work(); });
+    }
+    ~CopyPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    // runs fn(0..n-1), the caller takes part; returns when all are done
+    void run(int n, const std::function<void(int)> &fn) {
+        if (n <= 0) return;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn; n_ = n; next_ = 0; left_ = n;
+        }
+        cv_.notify_all();
+        for (;;) {
+            int i;
+            { std::lock_guard<std::mutex> lk(mu_); if (next_ >= n_) break; i = next_++; }
+            fn(i);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--left_ == 0) done_.notify_all();
+        }
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return left_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    void work() {
+        for (;;) {
+            int i;
+            const std::function<void(int)> *fn;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [this] { return stop_ || (fn_ && next_ < n_); });
+                if (stop_) return;
+                i = next_++; fn = fn_;
+            }
+            (*fn)(i);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--left_ == 0) done_.notify_all();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)> *fn_ = nullptr;
+    int n_ = 0, next_ = 0, left_ = 0;
+    bool stop_ = false;
+};
+
+// ---- per-device state of the host tier -----------------------------------------------------------------------------------
+constexpr int NBUF = 3;                                  // ring depth: chunk k uploads while k-1 computes and k-2 downloads
+
+struct PinBuf {                                          // grow-only pinned host buffer
+    char *p = nullptr; size_t n = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= n && p) return FIB_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipHostMalloc((void **)&p, bytes ? bytes : 1, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return fib::fail(FIB_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
+        n = bytes;
+        return FIB_OK;
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+};
+
+struct CachedPlan { std::string key; void *plan = nullptr; int kind = 0; uint64_t stamp = 0; };   // kind 0: dti/adc, 1: odf
+
+struct DevState {
+    int device = 0;
+    std::mutex mu;                                       // one host-tier call at a time per entry of the device set
+    bool ready = false;
+    hipStream_t s_in = nullptr, s_cmp = nullptr, s_out = nullptr;
+    hipEvent_t e_in[NBUF] = {}, e_cmp[NBUF] = {}, e_out[NBUF] = {};
+    PinBuf pin_in[NBUF], pin_out[NBUF];
+    fib::DevBuf<char> dev_in[NBUF], dev_out[NBUF], dev_keep;
+    std::unique_ptr<CopyPool> pool;
+    std::vector<CachedPlan> plans;
+    uint64_t clock = 0;
+    fib_stream_ws *ws = nullptr;
+
+    int init(int nthreads) {
+        if (ready) return FIB_OK;
+        FIB_HIP(hipSetDevice(device));
+        FIB_HIP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+        FIB_HIP(hipStreamCreateWithFlags(&s_cmp, hipStreamNonBlocking));
+        FIB_HIP(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+        for (int b = 0; b < NBUF; b++) {
+            FIB_HIP(hipEventCreateWithFlags(&e_in[b], hipEventDisableTiming));
+            FIB_HIP(hipEventCreateWithFlags(&e_cmp[b], hipEventDisableTiming));
+            FIB_HIP(hipEventCreateWithFlags(&e_out[b], hipEventDisableTiming));
+        }
+        pool.reset(new CopyPool(nthreads));
+        ready = true;
+        return FIB_OK;
+    }
+    void drop_plans() {
+        for (auto &c : plans) {
+            if (c.kind == 0) fib_dti_plan_destroy((fib_dti_plan *)c.plan); else fib_odf_plan_destroy((fib_odf_plan *)c.plan);
+        }
+        plans.clear();
+    }
+    ~DevState() {
+        if (!ready) return;
+        (void)hipSetDevice(device);
+        drop_plans();
+        if (ws) fibd_stream_ws_destroy(ws);
+        for (int b = 0; b < NBUF; b++) { (void)hipEventDestroy(e_in[b]); (void)hipEventDestroy(e_cmp[b]); (void)hipEventDestroy(e_out[b]); }
+        (void)hipStreamDestroy(s_in); (void)hipStreamDestroy(s_cmp); (void)hipStreamDestroy(s_out);
+    }
+};
+
+// The device set of the host tier (fib_init).  Entry i is an independent worker: the same device may appear twice (two
+// concurrent pipelines on one GPU; used by the tests on a 1-GPU box).
+struct HostCtx {
+    std::mutex mu;
+    std::vector<std::unique_ptr<DevState>> devs;         // the set for device == FIB_DEVICE_ALL
+    std::vector<std::unique_ptr<DevState>> single;       // workers for calls that name one device
+};
+HostCtx &ctx() { static HostCtx c; return c; }
+
+int copy_threads(int nworkers) {
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 8;
+    if (const char *e = getenv("FIBERS_COPY_THREADS")) { const int t = atoi(e); if (t >= 1) return t; }
+    int t = (int)hw / (2 * (nworkers > 0 ? nworkers : 1));
+    return t < 2 ? 2 : (t > 16 ? 16 : t);                // 8-16 threads reach the host's copy bandwidth (tools/probes/host_probe.hip)
+}
+
+// workers of a call: the fib_init set for FIB_DEVICE_ALL, else the (lazily created) worker of that device
+int workers_for(int device, std::vector<DevState *> &out) {
+    HostCtx &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (device == FIB_DEVICE_ALL) {
+        if (c.devs.empty()) {                            // no fib_init: every visible device
+            const int n = fib_device_count();
+            if (n <= 0) return fib::fail(FIB_ERR_NO_DEVICE, "no HIP device is available and this back end has no CPU fallback");
+            for (int d = 0; d < n; d++) { c.devs.emplace_back(new DevState()); c.devs.back()->device = d; }
+        }
+        for (auto &d : c.devs) out.push_back(d.get());
+        return FIB_OK;
+    }
+    RC(fib::use_device(device));
+    for (auto &d : c.single) if (d->device == device) { out.push_back(d.get()); return FIB_OK; }
+    c.single.emplace_back(new DevState());
+    c.single.back()->device = device;
+    out.push_back(c.single.back().get());
+    return FIB_OK;
+}
+
+// ---- plan cache ----------------------------------------------------------------------------------------------------------------
+void key_add(std::string &k, const void *p, size_t bytes) { k.append((const char *)&bytes, sizeof bytes); if (p) k.append((const char *)p, bytes); }
+
+template <typename MakeFn>
+int cached_plan(DevState &d, int kind, const std::string &key, MakeFn make, void **plan) {
+    for (auto &c : d.plans) if (c.kind == kind && c.key == key) { c.stamp = ++d.clock; *plan = c.plan; return FIB_OK; }
+    void *p = nullptr;
+    RC(make(&p));
+    if (d.plans.size() >= 4) {                           // evict the least recently used
+        size_t lru = 0;
+        for (size_t i = 1; i < d.plans.size(); i++) if (d.plans[i].stamp < d.plans[lru].stamp) lru = i;
+        if (d.plans[lru].kind == 0) fib_dti_plan_destroy((fib_dti_plan *)d.plans[lru].plan); else fib_odf_plan_destroy((fib_odf_plan *)d.plans[lru].plan);
+        d.plans.erase(d.plans.begin() + lru);
+    }
+    d.plans.push_back(CachedPlan{key, p, kind, ++d.clock});
+    *plan = p;
+    return FIB_OK;
+}
+
+// ---- the chunk pipeline --------------------------------------------------------------------------------------------------------
+struct Rows { const float *in; float *out; int nrows; };   // a planar host array: nrows rows of nvox floats (row stride = nvox)
+
+// what a fit does with one chunk, all pointers on the device: din = the input rows back to back (row stride n), dmask = n
+// bytes, dout = the output rows back to back (row stride n)
+using ChunkFn = std::function<int(int chunk, int64_t v0, int64_t n, const float *din, const uint8_t *dmask, float *dout, hipStream_t st)>;
+
+int64_t pick_chunk(int64_t nrange, int rows_in, int rows_out) {
+    const int rows = rows_in > rows_out ? rows_in : rows_out;
+    int64_t c = 131072;                                  // two 256-voxel work items per CU for the contraction kernel
+    while (c > 8192 && c * rows * 4 > (int64_t)192 << 20) c >>= 1;
+    if (const char *e = getenv("FIBERS_HOST_CHUNK")) { const long long v = atoll(e); if (v >= 1024) c = v / 4 * 4; }
+    return c < nrange ? c : (nrange + 3) / 4 * 4;
+}
+
+// voxels [vbeg, vend) of a volume of nvox voxels through device d.  Blocking.  The caller holds d.mu.
+int run_chunks(DevState &d, int64_t vbeg, int64_t vend, int64_t nvox, const std::vector<Rows> &ins, const void *mask, int mask_dtype,
+               const std::vector<Rows> &outs, int64_t chunk, const ChunkFn &fn) {
+    if (vend <= vbeg) return FIB_OK;
+    FIB_HIP(hipSetDevice(d.device));
+    int rin = 0, rout = 0;
+    for (auto &r : ins) rin += r.nrows;
+    for (auto &r : outs) rout += r.nrows;
+    const size_t in_bytes = (size_t)rin * chunk * 4 + (size_t)chunk, out_bytes = (size_t)rout * chunk * 4;
+    for (int b = 0; b < NBUF; b++) {
+        RC(d.pin_in[b].ensure(in_bytes));
+        RC(d.pin_out[b].ensure(out_bytes));
+        RC(d.dev_in[b].ensure(in_bytes));
+        RC(d.dev_out[b].ensure(out_bytes));
+    }
+    const int nchunks = (int)fib::cdiv(vend - vbeg, chunk);
+    std::atomic<int> err{FIB_OK};
+    auto scatter = [&](int k) {                          // chunk k: pinned ring -> the caller's arrays
+        const int b = k % NBUF;
+        const int64_t v0 = vbeg + (int64_t)k * chunk, n = std::min<int64_t>(chunk, vend - v0);
+        if (hipEventSynchronize(d.e_out[b]) != hipSuccess) { err = fib::fail(FIB_ERR_HIP, "device-to-host copy of chunk %d failed", k); return; }
+        std::vector<std::pair<float *, const float *>> rows;
+        const float *src = reinterpret_cast<const float *>(d.pin_out[b].p);
+        for (auto &r : outs) for (int i = 0; i < r.nrows; i++) { rows.emplace_back(r.out + (int64_t)i * nvox + v0, src); src += n; }
+        d.pool->run((int)rows.size(), [&](int i) { memcpy(rows[i].first, rows[i].second, (size_t)n * 4); });
+    };
+    auto enqueue = [&](int k) -> int {                   // chunk k: gather, upload, compute, download (asynchronous from the upload on)
+        const int b = k % NBUF;
+        const int64_t v0 = vbeg + (int64_t)k * chunk, n = std::min<int64_t>(chunk, vend - v0);
+        // the pinned input buffer is free once the upload of chunk k - NBUF has completed
+        if (k >= NBUF) FIB_HIP(hipEventSynchronize(d.e_in[b]));
+        {
+            std::vector<std::pair<float *, const float *>> rows;
+            float *dst = reinterpret_cast<float *>(d.pin_in[b].p);
+            for (auto &r : ins) for (int i = 0; i < r.nrows; i++) { rows.emplace_back(dst, r.in + (int64_t)i * nvox + v0); dst += n; }
+            uint8_t *m8 = reinterpret_cast<uint8_t *>(d.pin_in[b].p) + (size_t)rin * n * 4;
+            std::atomic<int> merr{FIB_OK};
+            d.pool->run((int)rows.size() + 1, [&](int i) {
+                if (i < (int)rows.size()) memcpy(rows[i].first, rows[i].second, (size_t)n * 4);
+                else if (mask_convert_range(mask, mask_dtype, v0, n, false, m8) != FIB_OK) merr = FIB_ERR_INVALID;
+            });
+            if (merr != FIB_OK) return fib::fail(FIB_ERR_INVALID, "unknown mask dtype %d", mask_dtype);
+        }
+        const size_t ib = (size_t)rin * n * 4 + (size_t)n;
+        // device buffers of this ring slot: the kernels of chunk k - NBUF have read dev_in, its download has read dev_out
+        if (k >= NBUF) { FIB_HIP(hipStreamWaitEvent(d.s_in, d.e_cmp[b], 0)); FIB_HIP(hipStreamWaitEvent(d.s_cmp, d.e_out[b], 0)); }
+        FIB_HIP(hipMemcpyAsync(d.dev_in[b].p, d.pin_in[b].p, ib, hipMemcpyHostToDevice, d.s_in));
+        FIB_HIP(hipEventRecord(d.e_in[b], d.s_in));
+        FIB_HIP(hipStreamWaitEvent(d.s_cmp, d.e_in[b], 0));
+        RC(fn(k, v0, n, reinterpret_cast<const float *>(d.dev_in[b].p), reinterpret_cast<const uint8_t *>(d.dev_in[b].p) + (size_t)rin * n * 4,
+              reinterpret_cast<float *>(d.dev_out[b].p), d.s_cmp));
+        FIB_HIP(hipEventRecord(d.e_cmp[b], d.s_cmp));
+        FIB_HIP(hipStreamWaitEvent(d.s_out, d.e_cmp[b], 0));
+        FIB_HIP(hipMemcpyAsync(d.pin_out[b].p, d.dev_out[b].p, (size_t)rout * n * 4, hipMemcpyDeviceToHost, d.s_out));
+        FIB_HIP(hipEventRecord(d.e_out[b], d.s_out));
+        return FIB_OK;
+    };
+    for (int k = 0; k < nchunks + 2 && err == FIB_OK; k++) {
+        if (k >= 2) scatter(k - 2);
+        if (k < nchunks && err == FIB_OK) { const int rc = enqueue(k); if (rc != FIB_OK) err = rc; }
+    }
+    // leave the streams idle whatever happened (the ring buffers are reused by the next call)
+    (void)hipStreamSynchronize(d.s_in); (void)hipStreamSynchronize(d.s_cmp); (void)hipStreamSynchronize(d.s_out);
+    return err;
+}
+
+// contiguous slab of voxels for worker i of n (the reference's z-slice blocks, here at 4-voxel granularity so that rows
+// stay 16-byte aligned on the device)
+void slab(int64_t nvox, int n, int i, int64_t &v0, int64_t &v1) {
+    const int64_t q = (nvox + 3) / 4, per = q / n, rem = q % n;
+    const int64_t a = per * i + std::min<int64_t>(i, rem), b = a + per + (i < rem ? 1 : 0);
+    v0 = std::min(a * 4, nvox); v1 = std::min(b * 4, nvox);
+}
+
+// runs job(worker index, worker) on every worker of the set, one host thread each; the first error wins
+int for_each_worker(const std::vector<DevState *> &ws, const std::function<int(int, DevState &)> &job) {
+    std::vector<int> rcs(ws.size(), FIB_OK);
+    std::vector<std::string> msgs(ws.size());
+    auto body = [&](int i) {
+        try {
+            std::lock_guard<std::mutex> lk(ws[i]->mu);
+            fib::DeviceGuard guard;
+            int rc = ws[i]->init(copy_threads((int)ws.size()));
+            if (rc == FIB_OK) rc = job(i, *ws[i]);
+            rcs[i] = rc;
+            if (rc != FIB_OK) msgs[i] = fib_last_error();       // (thread-local message of the worker thread)
+        } catch (const std::bad_alloc &) { rcs[i] = FIB_ERR_NOMEM; msgs[i] = "out of host memory"; }
+        catch (...) { rcs[i] = FIB_ERR_INVALID; msgs[i] = "internal error in a device worker"; }
+    };
+    if (ws.size() == 1) body(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < ws.size(); i++) th.emplace_back(body, (int)i);
+        for (auto &t : th) t.join();
+    }
+    for (size_t i = 0; i < ws.size(); i++) if (rcs[i] != FIB_OK) return fib::fail(rcs[i], "%s", msgs[i].c_str());
+    return FIB_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// device set
+// ------------------------------------------------------------------------------------------------------------------------------
+extern "C" int fib_init(int ndev, const int *devs) try {
+    FIB_CHECK(ndev >= 0 && (ndev == 0 || devs), FIB_ERR_INVALID, "invalid device list");
+    const int have = fib_device_count();
+    FIB_CHECK(have > 0, FIB_ERR_NO_DEVICE, "no HIP device is available and this back end has no CPU fallback");
+    for (int i = 0; i < ndev; i++) FIB_CHECK(devs[i] >= 0 && devs[i] < have, FIB_ERR_NO_DEVICE, "device %d is not available (%d devices)", devs[i], have);
+    HostCtx &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    fib::DeviceGuard guard;
+    for (auto &d : c.devs) { std::lock_guard<std::mutex> lk2(d->mu); }   // wait for calls in flight
+    c.devs.clear();
+    const int n = ndev > 0 ? ndev : have;
+    for (int i = 0; i < n; i++) { c.devs.emplace_back(new DevState()); c.devs.back()->device = ndev > 0 ? devs[i] : i; }
+    return FIB_OK;
+} FIB_API_CATCH
+
+extern "C" void fib_shutdown(void) try {
+    HostCtx &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    fib::DeviceGuard guard;
+    c.devs.clear();
+    c.single.clear();
+} FIB_API_CATCH_VOID
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// dti_fit / adc_fit
+// ------------------------------------------------------------------------------------------------------------------------------
+namespace {
+int dti_plan_for(DevState &d, const float *bval, const float *bvec, int nvol, fib_dti_plan **plan) {
+    std::string key;
+    key_add(key, bval, sizeof(float) * nvol);
+    key_add(key, bvec, bvec ? sizeof(float) * 3 * nvol : 0);
+    void *p = nullptr;
+    RC(cached_plan(d, 0, key, [&](void **out) { fib_dti_plan *q = nullptr; int rc = fib_dti_plan_create(d.device, bval, bvec, nvol, &q); *out = q; return rc; }, &p));
+    *plan = (fib_dti_plan *)p;
+    return FIB_OK;
+}
 }  // namespace
 
 extern "C" int fib_dti_fit(int device, const float *dwi, int nx, int ny, int nz, int nvol,
                            const void *mask, int mask_dtype, const float *bval, const float *bvec,
-                           const fib_dti_out *out) {
+                           const fib_dti_out *out) try {
     FIB_CHECK(bval != nullptr && nvol > 0, FIB_ERR_MISSING_BVAL, "Missing b-value table from input DWI structure");
     FIB_CHECK(bvec != nullptr, FIB_ERR_MISSING_BVEC, "Missing gradient table from input DWI structure");
     FIB_CHECK(dwi && mask && out, FIB_ERR_INVALID, "NULL argument");
     FIB_CHECK(nx > 0 && ny > 0 && nz > 0, FIB_ERR_INVALID, "volume dimensions must be positive");
-    fib::DeviceGuard guard;
-    RC(fib::use_device(device));
+    FIB_CHECK(dtype_size(mask_dtype) > 0, FIB_ERR_INVALID, "unknown mask dtype %d", mask_dtype);
+    FIB_CHECK(out->s0 && out->eigval1 && out->eigval2 && out->eigval3 && out->eigvec1 && out->eigvec2 && out->eigvec3 && out->rd && out->md && out->fa,
+              FIB_ERR_INVALID, "NULL output volume");
     const int64_t nvox = (int64_t)nx * ny * nz;
-    fib_dti_plan *praw = nullptr;
-    RC(fib_dti_plan_create(device, bval, bvec, nvol, &praw));
-    std::unique_ptr<fib_dti_plan, PlanDeleter> plan(praw);
-    std::vector<uint8_t> m8;
-    RC(mask_convert(mask, mask_dtype, nvox, false, m8));
-    fib::DevBuf<float> d_dwi, d_out;
-    fib::DevBuf<uint8_t> d_mask;
-    RC(d_dwi.alloc((size_t)nvox * nvol));
-    RC(d_mask.alloc((size_t)nvox));
-    RC(d_out.alloc((size_t)nvox * 16));
-    RC(h2d(d_dwi.p, dwi, sizeof(float) * nvox * nvol));
-    RC(h2d(d_mask.p, m8.data(), (size_t)nvox));
-    float *b = d_out.p;
-    fib_dti_out dev{b, b + nvox, b + 2 * nvox, b + 3 * nvox, b + 4 * nvox, b + 7 * nvox, b + 10 * nvox,
-                    b + 13 * nvox, b + 14 * nvox, b + 15 * nvox};
-    RC(fibd_dti_fit(plan.get(), d_dwi.p, d_mask.p, nvox, &dev, nullptr));
-    FIB_HIP(hipDeviceSynchronize());
-    const size_t sb = sizeof(float) * nvox;
-    RC(d2h(out->s0, dev.s0, sb));
-    RC(d2h(out->eigval1, dev.eigval1, sb));
-    RC(d2h(out->eigval2, dev.eigval2, sb));
-    RC(d2h(out->eigval3, dev.eigval3, sb));
-    RC(d2h(out->eigvec1, dev.eigvec1, 3 * sb));
-    RC(d2h(out->eigvec2, dev.eigvec2, 3 * sb));
-    RC(d2h(out->eigvec3, dev.eigvec3, 3 * sb));
-    RC(d2h(out->rd, dev.rd, sb));
-    RC(d2h(out->md, dev.md, sb));
-    RC(d2h(out->fa, dev.fa, sb));
-    return FIB_OK;
-}
+    std::vector<DevState *> ws;
+    RC(workers_for(device, ws));
+    const std::vector<Rows> ins = {{dwi, nullptr, nvol}};
+    const std::vector<Rows> outs = {{nullptr, out->s0, 1}, {nullptr, out->eigval1, 1}, {nullptr, out->eigval2, 1}, {nullptr, out->eigval3, 1},
+                                    {nullptr, out->eigvec1, 3}, {nullptr, out->eigvec2, 3}, {nullptr, out->eigvec3, 3},
+                                    {nullptr, out->rd, 1}, {nullptr, out->md, 1}, {nullptr, out->fa, 1}};
+    return for_each_worker(ws, [&](int i, DevState &d) -> int {
+        int64_t v0, v1;
+        slab(nvox, (int)ws.size(), i, v0, v1);
+        fib_dti_plan *plan = nullptr;
+        RC(dti_plan_for(d, bval, bvec, nvol, &plan));
+        return run_chunks(d, v0, v1, nvox, ins, mask, mask_dtype, outs, pick_chunk(v1 - v0, nvol, 16),
+                          [&](int, int64_t, int64_t n, const float *din, const uint8_t *dm, float *b, hipStream_t st) -> int {
+                              fib_dti_out dev{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 7 * n, b + 10 * n, b + 13 * n, b + 14 * n, b + 15 * n};
+                              return fibd_dti_fit(plan, din, dm, n, &dev, st);
+                          });
+    });
+} FIB_API_CATCH
 
-extern "C" int fib_st_eigen(int device, const float *const S[6], int64_t nvox, float *eigvec, float *eigval) {
+extern "C" int fib_adc_fit(int device, const float *dwi, int nx, int ny, int nz, int nvol,
+                           const void *mask, int mask_dtype, const float *bval, float *adc, float *s0) try {
+    FIB_CHECK(bval != nullptr && nvol > 0, FIB_ERR_MISSING_BVAL, "Missing b-value table from input DWI structure");
+    FIB_CHECK(dwi && mask && adc && s0, FIB_ERR_INVALID, "NULL argument");
+    FIB_CHECK(nx > 0 && ny > 0 && nz > 0, FIB_ERR_INVALID, "volume dimensions must be positive");
+    FIB_CHECK(dtype_size(mask_dtype) > 0, FIB_ERR_INVALID, "unknown mask dtype %d", mask_dtype);
+    const int64_t nvox = (int64_t)nx * ny * nz;
+    std::vector<DevState *> ws;
+    RC(workers_for(device, ws));
+    const std::vector<Rows> ins = {{dwi, nullptr, nvol}};
+    const std::vector<Rows> outs = {{nullptr, adc, 1}, {nullptr, s0, 1}};
+    return for_each_worker(ws, [&](int i, DevState &d) -> int {
+        int64_t v0, v1;
+        slab(nvox, (int)ws.size(), i, v0, v1);
+        fib_dti_plan *plan = nullptr;
+        RC(dti_plan_for(d, bval, nullptr, nvol, &plan));
+        return run_chunks(d, v0, v1, nvox, ins, mask, mask_dtype, outs, pick_chunk(v1 - v0, nvol, 2),
+                          [&](int, int64_t, int64_t n, const float *din, const uint8_t *dm, float *b, hipStream_t st) -> int {
+                              return fibd_adc_fit(plan, din, dm, n, b, b + n, st);
+                          });
+    });
+} FIB_API_CATCH
+
+extern "C" int fib_st_eigen(int device, const float *const S[6], int64_t nvox, float *eigvec, float *eigval) try {
     FIB_CHECK(S && eigvec && eigval, FIB_ERR_INVALID, "NULL argument");
     FIB_CHECK(nvox > 0, FIB_ERR_INVALID, "nvox must be positive");
     for (int k = 0; k < 6; k++) FIB_CHECK(S[k] != nullptr, FIB_ERR_INVALID, "NULL structure tensor volume %d", k);
@@ -104,72 +472,103 @@ extern "C" int fib_st_eigen(int device, const float *const S[6], int64_t nvox, f
     RC(d2h(eigvec, d_out.p, sizeof(float) * nvox * 9));
     RC(d2h(eigval, d_out.p + (size_t)9 * nvox, sizeof(float) * nvox * 3));
     return FIB_OK;
-}
+} FIB_API_CATCH
 
-extern "C" int fib_adc_fit(int device, const float *dwi, int nx, int ny, int nz, int nvol,
-                           const void *mask, int mask_dtype, const float *bval, float *adc, float *s0) {
-    FIB_CHECK(bval != nullptr && nvol > 0, FIB_ERR_MISSING_BVAL, "Missing b-value table from input DWI structure");
-    FIB_CHECK(dwi && mask && adc && s0, FIB_ERR_INVALID, "NULL argument");
-    FIB_CHECK(nx > 0 && ny > 0 && nz > 0, FIB_ERR_INVALID, "volume dimensions must be positive");
-    fib::DeviceGuard guard;
-    RC(fib::use_device(device));
-    const int64_t nvox = (int64_t)nx * ny * nz;
-    fib_dti_plan *praw = nullptr;
-    RC(fib_dti_plan_create(device, bval, nullptr, nvol, &praw));
-    std::unique_ptr<fib_dti_plan, PlanDeleter> plan(praw);
-    std::vector<uint8_t> m8;
-    RC(mask_convert(mask, mask_dtype, nvox, false, m8));
-    fib::DevBuf<float> d_dwi, d_out;
-    fib::DevBuf<uint8_t> d_mask;
-    RC(d_dwi.alloc((size_t)nvox * nvol));
-    RC(d_mask.alloc((size_t)nvox));
-    RC(d_out.alloc((size_t)nvox * 2));
-    RC(h2d(d_dwi.p, dwi, sizeof(float) * nvox * nvol));
-    RC(h2d(d_mask.p, m8.data(), (size_t)nvox));
-    RC(fibd_adc_fit(plan.get(), d_dwi.p, d_mask.p, nvox, d_out.p, d_out.p + nvox, nullptr));
-    FIB_HIP(hipDeviceSynchronize());
-    RC(d2h(adc, d_out.p, sizeof(float) * nvox));
-    RC(d2h(s0, d_out.p + nvox, sizeof(float) * nvox));
-    return FIB_OK;
-}
-
-// ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------------------------
 // gqi_rec / dsi_rec
-// ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------------------------
 namespace {
 
-struct OdfPlanDeleter { void operator()(fib_odf_plan *p) const { fib_odf_plan_destroy(p); } };
+struct OdfSpec {                                        // what identifies a GQIwork / DSIwork
+    bool dsi; const float *bval, *bvec; int nvol; const float *verts; int nverts; const int32_t *faces; int nfaces; float sigma; int hann_width;
+};
+int odf_plan_for(DevState &d, const OdfSpec &s, fib_odf_plan **plan) {
+    std::string key;
+    key.push_back(s.dsi ? 'D' : 'G');
+    key_add(key, s.bval, sizeof(float) * s.nvol);
+    key_add(key, s.bvec, sizeof(float) * 3 * s.nvol);
+    key_add(key, s.verts, sizeof(float) * 3 * s.nverts);
+    key_add(key, s.faces, sizeof(int32_t) * 3 * s.nfaces);
+    key_add(key, s.dsi ? (const void *)&s.hann_width : (const void *)&s.sigma, 4);
+    void *p = nullptr;
+    RC(cached_plan(d, 1, key, [&](void **out) {
+        fib_odf_plan *q = nullptr;
+        const int rc = s.dsi ? fib_dsi_plan_create(d.device, s.bval, s.bvec, s.nvol, s.verts, s.nverts, s.faces, s.nfaces, s.hann_width, &q)
+                             : fib_gqi_plan_create(d.device, s.bval, s.bvec, s.nvol, s.verts, s.nverts, s.faces, s.nfaces, s.sigma, &q);
+        *out = q;
+        return rc;
+    }, &p));
+    *plan = (fib_odf_plan *)p;
+    return FIB_OK;
+}
 
-int odf_rec_host(fib_odf_plan *praw, int nvol, const float *dwi, int nx, int ny, int nz,
-                 const void *mask, int mask_dtype, int nvert, float *pdf, float *odf,
-                 float *const peak[3], float *const qa[3]) {
-    std::unique_ptr<fib_odf_plan, OdfPlanDeleter> plan(praw);
+int odf_rec_host(int device, const OdfSpec &spec, const float *dwi, int nx, int ny, int nz, const void *mask, int mask_dtype,
+                 float *pdf, float *odf, float *const peak[3], float *const qa[3]) {
+    FIB_CHECK(spec.bval != nullptr && spec.nvol > 0, FIB_ERR_MISSING_BVAL, "Missing b-value table from input DWI structure");
+    FIB_CHECK(spec.bvec != nullptr, FIB_ERR_MISSING_BVEC, "Missing gradient table from input DWI structure");
+    FIB_CHECK(spec.verts && spec.faces && spec.nverts >= 2 && spec.nverts % 2 == 0 && spec.nfaces > 0, FIB_ERR_INVALID, "invalid ODF tessellation");
     FIB_CHECK(dwi && mask && odf && peak && qa, FIB_ERR_INVALID, "NULL argument");
     FIB_CHECK(nx > 0 && ny > 0 && nz > 0, FIB_ERR_INVALID, "volume dimensions must be positive");
+    FIB_CHECK(dtype_size(mask_dtype) > 0, FIB_ERR_INVALID, "unknown mask dtype %d", mask_dtype);
     for (int k = 0; k < 3; k++) FIB_CHECK(peak[k] && qa[k], FIB_ERR_INVALID, "NULL peak/qa output volume");
     const int64_t nvox = (int64_t)nx * ny * nz;
-    std::vector<uint8_t> m8;
-    RC(mask_convert(mask, mask_dtype, nvox, false, m8));
-    fib::DevBuf<float> d_dwi, d_odf, d_pdf, d_pq;
-    fib::DevBuf<uint8_t> d_mask;
-    RC(d_dwi.alloc((size_t)nvox * nvol));
-    RC(d_mask.alloc((size_t)nvox));
-    RC(d_odf.alloc((size_t)nvox * nvert));
-    if (pdf) RC(d_pdf.alloc((size_t)nvox * nvol));
-    RC(d_pq.alloc((size_t)nvox * 12));
-    RC(h2d(d_dwi.p, dwi, sizeof(float) * nvox * nvol));
-    RC(h2d(d_mask.p, m8.data(), (size_t)nvox));
-    float *pk[3] = {d_pq.p, d_pq.p + 3 * nvox, d_pq.p + 6 * nvox};
-    float *q[3] = {d_pq.p + 9 * nvox, d_pq.p + 10 * nvox, d_pq.p + 11 * nvox};
-    RC(fibd_odf_rec(plan.get(), d_dwi.p, d_mask.p, nvox, pdf ? d_pdf.p : nullptr, d_odf.p, pk, q, nullptr, 1, nullptr));
-    FIB_HIP(hipDeviceSynchronize());
-    RC(d2h(odf, d_odf.p, sizeof(float) * nvox * nvert));
-    if (pdf) RC(d2h(pdf, d_pdf.p, sizeof(float) * nvox * nvol));
-    for (int k = 0; k < 3; k++) {
-        RC(d2h(peak[k], pk[k], sizeof(float) * nvox * 3));
-        RC(d2h(qa[k], q[k], sizeof(float) * nvox));
-    }
-    return FIB_OK;
+    const int nvol = spec.nvol, nvert = spec.nverts / 2;
+    std::vector<DevState *> ws;
+    RC(workers_for(device, ws));
+    const int nw = (int)ws.size();
+    const std::vector<Rows> ins = {{dwi, nullptr, nvol}};
+    std::vector<Rows> outs;
+    if (pdf) outs.push_back({nullptr, pdf, nvol});
+    outs.push_back({nullptr, odf, nvert});
+    for (int k = 0; k < 3; k++) outs.push_back({nullptr, peak[k], 3});
+    const int rows_out = (pdf ? nvol : 0) + nvert + 9;
+    // per worker: qa of its slab stays on the device until the global odfmax is known; one {max, NaN flag} pair per chunk
+    struct Slab { int64_t v0 = 0, v1 = 0; float *qa = nullptr; std::vector<float> maxes; };
+    std::vector<Slab> slabs((size_t)nw);
+    RC(for_each_worker(ws, [&](int i, DevState &d) -> int {
+        Slab &sl = slabs[i];
+        slab(nvox, nw, i, sl.v0, sl.v1);
+        const int64_t nr = sl.v1 - sl.v0;
+        if (nr <= 0) return FIB_OK;
+        fib_odf_plan *plan = nullptr;
+        RC(odf_plan_for(d, spec, &plan));
+        const int64_t chunk = pick_chunk(nr, nvol, rows_out);
+        const int nchunks = (int)fib::cdiv(nr, chunk);
+        RC(d.dev_keep.ensure(((size_t)3 * nr + (size_t)2 * nchunks) * sizeof(float)));
+        sl.qa = reinterpret_cast<float *>(d.dev_keep.p);
+        float *dmax = sl.qa + 3 * nr;
+        RC(run_chunks(d, sl.v0, sl.v1, nvox, ins, mask, mask_dtype, outs, chunk,
+                      [&](int k, int64_t v0, int64_t n, const float *din, const uint8_t *dm, float *b, hipStream_t st) -> int {
+                          float *dpdf = pdf ? b : nullptr, *dodf = b + (size_t)(pdf ? nvol : 0) * n, *dpk = dodf + (size_t)nvert * n;
+                          float *pk[3] = {dpk, dpk + 3 * n, dpk + 6 * n};
+                          float *q[3] = {sl.qa + (v0 - sl.v0), sl.qa + nr + (v0 - sl.v0), sl.qa + 2 * nr + (v0 - sl.v0)};
+                          return fibd_odf_rec(plan, din, dm, n, dpdf, dodf, pk, q, dmax + 2 * k, 0, st);
+                      }));
+        sl.maxes.resize((size_t)2 * nchunks);
+        FIB_HIP(hipMemcpy(sl.maxes.data(), dmax, sl.maxes.size() * sizeof(float), hipMemcpyDeviceToHost));
+        return FIB_OK;
+    }));
+    // odfmax = maximum(mean(odf, dims=4)) over the whole volume (gqi.jl:164, dsi.jl:263); maximum() propagates NaN
+    float odfmax = -INFINITY;
+    bool anynan = false;
+    for (auto &sl : slabs)
+        for (size_t c = 0; c + 1 < sl.maxes.size(); c += 2) {
+            if (sl.maxes[c + 1] != 0.0f || sl.maxes[c] != sl.maxes[c]) anynan = true;
+            else if (sl.maxes[c] > odfmax) odfmax = sl.maxes[c];
+        }
+    if (anynan) odfmax = __builtin_nanf("");
+    // qa[k] ./= odfmax (gqi.jl:166-168) on every device, then out
+    return for_each_worker(ws, [&](int i, DevState &d) -> int {
+        Slab &sl = slabs[i];
+        const int64_t nr = sl.v1 - sl.v0;
+        if (nr <= 0) return FIB_OK;
+        FIB_HIP(hipSetDevice(d.device));
+        float *q[3] = {sl.qa, sl.qa + nr, sl.qa + 2 * nr};
+        RC(fibd_qa_normalize(q, nr, odfmax, d.s_cmp));
+        for (int k = 0; k < 3; k++) FIB_HIP(hipMemcpyAsync(qa[k] + sl.v0, q[k], (size_t)nr * sizeof(float), hipMemcpyDeviceToHost, d.s_cmp));
+        FIB_HIP(hipStreamSynchronize(d.s_cmp));
+        return FIB_OK;
+    });
 }
 
 }  // namespace
@@ -177,31 +576,25 @@ int odf_rec_host(fib_odf_plan *praw, int nvol, const float *dwi, int nx, int ny,
 extern "C" int fib_gqi_rec(int device, const float *dwi, int nx, int ny, int nz, int nvol,
                            const void *mask, int mask_dtype, const float *bval, const float *bvec,
                            const float *verts, int nverts, const int32_t *faces, int nfaces, float sigma,
-                           float *odf, float *const peak[3], float *const qa[3]) {
-    fib::DeviceGuard guard;
-    fib_odf_plan *p = nullptr;
-    RC(fib_gqi_plan_create(device, bval, bvec, nvol, verts, nverts, faces, nfaces, sigma, &p));
-    FIB_HIP(hipSetDevice(device));
-    return odf_rec_host(p, nvol, dwi, nx, ny, nz, mask, mask_dtype, nverts / 2, nullptr, odf, peak, qa);
-}
+                           float *odf, float *const peak[3], float *const qa[3]) try {
+    const OdfSpec spec{false, bval, bvec, nvol, verts, nverts, faces, nfaces, sigma, 0};
+    return odf_rec_host(device, spec, dwi, nx, ny, nz, mask, mask_dtype, nullptr, odf, peak, qa);
+} FIB_API_CATCH
 
 extern "C" int fib_dsi_rec(int device, const float *dwi, int nx, int ny, int nz, int nvol,
                            const void *mask, int mask_dtype, const float *bval, const float *bvec,
                            const float *verts, int nverts, const int32_t *faces, int nfaces, int hann_width,
-                           float *pdf, float *odf, float *const peak[3], float *const qa[3]) {
+                           float *pdf, float *odf, float *const peak[3], float *const qa[3]) try {
     FIB_CHECK(pdf != nullptr, FIB_ERR_INVALID, "NULL pdf output volume");
-    fib::DeviceGuard guard;
-    fib_odf_plan *p = nullptr;
-    RC(fib_dsi_plan_create(device, bval, bvec, nvol, verts, nverts, faces, nfaces, hann_width, &p));
-    FIB_HIP(hipSetDevice(device));
-    return odf_rec_host(p, nvol, dwi, nx, ny, nz, mask, mask_dtype, nverts / 2, pdf, odf, peak, qa);
-}
+    const OdfSpec spec{true, bval, bvec, nvol, verts, nverts, faces, nfaces, 0.0f, hann_width};
+    return odf_rec_host(device, spec, dwi, nx, ny, nz, mask, mask_dtype, pdf, odf, peak, qa);
+} FIB_API_CATCH
 
-// rumba_rec (rusd.jl:419-636), host buffers
+// rumba_rec (rusd.jl:419-636), host buffers.  A whole-volume fixed-point iteration: not chunked.
 extern "C" int fib_rumba_rec(int device, const float *dwi, int nx, int ny, int nz, int nvol, const void *mask, int mask_dtype,
                              const float *bval, const float *bvec, const float *verts, int nverts, int niter,
                              float lam_para, float lam_perp, float lam_csf, float lam_gm, int ncoils, int sos_grappa, int ipat_factor,
-                             int use_tv, const fib_rumba_out *out, float *snr_mean, float *snr_std) {
+                             int use_tv, const fib_rumba_out *out, float *snr_mean, float *snr_std) try {
     FIB_CHECK(dwi && mask && out, FIB_ERR_INVALID, "NULL argument");
     FIB_CHECK(nx > 0 && ny > 0 && nz > 0, FIB_ERR_INVALID, "volume dimensions must be positive");
     fib::DeviceGuard guard;
@@ -233,13 +626,13 @@ extern "C" int fib_rumba_rec(int device, const float *dwi, int nx, int ny, int n
     RC(d2h(out->var, dev.var, sizeof(float) * nvox));
     for (int i = 0; i < 5; i++) RC(d2h(out->peak[i], dev.peak[i], sizeof(float) * nvox * 3));
     return FIB_OK;
-}
+} FIB_API_CATCH
 
 // find_peaks!(W) (gqi.jl:180-201) for nvox ODFs held in host memory: odf [nvox x nvert] planar (vertex-major rows of
 // nvox values, like MRI.vol[:,:,:,v]); isort_top [3 x nvox] planar, 0-based first-half vertex rows, -1 where the
 // tessellation has fewer vertices; nvalid [nvox] = count(odf_peak .> 0) (gqi.jl:200).
 extern "C" int fib_find_peaks(int device, const float *odf, int64_t nvox, const float *verts, int nverts,
-                              const int32_t *faces, int nfaces, int32_t *isort_top, int32_t *nvalid) {
+                              const int32_t *faces, int nfaces, int32_t *isort_top, int32_t *nvalid) try {
     FIB_CHECK(odf && verts && faces && isort_top && nvalid, FIB_ERR_INVALID, "NULL argument");
     FIB_CHECK(nvox > 0 && nverts >= 2 && nverts % 2 == 0 && nfaces > 0, FIB_ERR_INVALID, "invalid sizes");
     fib::DeviceGuard guard;
@@ -261,99 +654,125 @@ extern "C" int fib_find_peaks(int device, const float *odf, int64_t nvox, const 
     FIB_HIP(hipMemcpy(isort_top, d_top.p, (size_t)nvox * 3 * sizeof(int32_t), hipMemcpyDeviceToHost));
     FIB_HIP(hipMemcpy(nvalid, d_nv.p, (size_t)nvox * sizeof(int32_t), hipMemcpyDeviceToHost));
     return FIB_OK;
-}
+} FIB_API_CATCH
 
-// ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------------------------
 // stream
-// ------------------------------------------------------------------------------------------
-extern "C" void fib_tract_free(fib_tract_out *out) {
+// ------------------------------------------------------------------------------------------------------------------------------
+extern "C" void fib_tract_free(fib_tract_out *out) try {
     if (!out) return;
     free(out->npts); free(out->seed_index); free(out->xyz); free(out->flags);
     out->npts = nullptr; out->seed_index = nullptr; out->xyz = nullptr; out->flags = nullptr;
     out->nlines = 0; out->npoints = 0;
-}
+} FIB_API_CATCH_VOID
 
-static int stream_host(int device, const fib_stream_params *prm, const float *const *ovec, const float *const *f,
-                       float f_thresh, const float *fa, float fa_thresh, const void *mask, int mask_dtype,
-                       const void *seed, int seed_dtype, const float *sublist, int32_t nsub,
-                       const float *lcms, float lcm_thresh, uint64_t rng_seed, fib_tract_out *out);
+namespace {
 
-extern "C" int fib_stream(int device, const fib_stream_params *prm, const float *const *ovec, const float *const *f,
-                          float f_thresh, const float *fa, float fa_thresh, const void *mask, int mask_dtype,
-                          const void *seed, int seed_dtype, const float *sublist, int32_t nsub, fib_tract_out *out) {
-    return stream_host(device, prm, ovec, f, f_thresh, fa, fa_thresh, mask, mask_dtype, seed, seed_dtype, sublist, nsub,
-                       nullptr, 0.0f, 0, out);
-}
+struct StreamIn {
+    const fib_stream_params *prm; const float *const *ovec; const float *const *f; float f_thresh; const float *fa; float fa_thresh;
+    const float *sublist; int32_t nsub; const float *lcms; float lcm_thresh; uint64_t rng_seed; int strd0, strd1;
+};
+// what one worker traced: lines in (seed, sub) order of ITS seed shard; seed_index counts seeds of the whole list
+struct Shard { int64_t nl = 0, np = 0; std::vector<int32_t> npts; std::vector<int64_t> sidx; std::vector<float> xyz; std::vector<uint8_t> flags; };
 
-extern "C" int fib_stream_lcm(int device, const fib_stream_params *prm, const float *const *ovec, const float *const *f,
-                              float f_thresh, const float *fa, float fa_thresh, const void *mask, int mask_dtype,
-                              const void *seed, int seed_dtype, const float *sublist, int32_t nsub,
-                              const float *lcms, float lcm_thresh, uint64_t rng_seed, fib_tract_out *out) {
-    FIB_CHECK(lcms != nullptr, FIB_ERR_INVALID, "NULL lcms volume");
-    return stream_host(device, prm, ovec, f, f_thresh, fa, fa_thresh, mask, mask_dtype, seed, seed_dtype, sublist, nsub,
-                       lcms, lcm_thresh, rng_seed, out);
-}
-
-static int stream_host(int device, const fib_stream_params *prm, const float *const *ovec, const float *const *f,
-                       float f_thresh, const float *fa, float fa_thresh, const void *mask, int mask_dtype,
-                       const void *seed, int seed_dtype, const float *sublist, int32_t nsub,
-                       const float *lcms, float lcm_thresh, uint64_t rng_seed, fib_tract_out *out) {
-    FIB_CHECK(prm && ovec && sublist && out, FIB_ERR_INVALID, "NULL argument");
-    FIB_CHECK(prm->nx > 0 && prm->ny > 0 && prm->nz > 0, FIB_ERR_INVALID, "volume dimensions must be positive");
-    FIB_CHECK(prm->nvec >= 1 && prm->nvec <= 8, FIB_ERR_UNSUPPORTED, "1..8 orientation vectors per voxel are supported");
-    FIB_CHECK(nsub >= 1, FIB_ERR_INVALID, "sublist must hold at least one offset");
-    memset(out, 0, sizeof *out);
-    fib::DeviceGuard guard;
-    RC(fib::use_device(device));
-    const int nvec = prm->nvec;
-    const int64_t nvox = (int64_t)prm->nx * prm->ny * prm->nz;
-    fib::DevBuf<float> d_vec, d_f, d_fa, d_field, d_sub;
+// seeds[i], i = w, w + nw, ... (round-robin: balances line length; the reference's contiguous chunks, stream.jl:757-759, do not)
+int stream_worker(DevState &d, int w, int nw, const StreamIn &in, const std::vector<uint8_t> *m8, const std::vector<int64_t> &seeds,
+                  std::vector<uint8_t> *seed_mask_out, Shard &sh) {
+    const fib_stream_params &prm0 = *in.prm;
+    const int nvec = prm0.nvec;
+    const int64_t nvox = (int64_t)prm0.nx * prm0.ny * prm0.nz;
+    FIB_HIP(hipSetDevice(d.device));
+    if (!d.ws) RC(fibd_stream_ws_create(d.device, &d.ws));
+    hipStream_t st = d.s_cmp;
+    fib::DevBuf<float> d_vec, d_f, d_fa, d_field, d_sub, d_lcms;
     fib::DevBuf<uint8_t> d_mask, d_mout;
     RC(d_vec.alloc((size_t)nvox * 3 * nvec));
     RC(d_field.alloc((size_t)nvox * 4 * nvec));
     RC(d_mout.alloc((size_t)nvox));
     const float *dv[8] = {}, *df[8] = {};
     for (int k = 0; k < nvec; k++) {
-        FIB_CHECK(ovec[k] != nullptr, FIB_ERR_INVALID, "NULL orientation volume %d", k);
-        RC(h2d(d_vec.p + (size_t)k * nvox * 3, ovec[k], sizeof(float) * nvox * 3));
+        RC(h2d(d_vec.p + (size_t)k * nvox * 3, in.ovec[k], sizeof(float) * nvox * 3));
         dv[k] = d_vec.p + (size_t)k * nvox * 3;
     }
-    if (f) {
+    if (in.f) {
         RC(d_f.alloc((size_t)nvox * nvec));
-        for (int k = 0; k < nvec; k++) {
-            FIB_CHECK(f[k] != nullptr, FIB_ERR_INVALID, "NULL amplitude volume %d", k);
-            RC(h2d(d_f.p + (size_t)k * nvox, f[k], sizeof(float) * nvox));
-            df[k] = d_f.p + (size_t)k * nvox;
-        }
+        for (int k = 0; k < nvec; k++) { RC(h2d(d_f.p + (size_t)k * nvox, in.f[k], sizeof(float) * nvox)); df[k] = d_f.p + (size_t)k * nvox; }
     }
-    if (fa) { RC(d_fa.alloc((size_t)nvox)); RC(h2d(d_fa.p, fa, sizeof(float) * nvox)); }
-    std::vector<uint8_t> m8;
-    if (mask) {
-        RC(mask_convert(mask, mask_dtype, nvox, true, m8));        // mask.vol .> 0, stream.jl:102
-        RC(d_mask.alloc((size_t)nvox));
-        RC(h2d(d_mask.p, m8.data(), (size_t)nvox));
+    if (in.fa) { RC(d_fa.alloc((size_t)nvox)); RC(h2d(d_fa.p, in.fa, sizeof(float) * nvox)); }
+    if (m8) { RC(d_mask.alloc((size_t)nvox)); RC(h2d(d_mask.p, m8->data(), (size_t)nvox)); }
+    RC(fibd_stream_field(nvec, nvox, dv, in.f ? df : nullptr, in.f_thresh, in.fa ? d_fa.p : nullptr, in.fa_thresh,
+                         m8 ? d_mask.p : nullptr, d_field.p, d_mout.p, st));
+    if (seed_mask_out) {                                 // first pass (no seed volume): the tracking mask back to the host
+        seed_mask_out->resize((size_t)nvox);
+        FIB_HIP(hipStreamSynchronize(st));
+        RC(d2h(seed_mask_out->data(), d_mout.p, (size_t)nvox));
+        return FIB_OK;
     }
-    RC(fibd_stream_field(nvec, nvox, dv, f ? df : nullptr, f_thresh, fa ? d_fa.p : nullptr, fa_thresh,
-                         mask ? d_mask.p : nullptr, d_field.p, d_mout.p, nullptr));
-    // seed voxels: findall(W.mask) (stream.jl:744) or findall(seed.vol .> 0) (stream.jl:751), column-major order
-    std::vector<uint8_t> s8;
-    if (seed) {
-        RC(mask_convert(seed, seed_dtype, nvox, true, s8));
-    } else {
-        s8.resize((size_t)nvox);
-        FIB_HIP(hipDeviceSynchronize());
-        RC(d2h(s8.data(), d_mout.p, (size_t)nvox));
-    }
-    std::vector<int64_t> seeds;
-    for (int64_t i = 0; i < nvox; i++) if (s8[i]) seeds.push_back(i);
+    std::vector<int64_t> mine;
+    for (size_t i = (size_t)w; i < seeds.size(); i += (size_t)nw) mine.push_back(seeds[i]);
     fib::DevBuf<int64_t> d_seeds;
-    RC(d_seeds.alloc(seeds.size()));
-    if (!seeds.empty()) RC(h2d(d_seeds.p, seeds.data(), sizeof(int64_t) * seeds.size()));
-    RC(d_sub.alloc((size_t)nsub * 3));
-    RC(h2d(d_sub.p, sublist, sizeof(float) * 3 * nsub));
+    RC(d_seeds.alloc(mine.size()));
+    if (!mine.empty()) RC(h2d(d_seeds.p, mine.data(), sizeof(int64_t) * mine.size()));
+    RC(d_sub.alloc((size_t)in.nsub * 3));
+    RC(h2d(d_sub.p, in.sublist, sizeof(float) * 3 * in.nsub));
+    fib_stream_params prm = prm0;
+    prm.ws = d.ws;
     fib_stream_job *job = nullptr;
     int64_t nl = 0, np = 0;
-    fib::DevBuf<float> d_lcms;
+    if (in.lcms) {
+        // the uniforms of a line are a function of its index in the WHOLE list (the header's random-number contract), which a
+        // shard of a round-robin split cannot express -> LCM runs use one worker (stream_host)
+        RC(d_lcms.alloc((size_t)nvox * 10));
+        RC(h2d(d_lcms.p, in.lcms, sizeof(float) * nvox * 10));
+        RC(fibd_stream_trace_lcm(&prm, d_field.p, d_lcms.p, in.lcm_thresh, in.strd0, in.strd1, in.rng_seed, d_seeds.p, (int64_t)mine.size(),
+                                 d_sub.p, in.nsub, st, &job, &nl, &np));
+    } else {
+        RC(fibd_stream_trace(&prm, d_field.p, d_seeds.p, (int64_t)mine.size(), d_sub.p, in.nsub, st, &job, &nl, &np));
+    }
+    struct JobGuard { fib_stream_job *j; ~JobGuard() { fib_stream_job_destroy(j); } } jg{job};
+    sh.nl = nl; sh.np = np;
+    sh.npts.resize((size_t)nl); sh.sidx.resize((size_t)nl); sh.xyz.resize((size_t)np * 3);
+    if (in.lcms) sh.flags.resize((size_t)np);
+    if (nl > 0) {
+        fib::DevBuf<int32_t> d_npts;
+        fib::DevBuf<int64_t> d_sidx;
+        fib::DevBuf<float> d_xyz;
+        fib::DevBuf<uint8_t> d_flags;
+        RC(d_npts.alloc((size_t)nl));
+        RC(d_sidx.alloc((size_t)nl));
+        RC(d_xyz.alloc((size_t)np * 3));
+        if (in.lcms) RC(d_flags.alloc((size_t)np));
+        RC(fibd_stream_pack_flags(job, d_npts.p, d_sidx.p, d_xyz.p, in.lcms ? d_flags.p : nullptr, st));
+        FIB_HIP(hipStreamSynchronize(st));
+        RC(d2h(sh.npts.data(), d_npts.p, sizeof(int32_t) * nl));
+        RC(d2h(sh.sidx.data(), d_sidx.p, sizeof(int64_t) * nl));
+        RC(d2h(sh.xyz.data(), d_xyz.p, sizeof(float) * 3 * np));
+        if (in.lcms) RC(d2h(sh.flags.data(), d_flags.p, (size_t)np));
+        // seed_index = local seed * nsub + sub  ->  global: seed (w + nw * local) of the whole list
+        if (nw > 1) for (auto &s : sh.sidx) { const int64_t ls = s / in.nsub, sub = s % in.nsub; s = ((int64_t)w + (int64_t)nw * ls) * in.nsub + sub; }
+    }
+    return FIB_OK;
+}
+
+int stream_host(int device, const fib_stream_params *prm, const float *const *ovec, const float *const *f,
+                float f_thresh, const float *fa, float fa_thresh, const void *mask, int mask_dtype,
+                const void *seed, int seed_dtype, const float *sublist, int32_t nsub,
+                const float *lcms, float lcm_thresh, uint64_t rng_seed, fib_tract_out *out) {
+    FIB_CHECK(prm && ovec && sublist && out, FIB_ERR_INVALID, "NULL argument");
+    FIB_CHECK(prm->nx > 0 && prm->ny > 0 && prm->nz > 0, FIB_ERR_INVALID, "volume dimensions must be positive");
+    FIB_CHECK(prm->nvec >= 1 && prm->nvec <= 8, FIB_ERR_UNSUPPORTED, "1..8 orientation vectors per voxel are supported");
+    FIB_CHECK(nsub >= 1, FIB_ERR_INVALID, "sublist must hold at least one offset");
+    memset(out, 0, sizeof *out);
+    const int nvec = prm->nvec;
+    const int64_t nvox = (int64_t)prm->nx * prm->ny * prm->nz;
+    for (int k = 0; k < nvec; k++) {
+        FIB_CHECK(ovec[k] != nullptr, FIB_ERR_INVALID, "NULL orientation volume %d", k);
+        if (f) FIB_CHECK(f[k] != nullptr, FIB_ERR_INVALID, "NULL amplitude volume %d", k);
+    }
+    std::vector<DevState *> ws;
+    RC(workers_for(device, ws));
+    if (lcms && ws.size() > 1) ws.resize(1);             // (see stream_worker)
+    StreamIn in{prm, ovec, f, f_thresh, fa, fa_thresh, sublist, nsub, lcms, lcm_thresh, rng_seed, 0, 1};
     if (lcms) {
         // through-plane dimension = the one in which the first orientation volume is zero everywhere (stream.jl:221-223)
         bool allzero[3] = {true, true, true};
@@ -362,35 +781,66 @@ static int stream_host(int device, const fib_stream_params *prm, const float *co
         int strd[3], ns = 0;
         for (int c = 0; c < 3; c++) if (!allzero[c]) strd[ns++] = c;
         FIB_CHECK(ns >= 2, FIB_ERR_INVALID, "LCM-guided tracking needs two in-plane dimensions with non-zero orientation components");
-        RC(d_lcms.alloc((size_t)nvox * 10));
-        RC(h2d(d_lcms.p, lcms, sizeof(float) * nvox * 10));
-        RC(fibd_stream_trace_lcm(prm, d_field.p, d_lcms.p, lcm_thresh, strd[0], strd[1], rng_seed, d_seeds.p, (int64_t)seeds.size(),
-                                 d_sub.p, nsub, nullptr, &job, &nl, &np));
-    } else
-    RC(fibd_stream_trace(prm, d_field.p, d_seeds.p, (int64_t)seeds.size(), d_sub.p, nsub, nullptr, &job, &nl, &np));
-    struct JobGuard { fib_stream_job *j; ~JobGuard() { fib_stream_job_destroy(j); } } jg{job};
+        in.strd0 = strd[0]; in.strd1 = strd[1];
+    }
+    std::vector<uint8_t> m8, s8;
+    if (mask) RC(mask_convert(mask, mask_dtype, nvox, true, m8));   // mask.vol .> 0, stream.jl:102
+    // seed voxels: findall(W.mask) (stream.jl:744) or findall(seed.vol .> 0) (stream.jl:751), column-major order
+    if (seed) RC(mask_convert(seed, seed_dtype, nvox, true, s8));
+    else {
+        Shard none;
+        std::vector<int64_t> noseeds;
+        RC(for_each_worker({ws[0]}, [&](int, DevState &d) { return stream_worker(d, 0, 1, in, mask ? &m8 : nullptr, noseeds, &s8, none); }));
+    }
+    std::vector<int64_t> seeds;
+    for (int64_t i = 0; i < nvox; i++) if (s8[i]) seeds.push_back(i);
+    const int nw = (int)ws.size();
+    std::vector<Shard> shards((size_t)nw);
+    RC(for_each_worker(ws, [&](int w, DevState &d) { return stream_worker(d, w, nw, in, mask ? &m8 : nullptr, seeds, nullptr, shards[w]); }));
+    // merge in (seed, sub) order == the reference's order under static scheduling (stream.jl:757-787)
+    int64_t nl = 0, np = 0;
+    for (auto &s : shards) { nl += s.nl; np += s.np; }
     out->nlines = nl; out->npoints = np;
     out->npts = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nl > 0 ? nl : 1));
     out->seed_index = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nl > 0 ? nl : 1));
     out->xyz = (float *)malloc(sizeof(float) * 3 * (size_t)(np > 0 ? np : 1));
     if (lcms) out->flags = (uint8_t *)malloc((size_t)(np > 0 ? np : 1));
     if (!out->npts || !out->seed_index || !out->xyz || (lcms && !out->flags)) { fib_tract_free(out); return fib::fail(FIB_ERR_NOMEM, "out of host memory"); }
-    if (nl > 0) {
-        fib::DevBuf<int32_t> d_npts;
-        fib::DevBuf<int64_t> d_sidx;
-        fib::DevBuf<float> d_xyz;
-        fib::DevBuf<uint8_t> d_flags;
-        int rc = d_npts.alloc((size_t)nl);
-        if (rc == FIB_OK) rc = d_sidx.alloc((size_t)nl);
-        if (rc == FIB_OK) rc = d_xyz.alloc((size_t)np * 3);
-        if (rc == FIB_OK && lcms) rc = d_flags.alloc((size_t)np);
-        if (rc == FIB_OK) rc = fibd_stream_pack_flags(job, d_npts.p, d_sidx.p, d_xyz.p, lcms ? d_flags.p : nullptr, nullptr);
-        if (rc == FIB_OK && hipDeviceSynchronize() != hipSuccess) rc = fib::fail(FIB_ERR_HIP, "streamline pack failed");
-        if (rc == FIB_OK) rc = d2h(out->npts, d_npts.p, sizeof(int32_t) * nl);
-        if (rc == FIB_OK) rc = d2h(out->seed_index, d_sidx.p, sizeof(int64_t) * nl);
-        if (rc == FIB_OK) rc = d2h(out->xyz, d_xyz.p, sizeof(float) * 3 * np);
-        if (rc == FIB_OK && lcms) rc = d2h(out->flags, d_flags.p, (size_t)np);
-        if (rc != FIB_OK) { fib_tract_free(out); return rc; }
+    if (nw == 1) {
+        Shard &s = shards[0];
+        if (nl) { memcpy(out->npts, s.npts.data(), sizeof(int32_t) * nl); memcpy(out->seed_index, s.sidx.data(), sizeof(int64_t) * nl); }
+        if (np) { memcpy(out->xyz, s.xyz.data(), sizeof(float) * 3 * np); if (lcms) memcpy(out->flags, s.flags.data(), (size_t)np); }
+        return FIB_OK;
+    }
+    std::vector<int64_t> li((size_t)nw, 0), pi((size_t)nw, 0);
+    int64_t ol = 0, op = 0;
+    while (ol < nl) {
+        int best = -1;
+        for (int w = 0; w < nw; w++)
+            if (li[w] < shards[w].nl && (best < 0 || shards[w].sidx[li[w]] < shards[best].sidx[li[best]])) best = w;
+        Shard &s = shards[best];
+        const int32_t n = s.npts[li[best]];
+        out->npts[ol] = n; out->seed_index[ol] = s.sidx[li[best]];
+        memcpy(out->xyz + 3 * op, s.xyz.data() + 3 * pi[best], sizeof(float) * 3 * n);
+        ol++; op += n; li[best]++; pi[best] += n;
     }
     return FIB_OK;
 }
+
+}  // namespace
+
+extern "C" int fib_stream(int device, const fib_stream_params *prm, const float *const *ovec, const float *const *f,
+                          float f_thresh, const float *fa, float fa_thresh, const void *mask, int mask_dtype,
+                          const void *seed, int seed_dtype, const float *sublist, int32_t nsub, fib_tract_out *out) try {
+    return stream_host(device, prm, ovec, f, f_thresh, fa, fa_thresh, mask, mask_dtype, seed, seed_dtype, sublist, nsub,
+                       nullptr, 0.0f, 0, out);
+} FIB_API_CATCH
+
+extern "C" int fib_stream_lcm(int device, const fib_stream_params *prm, const float *const *ovec, const float *const *f,
+                              float f_thresh, const float *fa, float fa_thresh, const void *mask, int mask_dtype,
+                              const void *seed, int seed_dtype, const float *sublist, int32_t nsub,
+                              const float *lcms, float lcm_thresh, uint64_t rng_seed, fib_tract_out *out) try {
+    FIB_CHECK(lcms != nullptr, FIB_ERR_INVALID, "NULL lcms volume");
+    return stream_host(device, prm, ovec, f, f_thresh, fa, fa_thresh, mask, mask_dtype, seed, seed_dtype, sublist, nsub,
+                       lcms, lcm_thresh, rng_seed, out);
+} FIB_API_CATCH

@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <vector>
 
 #include "../../include/fibers_hip.h"
@@ -27,6 +29,13 @@ int fail(int code, const char *fmt, ...);
     do {                                                    \
         if (!(cond)) return fib::fail((code), __VA_ARGS__); \
     } while (0)
+
+// No C++ exception crosses the C ABI (include/fibers_hip.h): every extern "C" body is a function-try-block that ends in one of these.
+#define FIB_API_CATCH                                                                                                  \
+    catch (const std::bad_alloc &) { return fib::fail(FIB_ERR_NOMEM, "out of host memory"); }                           \
+    catch (const std::exception &e_) { return fib::fail(FIB_ERR_INVALID, "internal error: %s", e_.what()); }            \
+    catch (...) { return fib::fail(FIB_ERR_INVALID, "internal error (unknown exception)"); }
+#define FIB_API_CATCH_VOID catch (...) { }
 
 // selects `device` after validating it; FIB_ERR_NO_DEVICE when there is none (no CPU fallback)
 int use_device(int device);

@@ -421,7 +421,7 @@ struct fib_dti_plan {
     mutable fib::DevBuf<int> partial_count;
 };
 
-extern "C" int fib_dti_plan_create(int device, const float *bval, const float *bvec, int nvol, fib_dti_plan **plan) {
+extern "C" int fib_dti_plan_create(int device, const float *bval, const float *bvec, int nvol, fib_dti_plan **plan) try {
     FIB_CHECK(plan != nullptr, FIB_ERR_INVALID, "plan output pointer is NULL");
     *plan = nullptr;
     FIB_CHECK(bval != nullptr && nvol > 0, FIB_ERR_MISSING_BVAL, "Missing b-value table from input DWI structure");
@@ -458,22 +458,22 @@ extern "C" int fib_dti_plan_create(int device, const float *bval, const float *b
     if (e != hipSuccess) { delete p; return fib::fail(FIB_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e)); }
     *plan = p;
     return FIB_OK;
-}
+} FIB_API_CATCH
 
-extern "C" void fib_dti_plan_destroy(fib_dti_plan *plan) {
+extern "C" void fib_dti_plan_destroy(fib_dti_plan *plan) try {
     if (!plan) return;
     fib::DeviceGuard guard;
     (void)hipSetDevice(plan->device);
     delete plan;
-}
+} FIB_API_CATCH_VOID
 
-extern "C" int fib_dti_plan_tables(const fib_dti_plan *plan, float *A, float *pA, int *np) {
+extern "C" int fib_dti_plan_tables(const fib_dti_plan *plan, float *A, float *pA, int *np) try {
     FIB_CHECK(plan != nullptr, FIB_ERR_INVALID, "plan is NULL");
     if (np) *np = plan->np;
     if (A) memcpy(A, plan->A.data(), plan->A.size() * sizeof(float));
     if (pA) memcpy(pA, plan->pA.data(), plan->pA.size() * sizeof(float));
     return FIB_OK;
-}
+} FIB_API_CATCH
 
 namespace {
 
@@ -528,7 +528,7 @@ int launch_fit(const fib_dti_plan *plan, const float *dwi, const uint8_t *mask, 
 }  // namespace
 
 extern "C" int fibd_dti_fit(const fib_dti_plan *plan, const float *dwi, const uint8_t *mask, int64_t nvox,
-                            const fib_dti_out *out, void *stream) {
+                            const fib_dti_out *out, void *stream) try {
     FIB_CHECK(plan && dwi && mask && out, FIB_ERR_INVALID, "NULL argument");
     FIB_CHECK(plan->np == 7, FIB_ERR_MISSING_BVEC, "Missing gradient table from input DWI structure");
     FIB_CHECK(out->s0 && out->eigval1 && out->eigval2 && out->eigval3 && out->eigvec1 && out->eigvec2 &&
@@ -538,10 +538,10 @@ extern "C" int fibd_dti_fit(const fib_dti_plan *plan, const float *dwi, const ui
     DtiOutPtrs o{out->s0, out->eigval1, out->eigval2, out->eigval3, out->eigvec1, out->eigvec2, out->eigvec3,
                  out->rd, out->md, out->fa};
     return launch_fit<7>(plan, dwi, mask, nvox, o, nullptr, (hipStream_t)stream);
-}
+} FIB_API_CATCH
 
 extern "C" int fibd_adc_fit(const fib_dti_plan *plan, const float *dwi, const uint8_t *mask, int64_t nvox,
-                            float *adc, float *s0, void *stream) {
+                            float *adc, float *s0, void *stream) try {
     FIB_CHECK(plan && dwi && mask && adc && s0, FIB_ERR_INVALID, "NULL argument");
     FIB_CHECK(plan->np == 2, FIB_ERR_INVALID, "plan was not created as an ADC plan (bvec == NULL)");
     fib::DeviceGuard guard;
@@ -549,7 +549,7 @@ extern "C" int fibd_adc_fit(const fib_dti_plan *plan, const float *dwi, const ui
     DtiOutPtrs o{};
     o.s0 = s0;
     return launch_fit<2>(plan, dwi, mask, nvox, o, adc, (hipStream_t)stream);
-}
+} FIB_API_CATCH
 
 // st_eigen (structens.jl:13-37): eigen(Symmetric(S, :L)) of the structure tensor of every voxel, the same closed form as
 // the diffusion tensor's (dti.jl:311).  eigval [nvox*3] ascending, eigvec [nvox*9]: component i of eigenvector j at
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void st_eigen_kernel(const StIn in, int64_t nv
 }
 }  // namespace
 
-extern "C" int fibd_st_eigen(const float *const S[6], int64_t nvox, float *eigvec, float *eigval, void *stream) {
+extern "C" int fibd_st_eigen(const float *const S[6], int64_t nvox, float *eigvec, float *eigval, void *stream) try {
     FIB_CHECK(S && eigvec && eigval, FIB_ERR_INVALID, "NULL argument");
     FIB_CHECK(nvox > 0, FIB_ERR_INVALID, "nvox must be positive");
     StIn in{};
@@ -579,9 +579,9 @@ extern "C" int fibd_st_eigen(const float *const S[6], int64_t nvox, float *eigve
     hipLaunchKernelGGL(st_eigen_kernel, dim3((unsigned)fib::cdiv(nvox, 256)), dim3(256), 0, (hipStream_t)stream, in, nvox, eigvec, eigval);
     FIB_HIP(hipGetLastError());
     return FIB_OK;
-}
+} FIB_API_CATCH
 
-extern "C" int fibd_dti_last_partial_count(const fib_dti_plan *plan, void *stream, int64_t *count) {
+extern "C" int fibd_dti_last_partial_count(const fib_dti_plan *plan, void *stream, int64_t *count) try {
     FIB_CHECK(plan && count, FIB_ERR_INVALID, "NULL argument");
     fib::DeviceGuard guard;
     FIB_HIP(hipSetDevice(plan->device));
@@ -590,4 +590,4 @@ extern "C" int fibd_dti_last_partial_count(const fib_dti_plan *plan, void *strea
     FIB_HIP(hipStreamSynchronize((hipStream_t)stream));
     *count = c;
     return FIB_OK;
-}
+} FIB_API_CATCH

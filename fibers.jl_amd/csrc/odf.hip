@@ -49,7 +49,6 @@ struct GemmArgs {
     int scale_frame;          // DSI: frame whose clamped sample times scale_coef is sum(p); -1: no scaling
     float scale_coef;
     int has_ineff;
-    unsigned long long *dbg;      // timing experiments only (FIBERS_GEMM3_STAMP): 6 words per workgroup
     const float *Aextra;          // split-bf16 kernel: f32 coefficients of the NX extra rows [ntile_m][Kpad/16][NX][16]
     int vec_ok;                   // split-bf16 kernel: output rows are 16-byte aligned (dwordx4 stores allowed)
     const int32_t *rowA, *rowB;   // optional output-row map for rows < nrow0: row r goes to frames rowA[r] and rowB[r] (>= 0)    // split-bf16 kernel, unscaled outputs (GQI): voxels holding a +Inf sample are listed and recomputed by odf_inf_fix_kernel
@@ -736,7 +735,7 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {      // ro
 // The two lane halves of a load need different frames; their byte offsets come from an LDS table (relative to the
 // lowest frame that the stage touches on that side: one buffer resource per stage and side).
 constexpr int FKMAX = 512, FSMAX = FKMAX / KT;
-template <int MB, int NX, int NW, bool STAMP = false, bool FOLD = false, bool FUSE = false>
+template <int MB, int NX, int NW, bool FOLD = false, bool FUSE = false>
 __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a) {
     static_assert(!FUSE || (MB == 10 && NX == 1 && !FOLD), "the fused peak scan is generated for 10 blocks + 1 extra row");
     constexpr int NPIECE = 3 * MB;                      // 1-KiB pieces per stage
@@ -793,8 +792,6 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
         }
         __syncthreads();
     }
-    unsigned long long st0 = 0, rt1 = 0, acc_epi = 0, ph_split = 0, ph_issue = 0, ph_mfma = 0, ph_bar = 0;
-    if (STAMP) { st0 = __builtin_amdgcn_s_memtime(); rt1 = __builtin_amdgcn_s_memrealtime(); }
 
     // ---- work list of this workgroup ---------------------------------------------------------------------------
     const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
@@ -928,16 +925,12 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
         for (int t = 0; t < ntiles; t++, g++) {
             const int cb = g & 1;
             const char *L = lds + cb * TILEB;
-            unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-            if (STAMP) q0 = __builtin_amdgcn_s_memtime();
             split(cur.tile_m, t);
-            if (STAMP) { __builtin_amdgcn_sched_barrier(0); q1 = __builtin_amdgcn_s_memtime(); }
             // the next stage (it may open the next work item): pieces into the other buffer, samples into braw
             const bool w1 = t + 1 < ntiles;
             stage_A(w1 ? cur.tile_m : (nxt.valid ? nxt.tile_m : cur.tile_m), w1 ? t + 1 : 0, cb ^ 1);
             load_B(w1 ? t + 1 : 0, w1 ? s_off : s_off_n, w1 || nxt.valid);
             __builtin_amdgcn_sched_barrier(0);          // the requests go out before the MFMA block, not after it
-            if (STAMP) q2 = __builtin_amdgcn_s_memtime();
             const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, bp[0]), b1 = __builtin_bit_cast(bf16x8_t, bp[1]), b2 = __builtin_bit_cast(bf16x8_t, bp[2]);
             const bf16x8_t *LA = reinterpret_cast<const bf16x8_t *>(L) + lane;
             // The fragment reads are pinned (sched_barrier) 2-5 MFMAs ahead of their first use, each into the registers
@@ -962,31 +955,19 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
                 __builtin_amdgcn_sched_barrier(0);
                 a2 = n2; a1 = n1; a0 = n0;
             }
-            if (STAMP) { __builtin_amdgcn_sched_barrier(0); q3 = __builtin_amdgcn_s_memtime(); }
             __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): the next stage's pieces and samples have landed
             __syncthreads();
-            if (STAMP) { const unsigned long long q4 = __builtin_amdgcn_s_memtime(); ph_split += q1 - q0; ph_issue += q2 - q1; ph_mfma += q3 - q2; ph_bar += q4 - q3; }
         }
-        unsigned long long te = 0;
-        if (STAMP) te = __builtin_amdgcn_s_memtime();
         if constexpr (FUSE)
             gemm3_epilogue_fused<NW>(a, acc, xacc[0], vmax, vnf, inb, lv, vox, lane, lds + 2 * TILEB + wave * TRB,
                                      lds + 2 * TILEB + NW * TRB + XTAB + FTAB + wave * FQ_LIST, q_posoff, q_slotv, q_vl);
         else
             gemm3_epilogue<MB, NX>(a, acc, xacc, vmax, vnf, inb, lv, vox, lane, cur.tile_m, sraw, lds + 2 * TILEB + wave * TRB);
-        if (STAMP) acc_epi += __builtin_amdgcn_s_memtime() - te;
         if (!nxt.valid) break;
         cur = nxt; inb = inb_n; vox = vox_n; s_off = s_off_n;
         nxt = work_at(g / ntiles + 1);
         vraw_nxt = nxt.valid ? vidx_at(nxt) : 0;
         clear();
-    }
-    if (STAMP) {
-        const unsigned long long st2 = __builtin_amdgcn_s_memtime(), rt2 = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0 && a.dbg) {
-            unsigned long long *d = a.dbg + (size_t)blockIdx.x * 8;
-            d[0] = st2 - st0; d[1] = acc_epi; d[2] = ph_split; d[3] = (unsigned long long)(g / ntiles); d[4] = rt2 - rt1; d[5] = ph_issue; d[6] = ph_mfma; d[7] = ph_bar;
-        }
     }
 }
 
@@ -1281,7 +1262,6 @@ __global__ __launch_bounds__(PW * 64) void odf_peaks_kernel(const PeakArgs a) {
     __syncthreads();
     if (tid >= 64) return;
     float mean = 0.0f;
-    bool mean_nan = false;
     const bool owner = half == 0;
     if (owner) {
         for (int gg = 1; gg < PG; gg++) {
@@ -1296,7 +1276,6 @@ __global__ __launch_bounds__(PW * 64) void odf_peaks_kernel(const PeakArgs a) {
         }
         if (hasnan) vmin = NAN;                                 // minimum() propagates NaN (gqi.jl:147)
         mean = vsum / (float)a.nvert;                           // mean(odf, dims=4) = sum ./ n, gqi.jl:164
-        mean_nan = mean != mean;
         if (inb) {
             if (a.isort_top) {
 #pragma unroll
@@ -2069,7 +2048,7 @@ int check_plan_args(const float *bval, const float *bvec, int nvol, const float 
 
 extern "C" int fib_gqi_plan_create(int device, const float *bval, const float *bvec, int nvol,
                                    const float *verts, int nverts, const int32_t *faces, int nfaces,
-                                   float sigma, fib_odf_plan **plan) {
+                                   float sigma, fib_odf_plan **plan) try {
     int rc = check_plan_args(bval, bvec, nvol, verts, nverts, faces, nfaces, plan);
     if (rc != FIB_OK) return rc;
     fib::DeviceGuard guard;
@@ -2084,11 +2063,11 @@ extern "C" int fib_gqi_plan_create(int device, const float *bval, const float *b
     if (rc != FIB_OK) { delete p; return rc; }
     *plan = p;
     return FIB_OK;
-}
+} FIB_API_CATCH
 
 extern "C" int fib_dsi_plan_create(int device, const float *bval, const float *bvec, int nvol,
                                    const float *verts, int nverts, const int32_t *faces, int nfaces,
-                                   int hann_width, fib_odf_plan **plan) {
+                                   int hann_width, fib_odf_plan **plan) try {
     int rc = check_plan_args(bval, bvec, nvol, verts, nverts, faces, nfaces, plan);
     if (rc != FIB_OK) return rc;
     FIB_CHECK(hann_width >= 0, FIB_ERR_INVALID, "hann_width must be >= 0");
@@ -2149,23 +2128,23 @@ extern "C" int fib_dsi_plan_create(int device, const float *bval, const float *b
     if (rc != FIB_OK) { delete p; return rc; }
     *plan = p;
     return FIB_OK;
-}
+} FIB_API_CATCH
 
-extern "C" void fib_odf_plan_destroy(fib_odf_plan *plan) {
+extern "C" void fib_odf_plan_destroy(fib_odf_plan *plan) try {
     if (!plan) return;
     fib::DeviceGuard guard;
     (void)hipSetDevice(plan->device);
     delete plan;
-}
+} FIB_API_CATCH_VOID
 
-extern "C" int fib_odf_plan_matrix(const fib_odf_plan *plan, float *A, int *nrows, int *nvol, int *nvert) {
+extern "C" int fib_odf_plan_matrix(const fib_odf_plan *plan, float *A, int *nrows, int *nvol, int *nvert) try {
     FIB_CHECK(plan != nullptr, FIB_ERR_INVALID, "plan is NULL");
     if (nrows) *nrows = plan->nrows;
     if (nvol) *nvol = plan->nvol;
     if (nvert) *nvert = plan->nvert;
     if (A) memcpy(A, plan->A.data(), plan->A.size() * sizeof(float));
     return FIB_OK;
-}
+} FIB_API_CATCH
 
 // ------------------------------------------------------------------------------------------
 // launches
@@ -2178,7 +2157,6 @@ void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
     if (ga.At3) {
         // persistent grid: one 8-wave workgroup per CU (two 4-wave workgroups per CU were measured 6 % slower), a multiple of 8
         // so that blockIdx & 7 is the XCD
-        static const int stamp = getenv("FIBERS_GEMM3_STAMP") ? atoi(getenv("FIBERS_GEMM3_STAMP")) : 0;
         int ncu = 256, dev = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -2187,39 +2165,12 @@ void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
         const int64_t items = fib::cdiv(ga.nvox, nw * 32) * ga.ntile_m;
         unsigned pg = (unsigned)std::min<int64_t>((int64_t)ncu * (8 / nw), items);
         pg = (pg + 7) / 8 * 8;
-        if (stamp && MB == 10 && NX == 1 && !ga.mean_hi) {              // timing experiment: in-kernel clock and epilogue share (stderr, 12th call)
-            static unsigned long long *dbg = nullptr;
-            static int calls = 0;
-            if (!dbg) (void)hipMalloc((void **)&dbg, (size_t)4096 * 8 * 8);
-            g2.dbg = dbg;
-            constexpr int PM = (MB == 10 && NX == 1) ? 10 : 5, PN = (MB == 10 && NX == 1) ? 1 : 0;
-            hipLaunchKernelGGL((odf_gemm3_kernel<PM, PN, 8, true>), dim3(pg), dim3(512), 0, st, g2);
-            if (++calls == 12) {
-                (void)hipStreamSynchronize(st);
-                std::vector<unsigned long long> h((size_t)pg * 8);
-                (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
-                std::vector<double> clk, item, epi, psp, pis, pmf, pba;
-                for (unsigned b = 0; b < pg; b++) {
-                    const unsigned long long *d = &h[(size_t)b * 8];
-                    if (d[4] == 0 || d[3] == 0) continue;
-                    const double n = (double)d[3];
-                    clk.push_back((double)d[0] / (double)d[4] * 100.0);
-                    item.push_back((double)d[0] / n); epi.push_back((double)d[1] / n);
-                    psp.push_back((double)d[2] / n); pis.push_back((double)d[5] / n); pmf.push_back((double)d[6] / n); pba.push_back((double)d[7] / n);
-                }
-                auto med = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
-                fprintf(stderr, "gemm3 stamps over %zu workgroups: clock %.0f MHz; cycles per work item %.0f (%.1f per MFMA), of which epilogue %.0f\n",
-                        clk.size(), med(clk), med(item), med(item) / (17.0 * 60.0), med(epi));
-                fprintf(stderr, "  wave 0, per work item: split %.0f, request issue %.0f, MFMA block %.0f, wait + barrier %.0f cycles\n", med(psp), med(pis), med(pmf), med(pba));
-            }
-            return;
-        }
         if (ga.fold) {
-            if constexpr (MB <= FOLD_MB_MAX) hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 8, false, true>), dim3(pg), dim3(512), 0, st, g2);
+            if constexpr (MB <= FOLD_MB_MAX) hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 8, true>), dim3(pg), dim3(512), 0, st, g2);
             return;
         }
         if constexpr (MB == 10 && NX == 1) {
-            if (ga.mean_hi) { hipLaunchKernelGGL((odf_gemm3_kernel<10, 1, 8, false, false, true>), dim3(pg), dim3(512), 0, st, g2); return; }
+            if (ga.mean_hi) { hipLaunchKernelGGL((odf_gemm3_kernel<10, 1, 8, false, true>), dim3(pg), dim3(512), 0, st, g2); return; }
         }
         hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 8>), dim3(pg), dim3(512), 0, st, g2);
     }
@@ -2296,7 +2247,7 @@ int launch_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox, int64
 
 extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const uint8_t *mask, int64_t nvox,
                             float *pdf, float *odf, float *const peak[3], float *const qa[3],
-                            float *odfmax_dev, int flags, void *stream) {
+                            float *odfmax_dev, int flags, void *stream) try {
     FIB_CHECK(plan && dwi && mask && odf && peak && qa, FIB_ERR_INVALID, "NULL argument");
     FIB_CHECK(nvox > 0, FIB_ERR_INVALID, "nvox must be positive");
     FIB_CHECK(nvox <= ((int64_t)1 << 27), FIB_ERR_UNSUPPORTED, "volumes of more than 2^27 voxels are not supported (32-bit lane offsets)");
@@ -2419,7 +2370,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         FIB_HIP(hipGetLastError());
     }
     return FIB_OK;
-}
+} FIB_API_CATCH
 
 // ---- plain use of the contraction kernels: O[M x n] = A[M x K] * max(S[K x n], 0) (row N4, RUMBA-SD) -----------------
 int fib::matrix_plan_create(int device, const float *A, int nrows, int ncols, fib_odf_plan **plan) {
@@ -2473,25 +2424,25 @@ int fib::matrix_plan_run(const fib_odf_plan *plan, const float *S, const uint8_t
     return FIB_OK;
 }
 
-extern "C" int fibd_qa_normalize(float *const qa[3], int64_t nvox, float odfmax, void *stream) {
+extern "C" int fibd_qa_normalize(float *const qa[3], int64_t nvox, float odfmax, void *stream) try {
     FIB_CHECK(qa && qa[0] && qa[1] && qa[2] && nvox > 0, FIB_ERR_INVALID, "NULL argument");
     hipLaunchKernelGGL(qa_normalize_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, qa[0], qa[1], qa[2], nvox,
                        (const float *)nullptr, odfmax);
     FIB_HIP(hipGetLastError());
     return FIB_OK;
-}
+} FIB_API_CATCH
 
-extern "C" int fibd_qa_normalize_dev(float *const qa[3], int64_t nvox, const float *odfmax_dev, void *stream) {
+extern "C" int fibd_qa_normalize_dev(float *const qa[3], int64_t nvox, const float *odfmax_dev, void *stream) try {
     FIB_CHECK(qa && qa[0] && qa[1] && qa[2] && odfmax_dev && nvox > 0, FIB_ERR_INVALID, "NULL argument");
     hipLaunchKernelGGL(qa_normalize_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, qa[0], qa[1], qa[2], nvox, odfmax_dev, 0.0f);
     FIB_HIP(hipGetLastError());
     return FIB_OK;
-}
+} FIB_API_CATCH
 
 extern "C" int fibd_find_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox,
-                               int32_t *isort_top, int32_t *nvalid, void *stream) {
+                               int32_t *isort_top, int32_t *nvalid, void *stream) try {
     FIB_CHECK(plan && odf && isort_top && nvalid && nvox > 0, FIB_ERR_INVALID, "NULL argument");
     fib::DeviceGuard guard;
     FIB_HIP(hipSetDevice(plan->device));
     return launch_peaks(plan, odf, nvox, nvox, nullptr, nullptr, isort_top, nvalid, false, (hipStream_t)stream);
-}
+} FIB_API_CATCH

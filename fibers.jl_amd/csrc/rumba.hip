@@ -316,17 +316,17 @@ struct fib_rumba_plan {
     mutable fib::DevBuf<float> w_sig, w_dodf, w_ir, w_x, w_fodf, w_fodf2, w_rl, w_rl2;
 };
 
-extern "C" void fib_rumba_plan_destroy(fib_rumba_plan *p) {
+extern "C" void fib_rumba_plan_destroy(fib_rumba_plan *p) try {
     if (!p) return;
     fib::DeviceGuard guard;
     (void)hipSetDevice(p->device);
     fib_odf_plan_destroy(p->pT);
     fib_odf_plan_destroy(p->pK);
     delete p;
-}
+} FIB_API_CATCH_VOID
 
 extern "C" int fib_rumba_plan_create(int device, const float *bval, const float *bvec, int nvol, const float *verts, int nverts,
-                                     float lam_para, float lam_perp, float lam_csf, float lam_gm, fib_rumba_plan **plan) {
+                                     float lam_para, float lam_perp, float lam_csf, float lam_gm, fib_rumba_plan **plan) try {
     FIB_CHECK(plan != nullptr, FIB_ERR_INVALID, "plan output pointer is NULL");
     *plan = nullptr;
     FIB_CHECK(bval != nullptr && nvol > 0, FIB_ERR_MISSING_BVAL, "Missing b-value table from input DWI structure");   // rusd.jl:421
@@ -413,22 +413,22 @@ extern "C" int fib_rumba_plan_create(int device, const float *bval, const float 
     gd.ok = true;
     *plan = p;
     return FIB_OK;
-}
+} FIB_API_CATCH
 
-extern "C" int fib_rumba_plan_kernel(const fib_rumba_plan *plan, float *K, int *ndir, int *ncomp) {
+extern "C" int fib_rumba_plan_kernel(const fib_rumba_plan *plan, float *K, int *ndir, int *ncomp) try {
     FIB_CHECK(plan != nullptr, FIB_ERR_INVALID, "plan is NULL");
     if (ndir) *ndir = plan->ndir;
     if (ncomp) *ncomp = plan->ncomp;
     if (K) memcpy(K, plan->K.data(), plan->K.size() * sizeof(float));
     return FIB_OK;
-}
+} FIB_API_CATCH
 
 // ------------------------------------------------------------------------------------------
 // reconstruction, device tier
 // ------------------------------------------------------------------------------------------
 extern "C" int fibd_rumba_rec(const fib_rumba_plan *plan, const float *dwi, const uint8_t *mask, int nx, int ny, int nz,
                               int niter, int ncoils, int sos_grappa, int ipat_factor, int use_tv,
-                              const fib_rumba_out *out, float *snr_mean, float *snr_std, void *stream) {
+                              const fib_rumba_out *out, float *snr_mean, float *snr_std, void *stream) try {
     FIB_CHECK(plan && dwi && mask && out, FIB_ERR_INVALID, "NULL argument");
     FIB_CHECK(nx > 0 && ny > 0 && nz > 0 && niter >= 0, FIB_ERR_INVALID, "invalid sizes");
     FIB_CHECK(ipat_factor >= 1, FIB_ERR_INVALID, "iPAT factor must be a positive integer");                          // rusd.jl:437
@@ -530,4 +530,4 @@ extern "C" int fibd_rumba_rec(const fib_rumba_plan *plan, const float *dwi, cons
     FIB_HIP(hipGetLastError());
     FIB_HIP(hipStreamSynchronize(st));                            // the work buffers are locals
     return FIB_OK;
-}
+} FIB_API_CATCH

@@ -299,16 +299,16 @@ void profile_push(const char *name, hipEvent_t a, hipEvent_t b) {
 
 extern "C" int fib_profile_enable(int on) { fib::g_prof_on = on != 0; return FIB_OK; }
 
-extern "C" int fib_profile_reset(void) {
+extern "C" int fib_profile_reset(void) try {
     std::lock_guard<std::mutex> lk(fib::g_prof_mu);
     for (auto &e : fib::g_prof) {
         for (auto &pr : e.pending) { (void)hipEventSynchronize(pr.second); (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     }
     fib::g_prof.clear();
     return FIB_OK;
-}
+} FIB_API_CATCH
 
-extern "C" int fib_profile_get(const char *kernel, double *total_ms, int64_t *count) {
+extern "C" int fib_profile_get(const char *kernel, double *total_ms, int64_t *count) try {
     FIB_CHECK(kernel && total_ms && count, FIB_ERR_INVALID, "NULL argument");
     std::lock_guard<std::mutex> lk(fib::g_prof_mu);
     *total_ms = 0; *count = 0;
@@ -323,12 +323,12 @@ extern "C" int fib_profile_get(const char *kernel, double *total_ms, int64_t *co
         *total_ms = e.ms; *count = e.count;
     }
     return FIB_OK;
-}
+} FIB_API_CATCH
 
 extern "C" const char *fib_last_error(void) { return fib::last_error(); }
 extern "C" const char *fib_version(void) { return "fibers-hip 0.1 (gfx950)"; }
-extern "C" int fib_device_count(void) {
+extern "C" int fib_device_count(void) try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
-}
+} FIB_API_CATCH

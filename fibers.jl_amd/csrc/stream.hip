@@ -708,24 +708,51 @@ __global__ __launch_bounds__(256) void copy_i32_kernel(const int32_t *src, int32
     if (i < n) dst[i] = src[i];
 }
 
-// grow-only scratch cache, one per device: avoids a multi-GB hipMalloc/hipFree per call
-struct ScratchCache {
-    std::mutex mu;
-    void *p[16] = {};
-    size_t bytes[16] = {};
-    bool busy[16] = {};
-};
-ScratchCache g_cache;
-
 }  // namespace
+
+// Caller-owned, grow-only scratch arena of the tracer (fib_stream_params::ws): avoids a multi-GB hipMalloc/hipFree per job.
+// One job at a time uses it; the job that releases it records an event on its stream and the next user waits for that
+// event on its own stream, so a pack kernel still reading the arena is never overtaken.
+struct fib_stream_ws {
+    int device = 0;
+    std::mutex mu;
+    void *p = nullptr;
+    size_t bytes = 0;
+    bool busy = false, pending = false;
+    hipEvent_t done = nullptr;
+};
+
+extern "C" int fibd_stream_ws_create(int device, fib_stream_ws **ws) try {
+    FIB_CHECK(ws != nullptr, FIB_ERR_INVALID, "NULL argument");
+    *ws = nullptr;
+    fib::DeviceGuard guard;
+    int rc = fib::use_device(device);
+    if (rc != FIB_OK) return rc;
+    fib_stream_ws *w = new fib_stream_ws();
+    w->device = device;
+    if (hipEventCreateWithFlags(&w->done, hipEventDisableTiming) != hipSuccess) { delete w; return fib::fail(FIB_ERR_HIP, "hipEventCreate failed"); }
+    *ws = w;
+    return FIB_OK;
+} FIB_API_CATCH
+
+extern "C" void fibd_stream_ws_destroy(fib_stream_ws *ws) try {
+    if (!ws) return;
+    fib::DeviceGuard guard;
+    (void)hipSetDevice(ws->device);
+    if (ws->pending) (void)hipEventSynchronize(ws->done);
+    if (ws->p) (void)hipFree(ws->p);
+    if (ws->done) (void)hipEventDestroy(ws->done);
+    delete ws;
+} FIB_API_CATCH_VOID
 
 struct fib_stream_job {
     int device = 0;
+    fib_stream_ws *ws = nullptr;    // arena the scratch was taken from (NULL: own allocation)
+    hipStream_t last_stream = nullptr;   // stream of the job's latest launch (trace or pack)
     fib_stream_params prm{};
     int64_t nseed = 0, nlines = 0;
     int nsub = 1, stride = 0;
     float *scratch = nullptr;
-    bool scratch_from_cache = false;
     // carved out of the same (cached) arena as the scratch: no hipMalloc/hipFree per call
     struct View32 { int32_t *p = nullptr; } npts, nfwd;
     struct ViewP { Pair *p = nullptr; } excl, block_tot, total;
@@ -735,24 +762,26 @@ struct fib_stream_job {
     TraceArgs ta{};                 // (two_pass) the arguments of the first pass
 };
 
-extern "C" void fib_stream_job_destroy(fib_stream_job *job) {
+extern "C" void fib_stream_job_destroy(fib_stream_job *job) try {
     if (!job) return;
     fib::DeviceGuard guard;
     (void)hipSetDevice(job->device);
     if (job->scratch) {
-        if (job->scratch_from_cache) {
-            std::lock_guard<std::mutex> lk(g_cache.mu);
-            g_cache.busy[job->device & 15] = false;
+        if (job->ws) {
+            std::lock_guard<std::mutex> lk(job->ws->mu);
+            job->ws->pending = hipEventRecord(job->ws->done, job->last_stream) == hipSuccess;
+            if (!job->ws->pending) (void)hipStreamSynchronize(job->last_stream);
+            job->ws->busy = false;
         } else {
-            (void)hipFree(job->scratch);
+            (void)hipFree(job->scratch);    // (hipFree waits for the device)
         }
     }
     delete job;
-}
+} FIB_API_CATCH_VOID
 
 extern "C" int fibd_stream_field(int32_t nvec, int64_t nvox, const float *const *ovec, const float *const *f,
                                  float f_thresh, const float *fa, float fa_thresh, const uint8_t *mask,
-                                 float *field4, uint8_t *mask_out, void *stream) {
+                                 float *field4, uint8_t *mask_out, void *stream) try {
     FIB_CHECK(ovec && field4 && nvox > 0, FIB_ERR_INVALID, "NULL argument");
     FIB_CHECK(nvec >= 1 && nvec <= 8, FIB_ERR_UNSUPPORTED, "1..8 orientation vectors per voxel are supported (got %d)", nvec);
     FieldArgs a{};
@@ -766,7 +795,7 @@ extern "C" int fibd_stream_field(int32_t nvec, int64_t nvox, const float *const 
     hipLaunchKernelGGL(stream_field_kernel, dim3((unsigned)fib::cdiv(nvox, 256)), dim3(256), 0, (hipStream_t)stream, a);
     FIB_HIP(hipGetLastError());
     return FIB_OK;
-}
+} FIB_API_CATCH
 
 namespace {
 struct LcmIn { const float *lcms = nullptr; float thresh = 0.0f; int sd0 = 0, sd1 = 1; unsigned long long seed = 0; };
@@ -777,21 +806,21 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
 
 extern "C" int fibd_stream_trace(const fib_stream_params *prm, const float *field4, const int64_t *seeds, int64_t nseed,
                                  const float *sublist, int32_t nsub, void *stream,
-                                 fib_stream_job **job_out, int64_t *nlines_out, int64_t *npoints_out) {
+                                 fib_stream_job **job_out, int64_t *nlines_out, int64_t *npoints_out) try {
     return stream_trace_impl(prm, field4, LcmIn{}, seeds, nseed, sublist, nsub, stream, job_out, nlines_out, npoints_out);
-}
+} FIB_API_CATCH
 
 extern "C" int fibd_stream_trace_lcm(const fib_stream_params *prm, const float *field4, const float *lcms, float lcm_thresh,
                                      int32_t strdim0, int32_t strdim1, uint64_t rng_seed,
                                      const int64_t *seeds, int64_t nseed, const float *sublist, int32_t nsub, void *stream,
-                                     fib_stream_job **job_out, int64_t *nlines_out, int64_t *npoints_out) {
+                                     fib_stream_job **job_out, int64_t *nlines_out, int64_t *npoints_out) try {
     FIB_CHECK(lcms != nullptr, FIB_ERR_INVALID, "NULL lcms volume");
     FIB_CHECK(strdim0 >= 0 && strdim0 < 3 && strdim1 >= 0 && strdim1 < 3 && strdim0 != strdim1, FIB_ERR_INVALID, "invalid in-plane dimensions");
     FIB_CHECK(prm && prm->search_dist == 0, FIB_ERR_UNSUPPORTED, "LCM-guided tracking is a macro-scale mode (search_dist must be 0)");
     LcmIn lin;
     lin.lcms = lcms; lin.thresh = lcm_thresh; lin.sd0 = strdim0; lin.sd1 = strdim1; lin.seed = rng_seed;
     return stream_trace_impl(prm, field4, lin, seeds, nseed, sublist, nsub, stream, job_out, nlines_out, npoints_out);
-}
+} FIB_API_CATCH
 
 namespace {
 int stream_trace_impl(const fib_stream_params *prm, const float *field4, const LcmIn &lin, const int64_t *seeds, int64_t nseed,
@@ -803,6 +832,7 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
     FIB_CHECK(nsub >= 1 && sublist, FIB_ERR_INVALID, "sublist must hold at least one offset (use [0,0,0] for nsub=0, stream.jl:180)");
     FIB_CHECK(prm->nx > 0 && prm->ny > 0 && prm->nz > 0 && prm->nvec >= 1 && prm->nvec <= 8, FIB_ERR_INVALID, "invalid volume / nvec");
     FIB_CHECK(prm->len_max >= 0 && prm->len_max < (1 << 24), FIB_ERR_INVALID, "invalid len_max");
+    FIB_CHECK(prm->search_dist <= 60, FIB_ERR_UNSUPPORTED, "search_dist up to 60 voxels is supported (got %d)", prm->search_dist);
     FIB_CHECK((int64_t)prm->nx * prm->ny * prm->nz * prm->nvec < ((int64_t)1 << 28), FIB_ERR_UNSUPPORTED,
               "orientation fields of 2^28 vectors or more are not supported (32-bit gather offsets)");
     int device = 0;
@@ -827,16 +857,20 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
     const size_t b_i32 = up((size_t)nl * sizeof(int32_t)), b_excl = up((size_t)nl * sizeof(Pair));
     const size_t b_btot = up((size_t)nblocks * sizeof(Pair)), b_tot = 256;
     const size_t sbytes = b_scratch + 2 * b_i32 + b_excl + b_btot + b_tot;
-    {   // scratch: reuse the per-device cache when it is free
-        std::lock_guard<std::mutex> lk(g_cache.mu);
-        const int d = device & 15;
-        if (!g_cache.busy[d]) {
-            if (g_cache.bytes[d] < sbytes) {
-                if (g_cache.p[d]) (void)hipFree(g_cache.p[d]);
-                g_cache.p[d] = nullptr; g_cache.bytes[d] = 0;
-                if (hipMalloc(&g_cache.p[d], sbytes) == hipSuccess) g_cache.bytes[d] = sbytes;
+    job->last_stream = st;
+    if (fib_stream_ws *ws = reinterpret_cast<fib_stream_ws *>(prm->ws)) {   // the caller's arena, when it is free and on this device
+        std::lock_guard<std::mutex> lk(ws->mu);
+        if (!ws->busy && ws->device == device) {
+            if (ws->bytes < sbytes) {
+                if (ws->pending) { (void)hipEventSynchronize(ws->done); ws->pending = false; }
+                if (ws->p) (void)hipFree(ws->p);
+                ws->p = nullptr; ws->bytes = 0;
+                if (hipMalloc(&ws->p, sbytes) == hipSuccess) ws->bytes = sbytes;
             }
-            if (g_cache.p[d]) { job->scratch = (float *)g_cache.p[d]; job->scratch_from_cache = true; g_cache.busy[d] = true; }
+            if (ws->p) {
+                if (ws->pending) { (void)hipStreamWaitEvent(st, ws->done, 0); ws->pending = false; }
+                job->scratch = (float *)ws->p; job->ws = ws; ws->busy = true;
+            }
         }
     }
     if (!job->scratch) {
@@ -867,7 +901,6 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
     if (prm->search_dist > 0) {
         // search_area (stream.jl:255-277), Float32 arithmetic like the reference's T; one entry per antipodal pair
         const int d = prm->search_dist, S = 2 * d + 1;
-        FIB_CHECK(d <= 60, FIB_ERR_UNSUPPORTED, "search_dist up to 60 voxels is supported (got %d)", d);
         std::vector<float4> tab;
         const float den = (float)d + 0.5f;
         const int64_t ncell = (int64_t)S * S * S;
@@ -963,6 +996,7 @@ static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, f
 
 // whole-tile kernel while 16 (len_max + 2) points (+ the .trk headers and the alignment slack) fit in LDS
 static int launch_pack(fib_stream_job *job, const PackArgs &pa, hipStream_t st) {
+    job->last_stream = st;
     const size_t smem = ((size_t)PK_LINES * job->stride * 3 + PK_LINES + 8) * sizeof(float);
     const char *e = getenv("FIBERS_PACK_KERNEL");
     if (smem <= 120 * 1024 && !(e && e[0] == 'w')) {
@@ -983,6 +1017,7 @@ static int retrace(fib_stream_job *job, int32_t *npts, int64_t *seed_index, floa
     if (voxel_size) { ta.trk = 1; ta.vs[0] = voxel_size[0]; ta.vs[1] = voxel_size[1]; ta.vs[2] = voxel_size[2]; }
     const unsigned grid = (unsigned)fib::cdiv(job->nlines, 256);
     hipStream_t st = (hipStream_t)stream;
+    job->last_stream = st;
     fib::ProfScope prof(voxel_size ? "stream_write_trk" : "stream_write", st);
     if (ta.nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1, false, 2>), dim3(grid), dim3(256), 0, st, ta);
     else if (ta.nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, false, 2>), dim3(grid), dim3(256), 0, st, ta);
@@ -991,7 +1026,7 @@ static int retrace(fib_stream_job *job, int32_t *npts, int64_t *seed_index, floa
     return FIB_OK;
 }
 
-extern "C" int fibd_stream_pack_flags(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, uint8_t *flags, void *stream) {
+extern "C" int fibd_stream_pack_flags(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, uint8_t *flags, void *stream) try {
     int rc = pack_plain(job, npts, seed_index, xyz, stream);
     if (rc != FIB_OK || job->kept_pts == 0) return rc;
     if (job->lcm)
@@ -1000,11 +1035,11 @@ extern "C" int fibd_stream_pack_flags(fib_stream_job *job, int32_t *npts, int64_
     else return FIB_OK;
     FIB_HIP(hipGetLastError());
     return FIB_OK;
-}
+} FIB_API_CATCH
 
-extern "C" int fibd_stream_pack(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, void *stream) {
+extern "C" int fibd_stream_pack(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, void *stream) try {
     return fibd_stream_pack_flags(job, npts, seed_index, xyz, nullptr, stream);   // (strips the flag bit of LCM runs)
-}
+} FIB_API_CATCH
 
 static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, void *stream) {
     FIB_CHECK(job != nullptr, FIB_ERR_INVALID, "job is NULL");
@@ -1025,7 +1060,7 @@ static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, f
     return FIB_OK;                                      // (LCM jobs: x still carries the flag bit; the caller strips it)
 }
 
-extern "C" int fibd_stream_pack_trk(fib_stream_job *job, const float voxel_size[3], void *body, void *stream) {
+extern "C" int fibd_stream_pack_trk(fib_stream_job *job, const float voxel_size[3], void *body, void *stream) try {
     FIB_CHECK(job != nullptr && voxel_size != nullptr, FIB_ERR_INVALID, "NULL argument");
     FIB_CHECK(!job->lcm, FIB_ERR_UNSUPPORTED, "the .trk body serialiser does not carry the per-point scalars of an LCM run");
     if (job->kept_lines == 0) return FIB_OK;
@@ -1044,16 +1079,17 @@ extern "C" int fibd_stream_pack_trk(fib_stream_job *job, const float voxel_size[
     { const int rcl = launch_pack(job, pa, (hipStream_t)stream); if (rcl != FIB_OK) return rcl; }
     FIB_HIP(hipGetLastError());
     return FIB_OK;
-}
+} FIB_API_CATCH
 
-extern "C" int fibd_stream_all_npts(fib_stream_job *job, int32_t *all_npts, void *stream) {
+extern "C" int fibd_stream_all_npts(fib_stream_job *job, int32_t *all_npts, void *stream) try {
     FIB_CHECK(job != nullptr, FIB_ERR_INVALID, "job is NULL");
     if (job->nlines == 0) return FIB_OK;
     FIB_CHECK(all_npts != nullptr, FIB_ERR_INVALID, "NULL output buffer");
     fib::DeviceGuard guard;
     FIB_HIP(hipSetDevice(job->device));
+    job->last_stream = (hipStream_t)stream;
     hipLaunchKernelGGL(copy_i32_kernel, dim3((unsigned)fib::cdiv(job->nlines, 256)), dim3(256), 0, (hipStream_t)stream,
                        job->npts.p, all_npts, job->nlines);
     FIB_HIP(hipGetLastError());
     return FIB_OK;
-}
+} FIB_API_CATCH

@@ -49,41 +49,59 @@ def _dwi_arg(dwi):
 
 
 def _check_tables(dwi, need_bvec=True):
+    """The reference's table checks (dti.jl:166-168, 223-229) plus the shapes the C ABI relies on.  Returns
+    (bval float32 contiguous [nframes], bvec float32 Fortran-ordered [nframes, 3] or None): the arrays whose pointers go
+    to the library — `dwi.bvec` itself may have been assigned in any memory order after the MRI was built."""
     if dwi.bval is None or len(dwi.bval) == 0:
         raise RuntimeError("Missing b-value table from input DWI structure")        # dti.jl:167,224
     if need_bvec and (dwi.bvec is None or len(dwi.bvec) == 0):
         raise RuntimeError("Missing gradient table from input DWI structure")       # dti.jl:228
-    if len(dwi.bval) != dwi.nframes:
-        raise ValueError("b-value table length %d does not match %d frames" % (len(dwi.bval), dwi.nframes))
+    bval = np.ascontiguousarray(dwi.bval, np.float32).reshape(-1)
+    if bval.shape[0] != dwi.nframes:
+        raise ValueError("b-value table length %d does not match %d frames" % (bval.shape[0], dwi.nframes))
+    bvec = None
+    if need_bvec:
+        bvec = np.asarray(dwi.bvec, np.float32)
+        if bvec.shape != (dwi.nframes, 3):
+            raise ValueError("gradient table must be [%d x 3], got %s" % (dwi.nframes, bvec.shape))
+        bvec = np.asfortranarray(bvec)
+    return bval, bvec
+
+
+def _mask_checked(mask, shape3):
+    """_mask_arg + the shape check every host wrapper needs (a mismatch would be an out-of-bounds read in the library)"""
+    m, mdt = _mask_arg(mask)
+    if m.shape != tuple(shape3):
+        raise ValueError("mask shape %s does not match DWI volume %s" % (m.shape, tuple(shape3)))
+    return m, mdt
 
 
 def dti_fit(dwi: MRI, mask: MRI, device: int = 0) -> DTI:
-    """Fit tensors to DWIs and return a `DTI` structure (dti.jl:221)."""
-    _check_tables(dwi)
+    """Fit tensors to DWIs and return a `DTI` structure (dti.jl:221).  device: a GPU index, or _lib.DEVICE_ALL for the
+    device set declared with fibers_jl_amd.init() (z-slab sharding, dti.jl:258)."""
+    bval, bvec = _check_tables(dwi)
     L = _lib.lib()
     vol = _dwi_arg(dwi)
     nx, ny, nz, nvol = vol.shape
-    m, mdt = _mask_arg(mask)
-    if m.shape != (nx, ny, nz):
-        raise ValueError("mask shape %s does not match DWI volume %s" % (m.shape, (nx, ny, nz)))
+    m, mdt = _mask_checked(mask, (nx, ny, nz))
     outs = {k: MRI.like(mask if isinstance(mask, MRI) else dwi, 3 if "vec" in k else 1) for k in DTI_FIELDS}
     o = _lib.DtiOut(*[outs[k].vol.ctypes.data for k in DTI_FIELDS])
     _lib.check(L.fib_dti_fit(device, vol.ctypes.data, nx, ny, nz, nvol, m.ctypes.data, mdt,
-                             dwi.bval.ctypes.data, dwi.bvec.ctypes.data, C.byref(o)))
+                             bval.ctypes.data, bvec.ctypes.data, C.byref(o)))
     return DTI(**outs)
 
 
 def adc_fit(dwi: MRI, mask: MRI, device: int = 0):
     """Fit the apparent diffusion coefficient; returns (adc, s0) (dti.jl:164)."""
-    _check_tables(dwi, need_bvec=False)
+    bval, _ = _check_tables(dwi, need_bvec=False)
     L = _lib.lib()
     vol = _dwi_arg(dwi)
     nx, ny, nz, nvol = vol.shape
-    m, mdt = _mask_arg(mask)
+    m, mdt = _mask_checked(mask, (nx, ny, nz))
     ref = mask if isinstance(mask, MRI) else dwi
     adc, s0 = MRI.like(ref, 1), MRI.like(ref, 1)
     _lib.check(L.fib_adc_fit(device, vol.ctypes.data, nx, ny, nz, nvol, m.ctypes.data, mdt,
-                             dwi.bval.ctypes.data, adc.vol.ctypes.data, s0.vol.ctypes.data))
+                             bval.ctypes.data, adc.vol.ctypes.data, s0.vol.ctypes.data))
     return adc, s0
 
 
@@ -132,6 +150,17 @@ def _stream_ptr(stream):
         import torch
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
     return C.c_void_p(getattr(stream, "cuda_stream", stream))
+
+
+def _sync(stream):
+    """wait for `stream` (a torch stream, a raw hipStream_t handle, or None = the current stream)"""
+    import torch
+    if stream is None:
+        torch.cuda.current_stream().synchronize()
+    elif hasattr(stream, "synchronize"):
+        stream.synchronize()
+    else:
+        torch.cuda.synchronize()
 
 
 def _chk_dev(t, dtype, what):

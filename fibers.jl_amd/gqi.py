@@ -7,7 +7,7 @@ from typing import List, Optional
 import numpy as np
 
 from . import _lib
-from .dti import _check_tables, _chk_dev, _dwi_arg, _mask_arg, _stream_ptr
+from .dti import _check_tables, _chk_dev, _dwi_arg, _mask_arg, _mask_checked, _stream_ptr
 from .mri import MRI
 from .odf import ODF, sphere_642
 
@@ -41,17 +41,17 @@ def _p3(arrs):
 
 def gqi_rec(dwi: MRI, mask: MRI, odf_dirs: ODF = sphere_642, sigma: float = 1.25, device: int = 0) -> GQI:
     """Generalized q-sampling imaging reconstruction (gqi.jl:109)."""
-    _check_tables(dwi)
+    bval, bvec = _check_tables(dwi)
     vol = _dwi_arg(dwi)
     nx, ny, nz, nvol = vol.shape
-    m, mdt = _mask_arg(mask)
+    m, mdt = _mask_checked(mask, (nx, ny, nz))
     v, f = _odf_args(odf_dirs)
     ref = mask if isinstance(mask, MRI) else dwi
     odf = MRI.like(ref, odf_dirs.nvert)
     peak = [MRI.like(ref, 3) for _ in range(3)]
     qa = [MRI.like(ref, 1) for _ in range(3)]
     _lib.check(_lib.lib().fib_gqi_rec(device, vol.ctypes.data, nx, ny, nz, nvol, m.ctypes.data, mdt,
-                                      dwi.bval.ctypes.data, dwi.bvec.ctypes.data,
+                                      bval.ctypes.data, bvec.ctypes.data,
                                       v.ctypes.data, v.shape[0], f.ctypes.data, f.shape[0], float(sigma),
                                       odf.vol.ctypes.data, _p3(peak), _p3(qa)))
     return GQI(odf, peak, qa)
@@ -59,10 +59,10 @@ def gqi_rec(dwi: MRI, mask: MRI, odf_dirs: ODF = sphere_642, sigma: float = 1.25
 
 def dsi_rec(dwi: MRI, mask: MRI, odf_dirs: ODF = sphere_642, hann_width: int = 32, device: int = 0) -> DSI:
     """Diffusion spectrum imaging reconstruction (dsi.jl:171)."""
-    _check_tables(dwi)
+    bval, bvec = _check_tables(dwi)
     vol = _dwi_arg(dwi)
     nx, ny, nz, nvol = vol.shape
-    m, mdt = _mask_arg(mask)
+    m, mdt = _mask_checked(mask, (nx, ny, nz))
     v, f = _odf_args(odf_dirs)
     ref = mask if isinstance(mask, MRI) else dwi
     pdf = MRI.like(ref, nvol)
@@ -70,7 +70,7 @@ def dsi_rec(dwi: MRI, mask: MRI, odf_dirs: ODF = sphere_642, hann_width: int = 3
     peak = [MRI.like(ref, 3) for _ in range(3)]
     qa = [MRI.like(ref, 1) for _ in range(3)]
     _lib.check(_lib.lib().fib_dsi_rec(device, vol.ctypes.data, nx, ny, nz, nvol, m.ctypes.data, mdt,
-                                      dwi.bval.ctypes.data, dwi.bvec.ctypes.data,
+                                      bval.ctypes.data, bvec.ctypes.data,
                                       v.ctypes.data, v.shape[0], f.ctypes.data, f.shape[0], int(hann_width),
                                       pdf.vol.ctypes.data, odf.vol.ctypes.data, _p3(peak), _p3(qa)))
     return DSI(pdf, odf, peak, qa)

@@ -6,7 +6,7 @@ from typing import List, Optional
 import numpy as np
 
 from . import _lib
-from .dti import _check_tables, _chk_dev, _dwi_arg, _mask_arg, _stream_ptr
+from .dti import _check_tables, _chk_dev, _dwi_arg, _mask_checked, _stream_ptr
 from .mri import MRI
 from .odf import ODF, sphere_724
 
@@ -36,13 +36,13 @@ def rumba_rec(dwi: MRI, mask: MRI, odf_dirs: ODF = sphere_724, niter: int = 600,
               lam_perp: float = 0.2e-3, lam_csf: float = 3.0e-3, lam_gm: float = 0.8e-4, ncoils: int = 1,
               coil_combine: str = "SMF-SENSE", ipat_factor: int = 1, use_tv: bool = True, device: int = 0) -> RUMBASD:
     """Robust and unbiased model-based spherical deconvolution (rusd.jl:419)."""
-    _check_tables(dwi)
+    bval, bvec = _check_tables(dwi)
     sos = _coil_mode(coil_combine)
     if ipat_factor < 1:
         raise ValueError("iPAT factor must be a positive integer")             # rusd.jl:437
     vol = _dwi_arg(dwi)
     nx, ny, nz, nvol = vol.shape
-    m, mdt = _mask_arg(mask)
+    m, mdt = _mask_checked(mask, vol.shape[:3])
     v = np.asfortranarray(odf_dirs.vertices, dtype=np.float32)
     ref = mask if isinstance(mask, MRI) else dwi
     fodf = MRI.like(ref, odf_dirs.nvert)
@@ -51,7 +51,7 @@ def rumba_rec(dwi: MRI, mask: MRI, odf_dirs: ODF = sphere_724, niter: int = 600,
     out = _lib.RumbaOut(fodf.vol.ctypes.data, *[s.vol.ctypes.data for s in sc], (C.c_void_p * 5)(*[p.vol.ctypes.data for p in peak]))
     sm, ss = C.c_float(0), C.c_float(0)
     _lib.check(_lib.lib().fib_rumba_rec(device, vol.ctypes.data, nx, ny, nz, nvol, m.ctypes.data, mdt,
-                                        dwi.bval.ctypes.data, dwi.bvec.ctypes.data, v.ctypes.data, v.shape[0], int(niter),
+                                        bval.ctypes.data, bvec.ctypes.data, v.ctypes.data, v.shape[0], int(niter),
                                         float(lam_para), float(lam_perp), float(lam_csf), float(lam_gm), int(ncoils), sos,
                                         int(ipat_factor), 1 if use_tv else 0, C.byref(out), C.byref(sm), C.byref(ss)))
     return RUMBASD(fodf, sc[0], sc[1], peak, sc[2], sc[3], float(sm.value), float(ss.value))

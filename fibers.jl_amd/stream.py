@@ -7,7 +7,7 @@ from typing import List, Optional, Sequence, Union
 import numpy as np
 
 from . import _lib
-from .dti import _chk_dev, _mask_arg, _stream_ptr
+from .dti import _chk_dev, _mask_arg, _stream_ptr, _sync
 from .mri import MRI
 from .tract import Tract
 
@@ -48,12 +48,41 @@ def _vol3(m, what):
     return a
 
 
-def _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff, search_dist=0, search_ang=10):
+class StreamWorkspace:
+    """Caller-owned scratch arena of the tracer on one device (fibd_stream_ws_create): keeps the multi-GB point scratch
+    between calls.  One job at a time takes it; concurrent jobs fall back to their own allocation."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        self.device = int(device)
+        _lib.check(_lib.lib().fibd_stream_ws_create(self.device, C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().fibd_stream_ws_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+_default_ws = {}
+
+
+def default_workspace(device: int) -> StreamWorkspace:
+    """the host mirror's workspace for `device` (what a StreamWork would own in the reference, stream.jl:43-60)"""
+    ws = _default_ws.get(int(device))
+    if ws is None:
+        ws = _default_ws[int(device)] = StreamWorkspace(device)
+    return ws
+
+
+def _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff, search_dist=0, search_ang=10, ws=None):
     """search_dist > 0 selects the microscopy regime (stream.jl:83, 547-619)"""
     nx, ny, nz = shape
     return _lib.StreamParams(nx, ny, nz, nvec, int(len_min), int(len_max if len_max is not None else max(shape)),
                              float(cosd32(ang_thresh)), float(np.float32(step_size)), float(np.float32(smooth_coeff)),
-                             int(search_dist), float(cosd32(search_ang)))
+                             int(search_dist), float(cosd32(search_ang)), ws._h if ws is not None else None)
 
 
 def stream(ovec: Union[MRI, Sequence[MRI]], *, f=None, f_thresh: float = 0.03, fa: Optional[MRI] = None,
@@ -191,7 +220,7 @@ def stream_field_device(ovec: List, f: Optional[List] = None, f_thresh: float = 
 
 def stream_device(field, shape, seeds, sublist, len_min=3, len_max=None, ang_thresh=45, step_size=0.5,
                   smooth_coeff=0.2, stream=None, want_all_npts=False, search_dist=0, search_ang=10,
-                  lcms=None, lcm_thresh=0.099, strdims=(0, 1), rng_seed=0, xyz_out=None):
+                  lcms=None, lcm_thresh=0.099, strdims=(0, 1), rng_seed=0, xyz_out=None, workspace="default"):
     """Trace + pack on the GPU.  field: [nvox, nvec, 4] from stream_field_device; seeds: int64 CUDA tensor of
     0-based column-major voxel indices (findall order); sublist: float32 CUDA [nsub, 3].
     search_dist > 0: microscopy regime (stream.jl:547-619; reference defaults there: search_dist 15, search_ang 10,
@@ -199,13 +228,16 @@ def stream_device(field, shape, seeds, sublist, len_min=3, len_max=None, ang_thr
     lcms (float32 CUDA [10, nvox], planar like MRI.vol[nx,ny,nz,10]): LCM-guided tracking (stream.jl:380-495) over the
     in-plane dimensions `strdims`, uniforms from the ABI's counter-based stream (`rng_seed`); adds `flags` uint8 [npoints].
     xyz_out: optional callable npoints -> float32 CUDA tensor of at least 3 * npoints elements to pack the points into (any
-    4-byte alignment).  Returns dict(npts int32 [nlines], seed_index int64 [nlines], xyz float32 [npoints, 3])."""
+    4-byte alignment).  workspace: a StreamWorkspace, None (scratch allocated and freed by the job) or "default" (the
+    host mirror's arena for the field's device).
+    Returns dict(npts int32 [nlines], seed_index int64 [nlines], xyz float32 [npoints, 3])."""
     import torch
     _chk_dev(field, torch.float32, "field")
     _chk_dev(seeds, torch.int64, "seeds")
     _chk_dev(sublist, torch.float32, "sublist")
     nvec = field.shape[1]
-    prm = _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff, search_dist, search_ang)
+    ws = default_workspace(field.device.index or 0) if isinstance(workspace, str) else workspace
+    prm = _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff, search_dist, search_ang, ws)
     job = C.c_void_p()
     nl, npnt = C.c_int64(0), C.c_int64(0)
     L = _lib.lib()
@@ -233,7 +265,7 @@ def stream_device(field, shape, seeds, sublist, len_min=3, len_max=None, ang_thr
         if want_all_npts:
             out["all_npts"] = torch.empty(seeds.numel() * sublist.shape[0], dtype=torch.int32, device=dev)
             _lib.check(L.fibd_stream_all_npts(job, out["all_npts"].data_ptr(), sp))
-        torch.cuda.current_stream().synchronize() if stream is None else None
+        _sync(stream)
     finally:
         L.fib_stream_job_destroy(job)
     return out

@@ -16,8 +16,21 @@ class Tract:
     volres: tuple = (1.0, 1.0, 1.0)       # trk.jl:17  voxel_size
     vox2ras: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=np.float32))   # trk.jl:28
     sublist: Optional[np.ndarray] = None
-    scalars: Optional[np.ndarray] = None  # float32 [npoints] (n_scalars = 1, trk.jl:19,41): LCM runs store the
+    scalars: Optional[np.ndarray] = None  # float32 [npoints] or [npoints, n_scalars] (trk.jl:19,41): LCM runs store the
                                           # method-difference indicator of every point here (stream.jl:538, 787)
+    properties: Optional[np.ndarray] = None   # float32 [nstr] or [nstr, n_properties] (trk.jl:21,42)
+
+    @property
+    def n_scalars(self) -> int:
+        if self.scalars is None:
+            return 0
+        return 1 if np.ndim(self.scalars) == 1 else int(np.shape(self.scalars)[1])
+
+    @property
+    def n_properties(self) -> int:
+        if self.properties is None:
+            return 0
+        return 1 if np.ndim(self.properties) == 1 else int(np.shape(self.properties)[1])
 
     @property
     def nstr(self) -> int:

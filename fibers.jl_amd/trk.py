@@ -45,31 +45,47 @@ def tract_header(ref: MRI, n_count=0, n_scalars=0, n_properties=0) -> bytes:
 
 
 def trk_body(tr: Tract, voxel_size) -> bytes:
-    """per line: Int32 npts, then T.((xyz .+ .5) .* voxel_size) per point (trk.jl:471-482; Float64 arithmetic)"""
+    """per line: Int32 npts, then per point T.((xyz .+ .5) .* voxel_size) followed by the point's scalars, then the line's
+    properties (trk.jl:471-482; Float64 arithmetic for the coordinates)"""
     vs = np.asarray(voxel_size, np.float32).astype(np.float64)
     pts = ((tr.xyz.astype(np.float64) + 0.5) * vs).astype(np.float32)
+    ns, npr = tr.n_scalars, tr.n_properties
+    npnt = pts.shape[0]
+    rec = pts
+    if ns:
+        sc = np.asarray(tr.scalars, np.float32).reshape(npnt, ns)
+        rec = np.concatenate([pts, sc], axis=1)
+    w = 3 + ns
     off = tr.offsets
-    out = np.empty(tr.nstr + 3 * pts.shape[0], np.float32)
-    starts = np.arange(tr.nstr, dtype=np.int64) + 3 * off[:-1]
+    out = np.empty(tr.nstr * (1 + npr) + w * npnt, np.float32)
+    starts = np.arange(tr.nstr, dtype=np.int64) * (1 + npr) + w * off[:-1]           # position of each line's Int32 npts
     out.view(np.int32)[starts] = tr.npts
     keep = np.ones(out.shape[0], bool)
     keep[starts] = False
-    out[keep] = pts.reshape(-1)
+    if npr:
+        pr = np.asarray(tr.properties, np.float32).reshape(tr.nstr, npr)
+        pstart = starts + 1 + w * tr.npts.astype(np.int64)
+        idx = (pstart[:, None] + np.arange(npr)[None, :]).reshape(-1)
+        out[idx] = pr.reshape(-1)
+        keep[idx] = False
+    out[keep] = rec.reshape(-1)
     return out.tobytes()
 
 
 def trk_write(tr: Tract, outfile: str, ref: MRI = None) -> bool:
     """trk_write(tr, outfile) (trk.jl:433-495).  Returns True if the byte count is not the expected one."""
     ref = ref if ref is not None else MRI(np.zeros(tuple(tr.volsize) + (1,), np.uint8), volres=tr.volres, vox2ras=tr.vox2ras)
-    hdr = tract_header(ref, n_count=tr.nstr)
+    hdr = tract_header(ref, n_count=tr.nstr, n_scalars=tr.n_scalars, n_properties=tr.n_properties)
     body = trk_body(tr, np.asarray(ref.volres, np.float32))
     with open(outfile, "wb") as fh:
         nb = fh.write(hdr) + fh.write(body)
-    return nb != 1000 + 4 * tr.nstr + 12 * int(tr.npts.sum())
+    npnt = int(tr.npts.sum())
+    return nb != 1000 + 4 * tr.nstr * (1 + tr.n_properties) + 4 * (3 + tr.n_scalars) * npnt
 
 
 def trk_read(infile: str) -> Tract:
-    """trk_read (trk.jl:358-423): xyz = file ./ voxel_size .- .5; scalars/properties are skipped over"""
+    """trk_read (trk.jl:358-423): xyz = file ./ voxel_size .- .5; per-point scalars and per-line properties are kept
+    (trk.jl:404-416)"""
     with open(infile, "rb") as fh:
         raw = fh.read()
     f = _HDR.unpack(raw[:1000])
@@ -80,17 +96,28 @@ def trk_read(infile: str) -> Tract:
     body = np.frombuffer(raw, np.float32, offset=1000)
     ibody = body.view(np.int32)
     npts = np.zeros(n_count, np.int32)
-    chunks = []
+    chunks, schunks, props = [], [], []
     pos = 0
     for i in range(n_count):
         n = int(ibody[pos]); pos += 1
         rec = body[pos: pos + n * (3 + n_scalars)].reshape(n, 3 + n_scalars)
         chunks.append(rec[:, :3])
-        pos += n * (3 + n_scalars) + n_props
+        schunks.append(rec[:, 3:])
+        pos += n * (3 + n_scalars)
+        props.append(body[pos: pos + n_props])
+        pos += n_props
         npts[i] = n
     xyz = np.concatenate(chunks) if chunks else np.zeros((0, 3), np.float32)
     xyz = (xyz / vs - np.float32(0.5)).astype(np.float32)                       # trk.jl:410-411
-    return Tract(xyz=xyz, npts=npts, volsize=tuple(int(d) for d in dim), volres=tuple(float(v) for v in vs), vox2ras=M)
+    scalars = properties = None
+    if n_scalars:
+        scalars = np.concatenate(schunks).astype(np.float32) if schunks else np.zeros((0, n_scalars), np.float32)
+        if n_scalars == 1:
+            scalars = scalars[:, 0]
+    if n_props:
+        properties = np.stack(props).astype(np.float32) if props else np.zeros((0, n_props), np.float32)
+    return Tract(xyz=xyz, npts=npts, volsize=tuple(int(d) for d in dim), volres=tuple(float(v) for v in vs), vox2ras=M,
+                 scalars=scalars, properties=properties)
 
 
 def str_add(tr: Tract, lines) -> Tract:
@@ -110,11 +137,11 @@ def str_add(tr: Tract, lines) -> Tract:
 def stream_to_trk(outfile, field, shape, seeds, sublist, ref: MRI, stream=None, **kw) -> dict:
     """GPU path: trace, then let the pack kernel emit the .trk body directly (device tier)."""
     import torch
-    from .stream import _params
-    from .dti import _stream_ptr
+    from .stream import _params, default_workspace
+    from .dti import _stream_ptr, _sync
     nvec = field.shape[1]
     prm = _params(shape, nvec, kw.get("len_min", 3), kw.get("len_max"), kw.get("ang_thresh", 45),
-                  kw.get("step_size", 0.5), kw.get("smooth_coeff", 0.2))
+                  kw.get("step_size", 0.5), kw.get("smooth_coeff", 0.2), ws=default_workspace(field.device.index or 0))
     job = C.c_void_p()
     nl, npnt = C.c_int64(0), C.c_int64(0)
     L = _lib.lib()
@@ -125,6 +152,7 @@ def stream_to_trk(outfile, field, shape, seeds, sublist, ref: MRI, stream=None, 
         body = torch.empty(nl.value + 3 * npnt.value, dtype=torch.float32, device=field.device)
         vs = (C.c_float * 3)(*[float(np.float32(v)) for v in ref.volres[:3]])
         _lib.check(L.fibd_stream_pack_trk(job, C.byref(vs), body.data_ptr(), sp))
+        _sync(stream)                                   # the pack ran on `stream`: .cpu() only orders against the current one
         host = body.cpu().numpy()
     finally:
         L.fib_stream_job_destroy(job)

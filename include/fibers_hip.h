@@ -200,9 +200,17 @@ typedef struct {
      * Reference defaults in that regime: search_dist 15, search_ang 10, nsub 0, ang_thresh 20, step 1, smooth 0. */
     int32_t search_dist;    /* 0: macro-scale tracking */
     float search_cosang;    /* cosd(search_ang) */
+    struct fib_stream_ws *ws;   /* optional scratch arena (fibd_stream_ws_create); NULL: the job allocates and frees its own */
 } fib_stream_params;
 
 typedef struct fib_stream_job fib_stream_job;
+/* Grow-only scratch arena of the tracer, owned by the caller (the reference's per-thread StreamWork scratch, stream.jl:43-60):
+ * worst-case point rows for every line (3.4 GB per million lines at len_max 140) are expensive to allocate per call.  One job
+ * at a time takes the arena; a job that finds it busy (or on another device) allocates its own scratch.  Releasing is
+ * stream-ordered: the next job waits on its own stream for the previous job's last launch. */
+typedef struct fib_stream_ws fib_stream_ws;
+int fibd_stream_ws_create(int device, fib_stream_ws **ws);
+void fibd_stream_ws_destroy(fib_stream_ws *ws);
 
 /* StreamWork mask + vector repack (stream.jl:95-145): mask_out = (mask > 0 | any nonzero vector)
  * & (fa >= fa_thresh); field[vox][k] = ovec[k][vox,:] * (mask_out & f[k] >= f_thresh), stored as
@@ -255,6 +263,20 @@ void fib_stream_job_destroy(fib_stream_job *job);
 /* ------------------------------------------------------------------------------------ */
 /* Host-buffer drop-in entry points (what the Julia wrapper ccalls)                       */
 /* ------------------------------------------------------------------------------------ */
+
+/* The host tier mirrors the reference's own parallel decomposition — `Threads.@threads for iz` over z-slices in the fits
+ * (dti.jl:258, gqi.jl:132, dsi.jl:197), contiguous seed chunks in `stream` (stream.jl:757-761) — with GPUs in place of
+ * threads.  `device` is a HIP device index, or FIB_DEVICE_ALL for the device set declared with fib_init: the volume is
+ * then cut into contiguous voxel slabs (one per entry, one host thread each), seeds are dealt round-robin, the global
+ * odfmax (gqi.jl:164) is reduced over the slabs before qa is normalised, and streamlines are merged back into the
+ * reference's (seed, sub) order.  Results do not depend on the device set.  Each entry of the set runs a three-stage
+ * pipeline over voxel chunks (pinned staging ring: upload || kernels || download), and caches its plans and buffers
+ * between calls; calls that share an entry are serialised, calls on different entries run concurrently.
+ * fib_init(ndev, devs): devs[i] may repeat (two pipelines on one GPU); ndev == 0 selects every visible device (also
+ * the default of FIB_DEVICE_ALL without fib_init).  fib_shutdown releases every cached plan, stream and buffer. */
+#define FIB_DEVICE_ALL (-1)
+int fib_init(int ndev, const int *devs);
+void fib_shutdown(void);
 
 /* dti_fit(dwi::MRI, mask::MRI)::DTI (dti.jl:221).  bval/bvec NULL or nvol<=0 reproduce the
  * reference's error() as FIB_ERR_MISSING_BVAL / FIB_ERR_MISSING_BVEC. */

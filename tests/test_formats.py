@@ -130,6 +130,41 @@ def test_trk_header_body_and_roundtrip(fj, tmp_path):
     assert back.nstr == 4 and back.npts[-1] == 4
 
 
+def test_trk_scalars_and_properties_follow_the_reference_layout(fj, tmp_path):
+    """trk_write interleaves the n_scalars values of a point after its xyz triple and appends the n_properties values of a
+    line after its last point (trk.jl:471-482); trk_read returns them (trk.jl:404-416).  A Tract from an LCM run carries
+    one scalar per point (stream.jl:787)."""
+    ref = fj.MRI(np.zeros((4, 5, 6, 1), np.float32), volres=(2.0, 1.0, 0.5))
+    rng = np.random.default_rng(1)
+    npts = np.array([3, 1, 4], np.int32)
+    xyz = rng.uniform(1, 4, (8, 3)).astype(np.float32)
+    sc = rng.uniform(0, 1, (8, 2)).astype(np.float32)
+    pr = rng.uniform(0, 1, (3, 3)).astype(np.float32)
+    tr = fj.Tract(xyz=xyz, npts=npts, volsize=(4, 5, 6), volres=ref.volres, vox2ras=ref.vox2ras, scalars=sc, properties=pr)
+    f = str(tmp_path / "s.trk")
+    assert fj.trk_write(tr, f, ref) is False
+    raw = open(f, "rb").read()
+    assert len(raw) == 1000 + 4 * (3 * (1 + 3) + 8 * (3 + 2))
+    hdr = struct.unpack("<6s3h3f3fh", raw[:38])
+    assert hdr[-1] == 2 and struct.unpack("<h", raw[238:240])[0] == 3           # n_scalars @36, n_properties @238
+    body = np.frombuffer(raw, np.float32, offset=1000)
+    # first line by hand: npts, then (x, y, z, s1, s2) per point, then 3 properties
+    assert body[:1].view(np.int32)[0] == 3
+    rec = body[1:1 + 15].reshape(3, 5)
+    want = ((xyz[:3].astype(np.float64) + 0.5) * np.array([2.0, 1.0, 0.5])).astype(np.float32)
+    assert np.array_equal(rec[:, :3], want) and np.array_equal(rec[:, 3:], sc[:3])
+    assert np.array_equal(body[16:19], pr[0])
+    assert body[19:20].view(np.int32)[0] == 1                                   # second line starts right after
+    back = fj.trk_read(f)
+    assert np.array_equal(back.npts, npts) and np.array_equal(back.scalars, sc) and np.array_equal(back.properties, pr)
+    np.testing.assert_allclose(back.xyz, xyz, atol=1e-6)
+    # one scalar per point (LCM runs): 1-D in, 1-D out
+    tr1 = fj.Tract(xyz=xyz, npts=npts, volsize=(4, 5, 6), volres=ref.volres, vox2ras=ref.vox2ras, scalars=sc[:, 0].copy())
+    assert fj.trk_write(tr1, f, ref) is False
+    b1 = fj.trk_read(f)
+    assert b1.scalars.shape == (8,) and np.array_equal(b1.scalars, sc[:, 0]) and b1.properties is None
+
+
 @pytest.mark.gpu
 def test_gpu_trk_serialiser_matches_host(fj, tmp_path):
     import torch

@@ -1,0 +1,167 @@
+"""The host-buffer tier (fibers_hip.h: fib_init / fib_* with FIB_DEVICE_ALL): slab sharding over a device set, the chunk
+pipeline, the plan cache and concurrent callers.  A 1-GPU box exercises the multi-worker paths with a device set that
+names device 0 more than once (two or three pipelines on one GPU); results must not depend on the device set or on the
+chunking (voxels are independent, gqi.jl:132-162; odfmax is a maximum, gqi.jl:164; seeds are independent,
+stream.jl:764-767)."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _gqi_case(fj, shape=(22, 18, 14), seed=3):
+    from fibers_jl_amd import phantom
+    bval, bvec = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3)
+    dwi, _, _ = phantom.make_volume(shape, bval, bvec, seed=seed, crossing=True)
+    rng = np.random.default_rng(seed)
+    mask = (rng.random(shape) < 0.8).astype(np.uint8)
+    return fj.MRI(dwi, bval, bvec), fj.MRI(np.asfortranarray(mask))
+
+
+def _same_gqi(a, b):
+    assert np.array_equal(a.odf.vol, b.odf.vol)
+    for k in range(3):
+        assert np.array_equal(a.peak[k].vol, b.peak[k].vol)
+        assert np.array_equal(a.qa[k].vol, b.qa[k].vol, equal_nan=True)
+
+
+def test_gqi_device_set_and_chunking_do_not_change_results(fj, orc, monkeypatch):
+    dwi, mask = _gqi_case(fj)
+    one = fj.gqi_rec(dwi, mask)                                  # one worker, one chunk
+    ref = orc.gqi_rec(dwi.vol, mask.vol[..., 0], dwi.bval, dwi.bvec, fj.sphere_642.vertices, fj.sphere_642.faces, 1.25, nthreads=4)
+    assert np.abs(one.odf.vol - ref["odf"]).max() <= 2e-5 * np.abs(ref["odf"]).max()
+    try:
+        monkeypatch.setenv("FIBERS_HOST_CHUNK", "1024")          # 6 chunks per call, ragged last chunk
+        _same_gqi(fj.gqi_rec(dwi, mask), one)
+        fj.init([0, 0, 0])                                       # three slabs, three host threads, one GPU
+        _same_gqi(fj.gqi_rec(dwi, mask, device=fj.DEVICE_ALL), one)
+        monkeypatch.delenv("FIBERS_HOST_CHUNK")
+        fj.init([0, 0])
+        _same_gqi(fj.gqi_rec(dwi, mask, device=fj.DEVICE_ALL), one)
+    finally:
+        fj.shutdown()
+
+
+def test_dti_and_dsi_over_a_device_set(fj, monkeypatch):
+    from fibers_jl_amd import phantom
+    shape = (13, 11, 9)
+    b2, g2 = phantom.scheme_dti(30, 3, 1000.0, seed=2)
+    d2, _, _ = phantom.make_volume(shape, b2, g2, seed=5, nonpositive_frac=0.01)
+    mask = fj.MRI(np.ones(shape, np.uint8))
+    one = fj.dti_fit(fj.MRI(d2, b2, g2), mask)
+    a1, s1 = fj.adc_fit(fj.MRI(d2, b2, g2), mask)
+    b5, g5 = phantom.scheme_dsi()
+    d5, _, _ = phantom.make_volume((6, 5, 4), b5, g5, seed=5)
+    m5 = fj.MRI(np.ones((6, 5, 4), np.uint8))
+    dsi1 = fj.dsi_rec(fj.MRI(d5, b5, g5), m5)
+    try:
+        monkeypatch.setenv("FIBERS_HOST_CHUNK", "1024")
+        fj.init([0, 0])
+        two = fj.dti_fit(fj.MRI(d2, b2, g2), mask, device=fj.DEVICE_ALL)
+        for k in fj.dti.DTI_FIELDS:
+            assert np.array_equal(getattr(one, k).vol, getattr(two, k).vol, equal_nan=True), k
+        a2, s2 = fj.adc_fit(fj.MRI(d2, b2, g2), mask, device=fj.DEVICE_ALL)
+        assert np.array_equal(a1.vol, a2.vol, equal_nan=True) and np.array_equal(s1.vol, s2.vol, equal_nan=True)
+        dsi2 = fj.dsi_rec(fj.MRI(d5, b5, g5), m5, device=fj.DEVICE_ALL)
+        assert np.array_equal(dsi1.pdf.vol, dsi2.pdf.vol) and np.array_equal(dsi1.odf.vol, dsi2.odf.vol)
+        for k in range(3):
+            assert np.array_equal(dsi1.peak[k].vol, dsi2.peak[k].vol) and np.array_equal(dsi1.qa[k].vol, dsi2.qa[k].vol, equal_nan=True)
+    finally:
+        fj.shutdown()
+
+
+def test_stream_sharded_over_a_device_set_keeps_the_reference_order(fj, orc):
+    from fibers_jl_amd import phantom
+    n = 14
+    ov = np.asfortranarray(phantom.fibre_field(n, n, n).astype(np.float32))
+    m = np.asfortranarray(phantom.ball_mask(n, n, n, radius=5.5))
+    sub = fj.make_sublist(3, np.random.default_rng(2))
+    one = fj.stream(fj.MRI(ov), mask=fj.MRI(m), sublist=sub)
+    ref = orc.stream(ov, sub, mask=m, nthreads=2)
+    assert np.array_equal(one.npts, ref["npts"]) and np.array_equal(one.xyz, ref["xyz"])
+    try:
+        fj.init([0, 0, 0])
+        three = fj.stream(fj.MRI(ov), mask=fj.MRI(m), sublist=sub, device=fj.DEVICE_ALL)
+    finally:
+        fj.shutdown()
+    assert np.array_equal(three.npts, one.npts) and np.array_equal(three.seed_index, one.seed_index)
+    assert np.array_equal(three.xyz, one.xyz)
+
+
+def test_concurrent_callers_on_two_workers_and_on_one(fj):
+    """two host threads, each with its own plan and pipeline (calls on different workers run concurrently; calls that
+    share a worker are serialised by the library): every result equals the single-threaded one"""
+    from fibers_jl_amd import _lib
+    dwi_a, mask_a = _gqi_case(fj, seed=3)
+    dwi_b, mask_b = _gqi_case(fj, shape=(16, 20, 12), seed=9)
+    want_a, want_b = fj.gqi_rec(dwi_a, mask_a), fj.gqi_rec(dwi_b, mask_b)
+    got, errs = {}, []
+
+    def run(tag, dwi, mask, reps):
+        try:
+            for _ in range(reps):
+                got[tag] = fj.gqi_rec(dwi, mask)
+        except Exception as e:                       # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=run, args=("a", dwi_a, mask_a, 3)), threading.Thread(target=run, args=("b", dwi_b, mask_b, 3))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    _same_gqi(got["a"], want_a)
+    _same_gqi(got["b"], want_b)
+    # device-resident tier: two plans on two streams from two threads
+    import torch
+    from fibers_jl_amd import phantom
+    dev = torch.device("cuda", 0)
+    bval, bvec = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3)
+    vols = [phantom.make_dwi_torch((20, 16, 12), bval, bvec, seed=s, device=dev)[0] for s in (1, 2)]
+    nvox = vols[0].shape[1]
+    mask = torch.ones(nvox, dtype=torch.uint8, device=dev)
+    plans = [fj.OdfPlan("gqi", bval, bvec, fj.sphere_642) for _ in range(2)]
+    want = [fj.odf_rec_device(plans[i], vols[i], mask) for i in range(2)]
+    torch.cuda.synchronize()
+    want = [{k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in w.items()} for w in want]
+    res = [None, None]
+
+    def run_dev(i):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            for _ in range(5):
+                res[i] = fj.odf_rec_device(plans[i], vols[i], mask, stream=st)
+            st.synchronize()
+        except Exception as e:                       # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=run_dev, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for i in range(2):
+        assert torch.equal(res[i]["odf"], want[i]["odf"]) and torch.equal(res[i]["odfmax"], want[i]["odfmax"])
+        for k in range(3):
+            assert torch.equal(res[i]["peak"][k], want[i]["peak"][k]) and torch.equal(res[i]["qa"][k], want[i]["qa"][k])
+    assert _lib.lib().fib_last_error() is not None
+
+
+def test_errors_come_back_as_codes_not_exceptions(fj):
+    """invalid arguments through the multi-worker path: a status code and a message from the worker thread, the process
+    lives on (no C++ exception crosses the ABI)"""
+    import ctypes as C
+    from fibers_jl_amd import _lib
+    dwi, mask = _gqi_case(fj)
+    L = _lib.lib()
+    try:
+        fj.init([0, 0])
+        with pytest.raises(fj.FibersError) as ei:                # tessellation with an odd vertex count: plan creation fails in the workers
+            odd = fj.ODF(fj.sphere_642.vertices[:-1], fj.sphere_642.faces)
+            fj.gqi_rec(dwi, mask, odf_dirs=odd, device=fj.DEVICE_ALL)
+        assert "tessellation" in str(ei.value)
+        bad = np.array([7], np.int32)
+        assert L.fib_init(1, bad.ctypes.data) == -2              # FIB_ERR_NO_DEVICE
+        assert b"not available" in L.fib_last_error()
+        rc = L.fib_gqi_rec(0, None, 2, 2, 2, 3, None, 0, None, None, None, 0, None, 0, C.c_float(1.25), None, _lib.P3(), _lib.P3())
+        assert rc < 0
+    finally:
+        fj.shutdown()
+    _same_gqi(fj.gqi_rec(dwi, mask), fj.gqi_rec(dwi, mask))      # still works afterwards
