@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the MI355X back end (contract: see the task description / DESIGN.md §Measurement).
+"""bench.py — headline benchmark of the MI355X back end (contract: the task description / DESIGN.md §3).
 
-Metric (BASELINE.json): Mvoxels/s (fit) + Mpoints/s (streamline) on a synthetic 140^3 x 270-direction
-HCP-like volume.  A "step" = one pass of the GQI reconstruction hot path (ODF GEMM on FP32 MFMA + ODF peak
-finder + global QA normalisation; gqi.jl:109-171) over one resident 140^3 x 270 volume per rank; `value` is
-whole-job Mvoxels/s with inputs already in HBM.  The same JSON line carries the DTI fit (140^3 x 64) and the
-streamline tracker (DTI-like field, ball mask, ~1 M seeds) as `extra`, the roofline of the dominant kernel
-and the CPU baseline (the oracle = C restatement of the reference CPU path, bounded sample).
+Metric (BASELINE.json): Mvoxels/s (fit) + Mpoints/s (streamline) on a synthetic 140^3 x 270-direction HCP-like volume
+at 1/2/4/8 GPUs.  A "step" = one pass of the GQI hot path (gqi.jl:109-171: ODF contraction on the matrix cores with
+find_peaks! fused into its epilogue, exact odfmax, QA normalisation) over ONE resident 140^3 x 270 volume.
 
-N>1: one process per GPU (torch.distributed, backend nccl == RCCL); every rank reconstructs its own volume
-(weak scaling; voxels are independent) and the only exchange step of the path — odfmax = max over all
-voxels of mean(odf) (gqi.jl:164) — is a 1-float all-reduce(MAX) inside the timed region."""
+N GPUs (one process per GPU, torch.distributed, backend nccl == RCCL over xGMI): the volume is cut into contiguous
+z-slabs as the reference threads its z loop (gqi.jl:132); every rank reconstructs its slab; the path's only exchange
+step, odfmax = maximum(mean(odf, dims=4)) (gqi.jl:164), is a 2-float all-reduce(MAX) inside the timed region, then qa ./=
+odfmax on every rank.  Strong scaling: the total work is fixed.  `value` is whole-job Mvoxels/s with inputs in HBM.
+`extra` carries, at every N: the DTI fit (140^3 x 64, slabs), streamline tracking (DTI field all-gathered from the slabs
+over RCCL inside the timed step, seeds round-robin) and the weak-scaling GQI figure (one whole volume per rank); at N = 1
+also DSI + 3-peak tracking, the microscopy / LCM modes, RUMBA-SD, the PCIe-inclusive host-tier call and CPU baselines."""
 import argparse
 import json
 import os
@@ -35,8 +36,18 @@ def prof_get(L, name):
     return ms.value, n.value
 
 
+# ---- CPU baselines: the oracle (C/OpenMP restatement of the reference's CPU path with its z-slice / seed-chunk threading) on
+# the box's host cores, bounded samples of the same workloads -----------------------------------------------------------------------
+def _slab_baseline(run, label, cores, target_s, unit_per_slice):
+    t_probe = run(cores)
+    nz = int(max(cores, min(SHAPE[2], round(target_s / max(t_probe, 1e-3)) * cores)))
+    nz = min(SHAPE[2], nz)
+    t = run(nz) if nz != cores else t_probe
+    return dict(value=unit_per_slice * nz / t / 1e6, unit="Mvoxels/s", cores=cores, kind="port",
+                sample="%s on a %dx%dx%d slab, %.1f s" % (label, SHAPE[0], SHAPE[1], nz, t))
+
+
 def cpu_baseline_gqi(bval, bvec, sph, seed, target_s=15.0):
-    """the oracle (C restatement of the reference CPU path, z-slice threading) on a bounded z-slab"""
     from oracle import oracle as orc
     from fibers_jl_amd import phantom
     cores = orc.max_threads()
@@ -48,18 +59,64 @@ def cpu_baseline_gqi(bval, bvec, sph, seed, target_s=15.0):
         t0 = time.perf_counter()
         orc.gqi_rec(dwi, mask, bval, bvec, sph.vertices, sph.faces, 1.25, nthreads=cores)
         return time.perf_counter() - t0
+    return _slab_baseline(run, "gqi_rec oracle (C/OpenMP restatement of gqi.jl:109-171, z-slice threads), %d frames" % len(bval),
+                          cores, target_s, nx * ny)
 
-    t_probe = run(cores)                                 # one slice per thread
-    nz = int(max(cores, min(SHAPE[2], round(cores * target_s / max(t_probe, 1e-3) / cores) * cores)))
-    t = run(nz)
-    reps = 1
-    while nz == SHAPE[2] and t * reps < target_s and reps < 8:      # the whole volume is short of the sample: repeat it
-        t = min(t, run(nz)) if False else (t * reps + run(nz)) / (reps + 1)
-        reps += 1
-    nvox = nx * ny * nz
-    return dict(value=nvox / t / 1e6, unit="Mvoxels/s", cores=cores, kind="port",
-                sample="gqi_rec oracle (C/OpenMP restatement of gqi.jl:109-171, z-slice threads) on a %dx%dx%d x %d-frame slab, "
-                       "%d pass(es), %.1f s each" % (nx, ny, nz, len(bval), reps, t))
+
+def cpu_baseline_dti(bval, bvec, target_s=5.0):
+    from oracle import oracle as orc
+    from fibers_jl_amd import phantom
+    cores = orc.max_threads()
+    nx, ny = SHAPE[0], SHAPE[1]
+
+    def run(nz):
+        dwi, _, _ = phantom.make_volume((nx, ny, nz), bval, bvec, 2)
+        mask = np.ones((nx, ny, nz), np.uint8)
+        t0 = time.perf_counter()
+        orc.dti_fit(dwi, mask, bval, bvec, nthreads=cores)
+        return time.perf_counter() - t0
+    return _slab_baseline(run, "dti_fit oracle (dti.jl:221-335), %d frames" % len(bval), cores, target_s, nx * ny)
+
+
+def cpu_baseline_dsi(bval, bvec, sph, target_s=8.0):
+    from oracle import oracle as orc
+    from fibers_jl_amd import phantom
+    cores = orc.max_threads()
+    nx, ny = SHAPE[0], SHAPE[1]
+
+    def run(nz):
+        dwi, _, _ = phantom.make_volume((nx, ny, nz), bval, bvec, 5)
+        mask = np.ones((nx, ny, nz), np.uint8)
+        t0 = time.perf_counter()
+        orc.dsi_rec(dwi, mask, bval, bvec, sph.vertices, sph.faces, 32, nthreads=cores)
+        return time.perf_counter() - t0
+    return _slab_baseline(run, "dsi_rec oracle (dsi.jl:171-270: 16^3 FFT + trilinear radial integration per voxel), %d frames" % len(bval),
+                          cores, target_s, nx * ny)
+
+
+def cpu_baseline_stream(target_s=5.0):
+    """tracking on the analytic fibre field, ball mask, one sub-voxel offset: a z-range of seeds of the full 140^3 field"""
+    from oracle import oracle as orc
+    from fibers_jl_amd import phantom
+    cores = orc.max_threads()
+    ov = np.asfortranarray(phantom.fibre_field(*SHAPE).astype(np.float32))
+    mask = phantom.ball_mask(*SHAPE)
+    sub = np.array([[0.1, -0.2, 0.3]], np.float32)
+
+    def run(nzs):
+        seed = np.zeros(SHAPE, np.uint8, order="F")
+        z0 = SHAPE[2] // 2 - nzs // 2
+        seed[:, :, z0:z0 + nzs] = mask[:, :, z0:z0 + nzs]
+        t0 = time.perf_counter()
+        r = orc.stream(ov, sub, mask=mask, seed=seed, nthreads=cores)
+        return time.perf_counter() - t0, int(r["xyz"].shape[0]), int(seed.sum())
+    t, npnt, ns = run(2)
+    nzs = int(max(2, min(SHAPE[2], round(2 * target_s / max(t, 1e-3)))))
+    if nzs > 2:
+        t, npnt, ns = run(nzs)
+    return dict(value=npnt / t / 1e6, unit="Mpoints/s", cores=cores, kind="port",
+                sample="stream oracle (stream.jl:625-790, contiguous seed chunks per thread) from %d seeds (%d z-slices of the ball mask) "
+                       "of the 140^3 field, %d points, %.1f s" % (ns, nzs, npnt, t))
 
 
 def main():
@@ -79,6 +136,7 @@ def main():
     # test hook (1-GPU box): FIBERS_BENCH_BACKEND=gloo FIBERS_BENCH_ONE_DEVICE=1 runs N ranks on cuda:0 over gloo, to
     # exercise the multi-rank control flow where RCCL cannot be used (it refuses two ranks on one device)
     backend = os.environ.get("FIBERS_BENCH_BACKEND", "nccl")
+    shape = tuple(int(v) for v in os.environ.get("FIBERS_BENCH_SHAPE", "140,140,140").split(","))   # (tests shrink the volume)
     if os.environ.get("FIBERS_BENCH_ONE_DEVICE"):
         local = 0
     if world > 1:
@@ -93,26 +151,16 @@ def main():
     dev = torch.device("cuda", local if world > 1 else 0)
 
     import fibers_jl_amd as fj
-    from fibers_jl_amd import phantom
+    from fibers_jl_amd import dist as fd, phantom
     L = fj.lib()
-    nvox = SHAPE[0] * SHAPE[1] * SHAPE[2]
+    nx, ny, nz = shape
+    nxy = nx * ny
+    nvox = nxy * nz
     sph = fj.sphere_642
-
-    # ---- headline: GQI + peaks, 140^3 x 270 ------------------------------------------------------
-    bval, bvec = phantom.scheme_gqi()
-    dwi, axes = phantom.make_dwi_torch(SHAPE, bval, bvec, seed=3 + rank, device=dev)
-    mask = torch.ones(nvox, dtype=torch.uint8, device=dev)
-    plan = fj.OdfPlan("gqi", bval, bvec, sph, sigma=1.25, device=dev.index)
-    out = fj.odf_rec_device(plan, dwi, mask, normalize=False)
-
-    def gqi_step():
-        if world == 1:                                                     # one volume, one GPU: qa ./= odfmax inside the library call
-            fj.odf_rec_device(plan, dwi, mask, out=out, normalize=True)
-            return
-        fj.odf_rec_device(plan, dwi, mask, out=out, normalize=False)
-        if world > 1:
-            dist.all_reduce(out["odfmax"][:1], op=dist.ReduceOp.MAX)      # gqi.jl:164 across ranks
-        fj.qa_normalize_device(out["qa"], out["odfmax"])                   # qa ./= the all-reduced odfmax, read on the device
+    z0, z1 = fd.slab_bounds(nz, world, rank)
+    v0, v1 = z0 * nxy, z1 * nxy
+    nloc = v1 - v0
+    counts = [(b - a) * nxy for a, b in (fd.slab_bounds(nz, world, r) for r in range(world))]
 
     def sync():
         torch.cuda.synchronize()
@@ -120,51 +168,77 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        gqi_step()
-    sync()
-    L.fib_profile_enable(1)
-    L.fib_profile_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gqi_step()
-    sync()
-    dt = time.perf_counter() - t0
-    L.fib_profile_enable(0)
+    def timed(fn, steps, warmup):
+        """W untimed steps, then K steps bracketed by barrier + synchronize; max over ranks"""
+        for _ in range(warmup):
+            fn()
+        sync()
+        L.fib_profile_enable(1)
+        L.fib_profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        sync()
+        dt = time.perf_counter() - t0
+        L.fib_profile_enable(0)
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    # ---- headline: GQI + peaks, ONE 140^3 x 270 volume, z-slabs over the ranks --------------------------------------------
+    bval, bvec = phantom.scheme_gqi()
+    nvol, nvert = len(bval), sph.nvert
+    dwi_full, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=3, device=dev)      # the same volume on every rank
+    dwi = dwi_full[:, v0:v1].contiguous() if world > 1 else dwi_full
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        del dwi_full
+        torch.cuda.empty_cache()
+    mask = torch.ones(nloc, dtype=torch.uint8, device=dev)
+    plan = fj.OdfPlan("gqi", bval, bvec, sph, sigma=1.25, device=dev.index)
+    out = fj.odf_rec_device(plan, dwi, mask, normalize=False)
+
+    def gqi_step():
+        if world == 1:                                                     # one GPU: qa ./= odfmax inside the library call
+            fj.odf_rec_device(plan, dwi, mask, out=out, normalize=True)
+        else:                                                              # slab + all-reduce(MAX) of {odfmax, NaN flag} + qa ./= odfmax
+            fd.odf_rec_sharded(plan, dwi, mask, out=out)
+
+    dt = timed(gqi_step, args.steps, args.warmup)
     gemm_ms, gemm_n = prof_get(L, "odf_gemm")
     peaks_ms, peaks_n = prof_get(L, "odf_peaks")
-    value = world * nvox * args.steps / dt / 1e6
+    refine_ms, refine_n = prof_get(L, "odfmax_refine")
+    value = nvox * args.steps / dt / 1e6
 
-    nvert, nvol = sph.nvert, len(bval)
-    flops = 2.0 * nvert * nvol * nvox                      # algorithmic: 173 340 flop/voxel
+    fused = os.environ.get("FIBERS_ODF_UNFUSED") is None and os.environ.get("FIBERS_ODF_GEMM", "bf16x3").lower() != "f32"
+    flops = 2.0 * nvert * nvol * nloc                      # algorithmic: 173 340 flop/voxel (SURVEY §8d), this rank's voxels per launch
     gemm_avg_ms = gemm_ms / max(gemm_n, 1)
     achieved = flops / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0
-    gemm_bytes = (4.0 * nvol + 1 + 4.0 * nvert) * nvox     # read DWI + mask, write ODF
+    gemm_bytes = (4.0 * nvol + 1 + 4.0 * nvert + (48 if fused else 0)) * nloc   # read DWI + mask, write ODF (+ peaks and qa when fused)
     split = os.environ.get("FIBERS_ODF_GEMM", "bf16x3").lower() != "f32"
     hbm2 = dict(achieved=gemm_bytes / (gemm_avg_ms * 1e-3) / 1e9 if gemm_n else 0.0, peak=PEAK_HBM_GBS, unit="GB/s",
                 algorithmic_bytes=gemm_bytes, frac=gemm_bytes / (gemm_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if gemm_n else 0.0)
-    pk = dict(avg_kernel_ms=peaks_ms / max(peaks_n, 1),
-              hbm_gbs=(4.0 * nvert + 48) * nvox / (peaks_ms / max(peaks_n, 1) * 1e-3) / 1e9 if peaks_n else 0.0)
+    pk = dict(avg_kernel_ms=peaks_ms / max(peaks_n, 1), refine_ms=refine_ms / max(refine_n, 1),
+              note="fused: what is left outside the contraction kernel (redo list + exact odfmax)" if fused else "separate peak kernel (ODF re-read)")
     if split:
         # every f32 product = 6 exact bf16 piece products -> the matrix cores execute 6 x the algorithmic flops (320 of the
         # 321 rows; K padded 270 -> 272); the binding roof is the BF16 MFMA peak / 6 for the algorithmic f32 flops
         peak_eff = PEAK_BF16_TFLOPS / 6.0
-        roofline = dict(bound="mfma", kernel="odf_gemm3_kernel<MB=10,NX=1,NW=8> (v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 splits "
-                                             "of both f32 operands: 6 piece products per f32 product; 320 rows on MFMA + 1 row on VALU)",
+        roofline = dict(bound="mfma", kernel="odf_gemm3_kernel<MB=10,NX=1,NW=8%s> (v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 splits of both f32 "
+                                             "operands: 6 piece products per f32 product; 320 rows on MFMA + 1 row on VALU%s)"
+                                             % (",FUSE" if fused else "", "; find_peaks! + peak/qa extraction on the accumulators" if fused else ""),
                         achieved=achieved, peak=peak_eff, unit="TFLOP/s", frac=achieved / peak_eff,
-                        note="achieved = algorithmic f32 flops (2*321*270 per voxel) / kernel time; peak = 2500 TFLOP/s dense BF16 / 6 piece "
-                             "products; executed BF16 MFMA rate = %.0f TFLOP/s of 2500" % (6.0 * 2.0 * 320 * 272 * nvox / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0),
+                        note="achieved = algorithmic f32 flops (2*321*270 per voxel) / kernel time (the fused kernel's time includes the peak finder); "
+                             "peak = 2500 TFLOP/s dense BF16 / 6 piece products; executed BF16 MFMA rate = %.0f TFLOP/s of 2500"
+                             % (6.0 * 2.0 * 320 * 272 * nloc / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0),
                         avg_kernel_ms=gemm_avg_ms, launches=gemm_n, traffic=None, hbm_secondary=hbm2, peaks_kernel=pk)
     else:
         roofline = dict(bound="mfma", kernel="odf_gemm_kernel<MB=10,NX=1> (v_mfma_f32_32x32x2_f32; 320 rows on MFMA + 1 row on VALU)", achieved=achieved,
                         peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_F32_TFLOPS,
                         avg_kernel_ms=gemm_avg_ms, launches=gemm_n, traffic=None, hbm_secondary=hbm2, peaks_kernel=pk)
     tr_file = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tr_file):
+    if os.path.exists(tr_file) and world == 1:
         try:
             roofline["traffic"] = json.load(open(tr_file)).get("odf_gemm_bytes_per_launch")
         except Exception:
@@ -172,84 +246,84 @@ def main():
 
     extra = {}
     if not args.no_extra:
-        # Every rank takes part (the ranks leave together).  C2: DTI fit, one 140^3 x 64 volume per rank (weak scaling, no
-        # exchange step).  C4: streamlines from ONE volume's principal eigenvector: rank 0's field is broadcast over
-        # RCCL/xGMI (the path's only bulk collective: 16 B/voxel), seeds shard round-robin, no data-path collective after.
-        del out, dwi
+        # ---- weak-scaling figure of the same step: one whole volume per rank, odfmax all-reduced -----------------------------
+        if world > 1:
+            del out, dwi
+            torch.cuda.empty_cache()
+            dwi_w, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=3 + rank, device=dev)
+            mask_w = torch.ones(nvox, dtype=torch.uint8, device=dev)
+            out_w = fj.odf_rec_device(plan, dwi_w, mask_w, normalize=False)
+            nst = max(2, args.steps // 2)
+            t_w = timed(lambda: fd.odf_rec_sharded(plan, dwi_w, mask_w, out=out_w), nst, 1)
+            extra["gqi_weak_scaling"] = dict(mvoxels_per_s=world * nvox * nst / t_w / 1e6, ms_per_step=t_w / nst * 1e3,
+                                             note="one whole 140^3 x 270 volume per rank, 2-float all-reduce(MAX) inside the step")
+            del dwi_w, out_w, mask_w
+        else:
+            del out, dwi
         torch.cuda.empty_cache()
+        # ---- C2: DTI fit, 140^3 x 64, z-slabs (no exchange step) --------------------------------------------------------------
         b2, g2 = phantom.scheme_dti(60, 4, 1000.0, seed=2)
-        d2, ax2 = phantom.make_dwi_torch(SHAPE, b2, g2, seed=2, device=dev, nfib=1)
+        d2f, _ = phantom.make_dwi_torch(shape, b2, g2, seed=2, device=dev, nfib=1)
+        d2 = d2f[:, v0:v1].contiguous() if world > 1 else d2f
+        del d2f
         p2 = fj.DtiPlan(b2, g2, device=dev.index)
         o2 = fj.dti_fit_device(p2, d2, mask)
-        sync()
-        L.fib_profile_enable(1); L.fib_profile_reset()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            fj.dti_fit_device(p2, d2, mask, out=o2)
-        sync()
-        t_dti = time.perf_counter() - t0
-        L.fib_profile_enable(0)
-        if world > 1:
-            tt = torch.tensor([t_dti], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t_dti = float(tt.item())
-        t_dti /= args.steps
+        t_dti = timed(lambda: fj.dti_fit_device(p2, d2, mask, out=o2), args.steps, 1) / args.steps
         k_ms, k_n = prof_get(L, "dti_fit")
-        dbytes = (4.0 * len(b2) + 1 + 64) * nvox
-        extra["dti_fit_140x64"] = dict(mvoxels_per_s=world * nvox / t_dti / 1e6, ms_per_step=t_dti * 1e3,
+        dbytes = (4.0 * len(b2) + 1 + 64) * nloc
+        extra["dti_fit_140x64"] = dict(mvoxels_per_s=nvox / t_dti / 1e6, ms_per_step=t_dti * 1e3,
                                        kernel_ms=k_ms / max(k_n, 1), algorithmic_bytes=dbytes,
                                        hbm_gbs=dbytes / (k_ms / max(k_n, 1) * 1e-3) / 1e9 if k_n else 0.0,
                                        hbm_frac=dbytes / (k_ms / max(k_n, 1) * 1e-3) / 1e9 / PEAK_HBM_GBS if k_n else 0.0,
-                                       note="one volume per rank; per-kernel figures are rank 0's")
-        # ---- streamlines from the DTI principal eigenvector, ball mask (C4) -----------------------
-        from fibers_jl_amd import dist as fd
-        bm = phantom.ball_mask_torch(SHAPE, dev)
-        field, mout = fj.stream_field_device([o2["eigvec1"]], fa=o2["fa"], fa_thresh=0.1, mask=bm)
+                                       note="one volume in z-slabs over the ranks; per-kernel figures are rank 0's slab")
+        # ---- C4: streamlines from the DTI principal eigenvector, ball mask: the slab's field is all-gathered over RCCL inside
+        # the timed step (the path's only bulk collective: 16 B/voxel), seeds round-robin, no collective after ----------------------
+        bm_full = phantom.ball_mask_torch(shape, dev)
+        field_loc, mout_loc = fj.stream_field_device([o2["eigvec1"]], fa=o2["fa"], fa_thresh=0.1, mask=bm_full[v0:v1].contiguous())
+        mout = fd.allgather_slabs(mout_loc, counts)
         seeds_all = torch.nonzero(mout).flatten()
         sub = torch.tensor([[0.1, -0.2, 0.3]], dtype=torch.float32, device=dev)
+        xyz_buf = {}
+
+        def xyz_out(npnt):                                                   # steady-state output buffer (no per-call allocation)
+            if xyz_buf.get("t") is None or xyz_buf["t"].numel() < 3 * npnt:
+                xyz_buf["t"] = torch.empty(int(3 * npnt * 1.05) + 16, dtype=torch.float32, device=dev)
+            return xyz_buf["t"]
+        res = {}
 
         def stream_step():
-            if world > 1:
-                dist.broadcast(field, src=0)                               # shared peak field over xGMI
-            seeds, _ = fd.shard_seeds(seeds_all, world, rank)
-            return fj.stream_device(field, SHAPE, seeds.contiguous(), sub)
-
-        res = stream_step()
-        sync()
-        L.fib_profile_enable(1); L.fib_profile_reset()
+            field = fd.allgather_slabs(field_loc, counts)                    # shared peak field over xGMI
+            res["r"] = fd.stream_sharded(field, shape, seeds_all, sub, xyz_out=xyz_out)
         nst = max(2, args.steps // 2)
-        t0 = time.perf_counter()
-        for _ in range(nst):
-            res = stream_step()
-        sync()
-        t_st = time.perf_counter() - t0
-        L.fib_profile_enable(0)
-        cnt = torch.tensor([float(res["xyz"].shape[0]), float(res["npts"].numel()), t_st], device=dev, dtype=torch.float64)
+        t_st = timed(stream_step, nst, 2)
+        r = res["r"]
+        cnt = torch.tensor([float(r["xyz"].shape[0]), float(r["npts"].numel())], device=dev, dtype=torch.float64)
         if world > 1:
-            tmax = cnt[2:].clone()
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dist.all_reduce(cnt[:2], op=dist.ReduceOp.SUM)
-            cnt[2] = tmax[0]
-        npoints, nlines, t_st = int(cnt[0].item()), int(cnt[1].item()), float(cnt[2].item()) / nst
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        npoints, nlines, t_st = int(cnt[0].item()), int(cnt[1].item()), t_st / nst
         tr_ms, tr_n = prof_get(L, "stream_trace")
         pk_ms, pk_n = prof_get(L, "stream_pack")
+        sc_ms, sc_n = prof_get(L, "stream_scan")
         extra["stream_dti_ball"] = dict(seeds=int(seeds_all.numel()), lines=nlines, points=npoints,
                                         mpoints_per_s=npoints / t_st / 1e6, ms_per_step=t_st * 1e3,
                                         trace_kernel_ms=tr_ms / max(tr_n, 1), pack_kernel_ms=pk_ms / max(pk_n, 1),
+                                        kernel_sum_ms=(tr_ms + pk_ms + sc_ms) / max(tr_n, 1),
                                         algorithmic_bytes=25.0 * npoints,
                                         hbm_gbs_trace=25.0 * (npoints / world) / (tr_ms / max(tr_n, 1) * 1e-3) / 1e9 if tr_n else 0.0,
-                                        note="one volume, seeds sharded round-robin over the ranks"
-                                             + (", field broadcast from rank 0 inside the timed step" if world > 1 else ""))
+                                        note="one volume; wall = field all-gather + trace + scan + pack into a pre-allocated buffer (+ one host sync for "
+                                             "the line count); seeds dealt round-robin over the ranks")
+        del res, r
         if world == 1:
+            field = field_loc
             # ---- microscopy regime (stream.jl:547-619) on the same field: every 8th seed, reference defaults ----------
             sm = seeds_all[::8].contiguous()
-            z1 = torch.zeros((1, 3), dtype=torch.float32, device=dev)
+            z1_ = torch.zeros((1, 3), dtype=torch.float32, device=dev)
             kw = dict(ang_thresh=20, step_size=1.0, smooth_coeff=0.0, search_dist=15, search_ang=10)
-            rm = fj.stream_device(field, SHAPE, sm, z1, **kw)
+            rm = fj.stream_device(field, shape, sm, z1_, **kw)
             torch.cuda.synchronize()
             L.fib_profile_enable(1); L.fib_profile_reset()
             t0 = time.perf_counter()
-            rm = fj.stream_device(field, SHAPE, sm, z1, **kw)
+            rm = fj.stream_device(field, shape, sm, z1_, **kw)
             torch.cuda.synchronize()
             t_m = time.perf_counter() - t0
             L.fib_profile_enable(0)
@@ -287,25 +361,24 @@ def main():
                                           trace_kernel_ms=lk_ms / max(lk_n, 1), flagged_fraction=float(rl["flags"].float().mean()),
                                           note="2048x2048x1 pixels, 3 orientations + one 10-element LCM per pixel, len_max 140")
             del rl, fld, lc, ov2, ang
-        if world == 1:
             # ---- RUMBA-SD (rusd.jl, row N4): 140^3 x 270 frames, ball mask, sphere_724 (364 compartments), 10 iterations ----
             torch.cuda.empty_cache()
             b4, g4 = phantom.scheme_gqi()
-            d4, _ = phantom.make_dwi_torch(SHAPE, b4, g4, seed=3, device=dev)
+            d4, _ = phantom.make_dwi_torch(shape, b4, g4, seed=3, device=dev)
             rp = fj.RumbaPlan(b4, g4, fj.sphere_724, device=dev.index)
-            fj.rumba_rec_device(rp, d4, bm, SHAPE, niter=2)
+            fj.rumba_rec_device(rp, d4, bm_full, shape, niter=2)
             torch.cuda.synchronize()
             L.fib_profile_enable(1); L.fib_profile_reset()
             nit = 10
             t0 = time.perf_counter()
-            rr = fj.rumba_rec_device(rp, d4, bm, SHAPE, niter=nit)
+            rr = fj.rumba_rec_device(rp, d4, bm_full, shape, niter=nit)
             torch.cuda.synchronize()
             t_r = time.perf_counter() - t0
             L.fib_profile_enable(0)
             gm_ms, gm_n = prof_get(L, "matrix_gemm")
             tv_ms, tv_n = prof_get(L, "rumba_tv")
             el_ms, el_n = prof_get(L, "rumba_elementwise")
-            nmask = int(bm.sum())
+            nmask = int(bm_full.sum())
             kk, _nd = rp.kernel().shape[1], rp.kernel().shape[0]
             extra["rumba_140_ball"] = dict(voxels=nmask, compartments=kk, dirs=_nd, iterations=nit, ms_total=t_r * 1e3,
                                            ms_per_iteration=(gm_ms + tv_ms + el_ms) / nit,
@@ -315,67 +388,98 @@ def main():
                                            snr_mean=rr["snr_mean"],
                                            note="three [364 x 253] contractions per iteration on the split-bf16 MFMA kernel; 600 iterations in the reference's default")
             del rr, d4, rp
-        del res, bm, seeds_all
+        del field_loc, mout_loc, seeds_all, o2, d2
 
     if not args.no_extra and rank == 0 and world == 1:
-        # ---- DSI 515-direction reconstruction + peaks (C5 fit part) ------------------------------------
-        del field, o2, d2
+        # ---- C5 fit part: DSI 515-direction reconstruction + peaks ---------------------------------------------------------------------
         torch.cuda.empty_cache()
         b5, g5 = phantom.scheme_dsi()
-        d5, _ = phantom.make_dwi_torch(SHAPE, b5, g5, seed=5, device=dev)
+        d5, _ = phantom.make_dwi_torch(shape, b5, g5, seed=5, device=dev)
         p5 = fj.OdfPlan("dsi", b5, g5, sph, hann_width=32, device=dev.index)
         o5 = fj.odf_rec_device(p5, d5, mask)
-        torch.cuda.synchronize()
-        L.fib_profile_enable(1); L.fib_profile_reset()
         nd = max(2, args.steps // 2)
-        t0 = time.perf_counter()
-        for _ in range(nd):
-            fj.odf_rec_device(p5, d5, mask, out=o5)
-        torch.cuda.synchronize()
-        t_dsi = (time.perf_counter() - t0) / nd
-        L.fib_profile_enable(0)
+        t_dsi = timed(lambda: fj.odf_rec_device(p5, d5, mask, out=o5), nd, 1) / nd
         g_ms, g_n = prof_get(L, "odf_gemm")
         f_ms, f_n = prof_get(L, "dsi_fold")
+        q_ms, q_n = prof_get(L, "odf_peaks")
         extra["dsi_rec_140x515"] = dict(mvoxels_per_s=nvox / t_dsi / 1e6, ms_per_step=t_dsi * 1e3,
-                                        gemm_kernel_ms=g_ms / max(g_n, 1), fold_kernel_ms=f_ms / max(f_n, 1),
+                                        gemm_kernel_ms=g_ms / max(g_n, 1), fold_kernel_ms=f_ms / max(f_n, 1), peaks_kernel_ms=q_ms / max(q_n, 1),
                                         note="antipodal folding inside the contraction kernel: 258 folded samples x (258 pdf + 321 odf) rows")
         # ---- C5 tracking: 3 peaks per voxel (f = qa, f_thresh = .03), ball mask, nsub = 10 -> ~10 M lines -------------
         del d5
-        bm = phantom.ball_mask_torch(SHAPE, dev)
-        field3, mout3 = fj.stream_field_device(o5["peak"], f=o5["qa"], f_thresh=0.03, mask=bm)
+        field3, mout3 = fj.stream_field_device(o5["peak"], f=o5["qa"], f_thresh=0.03, mask=bm_full)
         seeds3 = torch.nonzero(mout3).flatten()
         sub10 = torch.from_numpy(fj.make_sublist(10, np.random.default_rng(5))).to(dev)
-        r3 = fj.stream_device(field3, SHAPE, seeds3, sub10)
-        torch.cuda.synchronize()
-        L.fib_profile_enable(1); L.fib_profile_reset()
-        t0 = time.perf_counter()
-        for _ in range(2):
-            r3 = fj.stream_device(field3, SHAPE, seeds3, sub10)
-        torch.cuda.synchronize()
-        t3 = (time.perf_counter() - t0) / 2
-        L.fib_profile_enable(0)
+        xyz_buf.clear()
+        r3 = {}
+
+        def c5_step():
+            r3["r"] = fj.stream_device(field3, shape, seeds3, sub10, xyz_out=xyz_out)
+        t3 = timed(c5_step, 3, 2) / 3
         tr_ms, tr_n = prof_get(L, "stream_trace")
         pk_ms, pk_n = prof_get(L, "stream_pack")
-        np3 = int(r3["xyz"].shape[0])
-        extra["stream_dsi_3peaks_10M"] = dict(seeds=int(seeds3.numel()), nsub=10, lines=int(r3["npts"].numel()), points=np3,
+        sc_ms, sc_n = prof_get(L, "stream_scan")
+        np3 = int(r3["r"]["xyz"].shape[0])
+        extra["stream_dsi_3peaks_10M"] = dict(seeds=int(seeds3.numel()), nsub=10, lines=int(r3["r"]["npts"].numel()), points=np3,
                                               mpoints_per_s=np3 / t3 / 1e6, ms_per_step=t3 * 1e3,
                                               trace_kernel_ms=tr_ms / max(tr_n, 1), pack_kernel_ms=pk_ms / max(pk_n, 1),
-                                              algorithmic_bytes=49.0 * np3)
+                                              kernel_sum_ms=(tr_ms + pk_ms + sc_ms) / max(tr_n, 1), algorithmic_bytes=49.0 * np3,
+                                              note="wall = trace + scan + pack into a pre-allocated 15-GB buffer (+ npts / seed_index allocation and one "
+                                                   "host sync for the line count); kernel_sum = device time of the three kernels")
         del o5, r3, field3
+        torch.cuda.empty_cache()
+        # ---- the boundary a Julia caller pays for: fib_gqi_rec on host arrays (PCIe both ways, SURVEY §8d "report both") ------------
+        try:
+            import ctypes as C
+            from fibers_jl_amd import _lib
+            dh, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=3, device=dev)
+            host = np.ascontiguousarray(dh.cpu().numpy())                                  # [nvol, nvox] planar == MRI.vol memory
+            del dh
+            torch.cuda.empty_cache()
+            m8 = np.ones(nvox, np.uint8)
+            v = np.asfortranarray(sph.vertices, np.float32); f = np.asfortranarray(sph.faces, np.int32)
+            bv = np.ascontiguousarray(bval, np.float32); bg = np.asfortranarray(np.asarray(bvec, np.float32))
+            odf_h = np.ones((nvert, nvox), np.float32)
+            pk_h = [np.ones((3, nvox), np.float32) for _ in range(3)]
+            qa_h = [np.ones(nvox, np.float32) for _ in range(3)]
+
+            def call():
+                return L.fib_gqi_rec(0, host.ctypes.data, nx, ny, nz, nvol, m8.ctypes.data, 0, bv.ctypes.data, bg.ctypes.data,
+                                     v.ctypes.data, v.shape[0], f.ctypes.data, f.shape[0], 1.25, odf_h.ctypes.data,
+                                     _lib.P3(*[a.ctypes.data for a in pk_h]), _lib.P3(*[a.ctypes.data for a in qa_h]))
+            ts = []
+            for _ in range(4):
+                t0 = time.perf_counter()
+                _lib.check(call())
+                ts.append(time.perf_counter() - t0)
+            gb = (host.nbytes + odf_h.nbytes + sum(a.nbytes for a in pk_h + qa_h)) / 1e9
+            extra["gqi_host_tier"] = dict(e2e_pcie_ms=min(ts[1:]) * 1e3, mvoxels_per_s=nvox / min(ts[1:]) / 1e6, link_gbs=gb / min(ts[1:]),
+                                          bytes_over_link=gb * 1e9,
+                                          note="fib_gqi_rec on pageable host arrays (the call a Julia wrapper makes): gather -> pinned ring -> H2D || kernels "
+                                               "|| D2H -> scatter, outputs pre-touched; PCIe Gen5 x16, both directions busy")
+            del host, odf_h, pk_h, qa_h
+        except Exception as e:                                                              # noqa: BLE001
+            extra["gqi_host_tier"] = dict(error=str(e))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_gqi(bval, bvec, sph, seed=3)
+        if not args.no_extra:
+            b2, g2 = phantom.scheme_dti(60, 4, 1000.0, seed=2)
+            b5, g5 = phantom.scheme_dsi()
+            extra["cpu_baselines"] = dict(dti_fit=cpu_baseline_dti(b2, g2), dsi_rec=cpu_baseline_dsi(b5, g5, sph), stream=cpu_baseline_stream(),
+                                          note="the oracle (C/OpenMP restatement of the reference's CPU path, the reference's own decomposition) on this box's "
+                                               "host cores; Julia itself cannot run here")
 
     if rank == 0:
         line = dict(metric="Mvoxels/s fit (GQI ODF + peaks, 140^3 x 270-dir); Mpoints/s streamline in extra",
                     value=value, unit="Mvoxels/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                    ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+                    ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None,
                     dtype="f32" if not split else "f32 (exact 3xbf16 operand splits on the bf16 matrix cores, f32 accumulate)", data="synthetic",
-                    config=dict(workload="gqi_rec + find_peaks + qa normalisation, 140x140x140 x 270 frames "
-                                         "(18 x b=5 + 84 dirs x {1000,2000,3000}), sphere_642, mask = all ones, "
-                                         "one volume per GPU", voxels_per_gpu=nvox, frames=nvol, odf_vertices=nvert,
-                                parallelism="volumes sharded over ranks, 1-float all-reduce(MAX)" if world > 1 else "single GPU"),
+                    config=dict(workload="gqi_rec + find_peaks + qa normalisation, ONE %dx%dx%d x 270-frame volume "
+                                         "(18 x b=5 + 84 dirs x {1000,2000,3000}), sphere_642, mask = all ones" % shape,
+                                voxels=nvox, voxels_per_gpu=nloc, frames=nvol, odf_vertices=nvert,
+                                parallelism="contiguous z-slabs over the ranks (gqi.jl:132), 2-float all-reduce(MAX) of odfmax (gqi.jl:164)" if world > 1 else "single GPU"),
                     roofline=roofline, cpu_baseline=cpu, extra=extra)
         print(json.dumps(line))
     if world > 1:

@@ -29,9 +29,10 @@ def slab_of_planar(vol, shape, z0, z1):
 
 
 def shard_seeds(seeds, world: int, rank: int):
-    """round-robin: global seed i -> rank i % world; returns (local seeds, global seed numbers)"""
-    idx = np.arange(rank, len(seeds), world) if isinstance(seeds, np.ndarray) else None
-    if idx is not None:
+    """round-robin: global seed i -> rank i % world; returns (local seeds, global seed numbers), NumPy in -> NumPy out,
+    torch in -> torch out (same device)"""
+    if isinstance(seeds, np.ndarray):
+        idx = np.arange(rank, len(seeds), world)
         return seeds[idx], idx
     import torch
     gi = torch.arange(rank, seeds.numel(), world, device=seeds.device)
@@ -55,20 +56,35 @@ def allreduce_odfmax(odfmax, group=None):
 
 def allgather_slabs(local, counts: Sequence[int], group=None):
     """local: [counts[rank], ...] slab (voxel-major, e.g. the float4 field [nvox_local, nvec, 4]); returns the
-    full volume [sum(counts), ...] on every rank.  Slabs may differ in size (nz % world != 0), so the
-    collective is a padded all_gather (== G broadcasts over xGMI)."""
+    full volume [sum(counts), ...] on every rank.  Slabs may differ in size (nz % world != 0): with RCCL the
+    collective is one padded all_gather (G simultaneous broadcasts over the xGMI links); backends without a device
+    all_gather (gloo on CUDA tensors, used by the 1-GPU tests) run the G broadcasts one after the other."""
     import torch
     import torch.distributed as dist
     if not (dist.is_initialized() and dist.get_world_size(group) > 1):
         return local
-    world = dist.get_world_size(group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     counts = [int(c) for c in counts]
-    assert local.shape[0] == counts[dist.get_rank(group)]
+    assert local.shape[0] == counts[rank]
+    full = local.new_empty((sum(counts),) + tuple(local.shape[1:]))
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    if local.is_cuda and dist.get_backend(group) != "nccl":
+        for r in range(world):
+            piece = full[offs[r]:offs[r + 1]]
+            if r == rank:
+                piece.copy_(local)
+            dist.broadcast(piece, src=dist.get_global_rank(group, r) if group is not None else r, group=group)
+        return full
+    if len(set(counts)) == 1:                                  # equal slabs: gather straight into the result
+        dist.all_gather_into_tensor(full, local.contiguous(), group=group)
+        return full
     pad = local.new_zeros((max(counts),) + tuple(local.shape[1:]))
     pad[: local.shape[0]] = local
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad, group=group)
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    for r in range(world):
+        full[offs[r]:offs[r + 1]] = bufs[r][:counts[r]]
+    return full
 
 
 def merge_tracts(parts: List[dict]) -> dict:
@@ -96,23 +112,26 @@ def gather_objects(obj, group=None):
 # ---------------------------------------------------------------------------------------------
 # sharded drivers (device tier)
 # ---------------------------------------------------------------------------------------------
-def odf_rec_sharded(plan, dwi_local, mask_local, group=None, stream=None):
-    """gqi_rec / dsi_rec on this rank's z-slab + the global QA normalisation across ranks."""
+def odf_rec_sharded(plan, dwi_local, mask_local, group=None, stream=None, out=None):
+    """gqi_rec / dsi_rec on this rank's z-slab + the global QA normalisation across ranks (gqi.jl:164-168): the slab's
+    {odfmax, NaN flag} pair is all-reduced with MAX, the divisor never leaves the device."""
     from .gqi import odf_rec_device, qa_normalize_device
-    import torch
-    out = odf_rec_device(plan, dwi_local, mask_local, normalize=False, stream=stream)
+    out = odf_rec_device(plan, dwi_local, mask_local, out=out, normalize=False, stream=stream)
     allreduce_odfmax(out["odfmax"], group)
-    qa_normalize_device(out["qa"], out["odfmax"], stream=stream)     # the divisor is read on the device: no host round trip
+    qa_normalize_device(out["qa"], out["odfmax"], stream=stream)
     return out
 
 
 def stream_sharded(field_full, shape, seeds_all, sublist, group=None, **kw):
-    """round-robin seed shard of stream_device; returns this rank's lines with GLOBAL seed_index."""
+    """round-robin seed shard of stream_device; returns this rank's lines with GLOBAL seed_index.  seeds_all: int64 CUDA
+    tensor (or NumPy array) of the whole seed list in the reference's findall order."""
     import torch
     import torch.distributed as dist
     from .stream import stream_device
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if isinstance(seeds_all, np.ndarray):
+        seeds_all = torch.from_numpy(np.ascontiguousarray(seeds_all, np.int64)).to(field_full.device)
     local, gi = shard_seeds(seeds_all, world, rank)
     res = stream_device(field_full, shape, local.contiguous(), sublist, **kw)
     nsub = sublist.shape[0]

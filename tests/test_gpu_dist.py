@@ -1,0 +1,111 @@
+"""Two ranks, DEVICE kernels (-m gpu): the multi-GPU flow of fibers.jl_amd/dist.py — z-slab fits, the odfmax all-reduce with its
+NaN flag, the all-gather of the slab-fitted orientation field, round-robin seed shards — against the single-rank result of the
+same kernels, bit for bit.  The box has one GPU, so both ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one
+device); the sharding code is the one bench.py and a multi-GPU host run with backend nccl."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fibers_jl_amd as fj
+        from fibers_jl_amd import dist as fd, phantom
+        dev = torch.device("cuda", 0)
+        shape = (24, 20, 13)                                   # nz = 13: ragged slabs
+        nx, ny, nz = shape
+        nxy, nvox = nx * ny, nx * ny * nz
+        bval, bvec = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3)
+        dwi, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=4, device=dev, noise_frac=0.05)
+        rng = np.random.default_rng(1)
+        mask = torch.from_numpy((rng.random(nvox) < 0.9).astype(np.uint8)).to(dev)
+        plan = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642)
+        z0, z1 = fd.slab_bounds(nz, world, rank)
+        v0, v1 = z0 * nxy, z1 * nxy
+        counts = [(b - a) * nxy for a, b in (fd.slab_bounds(nz, world, r) for r in range(world))]
+        for poison in (False, True):
+            d = dwi.clone()
+            if poison:
+                d[3, nvox - 5] = float("nan")                  # a NaN voxel in the LAST slab: the flag must reach every rank
+            full = fj.odf_rec_device(plan, d, mask, normalize=True)
+            torch.cuda.synchronize()
+            full = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in full.items()}
+            loc = fd.odf_rec_sharded(plan, d[:, v0:v1].contiguous(), mask[v0:v1].contiguous())
+            torch.cuda.synchronize()
+            assert torch.equal(loc["odfmax"].nan_to_num(nan=-7.0), full["odfmax"].nan_to_num(nan=-7.0)), (rank, poison, loc["odfmax"], full["odfmax"])
+            assert torch.equal(loc["odf"].nan_to_num(nan=-7.0), full["odf"][:, v0:v1].nan_to_num(nan=-7.0))
+            for k in range(3):
+                assert torch.equal(loc["peak"][k], full["peak"][k][:, v0:v1])
+                assert torch.equal(loc["qa"][k].nan_to_num(nan=-7.0), full["qa"][k][v0:v1].nan_to_num(nan=-7.0))
+            if poison:
+                assert float(loc["odfmax"][1]) == 1.0 and bool(torch.isnan(loc["odfmax"][0]))
+                continue
+            # ---- field from the slab's peaks, all-gathered; seeds round-robin; lines merged back into reference order ----
+            f_loc, m_loc = fj.stream_field_device(loc["peak"], f=loc["qa"], f_thresh=0.03, mask=mask[v0:v1].contiguous())
+            f_full, m_full = fj.stream_field_device(full["peak"], f=full["qa"], f_thresh=0.03, mask=mask)
+            field = fd.allgather_slabs(f_loc, counts)
+            mout = fd.allgather_slabs(m_loc, counts)
+            assert torch.equal(field, f_full) and torch.equal(mout, m_full)
+            seeds = torch.nonzero(mout).flatten()
+            sub = torch.from_numpy(fj.make_sublist(2, np.random.default_rng(3))).to(dev)
+            one = fj.stream_device(f_full, shape, seeds, sub, len_min=2)
+            mine = fd.stream_sharded(field, shape, seeds, sub, len_min=2)
+            parts = fd.gather_objects({k: v.cpu().numpy() for k, v in mine.items()})
+            merged = fd.merge_tracts(parts)
+            assert np.array_equal(merged["npts"], one["npts"].cpu().numpy())
+            assert np.array_equal(merged["seed_index"], one["seed_index"].cpu().numpy())
+            assert np.array_equal(merged["xyz"], one["xyz"].cpu().numpy())
+        q.put((rank, "ok"))
+    except Exception as e:                                     # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_with_device_kernels_match_one_rank_bit_for_bit():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=600) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_bench_multi_rank_control_flow_on_one_device():
+    """bench.py's N = 2 path (slabs, all-reduce, field all-gather, seed shards, max-over-ranks timing) end to end on a small volume"""
+    import json
+    import subprocess
+    env = dict(os.environ, FIBERS_BENCH_BACKEND="gloo", FIBERS_BENCH_ONE_DEVICE="1", FIBERS_BENCH_SHAPE="40,36,30")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["extra"]["stream_dti_ball"]["points"] > 0 and line["extra"]["gqi_weak_scaling"]["mvoxels_per_s"] > 0
