@@ -1,0 +1,193 @@
+"""Three-way check, CPU side: the C oracle (oracle/fibers_oracle.c, the checker of every GPU parity test)
+against the independent NumPy-Float32 restatement written from the reference's .jl files (oracle/oracle_np.py), on seeded
+small cases.  The two share no code and deliberately use different formulations (face masks vs neighbour lists for
+find_peaks!, LAPACK vs closed-form / Jacobi for eigen and pinv, Float64 matmul vs an fmaf chain for mul!), so what agrees here
+is the reference's algorithm, not one author's reading of it twice.  The reference itself (Julia) cannot run in this image and
+ships no golden vectors: parity stays unpinned, see DESIGN.md §5."""
+import numpy as np
+import pytest
+
+from oracle import oracle_np as onp
+
+
+@pytest.fixture(scope="module")
+def ph():
+    from fibers_jl_amd import phantom
+    return phantom
+
+
+def _vox(vol, i, nlast=None):
+    """voxel i (column-major) of a [nx,ny,nz,n] volume ([nx,ny,nz] volumes: nlast=1)"""
+    return vol.reshape(-1, vol.shape[-1] if nlast is None else nlast, order="F")[i]
+
+
+def test_dti_fit_both_branches(orc, ph):
+    shape = (6, 5, 4)
+    bval, bvec = ph.scheme_dti(30, 3, 1000.0, seed=2)
+    dwi, _, _ = ph.make_volume(shape, bval, bvec, seed=5, nonpositive_frac=0.02)
+    dwi.reshape(-1, len(bval), order="F")[3, :] = 0.0                 # a voxel with no positive sample: all outputs zero
+    dwi.reshape(-1, len(bval), order="F")[4, :3] = -1.0               # all b0 frames non-positive: zero too (dti.jl:297)
+    mask = np.ones(shape, np.uint8)
+    ref = orc.dti_fit(dwi, mask, bval, bvec, nthreads=2)
+    W = onp.dti_work(bval, bvec)
+    Wc = orc.dti_work(bval, bvec)
+    np.testing.assert_allclose(W["A"], Wc["A"], rtol=0, atol=0)
+    np.testing.assert_allclose(W["pA"], Wc["pA"], rtol=2e-4, atol=2e-7 * np.abs(Wc["pA"]).max())
+    nfull = npart = nzero = 0
+    for i in range(np.prod(shape)):
+        r = onp.dti_fit_voxel(_vox(dwi, i), W)
+        got = {k: ref[k].reshape(-1, ref[k].shape[-1] if ref[k].ndim == 4 else 1, order="F")[i] for k in ref if isinstance(ref[k], np.ndarray)}
+        if r is None:
+            nzero += 1
+            assert all(np.all(v == 0) for v in got.values())
+            continue
+        part = not np.all(_vox(dwi, i) > 0)
+        npart += part
+        nfull += not part
+        tol = 6e-3 if part else 2e-4                                  # the row-subset pinv is ill-conditioned in Float32 (dti.jl:298)
+        np.testing.assert_allclose(got["s0"][0], r["s0"], rtol=tol)
+        lam = np.array([got["eigval1"][0], got["eigval2"][0], got["eigval3"][0]])
+        np.testing.assert_allclose(lam, r["eigval"], rtol=tol, atol=tol * abs(r["eigval"][0]))
+        np.testing.assert_allclose(got["md"][0], r["md"], rtol=tol)
+        np.testing.assert_allclose(got["rd"][0], r["rd"], rtol=tol, atol=tol * abs(r["eigval"][0]))
+        np.testing.assert_allclose(got["fa"][0], r["fa"], atol=5 * tol)
+        if (r["eigval"][0] - r["eigval"][1]) > 5e-2 * abs(r["eigval"][0]):
+            assert abs(float(np.dot(got["eigvec1"], r["eigvec"][0]))) > 1 - 10 * tol      # sign unspecified
+    assert nfull > 50 and npart > 20 and nzero >= 2
+
+
+def test_sym3_eigen_against_float64_eigh_on_degenerate_sweeps(orc):
+    """the closed-form 3x3 solver (what eigen(Symmetric(::SMatrix{3,3})) dispatches to, dti.jl:311) against LAPACK in Float64:
+    prolate (l2 == l3), oblate (l1 == l2), isotropic and near-degenerate spectra, gaps swept from 0 to 1e-3 in steps of 1e-6,
+    random orientations.  Eigenvalues to the algorithm's own conditioning (acos(r) near r = +-1 amplifies one ulp to sqrt(eps) of
+    the spread); eigenvectors wherever the gap separates them."""
+    rng = np.random.default_rng(7)
+    worst = 0.0
+    for kind in ("prolate", "oblate", "isotropic"):
+        for gap in np.concatenate([np.arange(0.0, 2e-5, 1e-6), np.geomspace(2e-5, 1e-3, 30)]):
+            q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+            base = 1.0e-3 * rng.uniform(0.5, 2.0)
+            if kind == "prolate":
+                lam = np.array([base * 3, base * (1 + gap), base])
+            elif kind == "oblate":
+                lam = np.array([base * 3 * (1 + gap), base * 3, base])
+            else:
+                lam = np.array([base * (1 + 2 * gap), base * (1 + gap), base])
+            D = (q * lam) @ q.T
+            D32 = D.astype(np.float32)
+            w, E = np.linalg.eigh(D32.astype(np.float64))
+            vals, vecs = orc.sym3_eigen(D32[0, 0], D32[1, 0], D32[2, 0], D32[1, 1], D32[2, 1], D32[2, 2])
+            vals = np.asarray(vals, np.float64)
+            spread = max(w[2] - w[0], 1e-30)
+            err = np.abs(np.sort(vals) - w).max()
+            worst = max(worst, err / max(abs(w[2]), 1e-30))
+            assert err <= 5e-7 * abs(w[2]) + 6e-4 * spread + 1e-12, (kind, gap, vals, w)   # a few Float32 ulps + the conditioning term
+            vecs = np.asarray(vecs, np.float64).reshape(3, 3)
+            order = np.argsort(vals)
+            for j in range(3):
+                others = np.delete(w, j)
+                if np.abs(others - w[j]).min() > 2e-2 * abs(w[2]):     # a separated eigenvalue: its vector is determined
+                    v = vecs[:, order[j]] if abs(np.linalg.norm(vecs[:, order[j]]) - 1) < 1e-3 else vecs[order[j]]
+                    assert abs(abs(float(v @ E[:, j])) - 1) < 2e-3, (kind, gap, j)
+    assert worst < 1e-3
+
+
+@pytest.mark.parametrize("sphere", ["sphere_642", "sphere_362", "sphere_724"])
+def test_gqi_voxels_and_odfmax(orc, ph, fj, sphere):
+    sph = getattr(fj, sphere)
+    shape = (4, 3, 3)
+    bval, bvec = ph.scheme_gqi(2, 14, (1000.0, 2500.0), 3)
+    dwi, _, _ = ph.make_volume(shape, bval, bvec, seed=11, crossing=True, nonpositive_frac=0.01)
+    dwi.reshape(-1, len(bval), order="F")[5, :] = -2.0                # skipped voxel (gqi.jl:142)
+    mask = np.ones(shape, np.uint8)
+    mask[1, 1, 1] = 0
+    ref = orc.gqi_rec(dwi, mask, bval, bvec, sph.vertices, sph.faces, 1.25, nthreads=2)
+    W = onp.gqi_work(bval, bvec, sph.vertices, sph.faces, 1.25)
+    np.testing.assert_allclose(W["A"], orc.gqi_work(bval, bvec, sph.vertices, sph.faces, 1.25)["A"], rtol=0, atol=6e-7)
+    odf = ref["odf"].reshape(-1, sph.nvert, order="F")
+    assert np.float32(ref["odfmax"]) == onp.odfmax_of(odf)            # sequential Float32 sum ./ n, then maximum (gqi.jl:164)
+    m = mask.reshape(-1, order="F")
+    same_peaks = 0
+    for i in range(np.prod(shape)):
+        r = onp.gqi_voxel(_vox(dwi, i), W) if m[i] else None
+        if r is None:
+            assert np.all(odf[i] == 0) and all(np.all(_vox(ref["peak"][k], i) == 0) for k in range(3))
+            continue
+        np.testing.assert_allclose(odf[i], r["odf"], rtol=0, atol=3e-6 * np.abs(r["odf"]).max())
+        # the C oracle's own ODF through the independent find_peaks!: identical peaks and raw qa
+        pk, qa = onp.odf_peaks_qa(odf[i], W)
+        for k in range(3):
+            assert np.array_equal(_vox(ref["peak"][k], i), pk[k])
+            np.testing.assert_allclose(_vox(ref["qa"][k], i, 1)[0] * np.float32(ref["odfmax"]), qa[k], rtol=3e-7, atol=1e-6 * abs(qa[0]) + 1e-30)
+        same_peaks += all(np.array_equal(r["peak"][k], pk[k]) for k in range(3))
+    assert same_peaks >= 0.9 * m.sum() - 1                            # (ties at rounding level may fall differently on the two ODFs)
+
+
+def test_find_peaks_formulations_agree_exactly(orc, fj):
+    """face-mask formulation (gqi.jl:185-196 verbatim) vs the neighbour-list one, incl. exact ties, zeros, negative lobes, NaN"""
+    rng = np.random.default_rng(3)
+    for sph in (fj.sphere_642, fj.sphere_362, fj.sphere_724):
+        faces0 = onp.fold_faces(sph.faces, sph.nvert)
+        cf = orc.fold_faces(sph.faces, sph.nvert)
+        assert np.array_equal(np.asarray(cf).reshape(-1, 3), faces0)
+        for case in range(40):
+            o = rng.normal(size=sph.nvert).astype(np.float32)
+            if case % 4 == 1:
+                o = np.round(o * 2) / 2                               # many exact ties
+            if case % 4 == 2:
+                o[rng.integers(0, sph.nvert, 5)] = 0.0
+                o[rng.integers(0, sph.nvert, 3)] = -0.0
+            if case % 4 == 3:
+                o[rng.integers(0, sph.nvert, 2)] = np.nan
+            isort_c, nv_c, pk_c = orc.find_peaks(o, cf)
+            isort_n, nv_n, pk_n = onp.find_peaks(o, faces0)
+            assert nv_c == nv_n, case
+            assert np.array_equal(pk_c, pk_n, equal_nan=True), case
+            assert np.array_equal(np.asarray(isort_c, np.int64), isort_n), case
+
+
+def test_dsi_voxels(orc, ph, fj):
+    sph = fj.sphere_642
+    shape = (3, 2, 2)
+    bval, bvec = ph.scheme_dsi()
+    dwi, _, _ = ph.make_volume(shape, bval, bvec, seed=5)
+    mask = np.ones(shape, np.uint8)
+    ref = orc.dsi_rec(dwi, mask, bval, bvec, sph.vertices, sph.faces, 32, nthreads=2)
+    W = onp.dsi_work(bval, bvec, sph.vertices, sph.faces, 32)
+    pdf = ref["pdf"].reshape(-1, len(bval), order="F")
+    odf = ref["odf"].reshape(-1, sph.nvert, order="F")
+    assert np.float32(ref["odfmax"]) == onp.odfmax_of(odf)
+    for i in range(np.prod(shape)):
+        r = onp.dsi_voxel(_vox(dwi, i), W)
+        np.testing.assert_allclose(pdf[i], r["pdf"], rtol=0, atol=2e-5 * np.abs(r["pdf"]).max())
+        np.testing.assert_allclose(odf[i], r["odf"], rtol=0, atol=5e-5 * np.abs(r["odf"]).max())
+        pk, qa = onp.odf_peaks_qa(odf[i], W)
+        for k in range(3):
+            assert np.array_equal(_vox(ref["peak"][k], i), pk[k])
+
+
+def test_streamlines_point_for_point(orc, ph):
+    """stream_new_line restated in NumPy Float32 against the C oracle: identical point lists (same operations in the same
+    order), incl. multi-vector picking, zero vectors, mask holes, the carried ivec_next and the cumulative len_max"""
+    rng = np.random.default_rng(9)
+    n = 9
+    ax = ph.fibre_field(n, n, n).astype(np.float32)
+    ax2 = np.stack([-ax[..., 1], ax[..., 0], np.zeros((n, n, n), np.float32)], -1)
+    ax2 /= np.maximum(np.linalg.norm(ax2, axis=-1, keepdims=True), 1e-12)
+    ov = [np.asfortranarray(ax), np.asfortranarray(ax2.astype(np.float32))]
+    ov[1][rng.random((n, n, n)) < 0.2] = 0                            # voxels with one vector only
+    mask = (rng.random((n, n, n)) < 0.93).astype(np.uint8)
+    sub = np.array([[0.1, -0.2, 0.3], [-0.25, 0.15, 0.05]], np.float32)
+    for smooth, len_max in ((0.2, None), (0.0, 6)):
+        ref = orc.stream(ov, sub, mask=mask, len_min=0, smooth_coeff=smooth, len_max=len_max, nthreads=2, return_all_npts=True)
+        mk, arr = orc.stream_work(ov, None, 0.03, None, 0.1, mask)
+        lines = orc.split_lines(ref)
+        li = 0
+        for si, seed in enumerate(ref["seeds"]):
+            for k in range(sub.shape[0]):
+                got = onp.stream_line([int(v) for v in seed], sub[k], arr, mk, smooth=smooth, len_max=len_max)
+                assert got.shape[0] == ref["all_npts"][si * sub.shape[0] + k]
+                want = lines[li]
+                li += 1
+                assert np.array_equal(got, want), (smooth, si, k)
+        assert li == len(lines)
