@@ -95,6 +95,7 @@ struct TraceArgs {
     float *out_xyz;
     int len_min, trk;
     float vs[3];
+    int dbg_nostore;            // timing experiments only (FIBERS_STREAM_NOSTORE): the refill kernel keeps its points to itself
 };
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -303,6 +304,129 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
         }
     }
     if (MODE != 2) { a.npts[li] = npts; a.nfwd[li] = nf; }
+}
+
+// ---- persistent-wave variant with refill (macro scale, angle picking, MODE 0 semantics) ---------------------------------
+// stream_trace_kernel gives every lane one line: a wave runs as long as its longest line (measured on a phantom with a broad
+// length distribution: 30-53 % of the lane-steps idle, tools/trace_divergence.py).  Here a wave is persistent and a lane is a
+// state machine over ONE flat step loop: (line, pass, position, direction).  A lane whose line has ended stores its counts and
+// waits; as soon as REFILL_MIN lanes of the wave wait (or the line queue cannot feed a whole wave any more) the waiting lanes
+// are counted with a ballot, one lane draws that many lines from the global queue (one atomic per refill, not per line) and
+// every waiting lane takes queue position base + its prefix rank among the waiting lanes.  Lines are handed out in ascending
+// order, so the 16 lines of a scratch tile are traced by neighbouring lanes at about the same time and the slot-major tile
+// layout (and with it the pack kernel) stays as it is; the stores of a step are no longer 4 x 192 contiguous bytes though.
+// The arithmetic of a step is the same code as in stream_trace_kernel: results are bit-identical.
+constexpr int REFILL_MIN = 16;
+template <int NVEC>
+__global__ __launch_bounds__(256) void stream_trace_refill_kernel(const TraceArgs a, unsigned long long *queue) {
+    const int lane = threadIdx.x & 63;
+    const int nvec = NVEC > 0 ? NVEC : a.nvec;
+    constexpr int64_t slot_floats = SCR_TILE * 3;
+    const char *fbase = reinterpret_cast<const char *>(a.field);
+    const float fnx = (float)a.nx, fny = (float)a.ny, fnz = (float)a.nz;
+    const float omc = 1.0f - a.smooth;
+    // lane state
+    int64_t li = -1;                                              // line being traced (-1: waiting for one)
+    int64_t lin = 0;
+    int pass = 0, ivec = 0, npts = 0, nf = 0;
+    float p0x = 0.f, p0y = 0.f, p0z = 0.f, px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
+    float *dst = nullptr;
+    bool drained = false;                                         // the queue is empty: no more refills for this wave
+    for (;;) {
+        const unsigned long long waiting = __ballot(li < 0);
+        if (waiting == ~0ull && drained) break;
+        if (!drained && (__popcll(waiting) >= REFILL_MIN || waiting == ~0ull)) {
+            const int nw = __popcll(waiting);
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(queue, (unsigned long long)nw);
+            base = __shfl(base, 0);
+            if ((int64_t)base + nw >= a.nlines) drained = true;   // (wave-uniform)
+            if (li < 0) {
+                const int64_t cand = (int64_t)base + __popcll(waiting & ((1ull << lane) - 1ull));
+                if (cand < a.nlines) {                            // start line `cand`: stream_new_line, stream.jl:645-650
+                    li = cand;
+                    const int64_t line = a.line0 + li;
+                    const int64_t iseed = line / a.nsub;
+                    const int isub = (int)(line - iseed * a.nsub);
+                    lin = a.seeds[iseed];
+                    const int sx = (int)(lin % a.nx), sy = (int)((lin / a.nx) % a.ny), sz = (int)(lin / ((int64_t)a.nx * a.ny));
+                    p0x = (float)(sx + 1) + a.sublist[3 * isub];
+                    p0y = (float)(sy + 1) + a.sublist[3 * isub + 1];
+                    p0z = (float)(sz + 1) + a.sublist[3 * isub + 2];
+                    pass = 0; ivec = 0; npts = 0; nf = 0;
+                    px = p0x; py = p0y; pz = p0z;
+                    const float4 s = a.field[lin * nvec];
+                    vx = s.x; vy = s.y; vz = s.z;
+                    dst = a.scratch + (li / SCR_TILE) * ((int64_t)2 * a.stride * slot_floats) + (li % SCR_TILE) * 3;
+                }
+            }
+        }
+        if (li < 0) continue;                                     // (lanes without work idle through this step)
+        // ---- one step of (line, pass): the body of stream_trace_kernel's inner loop --------------------------------------
+        bool pass_ends = false;
+        const float nxp = px + vx * a.step, nyp = py + vy * a.step, nzp = pz + vz * a.step;   // stream.jl:512
+        const float rx = rintf(nxp), ry = rintf(nyp), rz = rintf(nzp);                        // stream.jl:514
+        if (!(rx >= 1.0f && rx <= fnx && ry >= 1.0f && ry <= fny && rz >= 1.0f && rz <= fnz)) pass_ends = true;   // :517
+        else {
+            const uint32_t vox = (uint32_t)(((int)rx - 1) + a.nx * (((int)ry - 1) + a.ny * ((int)rz - 1)));
+            const float4 *cand = reinterpret_cast<const float4 *>(fbase + (size_t)(vox * (uint32_t)(nvec * 16)));
+            float bx = 0.0f, by = 0.0f, bz = 0.0f, bestc = 0.0f, besta = 0.0f;
+            int best = 0;
+#pragma unroll
+            for (int k = 0; k < nvec; k++) {                      // stream_pick_by_angle!, stream.jl:350-361
+                const float4 w = cand[k];
+                float c, ca;
+                if (w.x == 0.0f && w.y == 0.0f && w.z == 0.0f) { c = -INFINITY; ca = -INFINITY; }
+                else { c = dot3(vx, vy, vz, w.x, w.y, w.z); ca = fabsf(c); }
+                if (k == 0 || (!(besta != besta) && ((ca != ca) || ca > besta))) {
+                    best = k; besta = ca; bestc = c; bx = w.x; by = w.y; bz = w.z;
+                }
+            }
+            if (!(fabsf(bestc) < INFINITY)) pass_ends = true;     // stream.jl:363
+            else {
+                float wx, wy, wz;
+                if (bestc > 0.0f) { wx = bx; wy = by; wz = bz; } else { wx = -bx; wy = -by; wz = -bz; }   // :365-369
+                ivec = best;                                      // stream.jl:371
+                if (!a.dbg_nostore) { dst[0] = px; dst[1] = py; dst[2] = pz; }   // push!/prepend! of pos_now (stream.jl:660)
+                dst += slot_floats;
+                npts++;
+                if (pass == 0) nf++;
+                if (dot3(vx, vy, vz, wx, wy, wz) < a.cosang) pass_ends = true;        // stream.jl:670
+                else if (npts > a.len_max) pass_ends = true;                          // stream.jl:674
+                else {
+                    if (a.smooth != 0.0f) {                       // stream.jl:677-681
+                        wx = a.smooth * vx + omc * wx;
+                        wy = a.smooth * vy + omc * wy;
+                        wz = a.smooth * vz + omc * wz;
+                        const float m = fmaxf(fabsf(wx), fmaxf(fabsf(wy), fabsf(wz)));
+                        float n;
+                        if (m == 0.0f || !(m < INFINITY)) n = m;
+                        else {
+                            double acc = (double)(wx * wx);
+                            acc += (double)(wy * wy);
+                            acc += (double)(wz * wz);
+                            n = (float)sqrt(acc);
+                        }
+                        wx = wx / n; wy = wy / n; wz = wz / n;
+                    }
+                    px = nxp; py = nyp; pz = nzp;                 // stream.jl:684-685
+                    vx = wx; vy = wy; vz = wz;
+                }
+            }
+        }
+        if (pass_ends) {
+            if (pass == 0) {                                      // backward pass from the seed with the carried ivec (stream.jl:647-650)
+                pass = 1;
+                px = p0x; py = p0y; pz = p0z;
+                const float4 s = a.field[lin * nvec + ivec];
+                vx = -s.x; vy = -s.y; vz = -s.z;                  // s * fwd with fwd = -1 (exact)
+                dst = a.scratch + (li / SCR_TILE) * ((int64_t)2 * a.stride * slot_floats) + (li % SCR_TILE) * 3 + (int64_t)a.stride * slot_floats;
+            } else {
+                a.npts[li] = npts; a.nfwd[li] = nf;
+                li = -1;
+            }
+        }
+    }
 }
 
 // ---- microscopy regime: stream_micro_new_point! (stream.jl:547-619) -------------------------------------------
@@ -963,6 +1087,19 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
         job->ta = ta;
     } else
     { fib::ProfScope prof("stream_trace", st);
+    const char *rf = getenv("FIBERS_STREAM_REFILL");
+    if (rf && rf[0] == '1') {                            // persistent waves that refill finished lanes from a line queue
+        ta.dbg_nostore = getenv("FIBERS_STREAM_NOSTORE") ? 1 : 0;
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+        const unsigned pg = (unsigned)std::min<int64_t>((int64_t)ncu * 8, fib::cdiv(nl, 256));
+        unsigned long long *queue = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(job->total.p) + 64);
+        hipError_t eq = hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
+        if (eq != hipSuccess) return bail(fib::fail(FIB_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(eq)));
+        if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_refill_kernel<1>), dim3(pg), dim3(256), 0, st, ta, queue);
+        else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_refill_kernel<3>), dim3(pg), dim3(256), 0, st, ta, queue);
+        else                     hipLaunchKernelGGL((stream_trace_refill_kernel<0>), dim3(pg), dim3(256), 0, st, ta, queue);
+    } else
     if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1>), dim3(grid), dim3(256), 0, st, ta);
     else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3>), dim3(grid), dim3(256), 0, st, ta);
     else                     hipLaunchKernelGGL((stream_trace_kernel<0>), dim3(grid), dim3(256), 0, st, ta);

@@ -159,3 +159,31 @@ def ball_mask_torch(shape, device, radius=None):
     r = radius if radius is not None else min(shape) * 62.0 / 140.0
     c = [(n + 1) / 2.0 for n in shape]
     return (((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) <= r * r).to(torch.uint8)
+
+
+def bundle_field_torch(shape, device, seed=7, cell=14.0, hole_frac=0.12):
+    """Tracking phantom with a BROAD streamline-length distribution (the smooth field above makes almost every line use its
+    whole len_max budget): the volume is a Voronoi partition into straight "bundles" (random centres about `cell` voxels apart,
+    one random unit direction each), a fraction of the cells is empty (no vector: lines end at their border), and lines also end
+    where two bundles meet at more than the angle threshold.  Returns (ovec float32 [3, nvox] planar, mask uint8 [nvox])."""
+    import torch
+    nx, ny, nz = shape
+    nvox = nx * ny * nz
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    ncell = max(4, int(round(nvox / cell ** 3)))
+    ctr = torch.rand((ncell, 3), generator=g, device=device) * torch.tensor([nx, ny, nz], dtype=torch.float32, device=device)
+    dirs = torch.randn((ncell, 3), generator=g, device=device)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    empty = torch.rand(ncell, generator=g, device=device) < hole_frac
+    dirs[empty] = 0.0
+    ovec = torch.empty((3, nvox), dtype=torch.float32, device=device)
+    chunk = 1 << 15
+    for c0 in range(0, nvox, chunk):
+        c1 = min(nvox, c0 + chunk)
+        lin = torch.arange(c0, c1, device=device)
+        p = torch.stack([(lin % nx).float(), ((lin // nx) % ny).float(), (lin // (nx * ny)).float()], 1) + 0.5
+        owner = torch.cdist(p, ctr).argmin(1)
+        ovec[:, c0:c1] = dirs[owner].T
+    mask = ball_mask_torch(shape, device) & (ovec.abs().sum(0) > 0).to(torch.uint8)
+    return ovec.contiguous(), mask.contiguous()

@@ -278,3 +278,57 @@ def test_stream_randomised_configurations_exact(fj, orc, case):
                    fa=None if fa is None else fj.MRI(fa), mask=fj.MRI(mask), seed=None if seed is None else fj.MRI(seed), sublist=sub, **kw)
     assert tr.nstr == len(ref["npts"]) and np.array_equal(tr.npts, ref["npts"]) and np.array_equal(tr.seed_index, ref["seed_index"])
     assert np.array_equal(tr.xyz, ref["xyz"], equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nvec", [1, 3])
+def test_persistent_refill_tracer_is_bit_identical(fj, monkeypatch, nvec):
+    """FIBERS_STREAM_REFILL=1: persistent waves whose finished lanes draw new lines from a queue (ballot + prefix rank) on a
+    phantom with a broad length distribution; same lines, same points, same order as the one-lane-per-line kernel"""
+    import torch
+    from fibers_jl_amd import phantom
+    dev = torch.device("cuda", 0)
+    shape = (40, 36, 30)
+    ov, m = phantom.bundle_field_torch(shape, dev, seed=3, cell=7.0)
+    ovs = [ov]
+    for k in range(1, nvec):
+        o2, _ = phantom.bundle_field_torch(shape, dev, seed=3 + k, cell=9.0)
+        ovs.append(o2)
+    field, mout = fj.stream_field_device(ovs, mask=m)
+    seeds = torch.nonzero(mout).flatten()
+    sub = torch.from_numpy(fj.make_sublist(3, np.random.default_rng(1))).to(dev)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FIBERS_STREAM_REFILL", mode)
+        res[mode] = fj.stream_device(field, shape, seeds, sub, want_all_npts=True, len_min=2)
+    a, b = res["0"], res["1"]
+    assert a["npts"].numel() > 1000 and int(a["npts"].max()) > 3 * int(a["npts"].float().median())
+    for k in ("npts", "seed_index", "xyz", "all_npts"):
+        assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nvec", [1, 3])
+def test_persistent_refill_tracer_is_bit_identical(fj, monkeypatch, nvec):
+    """FIBERS_STREAM_REFILL=1: persistent waves whose finished lanes draw new lines from a queue (ballot + prefix rank) on a
+    phantom with a broad length distribution; same lines, same points, same order as the one-lane-per-line kernel"""
+    import torch
+    from fibers_jl_amd import phantom
+    dev = torch.device("cuda", 0)
+    shape = (40, 36, 30)
+    ov, m = phantom.bundle_field_torch(shape, dev, seed=3, cell=7.0)
+    ovs = [ov]
+    for k in range(1, nvec):
+        o2, _ = phantom.bundle_field_torch(shape, dev, seed=3 + k, cell=9.0)
+        ovs.append(o2)
+    field, mout = fj.stream_field_device(ovs, mask=m)
+    seeds = torch.nonzero(mout).flatten()
+    sub = torch.from_numpy(fj.make_sublist(3, np.random.default_rng(1))).to(dev)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FIBERS_STREAM_REFILL", mode)
+        res[mode] = fj.stream_device(field, shape, seeds, sub, want_all_npts=True, len_min=2)
+    a, b = res["0"], res["1"]
+    assert a["npts"].numel() > 1000 and int(a["npts"].max()) > 3 * int(a["npts"].float().median())
+    for k in ("npts", "seed_index", "xyz", "all_npts"):
+        assert torch.equal(a[k], b[k]), k
