@@ -616,8 +616,10 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
 #pragma unroll
                     for (int j = 0; j < 2; j++) {
                         const float4 v4 = trd[j * 64];
+                        typedef float nt4_t __attribute__((ext_vector_type(4)));
+                        const nt4_t v4n = {v4.x, v4.y, v4.z, v4.w};
                         char *dst = obase + posoff[m * 32 + 16 * hb + 8 * j + lrow];
-                        if (!decltype(guard)::value || qinb) *reinterpret_cast<float4 *>(dst) = v4;
+                        if (!decltype(guard)::value || qinb) __builtin_nontemporal_store(v4n, reinterpret_cast<nt4_t *>(dst));   // written once, not read again by this kernel
                     }
                     const unsigned cw = m < 2 ? cw0 : m < 4 ? cw1 : m < 6 ? cw2 : m < 8 ? cw3 : cw4;
                     unsigned byte = (cw >> (8 * (3 - (2 * (m & 1) + hb)))) & 0xffu;      // bit 7 - j: slot 16 m + 8 hb + j
@@ -852,7 +854,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(rem > 0 ? Sbase + (int64_t)t * KT * row_bytes : Sbase), 0, (int)nrec, 0x00020000);
 #pragma unroll
         for (int j = 0; j < 8; j++)
-            braw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)s_off, (int)(j * row_bytes), 0));
+            braw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)s_off, (int)(j * row_bytes), FUSE ? 2 : 0));   // (aux 2 = nt: the samples are read once)
     };
     auto lane_state = [&](const Work &w, int32_t vr, bool &inb, int64_t &vox, uint32_t &s_off) {
         inb = (int64_t)w.tile_n * WGV + wave * 32 + col < nlive;

@@ -818,7 +818,11 @@ __global__ __launch_bounds__(256) void stream_pack_tile_kernel(const PackArgs a)
     const int nq = (mis + len + 3) >> 2;
     for (int k = tid; k < nq; k += 256) {
         const float4 q = reinterpret_cast<const float4 *>(obuf)[k];
-        if (4 * k >= mis && 4 * k + 4 <= mis + len) *reinterpret_cast<float4 *>(gbase + 4 * k) = q;
+        if (4 * k >= mis && 4 * k + 4 <= mis + len) {            // written once, read by nobody on the device: non-temporal
+            typedef float nt4_t __attribute__((ext_vector_type(4)));
+            const nt4_t qn = {q.x, q.y, q.z, q.w};
+            __builtin_nontemporal_store(qn, reinterpret_cast<nt4_t *>(gbase + 4 * k));
+        }
         else {
             const float e[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
