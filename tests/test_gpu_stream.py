@@ -302,7 +302,7 @@ def test_persistent_refill_tracer_is_bit_identical(fj, monkeypatch, nvec):
         monkeypatch.setenv("FIBERS_STREAM_REFILL", mode)
         res[mode] = fj.stream_device(field, shape, seeds, sub, want_all_npts=True, len_min=2)
     a, b = res["0"], res["1"]
-    assert a["npts"].numel() > 1000 and int(a["npts"].max()) > 3 * int(a["npts"].float().median())
+    assert a["npts"].numel() > 1000 and int(a["npts"].max()) > 2 * int(a["npts"].float().median())   # a broad length distribution
     for k in ("npts", "seed_index", "xyz", "all_npts"):
         assert torch.equal(a[k], b[k]), k
 
@@ -329,6 +329,6 @@ def test_persistent_refill_tracer_is_bit_identical(fj, monkeypatch, nvec):
         monkeypatch.setenv("FIBERS_STREAM_REFILL", mode)
         res[mode] = fj.stream_device(field, shape, seeds, sub, want_all_npts=True, len_min=2)
     a, b = res["0"], res["1"]
-    assert a["npts"].numel() > 1000 and int(a["npts"].max()) > 3 * int(a["npts"].float().median())
+    assert a["npts"].numel() > 1000 and int(a["npts"].max()) > 2 * int(a["npts"].float().median())   # a broad length distribution
     for k in ("npts", "seed_index", "xyz", "all_npts"):
         assert torch.equal(a[k], b[k]), k
