@@ -605,33 +605,38 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
         const int lrow = ((P >> 1) & 3) | ((P & 1) << 2);
         char *obase = reinterpret_cast<char *>(a.out1) + (uint32_t)qvox * 4u;
         auto rows_out = [&](auto guard) {
+            // software pipeline over the 20 half blocks: half block h + 1 goes into the other tile before tile h is read back
+            auto put = [&](int h) {
+                const int m = h >> 1, hb = h & 1;
+                float *tw = reinterpret_cast<float *>(tr + hb * 2048) + kh * 32 + col;
 #pragma unroll
-            for (int m = 0; m < 10; m++) {
+                for (int r = 8 * hb; r < 8 * hb + 8; r++) tw[(8 * ((r >> 2) & 1) + 2 * (r & 3)) * 32] = acc[m][r];
+            };
+            put(0);
 #pragma unroll
-                for (int hb = 0; hb < 2; hb++) {
-                    float *tw = reinterpret_cast<float *>(tr + hb * 2048) + kh * 32 + col;
-                    const float4 *trd = reinterpret_cast<const float4 *>(tr + hb * 2048) + lane;
+            for (int h = 0; h < 20; h++) {
+                const int m = h >> 1, hb = h & 1;
+                if (h + 1 < 20) put(h + 1);
+                const float *tw = reinterpret_cast<const float *>(tr + hb * 2048) + kh * 32 + col;
+                const float4 *trd = reinterpret_cast<const float4 *>(tr + hb * 2048) + lane;
 #pragma unroll
-                    for (int r = 8 * hb; r < 8 * hb + 8; r++) tw[(8 * ((r >> 2) & 1) + 2 * (r & 3)) * 32] = acc[m][r];
-#pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        const float4 v4 = trd[j * 64];
-                        typedef float nt4_t __attribute__((ext_vector_type(4)));
-                        const nt4_t v4n = {v4.x, v4.y, v4.z, v4.w};
-                        char *dst = obase + posoff[m * 32 + 16 * hb + 8 * j + lrow];
-                        if (!decltype(guard)::value || qinb) __builtin_nontemporal_store(v4n, reinterpret_cast<nt4_t *>(dst));   // written once, not read again by this kernel
-                    }
-                    const unsigned cw = m < 2 ? cw0 : m < 4 ? cw1 : m < 6 ? cw2 : m < 8 ? cw3 : cw4;
-                    unsigned byte = (cw >> (8 * (3 - (2 * (m & 1) + hb)))) & 0xffu;      // bit 7 - j: slot 16 m + 8 hb + j
-                    if (__any(byte != 0u)) {
-                        while (byte != 0u) {
-                            const int b = 31 - __clz((int)byte);
-                            byte &= ~(1u << b);
-                            const int j = 7 - b;
-                            const float x = tw[(8 * (j >> 2) + 2 * (j & 3)) * 32];
-                            if (cnt < FQ_CAP) { lw[cnt * 128] = __float_as_uint(x); lw[cnt * 128 + 64] = (uint32_t)(16 * m + 8 * hb + j); }
-                            cnt++;
-                        }
+                for (int j = 0; j < 2; j++) {
+                    const float4 v4 = trd[j * 64];
+                    typedef float nt4_t __attribute__((ext_vector_type(4)));
+                    const nt4_t v4n = {v4.x, v4.y, v4.z, v4.w};
+                    char *dst = obase + posoff[m * 32 + 16 * hb + 8 * j + lrow];
+                    if (!decltype(guard)::value || qinb) __builtin_nontemporal_store(v4n, reinterpret_cast<nt4_t *>(dst));   // written once, not read again by this kernel
+                }
+                const unsigned cw = m < 2 ? cw0 : m < 4 ? cw1 : m < 6 ? cw2 : m < 8 ? cw3 : cw4;
+                unsigned byte = (cw >> (8 * (3 - (2 * (m & 1) + hb)))) & 0xffu;      // bit 7 - j: slot 16 m + 8 hb + j
+                if (__any(byte != 0u)) {
+                    while (byte != 0u) {
+                        const int b = 31 - __clz((int)byte);
+                        byte &= ~(1u << b);
+                        const int j = 7 - b;
+                        const float x = tw[(8 * (j >> 2) + 2 * (j & 3)) * 32];
+                        if (cnt < FQ_CAP) { lw[cnt * 128] = __float_as_uint(x); lw[cnt * 128 + 64] = (uint32_t)(16 * m + 8 * hb + j); }
+                        cnt++;
                     }
                 }
             }

@@ -45,7 +45,7 @@ def _dwi_arg(dwi):
     if dwi.vol.dtype != np.float32:
         # the reference's per-voxel methods dispatch on Vector{Float32} (dti.jl:286): other eltypes are a MethodError
         raise TypeError("dwi.vol must be float32 (the reference dispatches on Float32 only)")
-    return np.asfortranarray(dwi.vol)
+    return dwi.vol if dwi.vol.flags.f_contiguous else np.asfortranarray(dwi.vol)
 
 
 def _check_tables(dwi, need_bvec=True):

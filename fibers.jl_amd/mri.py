@@ -23,7 +23,7 @@ class MRI:
             v = v[..., None]
         if v.ndim != 4:
             raise ValueError("MRI.vol must be 3-D or 4-D")
-        self.vol = np.asfortranarray(v)
+        self.vol = v if v.flags.f_contiguous else np.asfortranarray(v)   # (a memory-mapped file stays a memory map)
         if self.bval is not None:
             self.bval = np.ascontiguousarray(self.bval, dtype=np.float32).reshape(-1)
         if self.bvec is not None:

@@ -114,8 +114,25 @@ def load_nifti_hdr(buf):
     return h
 
 
-def load_nifti(fname, headeronly=False):
-    """load_nifti (mri.jl:1577-1672) -> (hdr dict, array in file order, x fastest == Fortran order)"""
+def load_nifti(fname, headeronly=False, mmap=False):
+    """load_nifti (mri.jl:1577-1672) -> (hdr dict, array in file order, x fastest == Fortran order).
+    The reference shells out to `zcat` / `gunzip -c` for .gz files (mri.jl:1586-1591) and reads the whole volume into a Julia
+    array; here .gz is inflated in-process, and with mmap=True an uncompressed, native-endian, unscaled .nii is not read at
+    all: the returned array is a read-only memory map of the file, so the host tier of the fits gathers its chunks straight
+    from the page cache into the pinned staging ring (file -> pinned -> HBM, no intermediate copy of the volume)."""
+    if mmap and not fname.lower().endswith(".gz"):
+        with open(fname, "rb") as fh:
+            head = fh.read(352)
+        hdr = load_nifti_hdr(head)
+        last = max(i for i, v in enumerate(hdr["dim"]) if v != 0)
+        dim = [int(v) for v in hdr["dim"][1:last + 1]]
+        plain = hdr["scl_slope"] == 0 or (hdr["scl_inter"] == 0 and hdr["scl_slope"] == 1)
+        if hdr["datatype"] in _NIFTI_DTYPES and not hdr["do_bswap"] and plain and not headeronly:
+            dt = np.dtype(_NIFTI_DTYPES[hdr["datatype"]])
+            off = int(round(hdr["vox_offset"]))
+            if os.path.getsize(fname) != off + int(np.prod(dim)) * dt.itemsize:
+                raise ValueError("%s, read a %s volume but did not reach end of file" % (fname, tuple(dim)))
+            return hdr, np.memmap(fname, dtype=dt, mode="r", offset=off, shape=tuple(dim), order="F")
     with _open(fname, "rb") as fh:
         raw = fh.read()
     hdr = load_nifti_hdr(raw)
@@ -167,13 +184,14 @@ def _normalise_bvec(g):
     return g.astype(np.float32)
 
 
-def mri_read(infile, headeronly=False):
+def mri_read(infile, headeronly=False, mmap=False):
     """mri_read for NIfTI inputs (mri.jl:611-733): volume + optional <stem>.bval[s]/.bvec[s] tables,
-    gradient vectors normalised.  `vol` keeps the file's element type (the fits need Float32)."""
+    gradient vectors normalised.  `vol` keeps the file's element type (the fits need Float32).
+    mmap=True: see load_nifti (the volume stays in the file until a fit streams it to the GPU)."""
     low = infile.lower()
     if not (low.endswith(".nii") or low.endswith(".nii.gz")):
         raise ValueError("File extension not supported by this back end (NIfTI only): " + infile)
-    hdr, vol = load_nifti(infile, headeronly)
+    hdr, vol = load_nifti(infile, headeronly, mmap=mmap)
     volsz = [int(v) for v in hdr["dim"][1:] if v > 0]
     if len(volsz) >= 5 and not headeronly:                                        # mri.jl:660-666
         vol = vol.reshape(volsz[0], volsz[1], volsz[2], -1, order="F")

@@ -182,3 +182,37 @@ def test_gpu_trk_serialiser_matches_host(fj, tmp_path):
     fj.trk_write(tr, f1, ref)
     info = fj.stream_to_trk(f2, field, (n, n, n), seeds, sub, ref, len_min=4)
     assert info["nlines"] == tr.nstr and open(f1, "rb").read() == open(f2, "rb").read()
+
+
+@pytest.mark.gpu
+def test_fit_streams_a_memory_mapped_nifti_file(fj, tmp_path):
+    """N2 on the device path: mri_read(..., mmap=True) returns the .nii file itself as `vol`; fib_dti_fit / fib_gqi_rec gather
+    their chunks from the mapping into the pinned ring (file -> pinned -> HBM).  Same results as from an in-memory array."""
+    from fibers_jl_amd import phantom
+    shape = (20, 18, 16)
+    bval, bvec = phantom.scheme_dti(30, 3, 1000.0, seed=2)
+    dwi, _, _ = phantom.make_volume(shape, bval, bvec, seed=5, nonpositive_frac=0.005)
+    src = fj.MRI(dwi, bval, bvec, volres=(1.25, 1.25, 1.25), vox2ras=_affine())
+    f = str(tmp_path / "dwi.nii")
+    assert fj.mri_write(src, f) is False
+    np.savetxt(str(tmp_path / "dwi.bval"), bval[None], fmt="%g")
+    np.savetxt(str(tmp_path / "dwi.bvec"), bvec.T, fmt="%.8f")
+    m = fj.mri_read(f, mmap=True)
+    assert isinstance(m.vol, np.memmap) and m.vol.flags.f_contiguous and m.vol.dtype == np.float32
+    assert np.array_equal(np.asarray(m.vol), dwi) and np.array_equal(m.bval, bval)
+    mask = fj.MRI(np.ones(shape, np.uint8))
+    os.environ["FIBERS_HOST_CHUNK"] = "2048"
+    try:
+        a = fj.dti_fit(m, mask)
+        b = fj.dti_fit(fj.MRI(dwi, m.bval, m.bvec), mask)
+        for k in fj.dti.DTI_FIELDS:
+            assert np.array_equal(getattr(a, k).vol, getattr(b, k).vol, equal_nan=True), k
+        ga, gb = fj.gqi_rec(m, mask), fj.gqi_rec(fj.MRI(dwi, m.bval, m.bvec), mask)
+        assert np.array_equal(ga.odf.vol, gb.odf.vol) and all(np.array_equal(ga.qa[k].vol, gb.qa[k].vol, equal_nan=True) for k in range(3))
+    finally:
+        os.environ.pop("FIBERS_HOST_CHUNK", None)
+    # .nii.gz: inflated in-process (no zcat), mmap request falls back to an array
+    fz = str(tmp_path / "dwi2.nii.gz")
+    assert fj.mri_write(src, fz) is False
+    mz = fj.mri_read(fz, mmap=True)
+    assert not isinstance(mz.vol, np.memmap) and np.array_equal(mz.vol, dwi)
