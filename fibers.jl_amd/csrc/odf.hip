@@ -63,7 +63,6 @@ struct GemmArgs {
     float *mean_hi;               // [nvox] upper bound of each listed voxel's mean (NaN: the voxel is on the redo list)
     int32_t *redo_count, *redo_list;   // voxels the register scan could not finish (NaN / Inf columns, candidate-list overflow)
     int redo_cap;
-    int fuse_skip;                // timing experiments only (FIBERS_FUSE_SKIP bit mask: 1 scan, 2 statistics, 4 top-3 + outputs, 8 atomics, 16 ODF rows)
 };
 
 // scheduling hint: spread one k-step's fragment reads (ds_read2_b32 = 2 fragments) between the previous
@@ -562,7 +561,7 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
     // shifted into five 32-bit strings per lane (slot 32w + i -> bit 31 - i of word w) --------------------------------------
     unsigned cw0 = 0, cw1 = 0, cw2 = 0, cw3 = 0, cw4 = 0;
     bool cpole = false;
-    if (!(a.fuse_skip & 1)) {
+    {
 #define O(m, r) acc[m][r]
 #define F(i) ff##i
 #define X(j) fx##j
@@ -641,7 +640,6 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
                 }
             }
         };
-        if (a.fuse_skip & 16) {} else
         if (__all(qinb)) rows_out(std::false_type{}); else rows_out(std::true_type{});   // (the guarded copy: ragged end of the voxel list)
         if (inb && kh == 0) a.out1[(int64_t)FIB_F642_POLE * a.stride + vox] = xrow;
         if (cpole) { if (cnt < FQ_CAP) { lw[cnt * 128] = __float_as_uint(xrow); lw[cnt * 128 + 64] = 160u; } cnt++; }
@@ -649,7 +647,6 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
     // ---- minimum (gqi.jl:147), bounds of the mean (gqi.jl:164) over this half's 160 rows ---------------------------------
     float vmin = INFINITY;
     f32x2 vs2 = {0.0f, 0.0f};
-    if (!(a.fuse_skip & 2))
 #pragma unroll
     for (int m = 0; m < 10; m++)
 #pragma unroll
@@ -682,7 +679,7 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
     const bool redo = inb && (!finite || cnt > FQ_CAP || cnt_o > FQ_CAP);
     const float mean = vsum_t / (float)FQ_NV;
     const float eps = (2.1f * 5.9604645e-8f) * (float)FQ_NV * (fabsf(mean) + 2.0f * fabsf(fminf(vmin_t, 0.0f)));   // see odfmax_contribute
-    if (kh == 0 && inb && !(a.fuse_skip & 4)) {
+    if (kh == 0 && inb) {
         if (redo) {
             const int slot = atomicAdd(a.redo_count, 1);
             if (slot < a.redo_cap) a.redo_list[slot] = (int32_t)vox;
@@ -703,7 +700,7 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
     }
     unsigned e = (kh == 0 && inb && !redo) ? enc_ordered(mean - eps) : 0u;
     for (int off = 16; off >= 1; off >>= 1) { const unsigned oth = (unsigned)__shfl_xor((int)e, off); e = oth > e ? oth : e; }
-    if (lane == 0 && e && !(a.fuse_skip & 8)) atomicMax(&a.maxenc[2], e);
+    if (lane == 0 && e) atomicMax(&a.maxenc[2], e);
 }
 
 // ---- K2/K5, second form: the same f32 contraction on the bf16 matrix cores (16x the f32 MFMA rate) ----------
@@ -2299,7 +2296,6 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         for (int k = 0; k < 3; k++) { ga.peak[k] = peak[k]; ga.qa[k] = qa[k]; }
         ga.verts = plan->verts.p; ga.maxenc = plan->maxenc.p; ga.mean_hi = plan->mean_hi.p;
         ga.redo_count = plan->live_counts.p + 3; ga.redo_list = plan->redo_list.p; ga.redo_cap = (int)std::min<int64_t>(nvox, INT32_MAX);
-        if (const char *e = getenv("FIBERS_FUSE_SKIP")) ga.fuse_skip = atoi(e);
     }
     ga.K = plan->gK; ga.Kpad = plan->Kpad; ga.M = plan->gM; ga.nrow0 = plan->gRow0; ga.ntile_m = plan->ntile_m;
     const bool fuse_fold = plan->folded && ga.At3 != nullptr && plan->MB <= FOLD_MB_MAX && plan->Kpad <= FKMAX && plan->scale_frame_raw >= 0 &&

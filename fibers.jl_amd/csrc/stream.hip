@@ -95,7 +95,6 @@ struct TraceArgs {
     float *out_xyz;
     int len_min, trk;
     float vs[3];
-    int dbg_nostore;            // timing experiments only (FIBERS_STREAM_NOSTORE): the refill kernel keeps its points to itself
 };
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -387,7 +386,7 @@ __global__ __launch_bounds__(256) void stream_trace_refill_kernel(const TraceArg
                 float wx, wy, wz;
                 if (bestc > 0.0f) { wx = bx; wy = by; wz = bz; } else { wx = -bx; wy = -by; wz = -bz; }   // :365-369
                 ivec = best;                                      // stream.jl:371
-                if (!a.dbg_nostore) { dst[0] = px; dst[1] = py; dst[2] = pz; }   // push!/prepend! of pos_now (stream.jl:660)
+                dst[0] = px; dst[1] = py; dst[2] = pz;            // push!/prepend! of pos_now (stream.jl:660)
                 dst += slot_floats;
                 npts++;
                 if (pass == 0) nf++;
@@ -1093,7 +1092,6 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
     { fib::ProfScope prof("stream_trace", st);
     const char *rf = getenv("FIBERS_STREAM_REFILL");
     if (rf && rf[0] == '1') {                            // persistent waves that refill finished lanes from a line queue
-        ta.dbg_nostore = getenv("FIBERS_STREAM_NOSTORE") ? 1 : 0;
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
         const unsigned pg = (unsigned)std::min<int64_t>((int64_t)ncu * 8, fib::cdiv(nl, 256));

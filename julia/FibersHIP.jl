@@ -12,6 +12,13 @@ const libfibers = get(ENV, "FIBERS_HIP_LIB", "libfibers_hip.so")
 const FIB_DTYPE = Dict(UInt8=>0, Int8=>1, Int16=>2, UInt16=>3, Int32=>4, UInt32=>5,
                        Float32=>6, Float64=>7, Int64=>8, Bool=>9)
 
+# Multi-GPU: `device = FIB_DEVICE_ALL` shards a call over the device set declared here (contiguous voxel slabs for the fits,
+# as Threads.@threads shards the z loop in dti.jl:258 / gqi.jl:132 / dsi.jl:197; round-robin seeds for stream).  Without
+# fib_init the set is every visible GPU.  Results do not depend on the set.
+const FIB_DEVICE_ALL = Cint(-1)
+fib_init(devs::Vector{<:Integer}=Int[]) = fib_check(ccall((:fib_init, libfibers), Cint, (Cint, Ptr{Cint}), length(devs), Cint.(devs)))
+fib_shutdown() = ccall((:fib_shutdown, libfibers), Cvoid, ())
+
 function fib_check(rc::Cint)
   rc == 0 && return
   msg = unsafe_string(ccall((:fib_last_error, libfibers), Cstring, ()))
@@ -150,6 +157,7 @@ struct FibStreamParams
   nx::Int32; ny::Int32; nz::Int32; nvec::Int32; len_min::Int32; len_max::Int32
   cosang_thresh::Float32; step_size::Float32; smooth_coeff::Float32
   search_dist::Int32; search_cosang::Float32          # microscopy regime (stream.jl:83, 547-619) when search_dist > 0
+  ws::Ptr{Cvoid}                                      # optional tracer workspace (fibd_stream_ws_create); C_NULL for the host-buffer calls
 end
 
 mutable struct FibTractOut
@@ -180,7 +188,7 @@ function stream(ovec::Union{MRI,Vector{MRI}}; f::Union{MRI,Vector{MRI},Nothing}=
   sublist = nsub > 0 ? hcat([Float32.(rand(Uniform(-.5+eps(), .5-eps()), 3)) for _ in 1:nsub]...) : zeros(Float32, 3, 1)
   prm = Ref(FibStreamParams(nx, ny, nz, length(ovecs), len_min, len_max,
                             cosd(Float32(ang_thresh)), Float32(step_size), Float32(smooth_coeff),
-                            domicro ? Int32(search_dist) : Int32(0), cosd(Float32(search_ang))))
+                            domicro ? Int32(search_dist) : Int32(0), cosd(Float32(search_ang)), C_NULL))
   pv = [pointer(o.vol) for o in ovecs]
   pf = isnothing(fs) ? C_NULL : [pointer(x.vol) for x in fs]
   out = FibTractOut()

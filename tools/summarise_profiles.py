@@ -20,17 +20,18 @@ def short(n):
 
 
 lines = []
-for what in ("bench", "gqi", "dti", "stream", "dsi"):
+for what in ("bench", "benchfull", "gqi", "dti", "stream", "dsi"):
     fs = glob.glob(os.path.join(src, what, "**", "*kernel_stats.csv"), recursive=True)
     if not fs:
         continue
     shutil.copy(fs[0], os.path.join(dst, what + "_kernel_stats.csv"))
-    lines.append("== rocprofv3 --kernel-trace --stats -- python3 %s  (library kernels) ==" % ("bench.py --no-cpu-baseline" if what == "bench" else "tools/prof_step.py %s 5" % what))
+    lines.append("== rocprofv3 --kernel-trace --stats -- python3 %s  (library kernels) ==" % ("bench.py --no-cpu-baseline --no-extra" if what == "bench" else "bench.py --no-cpu-baseline" if what == "benchfull" else "tools/prof_step.py %s 5" % what))
     for r in csv.DictReader(open(fs[0])):
         if LIB.search(r["Name"]):
             lines.append("  %-60s calls=%4d avg_us=%10.1f min_us=%10.1f" % (short(r["Name"])[:60], int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
-if os.path.exists(os.path.join(src, "bench.json")):
-    shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "bench_under_rocprof.json"))
+for bj, name in (("bench.json", "bench_under_rocprof.json"), ("benchfull.json", "bench_full_under_rocprof.json")):
+    if os.path.exists(os.path.join(src, bj)):
+        shutil.copy(os.path.join(src, bj), os.path.join(dst, name))
 
 
 def pmc(sub):
@@ -63,7 +64,7 @@ json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 gem = [v for k, v in traffic.items() if k.startswith("odf_gemm")]
 if gem:   # what bench.py reports as roofline.traffic (per launch of the dominant kernel)
     json.dump({"odf_gemm_bytes_per_launch": gem[0]["hbm_bytes_per_launch"], "source": "profiles/%s/traffic.json" % tag,
-               "note": "FETCH_SIZE*1024*2 (gfx950 correction for wide coalesced reads) + WRITE_SIZE*1024, separate --pmc passes; algorithmic = 6.49e9",
+               "note": "FETCH_SIZE*1024*2 (gfx950 correction for wide coalesced reads) + WRITE_SIZE*1024, separate --pmc passes; algorithmic = 6.63e9 (DWI + mask in, ODF + peaks + qa out)",
                "kernels": traffic}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 open(os.path.join(dst, "summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
