@@ -245,6 +245,23 @@ def main():
             pass
 
     extra = {}
+    if not args.no_extra and world == 1:
+        # ---- the same step on the less flattering inputs of SURVEY §8d: ball mask (36 % of the volume inside) and ~1 % of the
+        # samples non-positive (exercises the clamp and the mask compaction; the headline uses an all-ones mask, all positive) ----
+        bm_h = phantom.ball_mask_torch(shape, dev)
+        g = torch.Generator(device=dev); g.manual_seed(17)
+        dwi_np = dwi.clone()
+        hit = torch.rand(dwi_np.shape, generator=g, device=dev) < 0.01
+        dwi_np[hit] = torch.where(torch.rand(int(hit.sum()), generator=g, device=dev) < 0.5, 0.0, -3.0)
+        del hit
+        out_b = fj.odf_rec_device(plan, dwi_np, bm_h, normalize=True)
+        t_b = timed(lambda: fj.odf_rec_device(plan, dwi_np, bm_h, out=out_b, normalize=True), max(2, args.steps // 2), 1) / max(2, args.steps // 2)
+        gb_ms, gb_n = prof_get(L, "odf_gemm")
+        nin = int(bm_h.sum())
+        extra["gqi_ball_mask_nonpositive"] = dict(voxels_in_mask=nin, ms_per_step=t_b * 1e3, mvoxels_in_mask_per_s=nin / t_b / 1e6,
+                                                  mvoxels_of_volume_per_s=nvox / t_b / 1e6, gemm_kernel_ms=gb_ms / max(gb_n, 1),
+                                                  note="ball mask r = 62 (998 592 voxels), 1 % of the samples set to 0 or -3; cost scales with the mask")
+        del dwi_np, out_b, bm_h
     if not args.no_extra:
         # ---- weak-scaling figure of the same step: one whole volume per rank, odfmax all-reduced -----------------------------
         if world > 1:
@@ -318,7 +335,7 @@ def main():
             # ---- microscopy regime (stream.jl:547-619) on the same field: every 8th seed, reference defaults ----------
             sm = seeds_all[::8].contiguous()
             z1_ = torch.zeros((1, 3), dtype=torch.float32, device=dev)
-            kw = dict(ang_thresh=20, step_size=1.0, smooth_coeff=0.0, search_dist=15, search_ang=10)
+            kw = dict(ang_thresh=20, step_size=1.0, smooth_coeff=0.0, search_dist=15, search_ang=10, xyz_out=xyz_out)
             rm = fj.stream_device(field, shape, sm, z1_, **kw)
             torch.cuda.synchronize()
             L.fib_profile_enable(1); L.fib_profile_reset()
@@ -345,7 +362,7 @@ def main():
             fld, mo = fj.stream_field_device(ov2, mask=torch.ones(n2 * n2, dtype=torch.uint8, device=dev))
             sd2 = torch.nonzero(mo).flatten()
             s2 = torch.tensor([[0.1, -0.2, 0.0]], dtype=torch.float32, device=dev)
-            kw = dict(lcms=lc, lcm_thresh=0.099, strdims=(0, 1), rng_seed=7, len_max=140)
+            kw = dict(lcms=lc, lcm_thresh=0.099, strdims=(0, 1), rng_seed=7, len_max=140, xyz_out=xyz_out)
             rl = fj.stream_device(fld, (n2, n2, 1), sd2, s2, **kw)
             torch.cuda.synchronize()
             L.fib_profile_enable(1); L.fib_profile_reset()

@@ -132,6 +132,8 @@ def stream_sharded(field_full, shape, seeds_all, sublist, group=None, **kw):
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if isinstance(seeds_all, np.ndarray):
         seeds_all = torch.from_numpy(np.ascontiguousarray(seeds_all, np.int64)).to(field_full.device)
+    if world == 1:                                             # the whole list: nothing to renumber
+        return stream_device(field_full, shape, seeds_all, sublist, **kw)
     local, gi = shard_seeds(seeds_all, world, rank)
     res = stream_device(field_full, shape, local.contiguous(), sublist, **kw)
     nsub = sublist.shape[0]
