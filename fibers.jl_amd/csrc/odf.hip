@@ -23,6 +23,8 @@
 // the ODF matches a CPU sgemv to rounding, which the strict-inequality peak finder needs.
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -63,6 +65,7 @@ struct GemmArgs {
     float *mean_hi;               // [nvox] upper bound of each listed voxel's mean (NaN: the voxel is on the redo list)
     int32_t *redo_count, *redo_list;   // voxels the register scan could not finish (NaN / Inf columns, candidate-list overflow)
     int redo_cap;
+    void *dump;                   // pipe kernel: 1 KB per wave (1024 workgroups at most) that lanes without a voxel store into
 };
 
 // scheduling hint: spread one k-step's fragment reads (ds_read2_b32 = 2 fragments) between the previous
@@ -539,7 +542,8 @@ __device__ __forceinline__ float fq_max2(float a, float b) { return __builtin_fm
 
 template <int NW>
 __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (&acc)[10], float xrow, float vmax, float vnf, bool inb, bool lv,
-                                                     int64_t vox, int lane, char *tr, char *lst, const uint64_t *posoff, const int *slotv, const float *vl) {
+                                                     int64_t vox, int lane, char *tr, char *lst, const uint64_t *posoff, const int *slotv, const float *vl,
+                                                     unsigned &en_run) {
     const int col = lane & 31, kh = lane >> 5;
     const float pm = fmaxf(vmax, __shfl_xor(vmax, 32));
     const float pn = vnf + __shfl_xor(vnf, 32);
@@ -699,8 +703,9 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
         }
     }
     unsigned e = (kh == 0 && inb && !redo) ? enc_ordered(mean - eps) : 0u;
-    for (int off = 16; off >= 1; off >>= 1) { const unsigned oth = (unsigned)__shfl_xor((int)e, off); e = oth > e ? oth : e; }
-    if (lane == 0 && e) atomicMax(&a.maxenc[2], e);
+    // the wave's running lower bound of the maximum mean: ONE atomicMax per wave when the kernel ends (a thousand waves raising
+    // the same word after every work item are waited for at the next stage's vmcnt(0))
+    en_run = e > en_run ? e : en_run;
 }
 
 // ---- K2/K5, second form: the same f32 contraction on the bf16 matrix cores (16x the f32 MFMA rate) ----------
@@ -867,6 +872,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
     f32x16 acc[MB];
     float xacc[NXA];
     float vmax = 0.0f, vnf = 0.0f;
+    unsigned en_run = 0u;                               // FUSE: running lower bound of the maximum mean (gemm3_epilogue_fused)
     auto clear = [&]() {
 #pragma unroll
         for (int m = 0; m < MB; m++)
@@ -964,7 +970,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
         }
         if constexpr (FUSE)
             gemm3_epilogue_fused<NW>(a, acc, xacc[0], vmax, vnf, inb, lv, vox, lane, lds + 2 * TILEB + wave * TRB,
-                                     lds + 2 * TILEB + NW * TRB + XTAB + FTAB + wave * FQ_LIST, q_posoff, q_slotv, q_vl);
+                                     lds + 2 * TILEB + NW * TRB + XTAB + FTAB + wave * FQ_LIST, q_posoff, q_slotv, q_vl, en_run);
         else
             gemm3_epilogue<MB, NX>(a, acc, xacc, vmax, vnf, inb, lv, vox, lane, cur.tile_m, sraw, lds + 2 * TILEB + wave * TRB);
         if (!nxt.valid) break;
@@ -973,7 +979,13 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
         vraw_nxt = nxt.valid ? vidx_at(nxt) : 0;
         clear();
     }
+    if constexpr (FUSE) {
+        for (int off = 32; off >= 1; off >>= 1) { const unsigned oth = (unsigned)__shfl_xor((int)en_run, off); en_run = oth > en_run ? oth : en_run; }
+        if (lane == 0 && en_run) atomicMax(&a.maxenc[2], en_run);
+    }
 }
+
+#include "odf_pipe.inc"
 
 // ---- mask compaction ---------------------------------------------------------------------------------------
 // vidx = ascending list of the voxels of every aligned 4-voxel group ("quad") that holds a voxel inside the mask, so
@@ -1875,6 +1887,7 @@ struct fib_odf_plan {
     fib::DevBuf<float> Aextraf;                      // its extra row (the pole of the layout's rotation)
     mutable fib::DevBuf<float> mean_hi;              // [nvox] per-voxel upper bound of the mean (fused path)
     mutable fib::DevBuf<int32_t> redo_list;          // [nvox] voxels left to odf_redo_kernel
+    fib::DevBuf<char> dump;                          // store target of lanes without a voxel (odf_pipe_kernel)
     fib::DevBuf<uint32_t> effbits;
     fib::DevBuf<int32_t> nbr, nbr64; // [nvert_even][deg_pad] LDS row of each neighbour (sentinel-padded)
     int deg_pad = 6, rows_pad = 0;
@@ -1981,7 +1994,7 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
         p->fused_shape = faces && p->gRow0 == 0 && p->scale_frame < 0 && M == FQ_NV && p->MB == 10 && p->NX == 1 && p->ntile_m == 1 && p->Kpad <= 512;
         if (p->fused_shape) {                                   // second image in the row order of sphere642_fused.inc
             build(fib_f642_pos_vertex, A3, AX);
-            if ((rc3 = p->At3f.alloc(A3.size())) != FIB_OK || (rc3 = p->Aextraf.alloc(AX.size())) != FIB_OK) return rc3;
+            if ((rc3 = p->At3f.alloc(A3.size())) != FIB_OK || (rc3 = p->Aextraf.alloc(AX.size())) != FIB_OK || (rc3 = p->dump.alloc((size_t)1024 * PP_NW * 1024)) != FIB_OK) return rc3;
             FIB_HIP(hipMemcpy(p->At3f.p, A3.data(), A3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             FIB_HIP(hipMemcpy(p->Aextraf.p, AX.data(), AX.size() * sizeof(float), hipMemcpyHostToDevice));
         }
@@ -2174,6 +2187,12 @@ void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
             return;
         }
         if constexpr (MB == 10 && NX == 1) {
+            if (ga.mean_hi && ga.dump) {                  // software-pipelined kernel: one 4-wave workgroup per CU, 128 voxels per item
+                const int64_t items4 = fib::cdiv(ga.nvox, 128);
+                const unsigned pg4 = (unsigned)std::min<int64_t>(std::min(ncu, 1024), items4);   // (the dump area holds 1024 workgroups)
+                hipLaunchKernelGGL(odf_pipe_kernel, dim3(pg4), dim3(256), 0, st, g2);
+                return;
+            }
             if (ga.mean_hi) { hipLaunchKernelGGL((odf_gemm3_kernel<10, 1, 8, false, true>), dim3(pg), dim3(512), 0, st, g2); return; }
         }
         hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 8>), dim3(pg), dim3(512), 0, st, g2);
@@ -2296,6 +2315,8 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         for (int k = 0; k < 3; k++) { ga.peak[k] = peak[k]; ga.qa[k] = qa[k]; }
         ga.verts = plan->verts.p; ga.maxenc = plan->maxenc.p; ga.mean_hi = plan->mean_hi.p;
         ga.redo_count = plan->live_counts.p + 3; ga.redo_list = plan->redo_list.p; ga.redo_cap = (int)std::min<int64_t>(nvox, INT32_MAX);
+        // the software-pipelined kernel spreads the epilogue over the 13 contraction stages after the first (protocols of 209+ frames)
+        { const char *pe = getenv("FIBERS_ODF_PIPE"); if (plan->Kpad / KT >= 1 + PP_NSLICE && pe && pe[0] == '1') ga.dump = plan->dump.p; }
     }
     ga.K = plan->gK; ga.Kpad = plan->Kpad; ga.M = plan->gM; ga.nrow0 = plan->gRow0; ga.ntile_m = plan->ntile_m;
     const bool fuse_fold = plan->folded && ga.At3 != nullptr && plan->MB <= FOLD_MB_MAX && plan->Kpad <= FKMAX && plan->scale_frame_raw >= 0 &&

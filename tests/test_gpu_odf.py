@@ -340,6 +340,48 @@ def test_peak_kernels_agree_incl_nan_poisoned_voxels(fj, monkeypatch):
     torch.testing.assert_close(torch.nan_to_num(res["fused"]["odf"][~rows], nan=-7.0), torch.nan_to_num(res["list"]["odf"][~rows], nan=-7.0), rtol=1e-5, atol=0)
 
 
+@pytest.mark.parametrize("case", ["full", "ball", "poison", "noisy"])
+def test_pipelined_gqi_kernel_is_bit_identical_to_the_fused_one(fj, case, monkeypatch):
+    """odf_pipe_kernel (FIBERS_ODF_PIPE=1: one wave per SIMD, the epilogue of work item i-1 issued between the MFMAs of item i)
+    against odf_gemm3_kernel<FUSE> on the same buffers: ODF rows, peaks, raw qa and odfmax bit for bit.  270-frame protocol
+    (17 contraction stages: the pipelined kernel needs 14), a voxel count that is not a multiple of the 128-voxel work item;
+    NaN / +Inf / all-zero / negative / identical voxels; uniform noise (tens of local maxima per voxel: list overflow and the
+    more-than-three-candidates-per-block path, both handed to odf_redo_kernel); a sparse mask."""
+    import torch
+    from fibers_jl_amd import phantom
+    dev = torch.device("cuda", 0)
+    shape = (37, 29, 23)
+    nvox = shape[0] * shape[1] * shape[2]
+    bval, bvec = phantom.scheme_gqi()
+    assert len(bval) >= 209
+    dwi, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=8, device=dev, noise_frac=0.1)
+    mask = torch.ones(nvox, dtype=torch.uint8, device=dev)
+    if case == "ball":
+        mask = phantom.ball_mask_torch(shape, dev)
+    if case == "poison":
+        dwi[5, 100] = float("nan"); dwi[7, 2000] = float("inf"); dwi[:, 3000] = 0.0; dwi[:, 3001] = -1.0
+        dwi[:, 5000:5064] = 1000.0
+        dwi[11, nvox - 1] = float("nan")
+    if case == "noisy":
+        g = torch.Generator(device=dev); g.manual_seed(11)
+        dwi = torch.rand(dwi.shape, generator=g, device=dev) * 100.0
+    plan = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642, sigma=1.25)
+    res = {}
+    for name, flag in (("pipe", "1"), ("fused", "0")):
+        monkeypatch.setenv("FIBERS_ODF_PIPE", flag)
+        o = fj.odf_rec_device(plan, dwi, mask, normalize=False)
+        torch.cuda.synchronize()
+        res[name] = dict(odf=o["odf"].clone(), peak=[t.clone() for t in o["peak"]], qa=[t.clone() for t in o["qa"]], odfmax=o["odfmax"].clone())
+    nn = lambda t: torch.nan_to_num(t, nan=-7.0, posinf=-8.0, neginf=-9.0)
+    assert torch.equal(nn(res["pipe"]["odf"]), nn(res["fused"]["odf"]))
+    for k in range(3):
+        assert torch.equal(nn(res["pipe"]["peak"][k]), nn(res["fused"]["peak"][k])), k
+        assert torch.equal(nn(res["pipe"]["qa"][k]), nn(res["fused"]["qa"][k])), k
+    assert torch.equal(nn(res["pipe"]["odfmax"]), nn(res["fused"]["odfmax"]))
+    assert int((res["pipe"]["peak"][0] != 0).any(0).sum()) > (0 if case == "ball" else nvox // 2)     # (it did find peaks)
+
+
+
 @pytest.mark.parametrize("mode", ["bf16x3", "f32"])
 def test_gqi_nonfinite_samples_propagate_like_the_reference(fj, orc, mode, monkeypatch):
     """gqi.jl:139-144 on samples that are not finite: `s[s .< 0] .= 0` turns -Inf into 0 and keeps NaN; `maximum(s) == 0`

@@ -177,6 +177,82 @@ def main():
     out.append("// O(m,r): own accumulator; F(i): register (m,r) of the other lane half (FDEF); X(j): replicated fixed vertex; Z: no neighbour")
     out.append("#define FIB_F642_PAIRS(FDEF, SLOT) \\")
     out.append(" \\\n".join(prog))
+    # the same program cut by accumulator block (16 slots each), every block self-contained: it (re)defines the foreign and the
+    # replicated fixed values it uses, so that nothing but the accumulators and the flag strings lives across blocks
+    # (odf_pipe_kernel runs one block per contraction stage of the NEXT work item)
+    xdef_of = {}
+    for i in range(8):
+        xdef_of[2 * i] = xdef_of[2 * i + 1] = "    XDEF(%d, %d, %d, %d)" % ((2 * i, 2 * i + 1) + divmod(152 + i, 16))
+    import re as _re
+    for blk in range(10):
+        lines, seenf, seenx = [], set(), set()
+        for sl in range(16 * blk, min(16 * blk + 16, 152)):
+            v = slot_v[0][sl]
+            ops = []
+            for u in adj[v]:
+                if g[u] == u:
+                    j = fix_id[u]
+                    if j != 16 and xdef_of[j] not in seenx:
+                        seenx.add(xdef_of[j]); lines.append(xdef_of[j])
+                    ops.append("X(%d)" % j)
+                elif slot_of[u][1] == 0:
+                    ops.append(own(slot_of[u][0]))
+                else:
+                    fs = slot_of[u][0]
+                    fi = foreign_slots.index(fs)
+                    if fi not in seenf:
+                        seenf.add(fi); lines.append("    FDEF(%d, %d, %d)" % ((fi,) + divmod(fs, 16)))
+                    ops.append("F(%d)" % fi)
+            ops += ["Z"] * (6 - len(ops))
+            lines.append("    SLOT(%d, %d, %d, %s)" % ((sl,) + divmod(sl, 16) + (", ".join(ops),)))
+        out.append("#define FIB_F642_BLOCK%d(FDEF, XDEF, SLOT) \\" % blk)
+        out.append(" \\\n".join(lines))
+    # the blocks once more, software-pipelined for odf_pipe_kernel: the cross-half fetch (FISSUE / XISSUE: one ds_bpermute) of a
+    # value is emitted LOOKAHEAD slots before the slot that first uses it (or in the block's PRE list), the selection of a
+    # replicated fixed value (XSEL) right before it.  Same slots, same operands, same order of the flags as FIB_F642_BLOCKn.
+    LOOKAHEAD = 5
+    for blk in range(10):
+        slots = list(range(16 * blk, min(16 * blk + 16, 152)))
+        need = []                         # per slot: (defs first used here, line)
+        seenf, seenx = set(), set()
+        for sl in slots:
+            v = slot_v[0][sl]
+            ops, defs = [], []
+            for u in adj[v]:
+                if g[u] == u:
+                    j = fix_id[u]
+                    if j != 16 and (j // 2) not in seenx:
+                        seenx.add(j // 2); defs.append(("X", j // 2))
+                    ops.append("X(%d)" % j)
+                elif slot_of[u][1] == 0:
+                    ops.append(own(slot_of[u][0]))
+                else:
+                    fs = slot_of[u][0]
+                    fi = foreign_slots.index(fs)
+                    if fi not in seenf:
+                        seenf.add(fi); defs.append(("F", fi, fs))
+                    ops.append("F(%d)" % fi)
+            ops += ["Z"] * (6 - len(ops))
+            need.append((defs, "    SLOT(%d, %d, %d, %s)" % ((sl,) + divmod(sl, 16) + (", ".join(ops),))))
+        pre, body = [], [[] for _ in slots]
+        for p_, (defs, line) in enumerate(need):
+            for d in defs:
+                if d[0] == "F":
+                    txt = "    FISSUE(%d, %d, %d)" % ((d[1],) + divmod(d[2], 16))
+                else:
+                    txt = "    XISSUE(%d, %d, %d)" % ((d[1],) + divmod(152 + d[1], 16))
+                (pre if p_ - LOOKAHEAD < 0 else body[p_ - LOOKAHEAD]).append(txt)
+        lines = []
+        for p_, (defs, line) in enumerate(need):
+            lines += body[p_]
+            for d in defs:
+                if d[0] == "X":
+                    lines.append("    XSEL(%d, %d, %d, %d, %d)" % ((d[1], 2 * d[1], 2 * d[1] + 1) + divmod(152 + d[1], 16)))
+            lines.append(line)
+        out.append("#define FIB_F642_PBLOCK%d_PRE(FISSUE, XISSUE) \\" % blk)
+        out.append(" \\\n".join(pre) if pre else "    ")
+        out.append("#define FIB_F642_PBLOCK%d_BODY(FISSUE, XISSUE, XSEL, SLOT) \\" % blk)
+        out.append(" \\\n".join(lines))
     out.append("// fixed vertices: XDEF replicates the two vertices of a fixed slot into both halves; FTEST2 / FPOLE test them (own-pair")
     out.append("// neighbours O() x3 are combined with the other half's, then the fixed neighbours X() x3)")
     out.append("#define FIB_F642_XDEFS(XDEF) \\")
