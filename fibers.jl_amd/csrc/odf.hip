@@ -66,6 +66,7 @@ struct GemmArgs {
     int32_t *redo_count, *redo_list;   // voxels the register scan could not finish (NaN / Inf columns, candidate-list overflow)
     int redo_cap;
     void *dump;                   // pipe kernel: 1 KB per wave (1024 workgroups at most) that lanes without a voxel store into
+    int anti;                     // fused kernel: anti-phase wave halves (see odf_gemm3_kernel)
 };
 
 // scheduling hint: spread one k-step's fragment reads (ds_read2_b32 = 2 fragments) between the previous
@@ -873,16 +874,26 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
     float xacc[NXA];
     float vmax = 0.0f, vnf = 0.0f;
     unsigned en_run = 0u;                               // FUSE: running lower bound of the maximum mean (gemm3_epilogue_fused)
-    auto clear = [&]() {
+    // Anti-phase halves (FUSE, 8 waves = 2 per SIMD): waves 0-3 ("early") run the MFMA block of stage t first and split the samples
+    // of stage t+1 afterwards, waves 4-7 split stage t first and run its MFMA block afterwards, so that on every SIMD one wave's
+    // VALU work falls into the other wave's MFMA block instead of both splitting with the matrix cores idle (s_setprio keeps the
+    // MFMA block ahead of the splitting wave: without it the two instruction streams just alternate).
+    constexpr bool ANTI = FUSE && NW == 8;
+    const bool early = ANTI && (a.anti & 1) != 0 && wave < NW / 2;
+    const bool prio = ANTI && (a.anti & 2) != 0;
+    float xfin[NXA], vmax_fin = 0.0f, vnf_fin = 0.0f;    // early waves: the sums of the item being accumulated (its last split is one stage ahead)
+#pragma unroll
+    for (int x = 0; x < NXA; x++) xfin[x] = 0.0f;
+    auto clear = [&](bool keep_sums) {
 #pragma unroll
         for (int m = 0; m < MB; m++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[m][r] = 0.0f;
 #pragma unroll
-        for (int x = 0; x < NXA; x++) xacc[x] = 0.0f;
-        vmax = 0.0f; vnf = 0.0f;
+        for (int x = 0; x < NXA; x++) xacc[x] = keep_sums ? xacc[x] : 0.0f;
+        vmax = keep_sums ? vmax : 0.0f; vnf = keep_sums ? vnf : 0.0f;
     };
-    clear();
+    clear(false);
 
     // clamp (gqi.jl:140, dsi.jl:209), positivity / non-finite tracking, exact 3-way bf16 split, extra rows
     u32x4_t bp[3];
@@ -925,6 +936,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
     load_B(0, s_off, true);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();                                     // (also: the extra rows' table is complete)
+    if (ANTI && early) split(cur.tile_m, 0);
     int g = 0;                                           // stages done: ring position
     for (;;) {
         float sraw = 0.0f;                               // DSI: the sample that sum(p) is a multiple of (dsi.jl:224-225)
@@ -935,7 +947,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
         for (int t = 0; t < ntiles; t++, g++) {
             const int cb = g & 1;
             const char *L = lds + cb * TILEB;
-            split(cur.tile_m, t);
+            if (!(ANTI && early)) split(cur.tile_m, t);
             // the next stage (it may open the next work item): pieces into the other buffer, samples into braw
             const bool w1 = t + 1 < ntiles;
             stage_A(w1 ? cur.tile_m : (nxt.valid ? nxt.tile_m : cur.tile_m), w1 ? t + 1 : 0, cb ^ 1);
@@ -946,6 +958,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
             // The fragment reads are pinned (sched_barrier) 2-5 MFMAs ahead of their first use, each into the registers
             // its predecessor has just left: left to itself hipcc sinks every ds_read to the MFMA that needs it.
             bf16x8_t a2 = LA[(2 * MB) * 64], a1 = LA[(1 * MB) * 64], a0 = LA[0];
+            if (prio) __builtin_amdgcn_s_setprio(2);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MB; m++) {
@@ -965,11 +978,22 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
                 __builtin_amdgcn_sched_barrier(0);
                 a2 = n2; a1 = n1; a0 = n0;
             }
+            if constexpr (ANTI) {
+                if (prio) __builtin_amdgcn_s_setprio(0);
+                if (early) {                              // the samples requested above: the next stage's split, now
+                    if (!w1) {                            // .. which opens the next work item: close this item's sums first
+#pragma unroll
+                        for (int x = 0; x < NXA; x++) { xfin[x] = xacc[x]; xacc[x] = 0.0f; }
+                        vmax_fin = vmax; vnf_fin = vnf; vmax = 0.0f; vnf = 0.0f;
+                    }
+                    split(w1 ? cur.tile_m : (nxt.valid ? nxt.tile_m : cur.tile_m), w1 ? t + 1 : 0);
+                }
+            }
             __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): the next stage's pieces and samples have landed
             __syncthreads();
         }
         if constexpr (FUSE)
-            gemm3_epilogue_fused<NW>(a, acc, xacc[0], vmax, vnf, inb, lv, vox, lane, lds + 2 * TILEB + wave * TRB,
+            gemm3_epilogue_fused<NW>(a, acc, early ? xfin[0] : xacc[0], early ? vmax_fin : vmax, early ? vnf_fin : vnf, inb, lv, vox, lane, lds + 2 * TILEB + wave * TRB,
                                      lds + 2 * TILEB + NW * TRB + XTAB + FTAB + wave * FQ_LIST, q_posoff, q_slotv, q_vl, en_run);
         else
             gemm3_epilogue<MB, NX>(a, acc, xacc, vmax, vnf, inb, lv, vox, lane, cur.tile_m, sraw, lds + 2 * TILEB + wave * TRB);
@@ -977,7 +1001,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
         cur = nxt; inb = inb_n; vox = vox_n; s_off = s_off_n;
         nxt = work_at(g / ntiles + 1);
         vraw_nxt = nxt.valid ? vidx_at(nxt) : 0;
-        clear();
+        clear(early);
     }
     if constexpr (FUSE) {
         for (int off = 32; off >= 1; off >>= 1) { const unsigned oth = (unsigned)__shfl_xor((int)en_run, off); en_run = oth > en_run ? oth : en_run; }
@@ -2316,6 +2340,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         ga.verts = plan->verts.p; ga.maxenc = plan->maxenc.p; ga.mean_hi = plan->mean_hi.p;
         ga.redo_count = plan->live_counts.p + 3; ga.redo_list = plan->redo_list.p; ga.redo_cap = (int)std::min<int64_t>(nvox, INT32_MAX);
         // the software-pipelined kernel spreads the epilogue over the 13 contraction stages after the first (protocols of 209+ frames)
+        { const char *pa = getenv("FIBERS_ODF_ANTI"); ga.anti = pa ? atoi(pa) : 3; }   // bit 0: anti-phase wave halves, bit 1: s_setprio around the MFMA block (default both; 0 = neither)
         { const char *pe = getenv("FIBERS_ODF_PIPE"); if (plan->Kpad / KT >= 1 + PP_NSLICE && pe && pe[0] == '1') ga.dump = plan->dump.p; }
     }
     ga.K = plan->gK; ga.Kpad = plan->Kpad; ga.M = plan->gM; ga.nrow0 = plan->gRow0; ga.ntile_m = plan->ntile_m;

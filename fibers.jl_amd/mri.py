@@ -18,7 +18,7 @@ class MRI:
     niftihdr: Optional[dict] = None              # header of the file this volume came from (mri.jl:126)
 
     def __post_init__(self):
-        v = np.asarray(self.vol)
+        v = np.asanyarray(self.vol)                  # (asanyarray: an np.memmap stays one)
         if v.ndim == 3:
             v = v[..., None]
         if v.ndim != 4:
