@@ -329,6 +329,22 @@ def main():
                                         hbm_gbs_trace=25.0 * (npoints / world) / (tr_ms / max(tr_n, 1) * 1e-3) / 1e9 if tr_n else 0.0,
                                         note="one volume; wall = field all-gather + trace + scan + pack into a pre-allocated buffer (+ one host sync for "
                                              "the line count); seeds dealt round-robin over the ranks")
+        # the trilinear option (fib_stream_params.interp = 1; not in the reference) on the same field and seeds, rank 0's share
+        if rank == 0:
+            field_all = fd.allgather_slabs(field_loc, counts) if world == 1 else None
+            if field_all is not None:
+                rt = {}
+
+                def tri_step():
+                    rt["r"] = fj.stream_device(field_all, shape, seeds_all, sub, xyz_out=xyz_out, interp="trilinear")
+                L.fib_profile_reset()
+                t_tri = timed(tri_step, nst, 1) / nst
+                tt_ms, tt_n = prof_get(L, "stream_trace")
+                npt = int(rt["r"]["xyz"].shape[0])
+                extra["stream_dti_ball_trilinear"] = dict(lines=int(rt["r"]["npts"].numel()), points=npt, mpoints_per_s=npt / t_tri / 1e6,
+                                                          ms_per_step=t_tri * 1e3, trace_kernel_ms=tt_ms / max(tt_n, 1),
+                                                          note="interp = trilinear: 8 x the field reads per step, same integrator")
+                del rt, field_all
         del res, r
         if world == 1:
             field = field_loc

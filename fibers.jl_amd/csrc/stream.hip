@@ -138,7 +138,9 @@ __device__ __forceinline__ int lcm_match_edge(int dx, int dy, int dz, int sd0, i
 // MODE 0: points into the slot-major scratch + counts (packed later by stream_pack_kernel);  MODE 1: counts only;
 // MODE 2: the counts and their scan are known: trace again, every point goes straight to its place in the packed output
 // (forward points descending from nf-1, backward points ascending from nf: stream.jl:652), no scratch at all.
-template <int NVEC, bool LCM = false, int MODE = 0>   // NVEC > 0: compile-time vector count; 0: runtime
+// TRI (params.interp = 1, not in the reference): the direction followed is the trilinear blend of the eight voxels around the
+// tentative position instead of the nearest voxel's vector -- see the TRI block below for the exact definition.
+template <int NVEC, bool LCM = false, int MODE = 0, bool TRI = false>   // NVEC > 0: compile-time vector count; 0: runtime
 __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= a.nlines) return;
@@ -205,6 +207,47 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
             float wx, wy, wz;
             if (bestc > 0.0f) { wx = bx; wy = by; wz = bz; } else { wx = -bx; wy = -by; wz = -bz; }   // :365-369
             ivec = best;                                          // stream.jl:371
+            if (TRI) {
+                // Trilinear option.  Everything above still decides whether the line goes on (bounds, the nearest voxel's pick must
+                // exist) and which vector index the backward pass starts from; the direction becomes
+                //   w = normalise( sum over the 8 corners c of floor(p') + {0,1}^3 inside the volume of  t_c * s_c * u_c ),
+                // t_c = (ax * ay) * az with a = frac or 1 - frac per axis, u_c = the corner's vector picked by the same angle rule
+                // against the current direction (corners without a vector contribute nothing), s_c = sign of its cosine; products
+                // and sums in Float32 in corner order x fastest, the norm as LinearAlgebra.norm does it (below).  A zero or
+                // non-finite blend ends the line.  The 8 x nvec float4 loads of a step hit L2 / the vector cache (the stencil moves
+                // by half a voxel per step); an LDS copy per lane (128 B x nvec x 256 lanes) was not worth its LDS traffic.
+                const float gx0 = floorf(nxp), gy0 = floorf(nyp), gz0 = floorf(nzp);
+                const float tx = nxp - gx0, ty = nyp - gy0, tz = nzp - gz0;
+                float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const int cx = c & 1, cy = (c >> 1) & 1, cz = c >> 2;
+                    const float gx = gx0 + (float)cx, gy = gy0 + (float)cy, gz = gz0 + (float)cz;
+                    if (!(gx >= 1.0f && gx <= fnx && gy >= 1.0f && gy <= fny && gz >= 1.0f && gz <= fnz)) continue;
+                    const float tc = ((cx ? tx : 1.0f - tx) * (cy ? ty : 1.0f - ty)) * (cz ? tz : 1.0f - tz);
+                    const uint32_t cv = (uint32_t)(((int)gx - 1) + a.nx * (((int)gy - 1) + a.ny * ((int)gz - 1)));
+                    const float4 *cc = reinterpret_cast<const float4 *>(fbase + (size_t)(cv * (uint32_t)(nvec * 16)));
+                    float ux = 0.0f, uy = 0.0f, uz = 0.0f, uc = 0.0f, ua = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < nvec; k++) {
+                        const float4 w = cc[k];
+                        float cs, ca;
+                        if (w.x == 0.0f && w.y == 0.0f && w.z == 0.0f) { cs = -INFINITY; ca = -INFINITY; }
+                        else { cs = dot3(vx, vy, vz, w.x, w.y, w.z); ca = fabsf(cs); }
+                        if (k == 0 || (!(ua != ua) && ((ca != ca) || ca > ua))) { ua = ca; uc = cs; ux = w.x; uy = w.y; uz = w.z; }
+                    }
+                    if (!(fabsf(uc) < INFINITY)) continue;
+                    const float sg = uc > 0.0f ? tc : -tc;
+                    sx = sx + sg * ux; sy = sy + sg * uy; sz = sz + sg * uz;
+                }
+                const float m = fmaxf(fabsf(sx), fmaxf(fabsf(sy), fabsf(sz)));
+                if (m == 0.0f || !(m < INFINITY)) break;
+                double acc = (double)(sx * sx);
+                acc += (double)(sy * sy);
+                acc += (double)(sz * sz);
+                const float n = (float)sqrt(acc);
+                wx = sx / n; wy = sy / n; wz = sz / n;
+            }
             bool isdiff = false;
             if (LCM) {
                 // stream_pick_by_lcm! (stream.jl:380-495), after the angle pick above set W.ivec_next (stream.jl:530-531)
@@ -960,6 +1003,9 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
     FIB_CHECK(prm->nx > 0 && prm->ny > 0 && prm->nz > 0 && prm->nvec >= 1 && prm->nvec <= 8, FIB_ERR_INVALID, "invalid volume / nvec");
     FIB_CHECK(prm->len_max >= 0 && prm->len_max < (1 << 24), FIB_ERR_INVALID, "invalid len_max");
     FIB_CHECK(prm->search_dist <= 60, FIB_ERR_UNSUPPORTED, "search_dist up to 60 voxels is supported (got %d)", prm->search_dist);
+    FIB_CHECK(prm->interp == 0 || prm->interp == 1, FIB_ERR_INVALID, "interp must be 0 (nearest voxel, the reference) or 1 (trilinear)");
+    FIB_CHECK(prm->interp == 0 || (prm->search_dist == 0 && !lin.lcms), FIB_ERR_UNSUPPORTED,
+              "trilinear interpolation is an option of macro-scale angle-picked tracking only");
     FIB_CHECK((int64_t)prm->nx * prm->ny * prm->nz * prm->nvec < ((int64_t)1 << 28), FIB_ERR_UNSUPPORTED,
               "orientation fields of 2^28 vectors or more are not supported (32-bit gather offsets)");
     int device = 0;
@@ -1082,6 +1128,18 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
         else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, true>), dim3(grid), dim3(256), 0, st, ta);
         else                     hipLaunchKernelGGL((stream_trace_kernel<0, true>), dim3(grid), dim3(256), 0, st, ta);
     } else
+    if (prm->interp) {                                  // trilinear option: one-lane-per-line kernels only
+        fib::ProfScope prof(job->two_pass ? "stream_count" : "stream_trace", st);
+        if (job->two_pass) {
+            if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1, false, 1, true>), dim3(grid), dim3(256), 0, st, ta);
+            else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, false, 1, true>), dim3(grid), dim3(256), 0, st, ta);
+            else                     hipLaunchKernelGGL((stream_trace_kernel<0, false, 1, true>), dim3(grid), dim3(256), 0, st, ta);
+        } else {
+            if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1, false, 0, true>), dim3(grid), dim3(256), 0, st, ta);
+            else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, false, 0, true>), dim3(grid), dim3(256), 0, st, ta);
+            else                     hipLaunchKernelGGL((stream_trace_kernel<0, false, 0, true>), dim3(grid), dim3(256), 0, st, ta);
+        }
+    } else
     if (job->two_pass) {
         fib::ProfScope prof("stream_count", st);
         if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1, false, 1>), dim3(grid), dim3(256), 0, st, ta);
@@ -1158,6 +1216,11 @@ static int retrace(fib_stream_job *job, int32_t *npts, int64_t *seed_index, floa
     hipStream_t st = (hipStream_t)stream;
     job->last_stream = st;
     fib::ProfScope prof(voxel_size ? "stream_write_trk" : "stream_write", st);
+    if (job->prm.interp) {
+        if (ta.nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1, false, 2, true>), dim3(grid), dim3(256), 0, st, ta);
+        else if (ta.nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, false, 2, true>), dim3(grid), dim3(256), 0, st, ta);
+        else                   hipLaunchKernelGGL((stream_trace_kernel<0, false, 2, true>), dim3(grid), dim3(256), 0, st, ta);
+    } else
     if (ta.nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1, false, 2>), dim3(grid), dim3(256), 0, st, ta);
     else if (ta.nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, false, 2>), dim3(grid), dim3(256), 0, st, ta);
     else                   hipLaunchKernelGGL((stream_trace_kernel<0, false, 2>), dim3(grid), dim3(256), 0, st, ta);

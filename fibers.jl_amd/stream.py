@@ -77,12 +77,15 @@ def default_workspace(device: int) -> StreamWorkspace:
     return ws
 
 
-def _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff, search_dist=0, search_ang=10, ws=None):
-    """search_dist > 0 selects the microscopy regime (stream.jl:83, 547-619)"""
+def _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff, search_dist=0, search_ang=10, ws=None, interp="nearest"):
+    """search_dist > 0 selects the microscopy regime (stream.jl:83, 547-619); interp: "nearest" (the reference) or "trilinear"
+    (fib_stream_params.interp in include/fibers_hip.h)"""
+    if interp not in ("nearest", "trilinear"):
+        raise ValueError("interp must be 'nearest' or 'trilinear'")
     nx, ny, nz = shape
     return _lib.StreamParams(nx, ny, nz, nvec, int(len_min), int(len_max if len_max is not None else max(shape)),
                              float(cosd32(ang_thresh)), float(np.float32(step_size)), float(np.float32(smooth_coeff)),
-                             int(search_dist), float(cosd32(search_ang)), ws._h if ws is not None else None)
+                             int(search_dist), float(cosd32(search_ang)), ws._h if ws is not None else None, 1 if interp == "trilinear" else 0)
 
 
 def stream(ovec: Union[MRI, Sequence[MRI]], *, f=None, f_thresh: float = 0.03, fa: Optional[MRI] = None,
@@ -90,7 +93,7 @@ def stream(ovec: Union[MRI, Sequence[MRI]], *, f=None, f_thresh: float = 0.03, f
            len_min: int = 3, len_max: Optional[int] = None, ang_thresh: Optional[float] = 45,
            step_size: Optional[float] = 0.5, smooth_coeff: Optional[float] = 0.2, lcms=None, lcm_thresh: float = 0.099,
            search_dist: int = 15, search_ang: float = 10, sublist=None, rng=None, rng_seed: int = 0,
-           device: int = 0) -> Tract:
+           device: int = 0, interp: str = "nearest") -> Tract:
     """Streamline tractography (stream.jl:730).  Returns a `Tract` whose lines are in the reference's order
     (seed voxels in column-major `findall` order, sub-voxel offsets innermost), points in 1-based voxel
     coordinates, each line ordered [forward reversed, backward] as stream.jl:652 builds it.
@@ -142,7 +145,7 @@ def stream(ovec: Union[MRI, Sequence[MRI]], *, f=None, f_thresh: float = 0.03, f
         sptr = sarr.ctypes.data
     sub = make_sublist(nsub, rng) if sublist is None else np.ascontiguousarray(sublist, np.float32).reshape(-1, 3)
     prm = _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff,
-                  int(search_dist) if domicro else 0, search_ang)
+                  int(search_dist) if domicro else 0, search_ang, interp=interp)
     ov = (C.c_void_p * nvec)(*[v.ctypes.data for v in vols])
     fv = None if fvols is None else (C.c_void_p * nvec)(*[v.ctypes.data for v in fvols])
     out = _lib.TractOut()
@@ -220,7 +223,7 @@ def stream_field_device(ovec: List, f: Optional[List] = None, f_thresh: float = 
 
 def stream_device(field, shape, seeds, sublist, len_min=3, len_max=None, ang_thresh=45, step_size=0.5,
                   smooth_coeff=0.2, stream=None, want_all_npts=False, search_dist=0, search_ang=10,
-                  lcms=None, lcm_thresh=0.099, strdims=(0, 1), rng_seed=0, xyz_out=None, workspace="default"):
+                  lcms=None, lcm_thresh=0.099, strdims=(0, 1), rng_seed=0, xyz_out=None, workspace="default", interp="nearest"):
     """Trace + pack on the GPU.  field: [nvox, nvec, 4] from stream_field_device; seeds: int64 CUDA tensor of
     0-based column-major voxel indices (findall order); sublist: float32 CUDA [nsub, 3].
     search_dist > 0: microscopy regime (stream.jl:547-619; reference defaults there: search_dist 15, search_ang 10,
@@ -229,7 +232,7 @@ def stream_device(field, shape, seeds, sublist, len_min=3, len_max=None, ang_thr
     in-plane dimensions `strdims`, uniforms from the ABI's counter-based stream (`rng_seed`); adds `flags` uint8 [npoints].
     xyz_out: optional callable npoints -> float32 CUDA tensor of at least 3 * npoints elements to pack the points into (any
     4-byte alignment).  workspace: a StreamWorkspace, None (scratch allocated and freed by the job) or "default" (the
-    host mirror's arena for the field's device).
+    host mirror's arena for the field's device).  interp="trilinear": the non-reference option of fib_stream_params.interp.
     Returns dict(npts int32 [nlines], seed_index int64 [nlines], xyz float32 [npoints, 3])."""
     import torch
     _chk_dev(field, torch.float32, "field")
@@ -237,7 +240,7 @@ def stream_device(field, shape, seeds, sublist, len_min=3, len_max=None, ang_thr
     _chk_dev(sublist, torch.float32, "sublist")
     nvec = field.shape[1]
     ws = default_workspace(field.device.index or 0) if isinstance(workspace, str) else workspace
-    prm = _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff, search_dist, search_ang, ws)
+    prm = _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff, search_dist, search_ang, ws, interp)
     job = C.c_void_p()
     nl, npnt = C.c_int64(0), C.c_int64(0)
     L = _lib.lib()

@@ -201,6 +201,12 @@ typedef struct {
     int32_t search_dist;    /* 0: macro-scale tracking */
     float search_cosang;    /* cosd(search_ang) */
     struct fib_stream_ws *ws;   /* optional scratch arena (fibd_stream_ws_create); NULL: the job allocates and frees its own */
+    /* 0: the reference's nearest-voxel lookup (stream.jl:514).  1: NOT in the reference — the direction followed is the trilinear
+     * blend of the 8 voxels around the tentative position: w = normalise(sum_c t_c s_c u_c), t_c the trilinear weight of corner c
+     * (corners outside the volume dropped), u_c the corner's vector picked by the angle rule of stream.jl:340-374 against the
+     * current direction (corners without a vector dropped), s_c the sign of its cosine; a zero blend ends the line.  Bounds,
+     * mask and the nearest voxel's pick still decide termination exactly as in the reference; macro scale, angle picking only. */
+    int32_t interp;
 } fib_stream_params;
 
 typedef struct fib_stream_job fib_stream_job;

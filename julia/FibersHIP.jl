@@ -158,6 +158,7 @@ struct FibStreamParams
   cosang_thresh::Float32; step_size::Float32; smooth_coeff::Float32
   search_dist::Int32; search_cosang::Float32          # microscopy regime (stream.jl:83, 547-619) when search_dist > 0
   ws::Ptr{Cvoid}                                      # optional tracer workspace (fibd_stream_ws_create); C_NULL for the host-buffer calls
+  interp::Int32                                       # 0: nearest voxel (stream.jl:514); 1: trilinear blend (not in the reference)
 end
 
 mutable struct FibTractOut
@@ -188,7 +189,7 @@ function stream(ovec::Union{MRI,Vector{MRI}}; f::Union{MRI,Vector{MRI},Nothing}=
   sublist = nsub > 0 ? hcat([Float32.(rand(Uniform(-.5+eps(), .5-eps()), 3)) for _ in 1:nsub]...) : zeros(Float32, 3, 1)
   prm = Ref(FibStreamParams(nx, ny, nz, length(ovecs), len_min, len_max,
                             cosd(Float32(ang_thresh)), Float32(step_size), Float32(smooth_coeff),
-                            domicro ? Int32(search_dist) : Int32(0), cosd(Float32(search_ang)), C_NULL))
+                            domicro ? Int32(search_dist) : Int32(0), cosd(Float32(search_ang)), C_NULL, Int32(0)))
   pv = [pointer(o.vol) for o in ovecs]
   pf = isnothing(fs) ? C_NULL : [pointer(x.vol) for x in fs]
   out = FibTractOut()

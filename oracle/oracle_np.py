@@ -225,9 +225,55 @@ def norm32(v):
     return f32(np.sqrt(np.sum((v * v).astype(np.float64))))
 
 
-def stream_line(seed, sub, ovecs, mask, step=0.5, cosang_thresh=None, smooth=0.2, len_max=None):
+def _pick_by_angle(vec, cands):
+    """stream_pick_by_angle! (stream.jl:340-374) on cands [3, nvec]: (k, cos_k) with cos = -Inf for zero vectors"""
+    nvec = cands.shape[1]
+    cos = np.full(nvec, -np.inf, f32)
+    cosabs = np.full(nvec, -np.inf, f32)
+    for k in range(nvec):
+        v = cands[:, k]
+        if not (v == 0).all():
+            cos[k] = (vec[0] * v[0] + vec[1] * v[1]) + vec[2] * v[2]
+            cosabs[k] = np.abs(cos[k])
+    nanpos = np.flatnonzero(np.isnan(cosabs))
+    k = int(nanpos[0]) if len(nanpos) else int(np.argmax(cosabs))
+    return k, cos[k]
+
+
+def trilinear_direction(nxt, vec, ovecs):
+    """The blend of fib_stream_params.interp = 1 (include/fibers_hip.h; NOT in the reference): corners of floor(nxt) + {0,1}^3
+    inside the volume, x fastest; weight (ax * ay) * az; each corner's vector picked against `vec` by the angle rule and
+    sign-aligned; Float32 products and sums in that order; LinearAlgebra.norm.  Returns None when the blend is zero / not finite."""
+    shape = ovecs.shape[2:]
+    g0 = np.floor(nxt).astype(f32)
+    t = (nxt - g0).astype(f32)
+    s = np.zeros(3, f32)
+    one = f32(1)
+    for c in range(8):
+        cx, cy, cz = c & 1, (c >> 1) & 1, c >> 2
+        g = g0 + np.array([cx, cy, cz], f32)
+        if not all(1 <= g[d] <= shape[d] for d in range(3)):
+            continue
+        tc = ((t[0] if cx else one - t[0]) * (t[1] if cy else one - t[1])) * (t[2] if cz else one - t[2])
+        gi = g.astype(np.int64) - 1
+        cands = ovecs[:, :, gi[0], gi[1], gi[2]]
+        k, ck = _pick_by_angle(vec, cands)
+        with np.errstate(invalid="ignore"):
+            if not np.isfinite(ck):
+                continue
+        sg = tc if ck > 0 else -tc
+        u = cands[:, k]
+        s = np.array([s[0] + sg * u[0], s[1] + sg * u[1], s[2] + sg * u[2]], f32)
+    m = np.max(np.abs(s))
+    if m == 0 or not np.isfinite(m):
+        return None
+    return (s / norm32(s)).astype(f32)
+
+
+def stream_line(seed, sub, ovecs, mask, step=0.5, cosang_thresh=None, smooth=0.2, len_max=None, interp="nearest"):
     """stream_new_line (stream.jl:625-690) with stream_new_point! (:501-541) and stream_pick_by_angle! (:340-374).
-    ovecs: [3, nvec, nx, ny, nz] Float32 (masked vectors zeroed, :141-145); seed: 1-based voxel (ix, iy, iz); returns [npts, 3]"""
+    ovecs: [3, nvec, nx, ny, nz] Float32 (masked vectors zeroed, :141-145); seed: 1-based voxel (ix, iy, iz); returns [npts, 3].
+    interp="trilinear": the library's non-reference option (trilinear_direction)."""
     nvec = ovecs.shape[1]
     shape = ovecs.shape[2:]
     step, smooth = f32(step), f32(smooth)
@@ -263,6 +309,10 @@ def stream_line(seed, sub, ovecs, mask, step=0.5, cosang_thresh=None, smooth=0.2
             v = ovecs[:, k, vox[0] - 1, vox[1] - 1, vox[2] - 1]
             vnext = v.copy() if cos[k] > 0 else -v                              # :365-369
             ivec = k                                                            # :371
+            if interp == "trilinear":
+                vnext = trilinear_direction(nxt.astype(f32), vec.astype(f32), ovecs)
+                if vnext is None:
+                    break
             if fwd == 1:
                 line.insert(0, pos.copy())                                      # prepend!, :660
             else:

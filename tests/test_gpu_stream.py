@@ -307,28 +307,38 @@ def test_persistent_refill_tracer_is_bit_identical(fj, monkeypatch, nvec):
         assert torch.equal(a[k], b[k]), k
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("nvec", [1, 3])
-def test_persistent_refill_tracer_is_bit_identical(fj, monkeypatch, nvec):
-    """FIBERS_STREAM_REFILL=1: persistent waves whose finished lanes draw new lines from a queue (ballot + prefix rank) on a
-    phantom with a broad length distribution; same lines, same points, same order as the one-lane-per-line kernel"""
-    import torch
-    from fibers_jl_amd import phantom
-    dev = torch.device("cuda", 0)
-    shape = (40, 36, 30)
-    ov, m = phantom.bundle_field_torch(shape, dev, seed=3, cell=7.0)
-    ovs = [ov]
-    for k in range(1, nvec):
-        o2, _ = phantom.bundle_field_torch(shape, dev, seed=3 + k, cell=9.0)
-        ovs.append(o2)
-    field, mout = fj.stream_field_device(ovs, mask=m)
-    seeds = torch.nonzero(mout).flatten()
-    sub = torch.from_numpy(fj.make_sublist(3, np.random.default_rng(1))).to(dev)
-    res = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("FIBERS_STREAM_REFILL", mode)
-        res[mode] = fj.stream_device(field, shape, seeds, sub, want_all_npts=True, len_min=2)
-    a, b = res["0"], res["1"]
-    assert a["npts"].numel() > 1000 and int(a["npts"].max()) > 2 * int(a["npts"].float().median())   # a broad length distribution
-    for k in ("npts", "seed_index", "xyz", "all_npts"):
-        assert torch.equal(a[k], b[k]), k
+@pytest.mark.parametrize("nvec,smooth", [(1, 0.2), (2, 0.2), (2, 0.0)])
+def test_trilinear_option_follows_its_definition(fj, orc, nvec, smooth):
+    """fib_stream_params.interp = 1 (north_star's trilinear option; NOT in the reference): every line equals the NumPy Float32
+    restatement of the definition in include/fibers_hip.h (oracle/oracle_np.py trilinear_direction) point for point -- corners
+    outside the volume, corners without a vector, mask holes, two vectors per voxel, the carried vector index, len_max.  With
+    interp = 0 the same call is the reference's nearest-voxel tracker (every other test of this file)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import oracle_np as onp
+    rng = np.random.default_rng(21 + nvec)
+    n = 10
+    f = _fields(n, 5)
+    ov = [f["noisy"]]
+    if nvec == 2:
+        o2 = f["circ"].copy()
+        o2[rng.random((n, n, n)) < 0.25] = 0                              # voxels with one vector only
+        ov.append(np.asfortranarray(o2))
+    mask = (rng.random((n, n, n)) < 0.92).astype(np.uint8)
+    sub = np.array([[0.1, -0.2, 0.3], [-0.25, 0.15, 0.05]], np.float32)
+    len_min, len_max = 3, 14
+    tr = fj.stream([fj.MRI(o) for o in ov], mask=fj.MRI(mask), sublist=sub, len_min=len_min, len_max=len_max, smooth_coeff=smooth,
+                   interp="trilinear")
+    near = fj.stream([fj.MRI(o) for o in ov], mask=fj.MRI(mask), sublist=sub, len_min=len_min, len_max=len_max, smooth_coeff=smooth)
+    mk, arr = orc.stream_work(ov, None, 0.03, None, 0.1, mask)
+    seeds = np.argwhere(np.transpose(mk, (2, 1, 0)))[:, ::-1] + 1            # findall order (x fastest), 1-based
+    npts, sidx, xyz = [], [], []
+    for si, seed in enumerate(seeds):
+        for k in range(sub.shape[0]):
+            line = onp.stream_line([int(v) for v in seed], sub[k], arr, mk, smooth=smooth, len_max=len_max, interp="trilinear")
+            if line.shape[0] >= len_min:
+                npts.append(line.shape[0]); sidx.append(si * sub.shape[0] + k); xyz.append(line)
+    assert tr.nstr == len(npts) and np.array_equal(tr.npts, np.array(npts, np.int32)) and np.array_equal(tr.seed_index, np.array(sidx, np.int64))
+    want = np.concatenate(xyz, 0)
+    assert np.array_equal(tr.xyz, want), float(np.abs(tr.xyz - want).max())
+    assert tr.nstr > 200 and (tr.nstr != near.nstr or not np.array_equal(tr.xyz, near.xyz))   # (it is a different tracker)
