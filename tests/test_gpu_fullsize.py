@@ -131,6 +131,27 @@ def test_c3_gqi_140cubed(fj, orc, dev):
     _odf_properties(fj, out, mask, plan, dwi, dev, 4.0)
 
 
+@pytest.mark.parametrize("env,val", [("FIBERS_ODF_ANTI", "0"), ("FIBERS_ODF_PIPE", "1")])
+def test_c3_gqi_kernel_variants_bit_identical_140cubed(fj, dev, monkeypatch, env, val):
+    """the fused GQI kernel without its anti-phase wave halves, and the software-pipelined kernel, against the default kernel
+    on the full 140^3 x 270 volume (ball mask: partial work items, workgroups with different item counts): every output bit"""
+    import torch
+    from fibers_jl_amd import phantom
+    bval, bvec = phantom.scheme_gqi()
+    dwi, _ = phantom.make_dwi_torch(SHAPE, bval, bvec, seed=3, device=dev)
+    mask = phantom.ball_mask_torch(SHAPE, dev)
+    plan = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642, sigma=1.25, device=0)
+    res = []
+    for on in (False, True):
+        if on:
+            monkeypatch.setenv(env, val)
+        o = fj.odf_rec_device(plan, dwi, mask)
+        torch.cuda.synchronize()
+        res.append([o["odf"].clone()] + [t.clone() for t in o["peak"]] + [t.clone() for t in o["qa"]] + [o["odfmax"].clone()])
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+
+
 @pytest.fixture(scope="module")
 def dsi_result(fj, dev):
     import torch
