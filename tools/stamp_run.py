@@ -1,6 +1,6 @@
 import os, sys, torch
 sys.path.insert(0, "/root/repo")
-os.environ["FIBERS_ODF_PIPE"] = "1"
+os.environ.setdefault("FIBERS_ODF_PIPE", "1")
 import fibers_jl_amd as fj
 from fibers_jl_amd import phantom
 dev = torch.device("cuda", 0)
