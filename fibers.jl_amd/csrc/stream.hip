@@ -219,13 +219,18 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
                 const float gx0 = floorf(nxp), gy0 = floorf(nyp), gz0 = floorf(nzp);
                 const float tx = nxp - gx0, ty = nyp - gy0, tz = nzp - gz0;
                 float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+                // per-axis validity of the low / high corner and the linear index of the low corner: no per-corner bounds test
+                const bool xl = gx0 >= 1.0f && gx0 <= fnx, xh = gx0 + 1.0f >= 1.0f && gx0 + 1.0f <= fnx;
+                const bool yl = gy0 >= 1.0f && gy0 <= fny, yh = gy0 + 1.0f >= 1.0f && gy0 + 1.0f <= fny;
+                const bool zl = gz0 >= 1.0f && gz0 <= fnz, zh = gz0 + 1.0f >= 1.0f && gz0 + 1.0f <= fnz;
+                const int cbase = ((int)gx0 - 1) + a.nx * (((int)gy0 - 1) + a.ny * ((int)gz0 - 1));
+                const float ax0 = 1.0f - tx, ay0 = 1.0f - ty, az0 = 1.0f - tz;
 #pragma unroll
                 for (int c = 0; c < 8; c++) {
                     const int cx = c & 1, cy = (c >> 1) & 1, cz = c >> 2;
-                    const float gx = gx0 + (float)cx, gy = gy0 + (float)cy, gz = gz0 + (float)cz;
-                    if (!(gx >= 1.0f && gx <= fnx && gy >= 1.0f && gy <= fny && gz >= 1.0f && gz <= fnz)) continue;
-                    const float tc = ((cx ? tx : 1.0f - tx) * (cy ? ty : 1.0f - ty)) * (cz ? tz : 1.0f - tz);
-                    const uint32_t cv = (uint32_t)(((int)gx - 1) + a.nx * (((int)gy - 1) + a.ny * ((int)gz - 1)));
+                    if (!((cx ? xh : xl) && (cy ? yh : yl) && (cz ? zh : zl))) continue;
+                    const float tc = ((cx ? tx : ax0) * (cy ? ty : ay0)) * (cz ? tz : az0);
+                    const uint32_t cv = (uint32_t)(cbase + cx + a.nx * (cy + a.ny * cz));
                     const float4 *cc = reinterpret_cast<const float4 *>(fbase + (size_t)(cv * (uint32_t)(nvec * 16)));
                     float ux = 0.0f, uy = 0.0f, uz = 0.0f, uc = 0.0f, ua = 0.0f;
 #pragma unroll
