@@ -2339,7 +2339,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         for (int k = 0; k < 3; k++) { ga.peak[k] = peak[k]; ga.qa[k] = qa[k]; }
         ga.verts = plan->verts.p; ga.maxenc = plan->maxenc.p; ga.mean_hi = plan->mean_hi.p;
         ga.redo_count = plan->live_counts.p + 3; ga.redo_list = plan->redo_list.p; ga.redo_cap = (int)std::min<int64_t>(nvox, INT32_MAX);
-        // the software-pipelined kernel spreads the epilogue over the 13 contraction stages after the first (protocols of 209+ frames)
+        // the software-pipelined kernel spreads the epilogue over the 14 contraction stages after the first (protocols of 225+ frames)
         { const char *pa = getenv("FIBERS_ODF_ANTI"); ga.anti = pa ? atoi(pa) : 3; }   // bit 0: anti-phase wave halves, bit 1: s_setprio around the MFMA block (default both; 0 = neither)
         { const char *pe = getenv("FIBERS_ODF_PIPE"); if (plan->Kpad / KT >= 1 + PP_NSLICE && pe && pe[0] == '1') ga.dump = plan->dump.p; }
     }

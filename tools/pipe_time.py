@@ -18,7 +18,7 @@ for _ in range(3):
     fj.odf_rec_device(plan, dwi, mask, normalize=False)
 torch.cuda.synchronize()
 res = []
-for rep in range(3):
+for rep in range(int(os.environ.get("FIBERS_TIME_REPS", "3"))):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
