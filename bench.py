@@ -230,7 +230,9 @@ def main():
                                              % (",FUSE" if fused else "", "; find_peaks! + peak/qa extraction on the accumulators" if fused else ""),
                         achieved=achieved, peak=peak_eff, unit="TFLOP/s", frac=achieved / peak_eff,
                         note="achieved = algorithmic f32 flops (2*321*270 per voxel) / kernel time (the fused kernel's time includes the peak finder); "
-                             "peak = 2500 TFLOP/s dense BF16 / 6 piece products; executed BF16 MFMA rate = %.0f TFLOP/s of 2500"
+                             "peak = 2500 TFLOP/s dense BF16 / 6 piece products; executed BF16 MFMA rate = %.0f TFLOP/s of 2500; the step runs at "
+                             "the board's power limit (extra.power_clock_under_load: ~1.35 kW, ~1.95 GHz of the nominal 2.4), three different "
+                             "schedules of the contraction take the same 2.07 ms (DESIGN.md K2/K5)"
                              % (6.0 * 2.0 * 320 * 272 * nloc / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0),
                         avg_kernel_ms=gemm_avg_ms, launches=gemm_n, traffic=None, hbm_secondary=hbm2, peaks_kernel=pk)
     else:
