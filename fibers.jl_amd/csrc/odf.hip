@@ -69,6 +69,26 @@ struct GemmArgs {
     int anti;                     // fused kernel: anti-phase wave halves (see odf_gemm3_kernel)
 };
 
+// Diagnostic build only (make stamp -> libfibers_hip_stamp.so, -DFIB_CLOCK_STAMP; in the product library no stamp executes):
+// the in-kernel clock of the contraction kernels = d(s_memtime) / d(s_memrealtime) x 100 MHz around a workgroup's whole work loop
+// (MI355X_MICROARCH.md "DVFS give-back" item 6).  Stamps leave through a buffer of their own that no kernel reads.
+#ifdef FIB_CLOCK_STAMP
+__device__ unsigned long long fib_clock_stamps[2048][4];        // per workgroup of the last launch: {shader cycles, 100-MHz ticks, kernel id, work items}
+#define FIB_STAMP_BEGIN() unsigned long long fcs_c0_, fcs_r0_; asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(fcs_c0_), "=s"(fcs_r0_) :: "memory")
+#define FIB_STAMP_END(kid, items)                                                                                                   \
+    do {                                                                                                                            \
+        unsigned long long fcs_c1_, fcs_r1_;                                                                                        \
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(fcs_c1_), "=s"(fcs_r1_) :: "memory");          \
+        if (threadIdx.x == 0 && blockIdx.x < 2048) {                                                                                \
+            fib_clock_stamps[blockIdx.x][0] = fcs_c1_ - fcs_c0_; fib_clock_stamps[blockIdx.x][1] = fcs_r1_ - fcs_r0_;               \
+            fib_clock_stamps[blockIdx.x][2] = (kid); fib_clock_stamps[blockIdx.x][3] = (unsigned long long)(items);                 \
+        }                                                                                                                           \
+    } while (0)
+#else
+#define FIB_STAMP_BEGIN() do { } while (0)
+#define FIB_STAMP_END(kid, items) do { } while (0)
+#endif
+
 // scheduling hint: spread one k-step's fragment reads (ds_read2_b32 = 2 fragments) between the previous
 // k-step's MFMAs instead of "read, wait, 2 MFMA" chains (hipcc otherwise minimises live registers)
 template <int MB>
@@ -938,6 +958,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
     __syncthreads();                                     // (also: the extra rows' table is complete)
     if (ANTI && early) split(cur.tile_m, 0);
     int g = 0;                                           // stages done: ring position
+    FIB_STAMP_BEGIN();
     for (;;) {
         float sraw = 0.0f;                               // DSI: the sample that sum(p) is a multiple of (dsi.jl:224-225)
         if (a.scale_frame >= 0) sraw = *reinterpret_cast<const float *>(Sbase + (int64_t)a.scale_frame * a.stride * 4 + (uint32_t)(vox * 4));
@@ -1003,6 +1024,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
         vraw_nxt = nxt.valid ? vidx_at(nxt) : 0;
         clear(early);
     }
+    FIB_STAMP_END(FUSE ? 2 : (FOLD ? 3 : 1), g / ntiles);
     if constexpr (FUSE) {
         for (int off = 32; off >= 1; off >>= 1) { const unsigned oth = (unsigned)__shfl_xor((int)en_run, off); en_run = oth > en_run ? oth : en_run; }
         if (lane == 0 && en_run) atomicMax(&a.maxenc[2], en_run);
@@ -2495,3 +2517,18 @@ extern "C" int fibd_find_peaks(const fib_odf_plan *plan, const float *odf, int64
     FIB_HIP(hipSetDevice(plan->device));
     return launch_peaks(plan, odf, nvox, nvox, nullptr, nullptr, isort_top, nvalid, false, (hipStream_t)stream);
 } FIB_API_CATCH
+
+#ifdef FIB_CLOCK_STAMP
+// diagnostic build: {cycles, ticks, kernel id, items} of the first `cap` workgroups of the last contraction launch
+extern "C" int fib_debug_clock_stamps(unsigned long long *out, int cap) try {
+    FIB_CHECK(out && cap > 0 && cap <= 2048, FIB_ERR_INVALID, "invalid stamp buffer");
+    FIB_HIP(hipDeviceSynchronize());
+    FIB_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(fib_clock_stamps), (size_t)cap * 4 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost));
+    return FIB_OK;
+} FIB_API_CATCH
+extern "C" int fib_debug_clock_clear(void) try {
+    static unsigned long long zeros[2048][4];
+    FIB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(fib_clock_stamps), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice));
+    return FIB_OK;
+} FIB_API_CATCH
+#endif
