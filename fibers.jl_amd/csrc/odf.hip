@@ -114,6 +114,15 @@ __device__ __forceinline__ float clamp_sample(float x) {
     return c;
 }
 
+// NaN-propagating maximum of three (IEEE-754-2019 maximum): the running maximum of a voxel's CLAMPED samples is > 0 iff some
+// sample is positive (gqi.jl:142, dsi.jl:207), NaN iff some sample is NaN, +Inf iff some sample is +Inf -- one instruction per
+// sample pair instead of a NaN-ignoring maximum plus two NaN trackers
+__device__ __forceinline__ float max3_nan(float a, float b, float c) {
+    float r;
+    asm("v_maximum3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // sortperm!(odf_peak, rev=true) (gqi.jl:198) orders by descending value with Base.isless semantics (NaN above
 // everything, +0.0 above -0.0) and keeps ascending index among equals.  Both are captured by one 64-bit key:
 // high word = order-preserving uint image of the float (NaN canonicalised to the top), low word = ~index.
@@ -410,16 +419,19 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
 // Epilogue of the split-bf16 kernel.  Fast path (16-byte aligned output rows): the wave's 32 voxels are 8 aligned quads
 // of consecutive voxels -> each half of a 32x32 block goes through the wave's 2-KiB LDS tile ([16 rows][32 voxels]; rows
 // r and r+4 interleaved so that both lane halves write different banks) and leaves as 2 dwordx4 stores of 8 rows x 128 B.
-template <int MB, int NX>
+// PRE (odf_gemm16_kernel): the caller has already summed the extra rows over the lanes of a voxel and applied the DSI scale;
+// ROWS = rows of an M tile (the 16x16x32 kernel's tiles are a whole number of 16-row blocks)
+template <int MB, int NX, bool PRE = false, int ROWS_ = 0>
 __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[MB], float (&xacc)[NX > 0 ? NX : 1], float vmax, float vnf,
                                                bool inb, bool lv, int64_t vox, int lane, int tile_m, float sraw, char *tr) {
-    constexpr int ROWS = MB * 32 + NX;
+    constexpr int ROWS = ROWS_ > 0 ? ROWS_ : MB * 32 + NX;
+    constexpr int XROW0 = ROWS - NX;                    // first extra row of a tile
     const int col = lane & 31, kh = lane >> 5;
     float pm = fmaxf(vmax, __shfl_xor(vmax, 32));
     float pn = vnf + __shfl_xor(vnf, 32);
     const bool nonfinite = pn != pn;                    // the voxel holds a NaN or +Inf sample (after the clamp)
     const bool valid = lv && (pm > 0.0f || nonfinite);
-    const bool do_scale = a.scale_frame >= 0;
+    const bool do_scale = !PRE && a.scale_frame >= 0;
     float scale = 1.0f;
     if (do_scale) {
         const float s = sraw < 0.0f ? 0.0f : sraw;
@@ -429,14 +441,16 @@ __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[
     // GQI: a NaN sample gives NaN pieces and a NaN column on its own; a +Inf sample too (Inf - Inf = NaN in the split), but
     // the reference's A*s has +-Inf rows there: the voxel is listed and odf_inf_fix_kernel recomputes its column.
     if (nonfinite && do_scale) scale = __builtin_nanf("");
-    if (!do_scale && a.fix_list != nullptr && tile_m == 0 && kh == 0 && lv && pm == INFINITY) {
+    if (a.scale_frame < 0 && a.fix_list != nullptr && tile_m == 0 && kh == 0 && lv && pm == INFINITY) {
         const int slot = atomicAdd(a.fix_count, 1);
         if (slot < a.fix_cap) a.fix_list[slot] = (int32_t)vox;
     }
     const bool plain = __all(valid && !nonfinite) && !do_scale;   // wave-uniform: store the accumulators as they are
     const float mulv = valid ? scale : 0.0f;
+    if (!PRE) {
 #pragma unroll
-    for (int x = 0; x < NX; x++) xacc[x] += __shfl_xor(xacc[x], 32);
+        for (int x = 0; x < NX; x++) xacc[x] += __shfl_xor(xacc[x], 32);
+    }
     // the voxel list is made of aligned quads (mask_write_kernel): lanes 4q..4q+3 hold four consecutive voxels, so the
     // lane that stores quad q of a row (lane & 7 == q after the transposition) takes its address from lane 4q
     const bool contig = a.vec_ok != 0;
@@ -459,7 +473,7 @@ __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[
         for (int m = 0; m < MB; m++) {
             const int row0 = tile_m * ROWS + m * 32;    // wave-uniform
             if (row0 >= a.M) break;
-            const bool whole = row0 + 32 <= a.M && !(mapped && row0 < a.nrow0);   // uniform: no row of the block needs a test
+            const bool whole = row0 + 32 <= a.M && m * 32 + 32 <= XROW0 && !(mapped && row0 < a.nrow0);   // uniform: no row of the block needs a test
             char *base = row_ptr(row0) + (int64_t)lrow * a.stride * 4 + voff;     // rows of one output volume are equidistant
             const bool split_out = row0 < a.nrow0 && row0 + 32 > a.nrow0;         // block straddles pdf | odf
 #pragma unroll
@@ -479,7 +493,7 @@ __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[
                         continue;
                     }
                     const int row = row0 + 16 * hb + 8 * j + lrow;
-                    if (row >= a.M) continue;
+                    if (row >= a.M || m * 32 + 16 * hb + 8 * j + lrow >= XROW0) continue;   // (a tile of the 16x16x32 kernel may end inside a 32-row block)
                     if (mapped && row < a.nrow0) {       // symmetric DSI: p(r) = p(-r), one computed row feeds two frames
                         const int fa = a.rowA[row], fb = a.rowB[row];
                         *reinterpret_cast<float4 *>(reinterpret_cast<char *>(a.out0 + (int64_t)fa * a.stride) + voff) = v4;
@@ -501,7 +515,7 @@ __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[
                 const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 float v = acc[m][r];
                 if (!plain) v = valid ? v * mulv : 0.0f;
-                if (row >= a.M) continue;
+                if (row >= a.M || m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh >= XROW0) continue;
                 if (mapped && row < a.nrow0) {
                     const int fa = a.rowA[row], fb = a.rowB[row];
                     a.out0[(int64_t)fa * a.stride + vox] = v;
@@ -515,7 +529,7 @@ __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[
     if (inb && kh == 0) {
 #pragma unroll
         for (int x = 0; x < NX; x++) {
-            const int row = tile_m * ROWS + MB * 32 + x;    // wave-uniform
+            const int row = tile_m * ROWS + XROW0 + x;    // wave-uniform
             if (row >= a.M) break;
             float v = xacc[x];
             if (!plain) v = valid ? v * mulv : 0.0f;
@@ -561,7 +575,7 @@ __device__ __forceinline__ float fq_max3z(float a, float b) { return __builtin_f
 __device__ __forceinline__ float fq_min3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 __device__ __forceinline__ float fq_max2(float a, float b) { return __builtin_fmaxf(a, b); }
 
-template <int NW>
+template <int NW, bool PRE = false>
 __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (&acc)[10], float xrow, float vmax, float vnf, bool inb, bool lv,
                                                      int64_t vox, int lane, char *tr, char *lst, const uint64_t *posoff, const int *slotv, const float *vl,
                                                      unsigned &en_run) {
@@ -574,7 +588,7 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
         const int slot = atomicAdd(a.fix_count, 1);
         if (slot < a.fix_cap) a.fix_list[slot] = (int32_t)vox;
     }
-    xrow += __shfl_xor(xrow, 32);
+    if (!PRE) xrow += __shfl_xor(xrow, 32);
     if (!__all(valid && !nonfinite)) {                  // wave-uniform, rare: skipped voxels and voxels outside the mask read 0
 #pragma unroll
         for (int m = 0; m < 10; m++)
@@ -928,9 +942,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
             float c0, c1;
             c0 = FOLD ? x0 : clamp_sample(x0);
             c1 = FOLD ? x1 : clamp_sample(x1);
-            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(vmax) : "v"(vmax), "v"(x0), "v"(x1));
-            vnf = __builtin_fmaf(c0, 0.0f, vnf);
-            vnf = __builtin_fmaf(c1, 0.0f, vnf);
+            vmax = max3_nan(vmax, c0, c1);              // (vnf is derived from it at the end of the item)
             const uint32_t h = cvt_pk_bf16(c0, c1);
             const float r0 = c0 - __uint_as_float(h << 16), r1 = c1 - __uint_as_float(h & 0xffff0000u);      // exact
             const uint32_t m = cvt_pk_bf16(r0, r1);
@@ -1013,11 +1025,17 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
             __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): the next stage's pieces and samples have landed
             __syncthreads();
         }
-        if constexpr (FUSE)
-            gemm3_epilogue_fused<NW>(a, acc, early ? xfin[0] : xacc[0], early ? vmax_fin : vmax, early ? vnf_fin : vnf, inb, lv, vox, lane, lds + 2 * TILEB + wave * TRB,
-                                     lds + 2 * TILEB + NW * TRB + XTAB + FTAB + wave * FQ_LIST, q_posoff, q_slotv, q_vl, en_run);
-        else
-            gemm3_epilogue<MB, NX>(a, acc, xacc, vmax, vnf, inb, lv, vox, lane, cur.tile_m, sraw, lds + 2 * TILEB + wave * TRB);
+        {
+            // the voxel's clamped-sample maximum over both k halves; vnf = NaN iff it is NaN or +Inf (the epilogues' "non-finite sample" flag)
+            float vm = early ? vmax_fin : vmax;
+            vm = max3_nan(vm, __shfl_xor(vm, 32), 0.0f);
+            const float vn = vm < INFINITY ? 0.0f : __builtin_nanf("");
+            if constexpr (FUSE)
+                gemm3_epilogue_fused<NW>(a, acc, early ? xfin[0] : xacc[0], vm, vn, inb, lv, vox, lane, lds + 2 * TILEB + wave * TRB,
+                                         lds + 2 * TILEB + NW * TRB + XTAB + FTAB + wave * FQ_LIST, q_posoff, q_slotv, q_vl, en_run);
+            else
+                gemm3_epilogue<MB, NX>(a, acc, xacc, vm, vn, inb, lv, vox, lane, cur.tile_m, sraw, lds + 2 * TILEB + wave * TRB);
+        }
         if (!nxt.valid) break;
         cur = nxt; inb = inb_n; vox = vox_n; s_off = s_off_n;
         nxt = work_at(g / ntiles + 1);
@@ -1032,6 +1050,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
 }
 
 #include "odf_pipe.inc"
+#include "odf_gemm16.inc"
 
 // ---- mask compaction ---------------------------------------------------------------------------------------
 // vidx = ascending list of the voxels of every aligned 4-voxel group ("quad") that holds a voxel inside the mask, so
@@ -1926,6 +1945,10 @@ struct fib_odf_plan {
     fib::DevBuf<float> Aextra;                       // f32 coefficients of the NX extra rows [ntile_m][NX][Kpad]
     fib::DevBuf<float> Gdev;                         // G, column-major [gM x gK] (odf_inf_fix_kernel)
     mutable fib::DevBuf<int32_t> inf_list;           // [nvox] voxels with a +Inf sample (GQI, split-bf16 kernel; grow-only)
+    // 16x16x32 form of the split-bf16 contraction (odf_gemm16_kernel): M tile = NB16 16-row blocks + NX16 f32 rows
+    int NB16 = 0, NX16 = 0, ntile16 = 1, nstage16 = 0;
+    fib::DevBuf<uint16_t> At4, At4f;                 // images in identity row order / in the fused scan's row order
+    fib::DevBuf<float> Aextra4, Aextra4f;            // extra rows [ntile16][NX16][nstage16 * 32]
     bool split_bf16 = false;
     bool fused_shape = false;                        // (GQI, 10 blocks + 1 extra row: the shape the fused scan is generated for)
     bool fused = false;                              // sphere_642 GQI plan: the contraction kernel finds the peaks on its accumulators
@@ -2043,6 +2066,82 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
             if ((rc3 = p->At3f.alloc(A3.size())) != FIB_OK || (rc3 = p->Aextraf.alloc(AX.size())) != FIB_OK || (rc3 = p->dump.alloc((size_t)1024 * PP_NW * 1024)) != FIB_OK) return rc3;
             FIB_HIP(hipMemcpy(p->At3f.p, A3.data(), A3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             FIB_HIP(hipMemcpy(p->Aextraf.p, AX.data(), AX.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
+    if (p->split_bf16 && getenv("FIBERS_ODF_SHAPE16")) {     // opt-in: measured 8-9 % slower than the 32x32x16 kernels (profiles/r03/shape_ab_*.log)
+        // ---- images of the 16x16x32 kernel (odf_gemm16.inc): tile shape minimising ntile * (MFMA cycles + per-stage split cost) ----
+        int best = INT32_MAX;
+        static const int nbs[] = {20, 19, 18, 17, 16, 14, 12, 10};
+        for (int nb : nbs)
+            for (int nx = 0; nx <= 1; nx++) {
+                const int rows = nb * 16 + nx, nt = (M + rows - 1) / rows;
+                const int cost = nt * (nb * 192 + 96 * nx + 1500);
+                if ((size_t)nt * nx * ((K + 31) / 32 * 32) > (size_t)2048) continue;     // the extra rows' LDS table
+                if (cost < best) { best = cost; p->NB16 = nb; p->NX16 = nx; p->ntile16 = nt; }
+            }
+        if (const char *e = getenv("FIBERS_GEMM16_TILE")) {  // tuning hook: "<NB>x<NX>"
+            int nb = 0, nx = 0;
+            if (sscanf(e, "%dx%d", &nb, &nx) == 2 && std::find(std::begin(nbs), std::end(nbs), nb) != std::end(nbs) && (nx == 0 || nx == 1)) {
+                p->NB16 = nb; p->NX16 = nx; p->ntile16 = (M + nb * 16 + nx - 1) / (nb * 16 + nx);
+            }
+        }
+        const int NB = p->NB16, NX = p->NX16, nst = (K + 31) / 32, kx = nst * 32, ROWS16 = NB * 16 + NX;
+        const int NB0 = (NB + 1) / 2, krem = K - (nst - 1) * 32;
+        const bool half_tail = krem <= 16;
+        p->nstage16 = nst;
+        auto bf16_rn = [](float f) -> uint16_t {
+            uint32_t u; memcpy(&u, &f, 4);
+            if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+            u += 0x7fffu + ((u >> 16) & 1u);
+            return (uint16_t)(u >> 16);
+        };
+        auto bf16_f = [](uint16_t h) -> float { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+        auto build16 = [&](const short *rowmap, std::vector<uint16_t> &A4, std::vector<float> &AX) {
+            A4.assign((size_t)p->ntile16 * nst * 3 * NB * 512, 0);
+            AX.assign((size_t)std::max(1, p->ntile16 * NX * kx), 0.0f);
+            for (int tm = 0; tm < p->ntile16; tm++) {
+                for (int t = 0; t < nst; t++) {
+                    const bool tail = half_tail && t == nst - 1;
+                    uint16_t *st = A4.data() + ((size_t)tm * nst + t) * 3 * NB * 512;
+                    for (int b = 0; b < NB; b++) {
+                        const int hb = b >= NB0, bl = hb ? b - NB0 : b, nbh = hb ? NB - NB0 : NB0;
+                        uint16_t *hp = st + (hb ? (size_t)3 * NB0 * 512 : 0);
+                        for (int l = 0; l < 64; l++)
+                            for (int j = 0; j < 8; j++) {
+                                const int row = tm * ROWS16 + 16 * b + (l & 15), qq = l >> 4;
+                                const int k = t * 32 + 8 * (tail ? (qq & 1) : qq) + j;
+                                if (row >= M || 16 * b + (l & 15) >= NB * 16 || k >= K) continue;
+                                const float v = p->G[(rowmap ? rowmap[row] : row) + (size_t)M * k];
+                                const uint16_t h1 = bf16_rn(v);
+                                const float r1 = v - bf16_f(h1);
+                                const uint16_t h2 = bf16_rn(r1);
+                                const float r2 = r1 - bf16_f(h2);
+                                const uint16_t h3 = bf16_rn(r2);
+                                // pieces of a full stage: a1, a2, a3; of the half tail: X = [a1|a1], Y = [a2|a2], Z = [a1|a3]
+                                const uint16_t hs[3] = {h1, h2, tail ? (qq < 2 ? h1 : h3) : h3};
+                                for (int pc = 0; pc < 3; pc++) hp[((size_t)(pc * nbh + bl) * 64 + l) * 8 + j] = hs[pc];
+                            }
+                    }
+                }
+                for (int x = 0; x < NX; x++)
+                    for (int k = 0; k < K; k++) {
+                        const int row = tm * ROWS16 + NB * 16 + x;
+                        if (row < M) AX[((size_t)tm * NX + x) * kx + k] = p->G[(rowmap ? rowmap[row] : row) + (size_t)M * k];
+                    }
+            }
+        };
+        std::vector<uint16_t> A4;
+        std::vector<float> AX4;
+        build16(nullptr, A4, AX4);
+        int rc4;
+        if ((rc4 = p->At4.alloc(A4.size())) != FIB_OK || (rc4 = p->Aextra4.alloc(AX4.size())) != FIB_OK) return rc4;
+        FIB_HIP(hipMemcpy(p->At4.p, A4.data(), A4.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        FIB_HIP(hipMemcpy(p->Aextra4.p, AX4.data(), AX4.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (p->fused_shape && NB == 20 && NX == 1 && p->ntile16 == 1) {
+            build16(fib_f642_pos_vertex, A4, AX4);
+            if ((rc4 = p->At4f.alloc(A4.size())) != FIB_OK || (rc4 = p->Aextra4f.alloc(AX4.size())) != FIB_OK) return rc4;
+            FIB_HIP(hipMemcpy(p->At4f.p, A4.data(), A4.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            FIB_HIP(hipMemcpy(p->Aextra4f.p, AX4.data(), AX4.size() * sizeof(float), hipMemcpyHostToDevice));
         }
     }
     std::vector<int32_t> nbr32;
@@ -2246,6 +2345,28 @@ void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
     else hipLaunchKernelGGL((odf_gemm_kernel<MB, NX>), dim3(grid), dim3(256), 0, st, ga);
 }
 
+// the 16x16x32 form: persistent grid as above, one 8-wave workgroup per CU
+template <int NB, int NX>
+void launch_gemm16_t(const GemmArgs &ga, bool fuse, hipStream_t st) {
+    int ncu = 256, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int64_t items = fib::cdiv(ga.nvox, 8 * 32) * ga.ntile_m;
+    unsigned pg = (unsigned)std::min<int64_t>((int64_t)ncu, items);
+    pg = (pg + 7) / 8 * 8;
+    if constexpr (NB == 20 && NX == 1) {
+        if (fuse) { hipLaunchKernelGGL((odf_gemm16_kernel<20, 1, 8, false, true>), dim3(pg), dim3(512), 0, st, ga); return; }
+    }
+    hipLaunchKernelGGL((odf_gemm16_kernel<NB, NX, 8>), dim3(pg), dim3(512), 0, st, ga);
+}
+bool launch_gemm16(int nb, int nx, const GemmArgs &ga, bool fuse, hipStream_t st) {
+#define FIB_G16_CASE(NBV, NXV) if (nb == NBV && nx == NXV) { launch_gemm16_t<NBV, NXV>(ga, fuse, st); return true; }
+    FIB_G16_CASE(20, 1) FIB_G16_CASE(20, 0) FIB_G16_CASE(19, 0) FIB_G16_CASE(19, 1) FIB_G16_CASE(18, 0) FIB_G16_CASE(18, 1) FIB_G16_CASE(17, 0) FIB_G16_CASE(17, 1)
+    FIB_G16_CASE(16, 0) FIB_G16_CASE(16, 1) FIB_G16_CASE(14, 0) FIB_G16_CASE(14, 1) FIB_G16_CASE(12, 0) FIB_G16_CASE(12, 1) FIB_G16_CASE(10, 0) FIB_G16_CASE(10, 1)
+#undef FIB_G16_CASE
+    return false;
+}
+
 size_t peaks_smem(const fib_odf_plan *p) {
     return ((size_t)(p->rows_pad + 1) * PV + (size_t)PG * PV * PREC) * sizeof(float);
 }
@@ -2390,9 +2511,22 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
     ga.has_ineff = plan->has_ineff ? 1 : 0;
     FIB_CHECK(fib::cdiv(nvox, WG_VOX) * plan->ntile_m < ((int64_t)1 << 31), FIB_ERR_UNSUPPORTED, "volume too large for one launch");
 
+    // the 16x16x32 form of the split-bf16 contraction (FIBERS_ODF_SHAPE16=1 at plan creation)
+    const bool use16 = ga.At3 != nullptr && plan->At4.p != nullptr && !plan->folded && nvox <= ((int64_t)1 << 25) && !ga.dump &&
+                       (!fuse || plan->At4f.p != nullptr);
+    if (use16) {
+        ga.At3 = fuse ? plan->At4f.p : plan->At4.p;
+        ga.Aextra = fuse ? plan->Aextra4f.p : plan->Aextra4.p;
+        ga.ntile_m = plan->ntile16;
+    }
     auto run_gemm = [&](GemmArgs g, hipStream_t s) -> int {
         const unsigned grid = (unsigned)(fib::cdiv(g.nvox, WG_VOX) * plan->ntile_m);
         fib::ProfScope prof("odf_gemm", s);
+        if (use16) {
+            if (!launch_gemm16(plan->NB16, plan->NX16, g, fuse, s)) return fib::fail(FIB_ERR_INVALID, "internal: no 16x16x32 GEMM variant for NB=%d NX=%d", plan->NB16, plan->NX16);
+            FIB_HIP(hipGetLastError());
+            return FIB_OK;
+        }
 #define FIB_GEMM_CASE(MBV, NXV) if (plan->MB == MBV && plan->NX == NXV) { launch_gemm<MBV, NXV>(g, grid, s); launched = true; }
         bool launched = false;
         FIB_GEMM_CASE(5, 0) FIB_GEMM_CASE(6, 0) FIB_GEMM_CASE(7, 0) FIB_GEMM_CASE(8, 0) FIB_GEMM_CASE(9, 0) FIB_GEMM_CASE(10, 0) FIB_GEMM_CASE(11, 0)
@@ -2485,6 +2619,12 @@ int fib::matrix_plan_run(const fib_odf_plan *plan, const float *S, const uint8_t
     ga.scale_frame = -1; ga.scale_coef = 0.0f; ga.stride = n; ga.has_ineff = 0;
     const unsigned grid = (unsigned)(fib::cdiv(n, WG_VOX) * plan->ntile_m);
     fib::ProfScope prof("matrix_gemm", st);
+    if (ga.At3 && plan->At4.p && n <= ((int64_t)1 << 25)) {
+        ga.At3 = plan->At4.p; ga.Aextra = plan->Aextra4.p; ga.ntile_m = plan->ntile16;
+        if (!launch_gemm16(plan->NB16, plan->NX16, ga, false, st)) return fib::fail(FIB_ERR_INVALID, "internal: no 16x16x32 GEMM variant for NB=%d NX=%d", plan->NB16, plan->NX16);
+        FIB_HIP(hipGetLastError());
+        return FIB_OK;
+    }
 #define FIB_GEMM_CASE(MBV, NXV) if (plan->MB == MBV && plan->NX == NXV) { launch_gemm<MBV, NXV>(ga, grid, st); launched = true; }
     bool launched = false;
     FIB_GEMM_CASE(5, 0) FIB_GEMM_CASE(6, 0) FIB_GEMM_CASE(7, 0) FIB_GEMM_CASE(8, 0) FIB_GEMM_CASE(9, 0) FIB_GEMM_CASE(10, 0) FIB_GEMM_CASE(11, 0)

@@ -44,7 +44,8 @@ def main():
     sph = fj.sphere_642
     mask = torch.ones(nvox, dtype=torch.uint8, device=dev)
     names = {1: "odf_gemm3_kernel<MB,NX,8> (unfused)", 2: "odf_gemm3_kernel<10,1,8,FUSE> (default GQI)", 3: "odf_gemm3_kernel<MB,NX,8,FOLD> (DSI)",
-             4: "odf_pipe_kernel", 5: "odf_dsi2_kernel"}
+             4: "odf_pipe_kernel", 5: "odf_gemm16_kernel<NB,NX,8> (16x16x32, unfused)", 6: "odf_gemm16_kernel<20,1,8,FUSE> (16x16x32, default GQI)",
+             7: "odf_gemm16_kernel FOLD (DSI)"}
     res = {}
 
     def measure(label, step):
@@ -77,24 +78,31 @@ def main():
                           kernel_ms_hipevent=ms.value / max(cnt.value, 1), step_ms_wall=wall * 1e3, steps=n)
 
     kernels = args.kernels.split(",")
-    if any(k in kernels for k in ("fused", "unfused", "pipe")):
+    if any(k.startswith("fused") or k.startswith("unfused") or k == "pipe" for k in kernels):
         bval, bvec = phantom.scheme_gqi()
         dwi, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=3, device=dev)
-        plan = fj.OdfPlan("gqi", bval, bvec, sph, sigma=1.25, device=0)
-        out = fj.odf_rec_device(plan, dwi, mask, normalize=False)
-        for k in kernels:
-            for v in ("FIBERS_ODF_UNFUSED", "FIBERS_ODF_PIPE"):
+        plans = {}
+        for k in kernels:                               # fused | unfused | pipe, suffix 16 = the 16x16x32 kernels (plan-time switch)
+            if not (k.startswith("fused") or k.startswith("unfused") or k == "pipe"):
+                continue
+            s32 = not k.endswith("16")
+            for v in ("FIBERS_ODF_UNFUSED", "FIBERS_ODF_PIPE", "FIBERS_ODF_SHAPE16"):
                 os.environ.pop(v, None)
-            if k == "unfused":
+            if not s32:
+                os.environ["FIBERS_ODF_SHAPE16"] = "1"
+            if s32 not in plans:
+                plans[s32] = fj.OdfPlan("gqi", bval, bvec, sph, sigma=1.25, device=0)
+            os.environ.pop("FIBERS_ODF_SHAPE16", None)
+            plan = plans[s32]
+            out = fj.odf_rec_device(plan, dwi, mask, normalize=False)
+            if k.startswith("unfused"):
                 os.environ["FIBERS_ODF_UNFUSED"] = "1"
             elif k == "pipe":
                 os.environ["FIBERS_ODF_PIPE"] = "1"
-            elif k != "fused":
-                continue
             measure("gqi_" + k, lambda: fj.odf_rec_device(plan, dwi, mask, out=out, normalize=True))
         for v in ("FIBERS_ODF_UNFUSED", "FIBERS_ODF_PIPE"):
             os.environ.pop(v, None)
-        del dwi, out, plan
+        del dwi, out, plans
         torch.cuda.empty_cache()
     if "dsi" in kernels:
         b5, g5 = phantom.scheme_dsi()
