@@ -65,8 +65,10 @@ struct GemmArgs {
     float *mean_hi;               // [nvox] upper bound of each listed voxel's mean (NaN: the voxel is on the redo list)
     int32_t *redo_count, *redo_list;   // voxels the register scan could not finish (NaN / Inf columns, candidate-list overflow)
     int redo_cap;
-    void *dump;                   // pipe kernel: 1 KB per wave (1024 workgroups at most) that lanes without a voxel store into
     int anti;                     // fused kernel: anti-phase wave halves (see odf_gemm3_kernel)
+    const void *At3b;             // odf_dsi2_kernel: image of the pdf tile (At3 / Aextra = the ODF tile in the fused scan's row order)
+    int one_slot, one_stride;     // .. its work list: voxel groups one_slot + i * one_stride of the workgroup's XCD (set by the kernel)
+    int dsi_na;                   // .. workgroups per XCD that take the ODF tile (the others take the pdf tile)
 };
 
 // Diagnostic build only (make stamp -> libfibers_hip_stamp.so, -DFIB_CLOCK_STAMP; in the product library no stamp executes):
@@ -421,9 +423,15 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
 // r and r+4 interleaved so that both lane halves write different banks) and leaves as 2 dwordx4 stores of 8 rows x 128 B.
 // PRE (odf_gemm16_kernel): the caller has already summed the extra rows over the lanes of a voxel and applied the DSI scale;
 // ROWS = rows of an M tile (the 16x16x32 kernel's tiles are a whole number of 16-row blocks)
-template <int MB, int NX, bool PRE = false, int ROWS_ = 0>
+template <int MB, int NX, bool PRE = false, int ROWS_ = 0, bool MAPLDS = false>
 __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[MB], float (&xacc)[NX > 0 ? NX : 1], float vmax, float vnf,
-                                               bool inb, bool lv, int64_t vox, int lane, int tile_m, float sraw, char *tr) {
+                                               bool inb, bool lv, int64_t vox, int lane, int tile_m, float sraw, char *tr,
+                                               const int32_t *mapA = nullptr, const int32_t *mapB = nullptr) {
+    // MAPLDS: mapA / mapB are LDS copies of a.rowA / a.rowB (a global load per stored row would sit between the transposition and
+    // its stores).  Two code paths, not one pointer chosen at run time: a generic pointer would make every lookup a flat load, and
+    // a flat load waits for all the row stores before it (vmcnt).
+    auto rowA_at = [&](int row) -> int { if constexpr (MAPLDS) return mapA[row]; else return a.rowA[row]; };
+    auto rowB_at = [&](int row) -> int { if constexpr (MAPLDS) return mapB[row]; else return a.rowB[row]; };
     constexpr int ROWS = ROWS_ > 0 ? ROWS_ : MB * 32 + NX;
     constexpr int XROW0 = ROWS - NX;                    // first extra row of a tile
     const int col = lane & 31, kh = lane >> 5;
@@ -495,7 +503,7 @@ __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[
                     const int row = row0 + 16 * hb + 8 * j + lrow;
                     if (row >= a.M || m * 32 + 16 * hb + 8 * j + lrow >= XROW0) continue;   // (a tile of the 16x16x32 kernel may end inside a 32-row block)
                     if (mapped && row < a.nrow0) {       // symmetric DSI: p(r) = p(-r), one computed row feeds two frames
-                        const int fa = a.rowA[row], fb = a.rowB[row];
+                        const int fa = rowA_at(row), fb = rowB_at(row);
                         *reinterpret_cast<float4 *>(reinterpret_cast<char *>(a.out0 + (int64_t)fa * a.stride) + voff) = v4;
                         if (fb >= 0) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(a.out0 + (int64_t)fb * a.stride) + voff) = v4;
                     } else {
@@ -517,7 +525,7 @@ __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[
                 if (!plain) v = valid ? v * mulv : 0.0f;
                 if (row >= a.M || m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh >= XROW0) continue;
                 if (mapped && row < a.nrow0) {
-                    const int fa = a.rowA[row], fb = a.rowB[row];
+                    const int fa = rowA_at(row), fb = rowB_at(row);
                     a.out0[(int64_t)fa * a.stride + vox] = v;
                     if (fb >= 0) a.out0[(int64_t)fb * a.stride + vox] = v;
                 } else {
@@ -534,7 +542,7 @@ __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[
             float v = xacc[x];
             if (!plain) v = valid ? v * mulv : 0.0f;
             if (mapped && row < a.nrow0) {
-                const int fa = a.rowA[row], fb = a.rowB[row];
+                const int fa = rowA_at(row), fb = rowB_at(row);
                 a.out0[(int64_t)fa * a.stride + vox] = v;
                 if (fb >= 0) a.out0[(int64_t)fb * a.stride + vox] = v;
             } else {
@@ -575,10 +583,10 @@ __device__ __forceinline__ float fq_max3z(float a, float b) { return __builtin_f
 __device__ __forceinline__ float fq_min3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 __device__ __forceinline__ float fq_max2(float a, float b) { return __builtin_fmaxf(a, b); }
 
-template <int NW, bool PRE = false>
+template <int NW, bool PRE = false, bool SCALE = false>
 __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (&acc)[10], float xrow, float vmax, float vnf, bool inb, bool lv,
                                                      int64_t vox, int lane, char *tr, char *lst, const uint64_t *posoff, const int *slotv, const float *vl,
-                                                     unsigned &en_run) {
+                                                     unsigned &en_run, float scale = 1.0f) {
     const int col = lane & 31, kh = lane >> 5;
     const float pm = fmaxf(vmax, __shfl_xor(vmax, 32));
     const float pn = vnf + __shfl_xor(vnf, 32);
@@ -589,7 +597,13 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
         if (slot < a.fix_cap) a.fix_list[slot] = (int32_t)vox;
     }
     if (!PRE) xrow += __shfl_xor(xrow, 32);
-    if (!__all(valid && !nonfinite)) {                  // wave-uniform, rare: skipped voxels and voxels outside the mask read 0
+    if constexpr (SCALE) {                              // DSI: p ./ sum(p) (dsi.jl:225) before the radial sums are looked at
+#pragma unroll
+        for (int m = 0; m < 10; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][r] = valid ? acc[m][r] * scale : 0.0f;
+        xrow = valid ? xrow * scale : 0.0f;
+    } else if (!__all(valid && !nonfinite)) {           // wave-uniform, rare: skipped voxels and voxels outside the mask read 0
 #pragma unroll
         for (int m = 0; m < 10; m++)
 #pragma unroll
@@ -779,25 +793,35 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {      // ro
 // The two lane halves of a load need different frames; their byte offsets come from an LDS table (relative to the
 // lowest frame that the stage touches on that side: one buffer resource per stage and side).
 constexpr int FKMAX = 512, FSMAX = FKMAX / KT;
-template <int MB, int NX, int NW, bool FOLD = false, bool FUSE = false>
-__global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a) {
-    static_assert(!FUSE || (MB == 10 && NX == 1 && !FOLD), "the fused peak scan is generated for 10 blocks + 1 extra row");
+// LDS of one instantiation: stage ring + per-wave transposition tiles + extra-row table + fold tables + fused-scan lists / tables
+template <int MB, int NX, int NW, bool FOLD, bool FUSE>
+constexpr int gemm3_lds_bytes() {
+    return 2 * 3 * MB * 1024 + NW * (FUSE ? 4096 : 2048) + (NX > 0 ? (FUSE ? 2048 : 8192) : 0) +
+           (FOLD ? 2 * FKMAX * 4 + 4 * FSMAX * 4 + (FUSE ? 0 : 2 * FKMAX * 4) : 0) + (FUSE ? NW * FQ_LIST + FQ_TABB : 0);
+}
+// ONE: the workgroup works on a single-tile image of its own (odf_dsi2_kernel: the DSI rows are cut into an ODF tile and a pdf tile
+// with images of different shapes); the work list still deals the items of both tiles (a.ntile_m = 2), and with an even number
+// of workgroups per XCD every workgroup keeps drawing items of its own tile
+template <int MB, int NX, int NW, bool FOLD = false, bool FUSE = false, bool ONE = false>
+__device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
+    static_assert(!FUSE || (MB == 10 && NX == 1), "the fused peak scan is generated for 10 blocks + 1 extra row");
     constexpr int NPIECE = 3 * MB;                      // 1-KiB pieces per stage
     constexpr int TILEB = NPIECE * 1024;                // bytes per stage
     constexpr int NA = (NPIECE + NW - 1) / NW;          // direct-to-LDS loads per wave and stage (a surplus load repeats the last piece)
     constexpr int WGV = NW * 32;                        // voxels per work item
     constexpr int NXA = NX > 0 ? NX : 1;
     constexpr int XTAB = NX > 0 ? (FUSE ? 2048 : 8192) : 0;   // coefficients of the extra rows, all stages of all M tiles: [ntile_m][NX][Kpad] f32
-    constexpr int FTAB = FOLD ? 2 * FKMAX * 4 + 4 * FSMAX * 4 : 0;
+    constexpr int FTAB = FOLD ? 2 * FKMAX * 4 + 4 * FSMAX * 4 + (FUSE ? 0 : 2 * FKMAX * 4) : 0;   // (a tile with pdf rows: + the row -> frame tables)
     constexpr int QTAB = FUSE ? NW * FQ_LIST + FQ_TABB : 0;   // fused peak scan: candidate lists + lookup tables
     constexpr int TRB = FUSE ? 4096 : 2048;                   // per-wave transposition tile(s) of the epilogue
-    __shared__ __attribute__((aligned(16))) char lds[2 * TILEB + NW * TRB + XTAB + FTAB + QTAB];
+    static_assert(2 * TILEB + NW * TRB + XTAB + FTAB + QTAB == gemm3_lds_bytes<MB, NX, NW, FOLD, FUSE>(), "LDS carve-up");
     uint64_t *q_posoff = reinterpret_cast<uint64_t *>(lds + 2 * TILEB + NW * TRB + XTAB + FTAB + (FUSE ? NW * FQ_LIST : 0));   // [320] matrix row -> byte offset of its output row
     int *q_slotv = reinterpret_cast<int *>(q_posoff + FQ_NPOS);                                                                               // [2][161] (half, slot) -> vertex
     float *q_vl = reinterpret_cast<float *>(q_slotv + FQ_NSLOT);                                                   // [321][3]
     uint32_t *f_off = reinterpret_cast<uint32_t *>(lds + 2 * TILEB + NW * TRB + XTAB);   // [2][FKMAX] byte offset of sample J's frame, side a / b
     int32_t *f_base = reinterpret_cast<int32_t *>(f_off + 2 * FKMAX);                      // [2][FSMAX] lowest frame of the stage
     int32_t *f_span = f_base + 2 * FSMAX;                                                  // [2][FSMAX] frames spanned (0: none)
+    int32_t *f_row = f_span + 2 * FSMAX;                                                   // [2][FKMAX] (FOLD, not FUSE) folded pdf row -> its two frames
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, kh = lane >> 5;
@@ -805,7 +829,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
     const uint32_t a_off = (uint32_t)lane * 16;
     if (NX > 0) {
         float *xt = reinterpret_cast<float *>(lds + 2 * TILEB + NW * TRB);
-        for (int i = tid; i < a.ntile_m * NX * a.Kpad; i += NW * 64) xt[i] = a.Aextra[i];
+        for (int i = tid; i < (ONE ? 1 : a.ntile_m) * NX * a.Kpad; i += NW * 64) xt[i] = a.Aextra[i];
     }
     if constexpr (FUSE) {
         for (int i = tid; i < FQ_NPOS; i += NW * 64) q_posoff[i] = (uint64_t)fib_f642_pos_vertex_dev[i] * (uint64_t)a.stride * 4u;
@@ -833,6 +857,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
             const int f = J < a.K ? (side ? a.rowB : a.rowA)[J] : -1;
             // (the host checked that a stage's span times the frame size stays below 0xE0000000; 0xF0000000 + 4 vox is past every span)
             f_off[side * FKMAX + J] = f >= 0 ? (uint32_t)(f - f_base[side * FSMAX + J / KT]) * row_bytes : 0xF0000000u;
+            if (!FUSE) f_row[side * FKMAX + J] = f;     // (the folded pdf rows are the folded samples: same tables, dsi_fold_kernel)
         }
         __syncthreads();
     }
@@ -845,8 +870,8 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
     auto work_at = [&](int i) {
         const int w = wslot + i * nslot;
         Work r;
-        r.tile_m = w % a.ntile_m;
-        r.tile_n = (w / a.ntile_m) * 8 + xcd;
+        r.tile_m = ONE ? 0 : w % a.ntile_m;
+        r.tile_n = ONE ? (a.one_slot + i * a.one_stride) * 8 + xcd : (w / a.ntile_m) * 8 + xcd;
         r.valid = r.tile_n < ntile_n;
         return r;
     };
@@ -1030,11 +1055,22 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
             float vm = early ? vmax_fin : vmax;
             vm = max3_nan(vm, __shfl_xor(vm, 32), 0.0f);
             const float vn = vm < INFINITY ? 0.0f : __builtin_nanf("");
-            if constexpr (FUSE)
-                gemm3_epilogue_fused<NW>(a, acc, early ? xfin[0] : xacc[0], vm, vn, inb, lv, vox, lane, lds + 2 * TILEB + wave * TRB,
-                                         lds + 2 * TILEB + NW * TRB + XTAB + FTAB + wave * FQ_LIST, q_posoff, q_slotv, q_vl, en_run);
-            else
-                gemm3_epilogue<MB, NX>(a, acc, xacc, vm, vn, inb, lv, vox, lane, cur.tile_m, sraw, lds + 2 * TILEB + wave * TRB);
+            if constexpr (FUSE) {
+                float fscale = 1.0f;                      // DSI (the FOLD form): 1 / sum(p), NaN where a sample is not finite (see gemm3_epilogue)
+                if (FOLD) { const float s0 = sraw < 0.0f ? 0.0f : sraw; fscale = vn != vn ? __builtin_nanf("") : 1.0f / (a.scale_coef * s0); }
+                gemm3_epilogue_fused<NW, false, FOLD>(a, acc, early ? xfin[0] : xacc[0], vm, vn, inb, lv, vox, lane, lds + 2 * TILEB + wave * TRB,
+                                                      lds + 2 * TILEB + NW * TRB + XTAB + FTAB + wave * FQ_LIST, q_posoff, q_slotv, q_vl, en_run, fscale);
+            }
+            else {
+                // (the lane index is laundered per work item: otherwise every lane-derived row index, table lookup and 64-bit row
+                // address of the epilogue is hoisted out of the persistent loop and parked in registers / scratch)
+                int le = lane;
+                asm volatile("" : "+v"(le));
+                if constexpr (FOLD)
+                    gemm3_epilogue<MB, NX, false, 0, true>(a, acc, xacc, vm, vn, inb, lv, vox, le, cur.tile_m, sraw, lds + 2 * TILEB + wave * TRB, f_row, f_row + FKMAX);
+                else
+                    gemm3_epilogue<MB, NX>(a, acc, xacc, vm, vn, inb, lv, vox, le, cur.tile_m, sraw, lds + 2 * TILEB + wave * TRB);
+            }
         }
         if (!nxt.valid) break;
         cur = nxt; inb = inb_n; vox = vox_n; s_off = s_off_n;
@@ -1042,15 +1078,45 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
         vraw_nxt = nxt.valid ? vidx_at(nxt) : 0;
         clear(early);
     }
-    FIB_STAMP_END(FUSE ? 2 : (FOLD ? 3 : 1), g / ntiles);
+    FIB_STAMP_END(ONE ? 8 : (FUSE ? 2 : (FOLD ? 3 : 1)), g / ntiles);
     if constexpr (FUSE) {
         for (int off = 32; off >= 1; off >>= 1) { const unsigned oth = (unsigned)__shfl_xor((int)en_run, off); en_run = oth > en_run ? oth : en_run; }
         if (lane == 0 && en_run) atomicMax(&a.maxenc[2], en_run);
     }
 }
 
-#include "odf_pipe.inc"
-#include "odf_gemm16.inc"
+template <int MB, int NX, int NW, bool FOLD = false, bool FUSE = false>
+__global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[gemm3_lds_bytes<MB, NX, NW, FOLD, FUSE>()];
+    gemm3_body<MB, NX, NW, FOLD, FUSE>(a, lds);
+}
+
+// ---- K5, DSI on sphere_642 with an antipodally symmetric lattice (config 5): dsi.jl:204-258 in ONE launch ------------------------------
+// The folded DSI map has gRow0 pdf rows + 321 ODF rows.  They are cut into two M tiles of different shapes: the ODF tile
+// (10 blocks + the pole row, rows in the order of sphere642_fused.inc) runs the fused epilogue -- 1 / sum(p) scale, ODF rows out,
+// find_peaks! on the accumulators, peak / qa / minimum / bounds of the mean -- exactly as the GQI kernel does, so the ODF is never
+// re-read (the separate peak kernel cost 0.86 of 6.9 ms and 3.5 GB); the pdf tile (MBB blocks) writes each folded row to its two
+// frames.  Both tiles of a voxel group run on the same XCD at about the same time and read the same samples (one HBM fetch, one
+// L2 hit), and fold + clamp + 3-way split run twice per
+// voxel instead of three times (three tiles of 6 blocks before).  Of the workgroups of an XCD the first dsi_na take ODF tiles, the
+// others pdf tiles, each kind walking the XCD's voxel groups with its own stride: the split follows the two tiles' costs.
+template <int MBB>
+__global__ __launch_bounds__(512, 2) void odf_dsi2_kernel(const GemmArgs a) {
+    constexpr int LA_ = gemm3_lds_bytes<10, 1, 8, true, true>(), LB_ = gemm3_lds_bytes<MBB, 0, 8, true, false>();
+    __shared__ __attribute__((aligned(16))) char lds[LA_ > LB_ ? LA_ : LB_];
+    const int wslot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    GemmArgs b = a;
+    if (wslot < a.dsi_na) {
+        b.one_slot = wslot; b.one_stride = a.dsi_na;
+        gemm3_body<10, 1, 8, true, true, true>(b, lds);
+    } else {
+        b.one_slot = wslot - a.dsi_na; b.one_stride = nslot - a.dsi_na;
+        b.At3 = a.At3b;
+        b.M = a.nrow0;                                   // the pdf rows only (rows >= M are padding of the tile)
+        gemm3_body<MBB, 0, 8, true, false, true>(b, lds);
+    }
+}
+
 
 // ---- mask compaction ---------------------------------------------------------------------------------------
 // vidx = ascending list of the voxels of every aligned 4-voxel group ("quad") that holds a voxel inside the mask, so
@@ -1945,18 +2011,16 @@ struct fib_odf_plan {
     fib::DevBuf<float> Aextra;                       // f32 coefficients of the NX extra rows [ntile_m][NX][Kpad]
     fib::DevBuf<float> Gdev;                         // G, column-major [gM x gK] (odf_inf_fix_kernel)
     mutable fib::DevBuf<int32_t> inf_list;           // [nvox] voxels with a +Inf sample (GQI, split-bf16 kernel; grow-only)
-    // 16x16x32 form of the split-bf16 contraction (odf_gemm16_kernel): M tile = NB16 16-row blocks + NX16 f32 rows
-    int NB16 = 0, NX16 = 0, ntile16 = 1, nstage16 = 0;
-    fib::DevBuf<uint16_t> At4, At4f;                 // images in identity row order / in the fused scan's row order
-    fib::DevBuf<float> Aextra4, Aextra4f;            // extra rows [ntile16][NX16][nstage16 * 32]
     bool split_bf16 = false;
     bool fused_shape = false;                        // (GQI, 10 blocks + 1 extra row: the shape the fused scan is generated for)
     bool fused = false;                              // sphere_642 GQI plan: the contraction kernel finds the peaks on its accumulators
+    bool dsi2_shape = false, dsi2 = false;           // folded DSI plan on sphere_642: odf_dsi2_kernel (fused ODF tile + pdf tile of MBB blocks)
+    int MBB = 0;
+    fib::DevBuf<uint16_t> At3b;                      // image of the pdf tile (the ODF tile's image / pole row: At3f / Aextraf)
     fib::DevBuf<uint16_t> At3f;                      // split-bf16 image with the rows in the order of sphere642_fused.inc
     fib::DevBuf<float> Aextraf;                      // its extra row (the pole of the layout's rotation)
     mutable fib::DevBuf<float> mean_hi;              // [nvox] per-voxel upper bound of the mean (fused path)
     mutable fib::DevBuf<int32_t> redo_list;          // [nvox] voxels left to odf_redo_kernel
-    fib::DevBuf<char> dump;                          // store target of lanes without a voxel (odf_pipe_kernel)
     fib::DevBuf<uint32_t> effbits;
     fib::DevBuf<int32_t> nbr, nbr64; // [nvert_even][deg_pad] LDS row of each neighbour (sentinel-padded)
     int deg_pad = 6, rows_pad = 0;
@@ -2060,88 +2124,50 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
         if ((rc3 = p->Aextra.alloc(AX.size())) != FIB_OK) return rc3;
         FIB_HIP(hipMemcpy(p->At3.p, A3.data(), A3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         FIB_HIP(hipMemcpy(p->Aextra.p, AX.data(), AX.size() * sizeof(float), hipMemcpyHostToDevice));
+        // single-tile image of mb blocks (+ nx extra rows) whose image row r holds row rowfn(r) of G (< 0: padding)
+        auto build_one = [&](int mb, int nx, auto rowfn, std::vector<uint16_t> &A3o, std::vector<float> &AXo) {
+            A3o.assign((size_t)nst * 3 * mb * 512, 0);
+            AXo.assign((size_t)std::max(1, nx * p->Kpad), 0.0f);
+            for (int t = 0; t < nst; t++) {
+                uint16_t *st = A3o.data() + (size_t)t * 3 * mb * 512;
+                for (int m = 0; m < mb; m++)
+                    for (int l = 0; l < 64; l++)
+                        for (int j = 0; j < 8; j++) {
+                            const int gr = rowfn(m * 32 + (l & 31)), k = t * KT + 8 * (l >> 5) + j;
+                            if (gr < 0 || k >= K) continue;
+                            const float v = p->G[gr + (size_t)M * k];
+                            const uint16_t h1 = bf16_rn(v);
+                            const float r1 = v - bf16_f(h1);
+                            const uint16_t h2 = bf16_rn(r1);
+                            const float r2 = r1 - bf16_f(h2);
+                            const uint16_t hs[3] = {h1, h2, bf16_rn(r2)};
+                            for (int pc = 0; pc < 3; pc++) st[((size_t)(pc * mb + m) * 64 + l) * 8 + j] = hs[pc];
+                        }
+            }
+            for (int x = 0; x < nx; x++)
+                for (int k = 0; k < K; k++) { const int gr = rowfn(mb * 32 + x); if (gr >= 0) AXo[(size_t)x * p->Kpad + k] = p->G[gr + (size_t)M * k]; }
+        };
+        // folded DSI on sphere_642: ODF tile in the fused scan's row order + pdf tile (odf_dsi2_kernel)
+        static const int mbbs[] = {5, 7, 9};
+        for (int mbb : mbbs) if (p->MBB == 0 && p->gRow0 <= mbb * 32) p->MBB = mbb;
+        p->dsi2_shape = faces && p->folded && p->gRow0 > 0 && p->MBB > 0 && M == p->gRow0 + FQ_NV && p->scale_frame >= 0 && p->Kpad <= 512 && nst >= 2 &&
+                        !getenv("FIBERS_DSI_THREE_TILES");
+        if (p->dsi2_shape) {
+            const int r0 = p->gRow0;
+            build_one(10, 1, [&](int r) { return r < FQ_NV ? r0 + fib_f642_pos_vertex[r] : -1; }, A3, AX);
+            if ((rc3 = p->At3f.alloc(A3.size())) != FIB_OK || (rc3 = p->Aextraf.alloc(AX.size())) != FIB_OK) return rc3;
+            FIB_HIP(hipMemcpy(p->At3f.p, A3.data(), A3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            FIB_HIP(hipMemcpy(p->Aextraf.p, AX.data(), AX.size() * sizeof(float), hipMemcpyHostToDevice));
+            build_one(p->MBB, 0, [&](int r) { return r < r0 ? r : -1; }, A3, AX);
+            if ((rc3 = p->At3b.alloc(A3.size())) != FIB_OK) return rc3;
+            FIB_HIP(hipMemcpy(p->At3b.p, A3.data(), A3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        }
         p->fused_shape = faces && p->gRow0 == 0 && p->scale_frame < 0 && M == FQ_NV && p->MB == 10 && p->NX == 1 && p->ntile_m == 1 && p->Kpad <= 512;
         if (p->fused_shape) {                                   // second image in the row order of sphere642_fused.inc
             build(fib_f642_pos_vertex, A3, AX);
-            if ((rc3 = p->At3f.alloc(A3.size())) != FIB_OK || (rc3 = p->Aextraf.alloc(AX.size())) != FIB_OK || (rc3 = p->dump.alloc((size_t)1024 * PP_NW * 1024)) != FIB_OK) return rc3;
+            if ((rc3 = p->At3f.alloc(A3.size())) != FIB_OK || (rc3 = p->Aextraf.alloc(AX.size())) != FIB_OK) return rc3;
             FIB_HIP(hipMemcpy(p->At3f.p, A3.data(), A3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             FIB_HIP(hipMemcpy(p->Aextraf.p, AX.data(), AX.size() * sizeof(float), hipMemcpyHostToDevice));
-        }
-    }
-    if (p->split_bf16 && getenv("FIBERS_ODF_SHAPE16")) {     // opt-in: measured 8-9 % slower than the 32x32x16 kernels (profiles/r03/shape_ab_*.log)
-        // ---- images of the 16x16x32 kernel (odf_gemm16.inc): tile shape minimising ntile * (MFMA cycles + per-stage split cost) ----
-        int best = INT32_MAX;
-        static const int nbs[] = {20, 19, 18, 17, 16, 14, 12, 10};
-        for (int nb : nbs)
-            for (int nx = 0; nx <= 1; nx++) {
-                const int rows = nb * 16 + nx, nt = (M + rows - 1) / rows;
-                const int cost = nt * (nb * 192 + 96 * nx + 1500);
-                if ((size_t)nt * nx * ((K + 31) / 32 * 32) > (size_t)2048) continue;     // the extra rows' LDS table
-                if (cost < best) { best = cost; p->NB16 = nb; p->NX16 = nx; p->ntile16 = nt; }
-            }
-        if (const char *e = getenv("FIBERS_GEMM16_TILE")) {  // tuning hook: "<NB>x<NX>"
-            int nb = 0, nx = 0;
-            if (sscanf(e, "%dx%d", &nb, &nx) == 2 && std::find(std::begin(nbs), std::end(nbs), nb) != std::end(nbs) && (nx == 0 || nx == 1)) {
-                p->NB16 = nb; p->NX16 = nx; p->ntile16 = (M + nb * 16 + nx - 1) / (nb * 16 + nx);
-            }
-        }
-        const int NB = p->NB16, NX = p->NX16, nst = (K + 31) / 32, kx = nst * 32, ROWS16 = NB * 16 + NX;
-        const int NB0 = (NB + 1) / 2, krem = K - (nst - 1) * 32;
-        const bool half_tail = krem <= 16;
-        p->nstage16 = nst;
-        auto bf16_rn = [](float f) -> uint16_t {
-            uint32_t u; memcpy(&u, &f, 4);
-            if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
-            u += 0x7fffu + ((u >> 16) & 1u);
-            return (uint16_t)(u >> 16);
-        };
-        auto bf16_f = [](uint16_t h) -> float { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
-        auto build16 = [&](const short *rowmap, std::vector<uint16_t> &A4, std::vector<float> &AX) {
-            A4.assign((size_t)p->ntile16 * nst * 3 * NB * 512, 0);
-            AX.assign((size_t)std::max(1, p->ntile16 * NX * kx), 0.0f);
-            for (int tm = 0; tm < p->ntile16; tm++) {
-                for (int t = 0; t < nst; t++) {
-                    const bool tail = half_tail && t == nst - 1;
-                    uint16_t *st = A4.data() + ((size_t)tm * nst + t) * 3 * NB * 512;
-                    for (int b = 0; b < NB; b++) {
-                        const int hb = b >= NB0, bl = hb ? b - NB0 : b, nbh = hb ? NB - NB0 : NB0;
-                        uint16_t *hp = st + (hb ? (size_t)3 * NB0 * 512 : 0);
-                        for (int l = 0; l < 64; l++)
-                            for (int j = 0; j < 8; j++) {
-                                const int row = tm * ROWS16 + 16 * b + (l & 15), qq = l >> 4;
-                                const int k = t * 32 + 8 * (tail ? (qq & 1) : qq) + j;
-                                if (row >= M || 16 * b + (l & 15) >= NB * 16 || k >= K) continue;
-                                const float v = p->G[(rowmap ? rowmap[row] : row) + (size_t)M * k];
-                                const uint16_t h1 = bf16_rn(v);
-                                const float r1 = v - bf16_f(h1);
-                                const uint16_t h2 = bf16_rn(r1);
-                                const float r2 = r1 - bf16_f(h2);
-                                const uint16_t h3 = bf16_rn(r2);
-                                // pieces of a full stage: a1, a2, a3; of the half tail: X = [a1|a1], Y = [a2|a2], Z = [a1|a3]
-                                const uint16_t hs[3] = {h1, h2, tail ? (qq < 2 ? h1 : h3) : h3};
-                                for (int pc = 0; pc < 3; pc++) hp[((size_t)(pc * nbh + bl) * 64 + l) * 8 + j] = hs[pc];
-                            }
-                    }
-                }
-                for (int x = 0; x < NX; x++)
-                    for (int k = 0; k < K; k++) {
-                        const int row = tm * ROWS16 + NB * 16 + x;
-                        if (row < M) AX[((size_t)tm * NX + x) * kx + k] = p->G[(rowmap ? rowmap[row] : row) + (size_t)M * k];
-                    }
-            }
-        };
-        std::vector<uint16_t> A4;
-        std::vector<float> AX4;
-        build16(nullptr, A4, AX4);
-        int rc4;
-        if ((rc4 = p->At4.alloc(A4.size())) != FIB_OK || (rc4 = p->Aextra4.alloc(AX4.size())) != FIB_OK) return rc4;
-        FIB_HIP(hipMemcpy(p->At4.p, A4.data(), A4.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-        FIB_HIP(hipMemcpy(p->Aextra4.p, AX4.data(), AX4.size() * sizeof(float), hipMemcpyHostToDevice));
-        if (p->fused_shape && NB == 20 && NX == 1 && p->ntile16 == 1) {
-            build16(fib_f642_pos_vertex, A4, AX4);
-            if ((rc4 = p->At4f.alloc(A4.size())) != FIB_OK || (rc4 = p->Aextra4f.alloc(AX4.size())) != FIB_OK) return rc4;
-            FIB_HIP(hipMemcpy(p->At4f.p, A4.data(), A4.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-            FIB_HIP(hipMemcpy(p->Aextra4f.p, AX4.data(), AX4.size() * sizeof(float), hipMemcpyHostToDevice));
         }
     }
     std::vector<int32_t> nbr32;
@@ -2171,6 +2197,7 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
         if (mine != ref) p->is_s642 = false;
     }
     p->fused = p->fused_shape && p->is_s642 && p->At3f.p != nullptr;
+    p->dsi2 = p->dsi2_shape && p->is_s642 && p->At3f.p != nullptr && p->At3b.p != nullptr;
     std::vector<int32_t> nbr64(nbr);
     for (auto &u : nbr64) if (u == p->rows_pad) u = p->nvert;
     if ((rc = p->nbr64.alloc(nbr64.size())) != FIB_OK) return rc;
@@ -2332,39 +2359,11 @@ void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
             return;
         }
         if constexpr (MB == 10 && NX == 1) {
-            if (ga.mean_hi && ga.dump) {                  // software-pipelined kernel: one 4-wave workgroup per CU, 128 voxels per item
-                const int64_t items4 = fib::cdiv(ga.nvox, 128);
-                const unsigned pg4 = (unsigned)std::min<int64_t>(std::min(ncu, 1024), items4);   // (the dump area holds 1024 workgroups)
-                hipLaunchKernelGGL(odf_pipe_kernel, dim3(pg4), dim3(256), 0, st, g2);
-                return;
-            }
             if (ga.mean_hi) { hipLaunchKernelGGL((odf_gemm3_kernel<10, 1, 8, false, true>), dim3(pg), dim3(512), 0, st, g2); return; }
         }
         hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 8>), dim3(pg), dim3(512), 0, st, g2);
     }
     else hipLaunchKernelGGL((odf_gemm_kernel<MB, NX>), dim3(grid), dim3(256), 0, st, ga);
-}
-
-// the 16x16x32 form: persistent grid as above, one 8-wave workgroup per CU
-template <int NB, int NX>
-void launch_gemm16_t(const GemmArgs &ga, bool fuse, hipStream_t st) {
-    int ncu = 256, dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    const int64_t items = fib::cdiv(ga.nvox, 8 * 32) * ga.ntile_m;
-    unsigned pg = (unsigned)std::min<int64_t>((int64_t)ncu, items);
-    pg = (pg + 7) / 8 * 8;
-    if constexpr (NB == 20 && NX == 1) {
-        if (fuse) { hipLaunchKernelGGL((odf_gemm16_kernel<20, 1, 8, false, true>), dim3(pg), dim3(512), 0, st, ga); return; }
-    }
-    hipLaunchKernelGGL((odf_gemm16_kernel<NB, NX, 8>), dim3(pg), dim3(512), 0, st, ga);
-}
-bool launch_gemm16(int nb, int nx, const GemmArgs &ga, bool fuse, hipStream_t st) {
-#define FIB_G16_CASE(NBV, NXV) if (nb == NBV && nx == NXV) { launch_gemm16_t<NBV, NXV>(ga, fuse, st); return true; }
-    FIB_G16_CASE(20, 1) FIB_G16_CASE(20, 0) FIB_G16_CASE(19, 0) FIB_G16_CASE(19, 1) FIB_G16_CASE(18, 0) FIB_G16_CASE(18, 1) FIB_G16_CASE(17, 0) FIB_G16_CASE(17, 1)
-    FIB_G16_CASE(16, 0) FIB_G16_CASE(16, 1) FIB_G16_CASE(14, 0) FIB_G16_CASE(14, 1) FIB_G16_CASE(12, 0) FIB_G16_CASE(12, 1) FIB_G16_CASE(10, 0) FIB_G16_CASE(10, 1)
-#undef FIB_G16_CASE
-    return false;
 }
 
 size_t peaks_smem(const fib_odf_plan *p) {
@@ -2475,21 +2474,30 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         int rcm = plan->mean_hi.ensure((size_t)nvox);
         if (rcm != FIB_OK) return rcm;
     }
-    if (fuse) {
+    auto setup_fused = [&]() -> int {                   // the arguments of gemm3_epilogue_fused
         int rcf = plan->redo_list.ensure((size_t)nvox);
         if (rcf != FIB_OK) return rcf;
         ga.At3 = plan->At3f.p; ga.Aextra = plan->Aextraf.p;
         for (int k = 0; k < 3; k++) { ga.peak[k] = peak[k]; ga.qa[k] = qa[k]; }
         ga.verts = plan->verts.p; ga.maxenc = plan->maxenc.p; ga.mean_hi = plan->mean_hi.p;
         ga.redo_count = plan->live_counts.p + 3; ga.redo_list = plan->redo_list.p; ga.redo_cap = (int)std::min<int64_t>(nvox, INT32_MAX);
-        // the software-pipelined kernel spreads the epilogue over the 14 contraction stages after the first (protocols of 225+ frames)
         { const char *pa = getenv("FIBERS_ODF_ANTI"); ga.anti = pa ? atoi(pa) : 3; }   // bit 0: anti-phase wave halves, bit 1: s_setprio around the MFMA block (default both; 0 = neither)
-        { const char *pe = getenv("FIBERS_ODF_PIPE"); if (plan->Kpad / KT >= 1 + PP_NSLICE && pe && pe[0] == '1') ga.dump = plan->dump.p; }
-    }
+        return FIB_OK;
+    };
+    if (fuse) { int rcf = setup_fused(); if (rcf != FIB_OK) return rcf; }
     ga.K = plan->gK; ga.Kpad = plan->Kpad; ga.M = plan->gM; ga.nrow0 = plan->gRow0; ga.ntile_m = plan->ntile_m;
-    const bool fuse_fold = plan->folded && ga.At3 != nullptr && plan->MB <= FOLD_MB_MAX && plan->Kpad <= FKMAX && plan->scale_frame_raw >= 0 &&
-                           (int64_t)plan->fold_span_max * nvox * 4 < (int64_t)0xE0000000ll && !getenv("FIBERS_DSI_UNFUSED");
-    if (fuse_fold) {
+    const bool fold_ok = plan->folded && ga.At3 != nullptr && plan->Kpad <= FKMAX && plan->scale_frame_raw >= 0 &&
+                         (int64_t)plan->fold_span_max * nvox * 4 < (int64_t)0xE0000000ll && !getenv("FIBERS_DSI_UNFUSED");
+    const bool fuse_fold = fold_ok && plan->MB <= FOLD_MB_MAX;
+    // folded DSI on sphere_642: one launch of odf_dsi2_kernel does contraction, scale, ODF / pdf rows and find_peaks!
+    const bool dsi2 = plan->dsi2 && fold_ok && ga.vec_ok;
+    if (dsi2) {
+        int rcf = setup_fused();
+        if (rcf != FIB_OK) return rcf;
+        ga.At3b = plan->At3b.p;
+        ga.ntile_m = 2;
+    }
+    if (fuse_fold || dsi2) {
         ga.fold = 1;
         ga.rowA = plan->foldA.p; ga.rowB = plan->foldB.p;
     } else if (plan->folded) {
@@ -2505,25 +2513,33 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         ga.S = plan->folded_dwi.p;
         ga.rowA = plan->foldA.p; ga.rowB = plan->foldB.p;
     }
-    ga.scale_frame = plan->nrow0 > 0 ? (fuse_fold ? plan->scale_frame_raw : plan->scale_frame) : -1;
+    ga.scale_frame = plan->nrow0 > 0 ? ((fuse_fold || dsi2) ? plan->scale_frame_raw : plan->scale_frame) : -1;
     ga.scale_coef = plan->scale_coef;
     ga.stride = nvox;
     ga.has_ineff = plan->has_ineff ? 1 : 0;
     FIB_CHECK(fib::cdiv(nvox, WG_VOX) * plan->ntile_m < ((int64_t)1 << 31), FIB_ERR_UNSUPPORTED, "volume too large for one launch");
 
-    // the 16x16x32 form of the split-bf16 contraction (FIBERS_ODF_SHAPE16=1 at plan creation)
-    const bool use16 = ga.At3 != nullptr && plan->At4.p != nullptr && !plan->folded && nvox <= ((int64_t)1 << 25) && !ga.dump &&
-                       (!fuse || plan->At4f.p != nullptr);
-    if (use16) {
-        ga.At3 = fuse ? plan->At4f.p : plan->At4.p;
-        ga.Aextra = fuse ? plan->Aextra4f.p : plan->Aextra4.p;
-        ga.ntile_m = plan->ntile16;
-    }
     auto run_gemm = [&](GemmArgs g, hipStream_t s) -> int {
         const unsigned grid = (unsigned)(fib::cdiv(g.nvox, WG_VOX) * plan->ntile_m);
         fib::ProfScope prof("odf_gemm", s);
-        if (use16) {
-            if (!launch_gemm16(plan->NB16, plan->NX16, g, fuse, s)) return fib::fail(FIB_ERR_INVALID, "internal: no 16x16x32 GEMM variant for NB=%d NX=%d", plan->NB16, plan->NX16);
+        if (dsi2) {                                      // persistent grid, an even number of workgroups per XCD (ODF tile | pdf tile)
+            int ncu = 256;
+            (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, plan->device);
+            const int64_t items = fib::cdiv(g.nvox, 8 * 32) * 2;
+            unsigned pg = (unsigned)std::min<int64_t>((int64_t)ncu, items);
+            pg = (pg + 15) / 16 * 16;
+            const int nslot = (int)pg / 8;
+            // share of the ODF tile's cost per voxel group (tools/dsi_na_sweep.py, 140^3 x 515: 68 us per ODF item, 59.7 per pdf item of 9
+            // blocks; ~4.5 us per block): 17 of 32 workgroups per XCD for the 515-point lattice
+            const double ca = 68.0, cb = 19.0 + 4.5 * plan->MBB;
+            int na = (int)(nslot * ca / (ca + cb) + 0.5);
+            if (const char *e = getenv("FIBERS_DSI_NA")) na = atoi(e);
+            g.dsi_na = std::max(1, std::min(nslot - 1, na));
+            switch (plan->MBB) {
+                case 5: hipLaunchKernelGGL(odf_dsi2_kernel<5>, dim3(pg), dim3(512), 0, s, g); break;
+                case 7: hipLaunchKernelGGL(odf_dsi2_kernel<7>, dim3(pg), dim3(512), 0, s, g); break;
+                default: hipLaunchKernelGGL(odf_dsi2_kernel<9>, dim3(pg), dim3(512), 0, s, g); break;
+            }
             FIB_HIP(hipGetLastError());
             return FIB_OK;
         }
@@ -2551,7 +2567,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         InfFixArgs fx{plan->Gdev.p, dwi, odf, ga.fix_count, ga.fix_list, ga.fix_cap, plan->gM, plan->gK, nvox};
         hipLaunchKernelGGL(odf_inf_fix_kernel, dim3(64), dim3(256), 0, st, fx);
     }
-    if (fuse) {
+    if (fuse || dsi2) {
         fib::ProfScope prof("odf_peaks", st);           // what is left of the peak finder: the redo list and the exact odfmax
         RedoArgs ra{odf, nvox, ga.redo_count, ga.redo_list, ga.redo_cap, plan->verts.p, {peak[0], peak[1], peak[2]}, {qa[0], qa[1], qa[2]}, plan->maxenc.p};
         hipLaunchKernelGGL(odf_redo_kernel, dim3(256), dim3(64), 0, st, ra);
@@ -2619,12 +2635,6 @@ int fib::matrix_plan_run(const fib_odf_plan *plan, const float *S, const uint8_t
     ga.scale_frame = -1; ga.scale_coef = 0.0f; ga.stride = n; ga.has_ineff = 0;
     const unsigned grid = (unsigned)(fib::cdiv(n, WG_VOX) * plan->ntile_m);
     fib::ProfScope prof("matrix_gemm", st);
-    if (ga.At3 && plan->At4.p && n <= ((int64_t)1 << 25)) {
-        ga.At3 = plan->At4.p; ga.Aextra = plan->Aextra4.p; ga.ntile_m = plan->ntile16;
-        if (!launch_gemm16(plan->NB16, plan->NX16, ga, false, st)) return fib::fail(FIB_ERR_INVALID, "internal: no 16x16x32 GEMM variant for NB=%d NX=%d", plan->NB16, plan->NX16);
-        FIB_HIP(hipGetLastError());
-        return FIB_OK;
-    }
 #define FIB_GEMM_CASE(MBV, NXV) if (plan->MB == MBV && plan->NX == NXV) { launch_gemm<MBV, NXV>(ga, grid, st); launched = true; }
     bool launched = false;
     FIB_GEMM_CASE(5, 0) FIB_GEMM_CASE(6, 0) FIB_GEMM_CASE(7, 0) FIB_GEMM_CASE(8, 0) FIB_GEMM_CASE(9, 0) FIB_GEMM_CASE(10, 0) FIB_GEMM_CASE(11, 0)

@@ -131,10 +131,9 @@ def test_c3_gqi_140cubed(fj, orc, dev):
     _odf_properties(fj, out, mask, plan, dwi, dev, 4.0)
 
 
-@pytest.mark.parametrize("env,val", [("FIBERS_ODF_ANTI", "0"), ("FIBERS_ODF_PIPE", "1")])
+@pytest.mark.parametrize("env,val", [("FIBERS_ODF_ANTI", "0")])
 def test_c3_gqi_kernel_variants_bit_identical_140cubed(fj, dev, monkeypatch, env, val):
-    """the fused GQI kernel without its anti-phase wave halves, and the software-pipelined kernel, against the default kernel
-    on the full 140^3 x 270 volume (ball mask: partial work items, workgroups with different item counts): every output bit"""
+    """the fused GQI kernel without its anti-phase wave halves against the default kernel on the full 140^3 x 270 volume (ball mask: partial work items, workgroups with different item counts): every output bit"""
     import torch
     from fibers_jl_amd import phantom
     bval, bvec = phantom.scheme_gqi()

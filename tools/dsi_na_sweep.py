@@ -1,0 +1,28 @@
+"""DSI two-tile kernel: time per step against the number of workgroups per XCD that take ODF tiles (FIBERS_DSI_NA)."""
+import sys, os, time, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import fibers_jl_amd as fj
+from fibers_jl_amd import phantom
+dev = torch.device("cuda", 0)
+L = fj.lib()
+shape = (140, 140, 140)
+b5, g5 = phantom.scheme_dsi()
+d5, _ = phantom.make_dwi_torch(shape, b5, g5, seed=5, device=dev)
+mask = torch.ones(140**3, dtype=torch.uint8, device=dev)
+p5 = fj.OdfPlan("dsi", b5, g5, fj.sphere_642, hann_width=32, device=0)
+o5 = fj.odf_rec_device(p5, d5, mask)
+for rep in range(2):
+    for na in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "14,15,16,17,18,19,20").split(",")]:
+        os.environ["FIBERS_DSI_NA"] = str(na)
+        for _ in range(3): fj.odf_rec_device(p5, d5, mask, out=o5)
+        torch.cuda.synchronize()
+        L.fib_profile_enable(1); L.fib_profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(20): fj.odf_rec_device(p5, d5, mask, out=o5)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / 20 * 1e3
+        L.fib_profile_enable(0)
+        ms, cnt = C.c_double(), C.c_int64()
+        L.fib_profile_get(b"odf_gemm", C.byref(ms), C.byref(cnt))
+        print("na %d: kernel %.3f ms, step %.3f ms" % (na, ms.value / cnt.value, wall), flush=True)

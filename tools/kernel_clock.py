@@ -7,7 +7,7 @@ kernel back to back for >= 2 s on the random phantom of the benchmark, and print
     clock = d(s_memtime) / d(s_memrealtime) x 100 MHz   (median / min / max over the workgroups of the last launch)
 next to the launch's wall time.  One JSON object on stdout.  The product library never executes a stamp.
 
-usage: python tools/kernel_clock.py [--seconds 2.5] [--shape 140,140,140] [--kernels fused,unfused,pipe,dsi]"""
+usage: python tools/kernel_clock.py [--seconds 2.5] [--shape 140,140,140] [--kernels fused,unfused,dsi]"""
 import argparse
 import ctypes as C
 import json
@@ -44,8 +44,7 @@ def main():
     sph = fj.sphere_642
     mask = torch.ones(nvox, dtype=torch.uint8, device=dev)
     names = {1: "odf_gemm3_kernel<MB,NX,8> (unfused)", 2: "odf_gemm3_kernel<10,1,8,FUSE> (default GQI)", 3: "odf_gemm3_kernel<MB,NX,8,FOLD> (DSI)",
-             4: "odf_pipe_kernel", 5: "odf_gemm16_kernel<NB,NX,8> (16x16x32, unfused)", 6: "odf_gemm16_kernel<20,1,8,FUSE> (16x16x32, default GQI)",
-             7: "odf_gemm16_kernel FOLD (DSI)"}
+             8: "odf_dsi2_kernel (DSI: fused ODF tile + pdf tile)"}
     res = {}
 
     def measure(label, step):
@@ -76,33 +75,31 @@ def main():
                           clock_ghz_min=float(ghz.min()) if len(live) else None, clock_ghz_max=float(ghz.max()) if len(live) else None,
                           loop_us_median=float(np.median(live[:, 1]) / 100.0) if len(live) else None,
                           kernel_ms_hipevent=ms.value / max(cnt.value, 1), step_ms_wall=wall * 1e3, steps=n)
+        if kid == 8 and len(live):                      # odf_dsi2_kernel: workgroups with an even index on their XCD run the ODF tile, odd ones the pdf tile
+            wg = np.nonzero(buf[:, 1] > 0)[0]
+            par = (wg >> 3) & 1
+            for t, nm in ((0, "odf_tile"), (1, "pdf_tile")):
+                sel = live[par == t]
+                if len(sel):
+                    res[label][nm] = dict(workgroups=int(len(sel)), loop_us_median=float(np.median(sel[:, 1]) / 100.0), loop_us_max=float(sel[:, 1].max() / 100.0),
+                                          clock_ghz_median=float(np.median(sel[:, 0].astype(np.float64) / sel[:, 1].astype(np.float64) * 0.1)),
+                                          items_median=float(np.median(sel[:, 3])))
 
     kernels = args.kernels.split(",")
-    if any(k.startswith("fused") or k.startswith("unfused") or k == "pipe" for k in kernels):
+    if any(k in ("fused", "unfused") for k in kernels):
         bval, bvec = phantom.scheme_gqi()
         dwi, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=3, device=dev)
-        plans = {}
-        for k in kernels:                               # fused | unfused | pipe, suffix 16 = the 16x16x32 kernels (plan-time switch)
-            if not (k.startswith("fused") or k.startswith("unfused") or k == "pipe"):
-                continue
-            s32 = not k.endswith("16")
-            for v in ("FIBERS_ODF_UNFUSED", "FIBERS_ODF_PIPE", "FIBERS_ODF_SHAPE16"):
-                os.environ.pop(v, None)
-            if not s32:
-                os.environ["FIBERS_ODF_SHAPE16"] = "1"
-            if s32 not in plans:
-                plans[s32] = fj.OdfPlan("gqi", bval, bvec, sph, sigma=1.25, device=0)
-            os.environ.pop("FIBERS_ODF_SHAPE16", None)
-            plan = plans[s32]
-            out = fj.odf_rec_device(plan, dwi, mask, normalize=False)
-            if k.startswith("unfused"):
+        plan = fj.OdfPlan("gqi", bval, bvec, sph, sigma=1.25, device=0)
+        out = fj.odf_rec_device(plan, dwi, mask, normalize=False)
+        for k in kernels:
+            os.environ.pop("FIBERS_ODF_UNFUSED", None)
+            if k == "unfused":
                 os.environ["FIBERS_ODF_UNFUSED"] = "1"
-            elif k == "pipe":
-                os.environ["FIBERS_ODF_PIPE"] = "1"
+            elif k != "fused":
+                continue
             measure("gqi_" + k, lambda: fj.odf_rec_device(plan, dwi, mask, out=out, normalize=True))
-        for v in ("FIBERS_ODF_UNFUSED", "FIBERS_ODF_PIPE"):
-            os.environ.pop(v, None)
-        del dwi, out, plans
+        os.environ.pop("FIBERS_ODF_UNFUSED", None)
+        del dwi, out, plan
         torch.cuda.empty_cache()
     if "dsi" in kernels:
         b5, g5 = phantom.scheme_dsi()
