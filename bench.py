@@ -10,8 +10,10 @@ z-slabs as the reference threads its z loop (gqi.jl:132); every rank reconstruct
 step, odfmax = maximum(mean(odf, dims=4)) (gqi.jl:164), is a 2-float all-reduce(MAX) inside the timed region, then qa ./=
 odfmax on every rank.  Strong scaling: the total work is fixed.  `value` is whole-job Mvoxels/s with inputs in HBM.
 `extra` carries, at every N: the DTI fit (140^3 x 64, slabs), streamline tracking (DTI field all-gathered from the slabs
-over RCCL inside the timed step, seeds round-robin) and the weak-scaling GQI figure (one whole volume per rank); at N = 1
-also DSI + 3-peak tracking, the microscopy / LCM modes, RUMBA-SD, the PCIe-inclusive host-tier call and CPU baselines."""
+over RCCL inside the timed step, seeds round-robin), BASELINE config 5 (DSI-515 in slabs with the global odfmax all-reduced,
+then the 3-peak field all-gathered and ~10 M seeds x offsets round-robin) and the weak-scaling GQI figure (one whole volume
+per rank); at N = 1 also the in-kernel clock (diagnostic build, child process), the microscopy / LCM modes, RUMBA-SD, the
+PCIe-inclusive host-tier call and the other CPU baselines."""
 import argparse
 import json
 import os
@@ -230,9 +232,9 @@ def main():
                                              % (",FUSE" if fused else "", "; find_peaks! + peak/qa extraction on the accumulators" if fused else ""),
                         achieved=achieved, peak=peak_eff, unit="TFLOP/s", frac=achieved / peak_eff,
                         note="achieved = algorithmic f32 flops (2*321*270 per voxel) / kernel time (the fused kernel's time includes the peak finder); "
-                             "peak = 2500 TFLOP/s dense BF16 / 6 piece products; executed BF16 MFMA rate = %.0f TFLOP/s of 2500; the step runs at "
-                             "the board's power limit (extra.power_clock_under_load: ~1.35 kW, ~1.95 GHz of the nominal 2.4), three different "
-                             "schedules of the contraction take the same 2.07 ms (DESIGN.md K2/K5)"
+                             "peak = 2500 TFLOP/s dense BF16 / 6 piece products; executed BF16 MFMA rate = %.0f TFLOP/s of 2500; the chip holds "
+                             "1.8-1.9 GHz of the nominal 2.4 inside this kernel (in_kernel_clock_ghz: s_memtime / s_memrealtime, diagnostic build); the "
+                             "16x16x32 MFMA shape holds 2.16 GHz but costs 27 %% more cycles (DESIGN.md K2/K5)"
                              % (6.0 * 2.0 * 320 * 272 * nloc / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0),
                         avg_kernel_ms=gemm_avg_ms, launches=gemm_n, traffic=None, hbm_secondary=hbm2, peaks_kernel=pk)
     else:
@@ -242,46 +244,31 @@ def main():
     tr_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr_file) and world == 1:
         try:
-            roofline["traffic"] = json.load(open(tr_file)).get("odf_gemm_bytes_per_launch")
+            tj = json.load(open(tr_file))
+            roofline["traffic"] = tj.get("odf_gemm_bytes_per_launch")
+            roofline["traffic_source"] = ("STORED figure, not measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE in separate passes over "
+                                          "tools/prof_step.py gqi (tools/collect_profiles.sh), last collected into %s" % tj.get("source", "profiles/traffic.json"))
         except Exception:
             pass
 
     extra = {}
     if not args.no_extra and world == 1:
-        # ---- board power and shader clock while the headline step runs back to back (rocm-smi from a helper thread; not part of
-        # any timed region): the step runs at the board's power cap, which is what holds the clock below its nominal 2.4 GHz ------
+        # ---- in-kernel clock of the contraction kernels (MI355X_MICROARCH.md "DVFS give-back" item 6): a child process loads the
+        # DIAGNOSTIC build (libfibers_hip_stamp.so: one s_memtime / s_memrealtime pair around each workgroup's work loop) and runs the
+        # GQI and DSI steps back to back for 2 s each on the same random phantoms; the product library never executes a stamp ------
         try:
-            import re
             import subprocess
-            import threading
-            samples, stop = [], threading.Event()
-
-            def watch():
-                while not stop.is_set():
-                    try:
-                        o = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
-                        mclk = re.search(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", o)
-                        mpow = re.search(r"Power \(W\):\s*([0-9.]+)", o)
-                        if mclk and mpow:
-                            samples.append((int(mclk.group(1)), float(mpow.group(1))))
-                    except Exception:
-                        return
-            th = threading.Thread(target=watch, daemon=True)
-            th.start()
-            t_end = time.perf_counter() + 4.0
-            while time.perf_counter() < t_end:
-                for _ in range(50):
-                    gqi_step()
-                torch.cuda.synchronize()
-            stop.set()
-            th.join(timeout=6)
-            use = samples[1:] if len(samples) > 2 else samples
-            if use:
-                extra["power_clock_under_load"] = dict(sclk_mhz=sum(c for c, _ in use) / len(use), board_power_w=sum(w for _, w in use) / len(use),
-                                                       samples=len(use), note="rocm-smi while the headline step runs back to back for 4 s (untimed); "
-                                                                              "nominal peak clock 2400 MHz, board power limit 1400 W")
-        except Exception:
-            pass
+            if os.path.exists(os.path.join(ROOT, "fibers.jl_amd", "libfibers_hip_stamp.so")) and shape == SHAPE:
+                o = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_clock.py"), "--seconds", "2.0", "--kernels", "fused,dsi"],
+                                   capture_output=True, text=True, timeout=300)
+                kc = json.loads([ln for ln in o.stdout.splitlines() if ln.startswith("{")][-1])
+                extra["in_kernel_clock"] = kc
+                if "gqi_fused" in kc and kc["gqi_fused"].get("clock_ghz_median"):
+                    ghz = kc["gqi_fused"]["clock_ghz_median"]
+                    roofline["in_kernel_clock_ghz"] = ghz
+                    roofline["frac_of_clock_adjusted_peak"] = roofline["frac"] * 2.4 / ghz if split else None
+        except Exception as e:                                                      # noqa: BLE001
+            extra["in_kernel_clock"] = dict(error=str(e))
         # ---- the same step on the less flattering inputs of SURVEY §8d: ball mask (36 % of the volume inside) and ~1 % of the
         # samples non-positive (exercises the clamp and the mask compaction; the headline uses an all-ones mask, all positive) ----
         bm_h = phantom.ball_mask_torch(shape, dev)
@@ -363,6 +350,11 @@ def main():
                                         kernel_sum_ms=(tr_ms + pk_ms + sc_ms) / max(tr_n, 1),
                                         algorithmic_bytes=25.0 * npoints,
                                         hbm_gbs_trace=25.0 * (npoints / world) / (tr_ms / max(tr_n, 1) * 1e-3) / 1e9 if tr_n else 0.0,
+                                        roofline=dict(bound="hbm", achieved=25.0 * (npoints / world) / ((tr_ms + pk_ms + sc_ms) / max(tr_n, 1) * 1e-3) / 1e9 if tr_n else 0.0,
+                                                      peak=PEAK_HBM_GBS, unit="GB/s",
+                                                      frac=25.0 * (npoints / world) / ((tr_ms + pk_ms + sc_ms) / max(tr_n, 1) * 1e-3) / 1e9 / PEAK_HBM_GBS if tr_n else 0.0,
+                                                      note="25 B per emitted point (SURVEY 8d, nvec = 1) x rank 0's points / device time of trace + scan + pack; the "
+                                                           "integrator is a dependent chain of gathers from the Infinity-Cache-resident field, VALU-bound by its exact f64 norm"),
                                         note="one volume; wall = field all-gather + trace + scan + pack into a pre-allocated buffer (+ one host sync for "
                                              "the line count); seeds dealt round-robin over the ranks")
         # the trilinear option (fib_stream_params.interp = 1; not in the reference) on the same field and seeds, rank 0's share
@@ -490,44 +482,83 @@ def main():
             del rr, d4, rp
         del field_loc, mout_loc, seeds_all, o2, d2
 
-    if not args.no_extra and rank == 0 and world == 1:
-        # ---- C5 fit part: DSI 515-direction reconstruction + peaks ---------------------------------------------------------------------
+    if not args.no_extra:
+        # ---- C5 (BASELINE config 5) at every N: DSI 515-direction reconstruction in z-slabs (dsi.jl:197) with the global odfmax
+        # all-reduced (dsi.jl:263); then the 3-peak field + mask all-gathered over RCCL inside the timed step and ~10 M seeds x
+        # offsets round-robin over the ranks (stream.jl:757-761) --------------------------------------------------------------------
         torch.cuda.empty_cache()
         b5, g5 = phantom.scheme_dsi()
-        d5, _ = phantom.make_dwi_torch(shape, b5, g5, seed=5, device=dev)
+        d5f, _ = phantom.make_dwi_torch(shape, b5, g5, seed=5, device=dev)
+        d5 = d5f[:, v0:v1].contiguous() if world > 1 else d5f
+        del d5f
+        torch.cuda.empty_cache()
         p5 = fj.OdfPlan("dsi", b5, g5, sph, hann_width=32, device=dev.index)
-        o5 = fj.odf_rec_device(p5, d5, mask)
+        o5 = fj.odf_rec_device(p5, d5, mask, normalize=False)
         nd = max(2, args.steps // 2)
-        t_dsi = timed(lambda: fj.odf_rec_device(p5, d5, mask, out=o5), nd, 1) / nd
+
+        def dsi_step():
+            if world == 1:
+                fj.odf_rec_device(p5, d5, mask, out=o5, normalize=True)
+            else:
+                fd.odf_rec_sharded(p5, d5, mask, out=o5)
+        t_dsi = timed(dsi_step, nd, 1) / nd
         g_ms, g_n = prof_get(L, "odf_gemm")
         f_ms, f_n = prof_get(L, "dsi_fold")
         q_ms, q_n = prof_get(L, "odf_peaks")
+        n5 = len(b5)
+        dsi_bytes = (4.0 * n5 + 1 + 4.0 * n5 + 4.0 * nvert + 48) * nloc          # 5 456 B / voxel (DWI + mask in; pdf, odf, peaks, qa out)
+        dsi_k_ms = g_ms / max(g_n, 1)
+        dsi_exec = 6.0 * 2.0 * (320 + 288) * 272 * nloc                          # executed bf16 flops: 6 piece products x (10 + 9 blocks) x 32 rows x 17 stages x 16
         extra["dsi_rec_140x515"] = dict(mvoxels_per_s=nvox / t_dsi / 1e6, ms_per_step=t_dsi * 1e3,
-                                        gemm_kernel_ms=g_ms / max(g_n, 1), fold_kernel_ms=f_ms / max(f_n, 1), peaks_kernel_ms=q_ms / max(q_n, 1),
-                                        note="antipodal folding inside the contraction kernel: 258 folded samples x (258 pdf + 321 odf) rows")
-        # ---- C5 tracking: 3 peaks per voxel (f = qa, f_thresh = .03), ball mask, nsub = 10 -> ~10 M lines -------------
+                                        gemm_kernel_ms=dsi_k_ms, fold_kernel_ms=f_ms / max(f_n, 1), peaks_kernel_ms=q_ms / max(q_n, 1),
+                                        roofline=dict(bound="mfma", kernel="odf_dsi2_kernel<9>: fused ODF tile (10 blocks + pole row, find_peaks on the accumulators) + pdf tile "
+                                                                            "(9 blocks) per voxel group, antipodal fold inside the sample load",
+                                                      achieved=dsi_exec / (dsi_k_ms * 1e-3) / 1e12 if g_n else 0.0, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                                                      frac=dsi_exec / (dsi_k_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if g_n else 0.0,
+                                                      note="executed dense-bf16 flops of the kernel / its hipEvent time, against 2500 TFLOP/s",
+                                                      hbm_secondary=dict(algorithmic_bytes=dsi_bytes, achieved=dsi_bytes / t_dsi / 1e9 if t_dsi else 0.0,
+                                                                         peak=PEAK_HBM_GBS, unit="GB/s", frac=dsi_bytes / t_dsi / 1e9 / PEAK_HBM_GBS,
+                                                                         note="algorithmic bytes of the whole step / step wall time")),
+                                        note="ONE volume in z-slabs over the ranks; folded lattice: 258 folded samples x (258 pdf + 321 odf) rows; per-kernel figures are rank 0's slab")
+        # ---- C5 tracking: 3 peaks per voxel (f = qa, f_thresh = .03), ball mask, nsub = 10 -> ~10 M lines ---------------------------
         del d5
-        field3, mout3 = fj.stream_field_device(o5["peak"], f=o5["qa"], f_thresh=0.03, mask=bm_full)
+        bm_full5 = phantom.ball_mask_torch(shape, dev)
+        f3_loc, m3_loc = fj.stream_field_device(o5["peak"], f=o5["qa"], f_thresh=0.03, mask=bm_full5[v0:v1].contiguous())
+        mout3 = fd.allgather_slabs(m3_loc, counts)
         seeds3 = torch.nonzero(mout3).flatten()
         sub10 = torch.from_numpy(fj.make_sublist(10, np.random.default_rng(5))).to(dev)
-        xyz_buf.clear()
+        xyz5 = {}
+
+        def xyz_out5(npnt):
+            if xyz5.get("t") is None or xyz5["t"].numel() < 3 * npnt:
+                xyz5["t"] = torch.empty(int(3 * npnt * 1.05) + 16, dtype=torch.float32, device=dev)
+            return xyz5["t"]
         r3 = {}
 
         def c5_step():
-            r3["r"] = fj.stream_device(field3, shape, seeds3, sub10, xyz_out=xyz_out)
+            field3 = fd.allgather_slabs(f3_loc, counts)                         # the shared 3-peak field over xGMI (48 B / voxel)
+            r3["r"] = fd.stream_sharded(field3, shape, seeds3, sub10, xyz_out=xyz_out5)
         t3 = timed(c5_step, 3, 2) / 3
         tr_ms, tr_n = prof_get(L, "stream_trace")
         pk_ms, pk_n = prof_get(L, "stream_pack")
         sc_ms, sc_n = prof_get(L, "stream_scan")
-        np3 = int(r3["r"]["xyz"].shape[0])
-        extra["stream_dsi_3peaks_10M"] = dict(seeds=int(seeds3.numel()), nsub=10, lines=int(r3["r"]["npts"].numel()), points=np3,
+        cnt3 = torch.tensor([float(r3["r"]["xyz"].shape[0]), float(r3["r"]["npts"].numel())], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(cnt3, op=dist.ReduceOp.SUM)
+        np3, nl3 = int(cnt3[0].item()), int(cnt3[1].item())
+        ksum3 = (tr_ms + pk_ms + sc_ms) / max(tr_n, 1)
+        extra["stream_dsi_3peaks_10M"] = dict(seeds=int(seeds3.numel()), nsub=10, lines=nl3, points=np3,
                                               mpoints_per_s=np3 / t3 / 1e6, ms_per_step=t3 * 1e3,
                                               trace_kernel_ms=tr_ms / max(tr_n, 1), pack_kernel_ms=pk_ms / max(pk_n, 1),
-                                              kernel_sum_ms=(tr_ms + pk_ms + sc_ms) / max(tr_n, 1), algorithmic_bytes=49.0 * np3,
-                                              note="wall = trace + scan + pack into a pre-allocated 15-GB buffer (+ npts / seed_index allocation and one "
-                                                   "host sync for the line count); kernel_sum = device time of the three kernels")
-        del o5, r3, field3
+                                              kernel_sum_ms=ksum3, algorithmic_bytes=49.0 * np3,
+                                              roofline=dict(bound="hbm", achieved=49.0 * (np3 / world) / (ksum3 * 1e-3) / 1e9 if tr_n else 0.0, peak=PEAK_HBM_GBS, unit="GB/s",
+                                                            frac=49.0 * (np3 / world) / (ksum3 * 1e-3) / 1e9 / PEAK_HBM_GBS if tr_n else 0.0,
+                                                            note="49 B per emitted point (SURVEY 8d, nvec = 3) x rank 0's points / device time of trace + scan + pack"),
+                                              note="wall = field all-gather + trace + scan + pack into a pre-allocated buffer (+ npts / seed_index allocation and one "
+                                                   "host sync for the line count); kernel_sum = device time of the three kernels on rank 0; seeds x offsets round-robin")
+        del o5, r3, f3_loc, m3_loc, mout3, seeds3, xyz5
         torch.cuda.empty_cache()
+    if not args.no_extra and rank == 0 and world == 1:
         # ---- the boundary a Julia caller pays for: fib_gqi_rec on host arrays (PCIe both ways, SURVEY §8d "report both") ------------
         try:
             import ctypes as C
@@ -553,18 +584,31 @@ def main():
                 _lib.check(call())
                 ts.append(time.perf_counter() - t0)
             gb = (host.nbytes + odf_h.nbytes + sum(a.nbytes for a in pk_h + qa_h)) / 1e9
+            # the same call into FRESHLY zero-allocated outputs, as a Julia caller makes them (`zeros`, mri.jl:251-255): the first touch
+            # of 3.65 GB of output pages falls inside the call
+            tf = []
+            for _ in range(2):
+                del odf_h, pk_h, qa_h
+                odf_h = np.zeros((nvert, nvox), np.float32)
+                pk_h = [np.zeros((3, nvox), np.float32) for _ in range(3)]
+                qa_h = [np.zeros(nvox, np.float32) for _ in range(3)]
+                t0 = time.perf_counter()
+                _lib.check(call())
+                tf.append(time.perf_counter() - t0)
             extra["gqi_host_tier"] = dict(e2e_pcie_ms=min(ts[1:]) * 1e3, mvoxels_per_s=nvox / min(ts[1:]) / 1e6, link_gbs=gb / min(ts[1:]),
+                                          e2e_pcie_first_touch_ms=min(tf) * 1e3, mvoxels_per_s_first_touch=nvox / min(tf) / 1e6,
                                           bytes_over_link=gb * 1e9,
                                           note="fib_gqi_rec on pageable host arrays (the call a Julia wrapper makes): gather -> pinned ring -> H2D || kernels "
-                                               "|| D2H -> scatter, outputs pre-touched; PCIe Gen5 x16, both directions busy")
+                                               "|| D2H -> scatter; PCIe Gen5 x16, both directions busy.  e2e_pcie_ms: outputs touched before the call; "
+                                               "e2e_pcie_first_touch_ms: outputs freshly zero-allocated (np.zeros = calloc), first touch inside the call")
             del host, odf_h, pk_h, qa_h
         except Exception as e:                                                              # noqa: BLE001
             extra["gqi_host_tier"] = dict(error=str(e))
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline_gqi(bval, bvec, sph, seed=3)
-        if not args.no_extra:
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_gqi(bval, bvec, sph, seed=3, target_s=15.0 if world == 1 else 6.0)    # (N > 1: a shorter sample; the other ranks wait)
+        if not args.no_extra and world == 1:
             b2, g2 = phantom.scheme_dti(60, 4, 1000.0, seed=2)
             b5, g5 = phantom.scheme_dsi()
             extra["cpu_baselines"] = dict(dti_fit=cpu_baseline_dti(b2, g2), dsi_rec=cpu_baseline_dsi(b5, g5, sph), stream=cpu_baseline_stream(),
@@ -583,6 +627,7 @@ def main():
                     roofline=roofline, cpu_baseline=cpu, extra=extra)
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()                                   # (rank 0 may still have been timing the CPU baseline)
         dist.destroy_process_group()
 
 

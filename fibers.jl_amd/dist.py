@@ -39,12 +39,21 @@ def shard_seeds(seeds, world: int, rank: int):
     return seeds[gi], gi
 
 
-def allreduce_odfmax(odfmax, group=None):
+def _torch_stream(stream):
+    """None, a torch.cuda.Stream or a raw hipStream_t handle -> the torch stream object (None: torch's current stream)"""
+    import torch
+    if stream is None or isinstance(stream, torch.cuda.Stream):
+        return stream
+    return torch.cuda.ExternalStream(int(stream))
+
+
+def allreduce_odfmax(odfmax, group=None, always=False):
     """odfmax: tensor [2] = {local max of per-voxel ODF means, nan flag}; in-place MAX over ranks.
-    A NaN anywhere must win (Julia's maximum propagates NaN): the flag is reduced too."""
+    A NaN anywhere must win (Julia's maximum propagates NaN): the flag is reduced too.
+    always: run the collective even in a one-rank group (tests: exercises the RCCL path on a 1-GPU box)."""
     import torch
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or always):
         m = torch.nan_to_num(odfmax[:1], nan=float("-inf"))
         dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
         fl = odfmax[1:2].clone()
@@ -54,14 +63,14 @@ def allreduce_odfmax(odfmax, group=None):
     return odfmax
 
 
-def allgather_slabs(local, counts: Sequence[int], group=None):
+def allgather_slabs(local, counts: Sequence[int], group=None, always=False):
     """local: [counts[rank], ...] slab (voxel-major, e.g. the float4 field [nvox_local, nvec, 4]); returns the
     full volume [sum(counts), ...] on every rank.  Slabs may differ in size (nz % world != 0): with RCCL the
     collective is one padded all_gather (G simultaneous broadcasts over the xGMI links); backends without a device
     all_gather (gloo on CUDA tensors, used by the 1-GPU tests) run the G broadcasts one after the other."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not (dist.is_initialized() and (dist.get_world_size(group) > 1 or always)):
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     counts = [int(c) for c in counts]
@@ -115,9 +124,15 @@ def gather_objects(obj, group=None):
 def odf_rec_sharded(plan, dwi_local, mask_local, group=None, stream=None, out=None):
     """gqi_rec / dsi_rec on this rank's z-slab + the global QA normalisation across ranks (gqi.jl:164-168): the slab's
     {odfmax, NaN flag} pair is all-reduced with MAX, the divisor never leaves the device."""
+    import contextlib
+    import torch
     from .gqi import odf_rec_device, qa_normalize_device
     out = odf_rec_device(plan, dwi_local, mask_local, out=out, normalize=False, stream=stream)
-    allreduce_odfmax(out["odfmax"], group)
+    # the collective runs on the stream the kernels run on: it follows the kernel that writes out["odfmax"] and precedes the
+    # normalisation in stream order, whatever torch's current stream is
+    ts = _torch_stream(stream)
+    with (torch.cuda.stream(ts) if ts is not None else contextlib.nullcontext()):
+        allreduce_odfmax(out["odfmax"], group)
     qa_normalize_device(out["qa"], out["odfmax"], stream=stream)
     return out
 

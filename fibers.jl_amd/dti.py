@@ -159,8 +159,8 @@ def _sync(stream):
         torch.cuda.current_stream().synchronize()
     elif hasattr(stream, "synchronize"):
         stream.synchronize()
-    else:
-        torch.cuda.synchronize()
+    else:                                               # a raw handle: wait for that stream, not for the current device
+        torch.cuda.ExternalStream(int(getattr(stream, "value", stream) or 0)).synchronize()
 
 
 def _chk_dev(t, dtype, what):
