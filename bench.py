@@ -374,7 +374,7 @@ def main():
                                                           note="interp = trilinear: 8 x the field reads per step, same integrator")
                 del rt, field_all
             # ---- divergent termination: the bundle phantom (Voronoi bundles, lines end where bundles meet at > 45 degrees: broad
-            # length distribution), the one-lane-per-line kernel and the persistent-wave refill kernel (FIBERS_STREAM_REFILL=1) ------
+            # length distribution); the share of lane-steps that idle because a wave runs as long as its longest line -----------------
             if world == 1:
                 ovb, mb = phantom.bundle_field_torch(shape, dev)
                 fb, mob = fj.stream_field_device([ovb], mask=mb)
@@ -382,26 +382,24 @@ def main():
                 div = {}
                 for nsub_b in (1, 10):
                     subb = torch.from_numpy(fj.make_sublist(nsub_b, np.random.default_rng(5))).to(dev) if nsub_b > 1 else sub
-                    for refill in ("0", "1"):
-                        os.environ["FIBERS_STREAM_REFILL"] = refill
-                        rb = {}
+                    rb = {}
 
-                        def bstep():
-                            rb["r"] = fj.stream_device(fb, shape, sb, subb, want_all_npts=True, xyz_out=xyz_out)
-                        L.fib_profile_reset()
-                        t_b = timed(bstep, 3, 1) / 3
-                        tb_ms, tb_n = prof_get(L, "stream_trace")
-                        nall = rb["r"]["all_npts"].cpu().numpy().astype(np.int64)
-                        it = nall + 2                                            # loop trips of a lane: its points + the two failed steps
-                        w = np.concatenate([it, np.zeros((-len(it)) % 64, np.int64)]).reshape(-1, 64)
-                        div["nsub%d_%s" % (nsub_b, "refill" if refill == "1" else "lane_per_line")] = dict(
-                            lines=int(len(nall)), points=int(rb["r"]["xyz"].shape[0]), npts_median=float(np.median(nall)), npts_max=int(nall.max()),
-                            static_lane_idle_frac=float(1.0 - it.sum() / (w.max(1).sum() * 64.0)),
-                            trace_kernel_ms=tb_ms / max(tb_n, 1), ms_per_step=t_b * 1e3, mpoints_per_s=int(rb["r"]["xyz"].shape[0]) / t_b / 1e6)
-                        del rb
-                os.environ.pop("FIBERS_STREAM_REFILL", None)
-                div["note"] = ("static_lane_idle_frac: share of lane-steps idle when a wave runs as long as its longest line; the refill kernel "
-                               "is bit-identical and slower (scattered stores, refill latency; DESIGN.md K6)")
+                    def bstep():
+                        rb["r"] = fj.stream_device(fb, shape, sb, subb, want_all_npts=True, xyz_out=xyz_out)
+                    L.fib_profile_reset()
+                    t_b = timed(bstep, 3, 1) / 3
+                    tb_ms, tb_n = prof_get(L, "stream_trace")
+                    nall = rb["r"]["all_npts"].cpu().numpy().astype(np.int64)
+                    it = nall + 2                                            # loop trips of a lane: its points + the two failed steps
+                    w = np.concatenate([it, np.zeros((-len(it)) % 64, np.int64)]).reshape(-1, 64)
+                    div["nsub%d" % nsub_b] = dict(
+                        lines=int(len(nall)), points=int(rb["r"]["xyz"].shape[0]), npts_median=float(np.median(nall)), npts_max=int(nall.max()),
+                        static_lane_idle_frac=float(1.0 - it.sum() / (w.max(1).sum() * 64.0)),
+                        trace_kernel_ms=tb_ms / max(tb_n, 1), ms_per_step=t_b * 1e3, mpoints_per_s=int(rb["r"]["xyz"].shape[0]) / t_b / 1e6)
+                    del rb
+                div["note"] = ("static_lane_idle_frac: share of lane-steps idle when a wave runs as long as its longest line.  Four compaction / refill "
+                               "forms of the tracer were built, bit-identical, and measured slower (profiles/r03/trace_compaction.log, DESIGN.md K6): "
+                               "one lane per line is final")
                 extra["stream_bundle_divergent"] = div
                 del ovb, mb, fb, mob, sb
         del res, r

@@ -353,167 +353,14 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
     if (MODE != 2) { a.npts[li] = npts; a.nfwd[li] = nf; }
 }
 
-// ---- persistent waves that compact themselves (macro scale, angle picking, MODE 0 semantics) -----------------------------------
-// stream_trace_kernel gives every lane one line and a wave runs as long as its longest line; worse, the step loop of a pass is a
-// divergent loop inside the loop over the two passes, so the backward passes of a wave start only when its slowest forward pass
-// has ended.  On a phantom with a broad length distribution 30-53 % of the lane-steps idle (tools/trace_divergence.py).
-// Here the two passes of stream_new_line (stream.jl:645-690) are two launches of ONE flat step loop -- the backward pass needs
-// nothing from the forward pass but its point count and the index of its last vector (the reference carries `ivec_next` over,
-// stream.jl:650), which ride in nfwd[] -- and a wave is persistent and works in rounds:
-//   refill   lanes 0..k-1 resume the k lines the wave set aside in the round before (its stash in LDS: line, counts, position,
-//            direction = 48 B), the other lanes start fresh lines, consecutive ones from the wave's own chunk of the global line
-//            queue (ONE global atomic per 512 lines: a single queue word serves ~88 atomics / us, and a first form of this
-//            kernel with one atomic per hand-over took three times as long as the kernel it was to replace);
-//   trace    the step loop of stream_trace_kernel, same arithmetic, same slot-major tile stores; at the top of every step the
-//            lanes still stepping count themselves (the exec mask), and when fewer than `thresh` are left while fresh lines
-//            remain, they stash their lines and the wave refills.
-// So a wave runs at least `thresh` lanes wide until the queue is empty, after which its lines run to their end.  Fresh lines are
-// handed out in ascending order: the 16 lines of a scratch tile are traced by neighbouring lanes at about the same time and the
-// tile layout (and the pack kernel) stays as it is.  Results are bit-identical to stream_trace_kernel's.
-constexpr int CQ_CHUNK = 512;                // lines a wave draws from the global queue at a time
-constexpr int SEG_WORDS = 12;                // stash entry: {line, ivec, npts, nf, pos xyz, vec xyz, -, -}
-template <int NVEC, int PASS>
-__global__ __launch_bounds__(256) void stream_trace_compact_kernel(const TraceArgs a, unsigned *queue, int thresh, int chunk) {
-    __shared__ __attribute__((aligned(16))) uint32_t stash[4][64][SEG_WORDS];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nvec = NVEC > 0 ? NVEC : a.nvec;
-    constexpr int64_t slot_floats = SCR_TILE * 3;
-    const char *fbase = reinterpret_cast<const char *>(a.field);
-    const float fnx = (float)a.nx, fny = (float)a.ny, fnz = (float)a.nz;
-    const float omc = 1.0f - a.smooth;
-    const unsigned nlines = (unsigned)a.nlines;                   // < 2^31 (checked by the launch code)
-    unsigned cn = 0, ce = 0;                                      // the wave's chunk of fresh lines [cn, ce)   (wave-uniform)
-    bool drained = false;                                         // the global queue is exhausted            (wave-uniform)
-    if (chunk == 0) {                                             // static partition: wave w owns one contiguous range of whole tiles
-        const unsigned gw = blockIdx.x * 4 + wv, nw = gridDim.x * 4;
-        const unsigned per = ((nlines + nw - 1) / nw + SCR_TILE - 1) / SCR_TILE * SCR_TILE;
-        const unsigned long long lo = (unsigned long long)gw * per, hi = lo + per;
-        cn = lo < nlines ? (unsigned)lo : nlines; ce = hi < nlines ? (unsigned)hi : nlines;
-        drained = true;
-    }
-    int nst = 0;                                                  // lines in the wave's stash                (wave-uniform)
-    for (;;) {
-        // ---- refill ---------------------------------------------------------------------------------------------------------
-        const int need = 64 - nst;
-        const unsigned avail = ce - cn;
-        unsigned c2 = 0, e2 = 0;
-        if (avail < (unsigned)need && !drained) {
-            unsigned b = 0;
-            if (lane == 0) b = atomicAdd(queue, (unsigned)chunk);
-            b = __builtin_amdgcn_readfirstlane(b);
-            if (b >= nlines) drained = true;
-            else { c2 = b; e2 = b + chunk < nlines ? b + chunk : nlines; }
-        }
-        int64_t li = -1;
-        int ivec = 0, npts = 0, nf = 0;
-        float px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
-        if (lane < nst) {
-            const uint4 *rec = reinterpret_cast<const uint4 *>(&stash[wv][lane][0]);
-            const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-            li = q0.x; ivec = (int)q0.y; npts = (int)q0.z; nf = (int)q0.w;
-            px = __uint_as_float(q1.x); py = __uint_as_float(q1.y); pz = __uint_as_float(q1.z); vx = __uint_as_float(q1.w);
-            vy = __uint_as_float(q2.x); vz = __uint_as_float(q2.y);
-        } else {
-            const unsigned f = (unsigned)(lane - nst);
-            if (f < avail) li = cn + f;
-            else if (f - avail < e2 - c2) li = c2 + (f - avail);
-            if (li >= 0) {                                        // a fresh line: stream_new_line, stream.jl:645-650
-                const int64_t line = a.line0 + li;
-                const int64_t iseed = line / a.nsub;
-                const int isub = (int)(line - iseed * a.nsub);
-                const int64_t lin = a.seeds[iseed];
-                const int sx = (int)(lin % a.nx), sy = (int)((lin / a.nx) % a.ny), sz = (int)(lin / ((int64_t)a.nx * a.ny));
-                px = (float)(sx + 1) + a.sublist[3 * isub];       // pos_now .= seed_vox .+ sub_vox, stream.jl:649
-                py = (float)(sy + 1) + a.sublist[3 * isub + 1];
-                pz = (float)(sz + 1) + a.sublist[3 * isub + 2];
-                if (PASS == 1) { const uint32_t w = (uint32_t)a.nfwd[li]; nf = (int)(w & 0xffffffu); ivec = (int)(w >> 24); npts = nf; }
-                const float4 s = a.field[lin * nvec + ivec];      // view(W.ovecs, :, ivec_next, seed...), stream.jl:650
-                const float fwd = PASS == 0 ? 1.0f : -1.0f;
-                vx = s.x * fwd; vy = s.y * fwd; vz = s.z * fwd;
-            }
-        }
-        if ((unsigned)need <= avail) cn += (unsigned)need;
-        else { const unsigned u2 = (unsigned)need - avail < e2 - c2 ? (unsigned)need - avail : e2 - c2; cn = c2 + u2; ce = e2; }
-        const bool more = cn < ce || !drained;                    // fresh lines are left: a thin wave sets its lines aside and refills
-        if (!__any(li >= 0)) break;
-        // ---- trace: the step loop of stream_trace_kernel ----------------------------------------------------------------------------
-        nst = 0;
-        if (li >= 0) {
-            float *d = a.scratch + (li / SCR_TILE) * ((int64_t)2 * a.stride * slot_floats) + (li % SCR_TILE) * 3 +
-                       (int64_t)(PASS == 0 ? nf : a.stride + npts - nf) * slot_floats;     // the line's next slot of this pass
-            bool stashed = false;
-            for (;;) {
-                if (more) {                                       // the lanes that are stepping right now
-                    const unsigned long long live = __ballot(1);
-                    if (__popcll(live) < thresh) {
-                        const int rank = __popcll(live & ((1ull << lane) - 1ull));
-                        uint4 *rec = reinterpret_cast<uint4 *>(&stash[wv][rank][0]);
-                        rec[0] = make_uint4((uint32_t)li, (uint32_t)ivec, (uint32_t)npts, (uint32_t)nf);
-                        rec[1] = make_uint4(__float_as_uint(px), __float_as_uint(py), __float_as_uint(pz), __float_as_uint(vx));
-                        rec[2] = make_uint4(__float_as_uint(vy), __float_as_uint(vz), 0u, 0u);
-                        nst = __popcll(live);
-                        stashed = true;
-                        break;
-                    }
-                }
-                const float nxp = px + vx * a.step, nyp = py + vy * a.step, nzp = pz + vz * a.step;   // stream.jl:512
-                const float rx = rintf(nxp), ry = rintf(nyp), rz = rintf(nzp);                        // stream.jl:514
-                if (!(rx >= 1.0f && rx <= fnx && ry >= 1.0f && ry <= fny && rz >= 1.0f && rz <= fnz)) break;   // :517
-                const uint32_t vox = (uint32_t)(((int)rx - 1) + a.nx * (((int)ry - 1) + a.ny * ((int)rz - 1)));
-                const float4 *cand = reinterpret_cast<const float4 *>(fbase + (size_t)(vox * (uint32_t)(nvec * 16)));
-                float bx = 0.0f, by = 0.0f, bz = 0.0f, bestc = 0.0f, besta = 0.0f;
-                int best = 0;
-#pragma unroll
-                for (int k = 0; k < nvec; k++) {                  // stream_pick_by_angle!, stream.jl:350-361
-                    const float4 w = cand[k];
-                    float c, ca;
-                    if (w.x == 0.0f && w.y == 0.0f && w.z == 0.0f) { c = -INFINITY; ca = -INFINITY; }
-                    else { c = dot3(vx, vy, vz, w.x, w.y, w.z); ca = fabsf(c); }
-                    if (k == 0 || (!(besta != besta) && ((ca != ca) || ca > besta))) {
-                        best = k; besta = ca; bestc = c; bx = w.x; by = w.y; bz = w.z;
-                    }
-                }
-                if (!(fabsf(bestc) < INFINITY)) break;            // stream.jl:363
-                float wx, wy, wz;
-                if (bestc > 0.0f) { wx = bx; wy = by; wz = bz; } else { wx = -bx; wy = -by; wz = -bz; }   // :365-369
-                ivec = best;                                      // stream.jl:371
-                d[0] = px; d[1] = py; d[2] = pz;                  // push!/prepend! of pos_now (stream.jl:660)
-                d += slot_floats;
-                npts++;
-                if (PASS == 0) nf++;
-                if (dot3(vx, vy, vz, wx, wy, wz) < a.cosang) break;   // stream.jl:670
-                if (npts > a.len_max) break;                      // stream.jl:674
-                if (a.smooth != 0.0f) {                           // stream.jl:677-681
-                    wx = a.smooth * vx + omc * wx;
-                    wy = a.smooth * vy + omc * wy;
-                    wz = a.smooth * vz + omc * wz;
-                    const float m = fmaxf(fabsf(wx), fmaxf(fabsf(wy), fabsf(wz)));
-                    float n;
-                    if (m == 0.0f || !(m < INFINITY)) n = m;
-                    else {
-                        double acc = (double)(wx * wx);
-                        acc += (double)(wy * wy);
-                        acc += (double)(wz * wz);
-                        n = (float)sqrt(acc);
-                    }
-                    wx = wx / n; wy = wy / n; wz = wz / n;
-                }
-                px = nxp; py = nyp; pz = nzp;                     // stream.jl:684-685
-                vx = wx; vy = wy; vz = wz;
-            }
-            if (!stashed) {
-                if (PASS == 0) a.nfwd[li] = (int32_t)((uint32_t)nf | ((uint32_t)ivec << 24));   // (the backward pass starts from this vector)
-                else { a.npts[li] = npts; a.nfwd[li] = nf; }
-            }
-        }
-        {                                                         // the stashing lanes know how many they are: make it wave-uniform
-            const unsigned long long sm = __ballot(nst > 0);
-            const int src = sm ? __ffsll((long long)sm) - 1 : 0;
-            nst = __builtin_amdgcn_readfirstlane(__shfl(nst, src));
-        }
-    }
-}
-
+// Divergent termination (lines of a wave end at different steps: 30-53 % of the lane-steps idle on a phantom with a broad length
+// distribution, 8 % on the benchmark field).  Four remedies were built, each bit-identical to this kernel, and each measured slower
+// on every workload (tools/trace_divergence.py; profiles/r03/trace_compaction.log): a per-lane state machine over one
+// flat step loop that refills finished lanes from a queue (round 2, two forms); rounds of launches with the surviving lines
+// compacted into a dense list in between (one returning atomic per hand-over on one word: ~88 / us); persistent waves that stash
+// their surviving lines in LDS and refill from their own share of the lines, with the two passes as two launches of a flat loop
+// (static shares: tail imbalance; a chunked global queue: the atomic rate again).  One lane per line is final; the source of the
+// others is in the repository's history.
 // ---- microscopy regime: stream_micro_new_point! (stream.jl:547-619) -------------------------------------------
 // The next point is the voxel, among those within search_dist voxels of the tentative position and inside a cone of
 // search_ang around the current direction, whose first orientation vector is best aligned with the current direction
@@ -1191,28 +1038,6 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
         job->ta = ta;
     } else
     { fib::ProfScope prof("stream_trace", st);
-    // persistent waves that compact themselves (stream_trace_compact_kernel); FIBERS_STREAM_COMPACT=0: one lane per line
-    int cthresh = 40;
-    { const char *rf = getenv("FIBERS_STREAM_COMPACT"); if (rf) cthresh = atoi(rf); }
-    if (cthresh > 0 && nl < ((int64_t)1 << 31) - 2 * CQ_CHUNK) {
-        int ncu = 256;
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
-        const unsigned pg = (unsigned)std::min<int64_t>((int64_t)ncu * 8, fib::cdiv(nl, 256));
-        unsigned *queue = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(job->total.p) + 64);
-        hipError_t eq = hipMemsetAsync(queue, 0, sizeof(unsigned), st);
-        if (eq != hipSuccess) return bail(fib::fail(FIB_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(eq)));
-        cthresh = std::min(cthresh, 64);
-        int cchunk = CQ_CHUNK;
-        if (const char *e = getenv("FIBERS_STREAM_CHUNK")) cchunk = atoi(e) > 0 ? std::max(64, atoi(e)) : 0;
-        if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_compact_kernel<1, 0>), dim3(pg), dim3(256), 0, st, ta, queue, cthresh, cchunk);
-        else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_compact_kernel<3, 0>), dim3(pg), dim3(256), 0, st, ta, queue, cthresh, cchunk);
-        else                     hipLaunchKernelGGL((stream_trace_compact_kernel<0, 0>), dim3(pg), dim3(256), 0, st, ta, queue, cthresh, cchunk);
-        eq = hipMemsetAsync(queue, 0, sizeof(unsigned), st);        // the backward passes (stream.jl:645-690 with dir = -1): the same queue again
-        if (eq != hipSuccess) return bail(fib::fail(FIB_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(eq)));
-        if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_compact_kernel<1, 1>), dim3(pg), dim3(256), 0, st, ta, queue, cthresh, cchunk);
-        else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_compact_kernel<3, 1>), dim3(pg), dim3(256), 0, st, ta, queue, cthresh, cchunk);
-        else                     hipLaunchKernelGGL((stream_trace_compact_kernel<0, 1>), dim3(pg), dim3(256), 0, st, ta, queue, cthresh, cchunk);
-    } else
     if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1>), dim3(grid), dim3(256), 0, st, ta);
     else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3>), dim3(grid), dim3(256), 0, st, ta);
     else                     hipLaunchKernelGGL((stream_trace_kernel<0>), dim3(grid), dim3(256), 0, st, ta);

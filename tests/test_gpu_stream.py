@@ -281,32 +281,6 @@ def test_stream_randomised_configurations_exact(fj, orc, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nvec", [1, 3])
-def test_persistent_refill_tracer_is_bit_identical(fj, monkeypatch, nvec):
-    """FIBERS_STREAM_REFILL=1: persistent waves whose finished lanes draw new lines from a queue (ballot + prefix rank) on a
-    phantom with a broad length distribution; same lines, same points, same order as the one-lane-per-line kernel"""
-    import torch
-    from fibers_jl_amd import phantom
-    dev = torch.device("cuda", 0)
-    shape = (40, 36, 30)
-    ov, m = phantom.bundle_field_torch(shape, dev, seed=3, cell=7.0)
-    ovs = [ov]
-    for k in range(1, nvec):
-        o2, _ = phantom.bundle_field_torch(shape, dev, seed=3 + k, cell=9.0)
-        ovs.append(o2)
-    field, mout = fj.stream_field_device(ovs, mask=m)
-    seeds = torch.nonzero(mout).flatten()
-    sub = torch.from_numpy(fj.make_sublist(3, np.random.default_rng(1))).to(dev)
-    res = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("FIBERS_STREAM_REFILL", mode)
-        res[mode] = fj.stream_device(field, shape, seeds, sub, want_all_npts=True, len_min=2)
-    a, b = res["0"], res["1"]
-    assert a["npts"].numel() > 1000 and int(a["npts"].max()) > 2 * int(a["npts"].float().median())   # a broad length distribution
-    for k in ("npts", "seed_index", "xyz", "all_npts"):
-        assert torch.equal(a[k], b[k]), k
-
-
 @pytest.mark.parametrize("nvec,smooth", [(1, 0.2), (2, 0.2), (2, 0.0)])
 def test_trilinear_option_follows_its_definition(fj, orc, nvec, smooth):
     """fib_stream_params.interp = 1 (north_star's trilinear option; NOT in the reference): every line equals the NumPy Float32

@@ -62,8 +62,10 @@ def run(label, ovec, mask, nsub):
     os.environ.pop("FIBERS_STREAM_COMPACT", None)
 
 
-# 0 = stream_trace_kernel (one lane per line); n > 0 = stream_trace_compact_kernel with hand-over threshold n
-CONFIGS = [0] + [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "24,32,40,48,56").split(",")]
+# 0 = stream_trace_kernel (one lane per line).  The compacting / refilling kernels this tool compared it with (hand-over threshold
+# n > 0 through FIBERS_STREAM_COMPACT) were removed after they lost on every workload: profiles/r03/trace_compaction.log holds
+# this tool's output for them, the repository's history their source.
+CONFIGS = [0]
 axes = torch.from_numpy(np.ascontiguousarray(np.moveaxis(phantom.fibre_field(*SHAPE).astype(np.float32), -1, 0).reshape(3, -1, order="F"))).to(dev)
 run("smooth", axes, phantom.ball_mask_torch(SHAPE, dev), 1)
 ov, m = phantom.bundle_field_torch(SHAPE, dev)
