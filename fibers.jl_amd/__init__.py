@@ -8,7 +8,7 @@ from ._lib import DEVICE_ALL, FibersError, LIB_PATH, init, lib, shutdown  # noqa
 from .mri import MRI  # noqa: F401
 from .odf import ODF, sphere_362, sphere_642, sphere_724  # noqa: F401
 from .dti import DTI, DtiPlan, adc_fit, adc_fit_device, dti_fit, dti_fit_device  # noqa: F401
-from .gqi import (DSI, GQI, OdfPlan, dsi_rec, find_peaks, find_peaks_device, gqi_rec, odf_rec_device,  # noqa: F401
+from .gqi import (DSI, GQI, OdfPlan, dsi_rec, find_peaks, find_peaks_device, find_peaks_work, gqi_rec, odf_rec_device,  # noqa: F401
                   qa_normalize_device)
 from .rumba import RUMBASD, RumbaPlan, rumba_rec, rumba_rec_device  # noqa: F401
 from .structens import st_eigen, st_eigen_device  # noqa: F401

@@ -94,6 +94,8 @@ _PROTOS = {
     "fib_rumba_rec": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, f32, f32, f32, f32, i32, i32, i32,
                             i32, C.POINTER(RumbaOut), C.POINTER(f32), C.POINTER(f32)]),
     "fib_find_peaks": (i32, [i32, vp, i64, vp, i32, vp, i32, vp, vp]),
+    "fib_find_peaks_work": (i32, [i32, vp, i64, vp, i32, vp, i32, vp, vp, vp]),
+    "fibd_find_peaks_work": (i32, [vp, vp, i64, vp, vp, vp, vp]),
     "fib_stream": (i32, [i32, C.POINTER(StreamParams), vp, vp, f32, vp, f32, vp, i32, vp, i32, vp, i32,
                          C.POINTER(TractOut)]),
     "fib_stream_lcm": (i32, [i32, C.POINTER(StreamParams), vp, vp, f32, vp, f32, vp, i32, vp, i32, vp, i32,

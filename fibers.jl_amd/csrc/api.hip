@@ -152,7 +152,7 @@ struct DevState {
     hipStream_t s_in = nullptr, s_cmp = nullptr, s_out = nullptr;
     hipEvent_t e_in[NBUF] = {}, e_cmp[NBUF] = {}, e_out[NBUF] = {};
     PinBuf pin_in[NBUF], pin_out[NBUF];
-    fib::DevBuf<char> dev_in[NBUF], dev_out[NBUF], dev_keep;
+    fib::DevBuf<char> dev_in[NBUF], dev_out[NBUF];
     std::unique_ptr<CopyPool> pool;
     std::vector<CachedPlan> plans;
     uint64_t clock = 0;
@@ -191,12 +191,16 @@ struct DevState {
 
 // The device set of the host tier (fib_init).  Entry i is an independent worker: the same device may appear twice (two
 // concurrent pipelines on one GPU; used by the tests on a 1-GPU box).
+// Workers are handed out as shared pointers: a call that fib_init / fib_shutdown overtakes keeps its workers alive until it returns.
+using Worker = std::shared_ptr<DevState>;
 struct HostCtx {
     std::mutex mu;
-    std::vector<std::unique_ptr<DevState>> devs;         // the set for device == FIB_DEVICE_ALL
-    std::vector<std::unique_ptr<DevState>> single;       // workers for calls that name one device
+    std::vector<Worker> devs;                            // the set for device == FIB_DEVICE_ALL
+    std::vector<Worker> single;                          // workers for calls that name one device
 };
-HostCtx &ctx() { static HostCtx c; return c; }
+// Never destroyed: at process exit the HIP runtime's own exit handlers may already have run, and destroying streams, events and
+// device buffers then crashes or hangs.  Only fib_shutdown releases resources.
+HostCtx &ctx() { static HostCtx *c = new HostCtx(); return *c; }
 
 int copy_threads(int nworkers) {
     unsigned hw = std::thread::hardware_concurrency();
@@ -207,7 +211,7 @@ int copy_threads(int nworkers) {
 }
 
 // workers of a call: the fib_init set for FIB_DEVICE_ALL, else the (lazily created) worker of that device
-int workers_for(int device, std::vector<DevState *> &out) {
+int workers_for(int device, std::vector<Worker> &out) {
     HostCtx &c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
     if (device == FIB_DEVICE_ALL) {
@@ -216,14 +220,14 @@ int workers_for(int device, std::vector<DevState *> &out) {
             if (n <= 0) return fib::fail(FIB_ERR_NO_DEVICE, "no HIP device is available and this back end has no CPU fallback");
             for (int d = 0; d < n; d++) { c.devs.emplace_back(new DevState()); c.devs.back()->device = d; }
         }
-        for (auto &d : c.devs) out.push_back(d.get());
+        for (auto &d : c.devs) out.push_back(d);
         return FIB_OK;
     }
     RC(fib::use_device(device));
-    for (auto &d : c.single) if (d->device == device) { out.push_back(d.get()); return FIB_OK; }
+    for (auto &d : c.single) if (d->device == device) { out.push_back(d); return FIB_OK; }
     c.single.emplace_back(new DevState());
     c.single.back()->device = device;
-    out.push_back(c.single.back().get());
+    out.push_back(c.single.back());
     return FIB_OK;
 }
 
@@ -336,7 +340,7 @@ void slab(int64_t nvox, int n, int i, int64_t &v0, int64_t &v1) {
 }
 
 // runs job(worker index, worker) on every worker of the set, one host thread each; the first error wins
-int for_each_worker(const std::vector<DevState *> &ws, const std::function<int(int, DevState &)> &job) {
+int for_each_worker(const std::vector<Worker> &ws, const std::function<int(int, DevState &)> &job) {
     std::vector<int> rcs(ws.size(), FIB_OK);
     std::vector<std::string> msgs(ws.size());
     auto body = [&](int i) {
@@ -384,6 +388,8 @@ extern "C" void fib_shutdown(void) try {
     HostCtx &c = ctx();
     std::lock_guard<std::mutex> lk(c.mu);
     fib::DeviceGuard guard;
+    for (auto &d : c.devs) { std::lock_guard<std::mutex> lk2(d->mu); }     // wait for calls in flight (a call that has its workers but
+    for (auto &d : c.single) { std::lock_guard<std::mutex> lk2(d->mu); }   // not yet their locks keeps them alive through its shared pointers)
     c.devs.clear();
     c.single.clear();
 } FIB_API_CATCH_VOID
@@ -414,7 +420,7 @@ extern "C" int fib_dti_fit(int device, const float *dwi, int nx, int ny, int nz,
     FIB_CHECK(out->s0 && out->eigval1 && out->eigval2 && out->eigval3 && out->eigvec1 && out->eigvec2 && out->eigvec3 && out->rd && out->md && out->fa,
               FIB_ERR_INVALID, "NULL output volume");
     const int64_t nvox = (int64_t)nx * ny * nz;
-    std::vector<DevState *> ws;
+    std::vector<Worker> ws;
     RC(workers_for(device, ws));
     const std::vector<Rows> ins = {{dwi, nullptr, nvol}};
     const std::vector<Rows> outs = {{nullptr, out->s0, 1}, {nullptr, out->eigval1, 1}, {nullptr, out->eigval2, 1}, {nullptr, out->eigval3, 1},
@@ -440,7 +446,7 @@ extern "C" int fib_adc_fit(int device, const float *dwi, int nx, int ny, int nz,
     FIB_CHECK(nx > 0 && ny > 0 && nz > 0, FIB_ERR_INVALID, "volume dimensions must be positive");
     FIB_CHECK(dtype_size(mask_dtype) > 0, FIB_ERR_INVALID, "unknown mask dtype %d", mask_dtype);
     const int64_t nvox = (int64_t)nx * ny * nz;
-    std::vector<DevState *> ws;
+    std::vector<Worker> ws;
     RC(workers_for(device, ws));
     const std::vector<Rows> ins = {{dwi, nullptr, nvol}};
     const std::vector<Rows> outs = {{nullptr, adc, 1}, {nullptr, s0, 1}};
@@ -513,7 +519,7 @@ int odf_rec_host(int device, const OdfSpec &spec, const float *dwi, int nx, int 
     for (int k = 0; k < 3; k++) FIB_CHECK(peak[k] && qa[k], FIB_ERR_INVALID, "NULL peak/qa output volume");
     const int64_t nvox = (int64_t)nx * ny * nz;
     const int nvol = spec.nvol, nvert = spec.nverts / 2;
-    std::vector<DevState *> ws;
+    std::vector<Worker> ws;
     RC(workers_for(device, ws));
     const int nw = (int)ws.size();
     const std::vector<Rows> ins = {{dwi, nullptr, nvol}};
@@ -523,7 +529,9 @@ int odf_rec_host(int device, const OdfSpec &spec, const float *dwi, int nx, int 
     for (int k = 0; k < 3; k++) outs.push_back({nullptr, peak[k], 3});
     const int rows_out = (pdf ? nvol : 0) + nvert + 9;
     // per worker: qa of its slab stays on the device until the global odfmax is known; one {max, NaN flag} pair per chunk
-    struct Slab { int64_t v0 = 0, v1 = 0; float *qa = nullptr; std::vector<float> maxes; };
+    // (the buffer belongs to the CALL, not to the worker: the worker's lock is released between the two passes below, and another
+    // thread's call on the same worker must not find -- or reallocate -- this call's qa)
+    struct Slab { int64_t v0 = 0, v1 = 0; float *qa = nullptr; std::vector<float> maxes; fib::DevBuf<float> keep; };
     std::vector<Slab> slabs((size_t)nw);
     RC(for_each_worker(ws, [&](int i, DevState &d) -> int {
         Slab &sl = slabs[i];
@@ -534,15 +542,17 @@ int odf_rec_host(int device, const OdfSpec &spec, const float *dwi, int nx, int 
         RC(odf_plan_for(d, spec, &plan));
         const int64_t chunk = pick_chunk(nr, nvol, rows_out);
         const int nchunks = (int)fib::cdiv(nr, chunk);
-        RC(d.dev_keep.ensure(((size_t)3 * nr + (size_t)2 * nchunks) * sizeof(float)));
-        sl.qa = reinterpret_cast<float *>(d.dev_keep.p);
+        FIB_HIP(hipSetDevice(d.device));
+        RC(sl.keep.alloc((size_t)3 * nr + (size_t)2 * nchunks));
+        sl.qa = sl.keep.p;
         float *dmax = sl.qa + 3 * nr;
         RC(run_chunks(d, sl.v0, sl.v1, nvox, ins, mask, mask_dtype, outs, chunk,
                       [&](int k, int64_t v0, int64_t n, const float *din, const uint8_t *dm, float *b, hipStream_t st) -> int {
                           float *dpdf = pdf ? b : nullptr, *dodf = b + (size_t)(pdf ? nvol : 0) * n, *dpk = dodf + (size_t)nvert * n;
                           float *pk[3] = {dpk, dpk + 3 * n, dpk + 6 * n};
                           float *q[3] = {sl.qa + (v0 - sl.v0), sl.qa + nr + (v0 - sl.v0), sl.qa + 2 * nr + (v0 - sl.v0)};
-                          return fibd_odf_rec(plan, din, dm, n, dpdf, dodf, pk, q, dmax + 2 * k, 0, st);
+                          // (one volume in pieces: the same peak-finder form for every piece, whatever the cut -- see FIB_ODF_SEPARATE_PEAKS)
+                          return fibd_odf_rec(plan, din, dm, n, dpdf, dodf, pk, q, dmax + 2 * k, nvox % 4 != 0 ? FIB_ODF_SEPARATE_PEAKS : 0, st);
                       }));
         sl.maxes.resize((size_t)2 * nchunks);
         FIB_HIP(hipMemcpy(sl.maxes.data(), dmax, sl.maxes.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -652,6 +662,29 @@ extern "C" int fib_find_peaks(int device, const float *odf, int64_t nvox, const 
     RC(fibd_find_peaks(p, d_odf.p, nvox, d_top.p, d_nv.p, nullptr));
     FIB_HIP(hipDeviceSynchronize());
     FIB_HIP(hipMemcpy(isort_top, d_top.p, (size_t)nvox * 3 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    FIB_HIP(hipMemcpy(nvalid, d_nv.p, (size_t)nvox * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return FIB_OK;
+} FIB_API_CATCH
+
+extern "C" int fib_find_peaks_work(int device, const float *odf, int64_t nvox, const float *verts, int nverts,
+                                   const int32_t *faces, int nfaces, float *odf_peak, int32_t *isort, int32_t *nvalid) try {
+    FIB_CHECK(odf && verts && faces && odf_peak && isort && nvalid, FIB_ERR_INVALID, "NULL argument");
+    FIB_CHECK(nvox > 0 && nverts >= 2 && nverts % 2 == 0 && nfaces > 0, FIB_ERR_INVALID, "invalid sizes");
+    fib::DeviceGuard guard;
+    const float bval1[1] = {1000.0f}, bvec1[3] = {1.0f, 0.0f, 0.0f};      // (the plan only contributes the folded neighbour table)
+    fib_odf_plan *p = nullptr;
+    RC(fib_gqi_plan_create(device, bval1, bvec1, 1, verts, nverts, faces, nfaces, 1.25f, &p));
+    struct PlanDel { fib_odf_plan *p; ~PlanDel() { fib_odf_plan_destroy(p); } } del{p};
+    FIB_HIP(hipSetDevice(device));
+    const size_t n = (size_t)nvox * (nverts / 2);
+    fib::DevBuf<float> d_odf, d_pk;
+    fib::DevBuf<int32_t> d_is, d_nv;
+    RC(d_odf.alloc(n)); RC(d_pk.alloc(n)); RC(d_is.alloc(n)); RC(d_nv.alloc((size_t)nvox));
+    FIB_HIP(hipMemcpy(d_odf.p, odf, n * sizeof(float), hipMemcpyHostToDevice));
+    RC(fibd_find_peaks_work(p, d_odf.p, nvox, d_pk.p, d_is.p, d_nv.p, nullptr));
+    FIB_HIP(hipDeviceSynchronize());
+    FIB_HIP(hipMemcpy(odf_peak, d_pk.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    FIB_HIP(hipMemcpy(isort, d_is.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     FIB_HIP(hipMemcpy(nvalid, d_nv.p, (size_t)nvox * sizeof(int32_t), hipMemcpyDeviceToHost));
     return FIB_OK;
 } FIB_API_CATCH
@@ -769,7 +802,7 @@ int stream_host(int device, const fib_stream_params *prm, const float *const *ov
         FIB_CHECK(ovec[k] != nullptr, FIB_ERR_INVALID, "NULL orientation volume %d", k);
         if (f) FIB_CHECK(f[k] != nullptr, FIB_ERR_INVALID, "NULL amplitude volume %d", k);
     }
-    std::vector<DevState *> ws;
+    std::vector<Worker> ws;
     RC(workers_for(device, ws));
     if (lcms && ws.size() > 1) ws.resize(1);             // (see stream_worker)
     StreamIn in{prm, ovec, f, f_thresh, fa, fa_thresh, sublist, nsub, lcms, lcm_thresh, rng_seed, 0, 1};

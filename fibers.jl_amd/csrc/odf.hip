@@ -1986,6 +1986,44 @@ __global__ __launch_bounds__(256) void qa_normalize_kernel(float *q0, float *q1,
     }
 }
 
+// find_peaks!(W) with ALL of its outputs (gqi.jl:180-201), one workgroup per voxel: odf_peak = the amplitudes of the local peaks, 0
+// elsewhere (:184-196); isort = sortperm(odf_peak, rev=true), the complete permutation (:198; descending by isless, equal
+// values in ascending index order: the rank of vertex v = the number of keys above its key, peak_key); nvalid = count(. > 0)
+// (:200).  Not a hot path (gqi_rec / dsi_rec need the first three entries only and take them from the fused scan or the tile
+// kernels): it exists so that the reference's function has a complete counterpart behind the C ABI.
+__global__ __launch_bounds__(256) void odf_peaks_work_kernel(const float *__restrict__ odf, int64_t stride, int64_t nvox, int nvert, int deg,
+                                                             const int32_t *__restrict__ nbr64, float *__restrict__ odf_peak,
+                                                             int32_t *__restrict__ isort, int32_t *__restrict__ nvalid) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long pk_keys[];   // [nvert] keys, then [nvert + 1] amplitudes
+    float *o = reinterpret_cast<float *>(pk_keys + nvert);
+    __shared__ int cnt;
+    for (int64_t vox = blockIdx.x; vox < nvox; vox += gridDim.x) {
+        __syncthreads();
+        for (int v = threadIdx.x; v < nvert; v += blockDim.x) o[v] = odf[(int64_t)v * stride + vox];
+        if (threadIdx.x == 0) { o[nvert] = __builtin_nanf(""); cnt = 0; }           // unused neighbour slots: `NaN >= x` is false
+        __syncthreads();
+        int mine = 0;
+        for (int v = threadIdx.x; v < nvert; v += blockDim.x) {
+            const float x = o[v];
+            bool killed = false;
+            for (int d = 0; d < deg; d++) killed |= o[nbr64[(size_t)v * deg + d]] >= x;   // gqi.jl:185-196
+            const float pk = killed ? 0.0f : x;
+            odf_peak[(int64_t)v * stride + vox] = pk;
+            pk_keys[v] = peak_key(pk, v);
+            mine += pk > 0.0f;
+        }
+        if (mine) atomicAdd(&cnt, mine);
+        __syncthreads();
+        for (int v = threadIdx.x; v < nvert; v += blockDim.x) {
+            const unsigned long long k = pk_keys[v];
+            int rank = 0;
+            for (int u = 0; u < nvert; u++) rank += pk_keys[u] > k;
+            isort[(int64_t)rank * stride + vox] = v;
+        }
+        if (threadIdx.x == 0) nvalid[vox] = cnt;
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -2469,7 +2507,8 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         ga.fix_count = plan->live_counts.p + 2; ga.fix_list = plan->inf_list.p; ga.fix_cap = (int)std::min<int64_t>(nvox, INT32_MAX);
     }
     // sphere_642 GQI plans: find_peaks! runs on the contraction kernel's accumulators (gemm3_epilogue_fused)
-    const bool fuse = plan->fused && ga.At3 != nullptr && ga.vec_ok && !getenv("FIBERS_ODF_UNFUSED");
+    const bool sep = (flags & FIB_ODF_SEPARATE_PEAKS) != 0 || getenv("FIBERS_ODF_UNFUSED") != nullptr;
+    const bool fuse = plan->fused && ga.At3 != nullptr && ga.vec_ok && !sep;
     {
         int rcm = plan->mean_hi.ensure((size_t)nvox);
         if (rcm != FIB_OK) return rcm;
@@ -2490,7 +2529,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
                          (int64_t)plan->fold_span_max * nvox * 4 < (int64_t)0xE0000000ll && !getenv("FIBERS_DSI_UNFUSED");
     const bool fuse_fold = fold_ok && plan->MB <= FOLD_MB_MAX;
     // folded DSI on sphere_642: one launch of odf_dsi2_kernel does contraction, scale, ODF / pdf rows and find_peaks!
-    const bool dsi2 = plan->dsi2 && fold_ok && ga.vec_ok;
+    const bool dsi2 = plan->dsi2 && fold_ok && ga.vec_ok && !sep;
     if (dsi2) {
         int rcf = setup_fused();
         if (rcf != FIB_OK) return rcf;
@@ -2682,3 +2721,18 @@ extern "C" int fib_debug_clock_clear(void) try {
     return FIB_OK;
 } FIB_API_CATCH
 #endif
+
+extern "C" int fibd_find_peaks_work(const fib_odf_plan *plan, const float *odf, int64_t nvox,
+                                    float *odf_peak, int32_t *isort, int32_t *nvalid, void *stream) try {
+    FIB_CHECK(plan && odf && odf_peak && isort && nvalid && nvox > 0, FIB_ERR_INVALID, "NULL argument");
+    FIB_CHECK(plan->nbr64.p != nullptr && plan->maxdeg > 0, FIB_ERR_INVALID, "the plan has no tessellation");
+    fib::DeviceGuard guard;
+    FIB_HIP(hipSetDevice(plan->device));
+    const size_t smem = (size_t)plan->nvert * sizeof(unsigned long long) + (size_t)(plan->nvert + 1) * sizeof(float);
+    FIB_CHECK(smem <= 64 * 1024, FIB_ERR_UNSUPPORTED, "ODF with %d vertices does not fit the peak finder's LDS", plan->nvert);
+    const unsigned grid = (unsigned)std::min<int64_t>(nvox, 8192);
+    hipLaunchKernelGGL(odf_peaks_work_kernel, dim3(grid), dim3(256), smem, (hipStream_t)stream, odf, nvox, nvox, plan->nvert, plan->deg_pad,
+                       plan->nbr64.p, odf_peak, isort, nvalid);
+    FIB_HIP(hipGetLastError());
+    return FIB_OK;
+} FIB_API_CATCH

@@ -95,6 +95,26 @@ def find_peaks(odf, odf_dirs: ODF = sphere_642, device: int = 0):
     return top.T.reshape(lead + (3,)), nvalid.reshape(lead)
 
 
+def find_peaks_work(odf, odf_dirs: ODF = sphere_642, device: int = 0):
+    """find_peaks!(W) (gqi.jl:180-201) with every output the reference's work struct receives.  odf: [..., nvert]; returns
+    (odf_peak float32 [..., nvert]: W.odf_peak, the amplitudes of the local peaks and 0 elsewhere; isort int32 [..., nvert]:
+    W.isort = sortperm(odf_peak, rev=true), 0-based; nvalid int32 [...]: the function's return value)."""
+    o = np.asarray(odf, dtype=np.float32)
+    nvert = odf_dirs.nvert
+    if o.shape[-1] != nvert:
+        raise ValueError("last axis of odf must be the %d half-sphere vertices" % nvert)
+    lead = o.shape[:-1]
+    nvox = int(np.prod(lead)) if lead else 1
+    planar = np.ascontiguousarray(o.reshape(nvox, nvert).T)             # [nvert, nvox]
+    v, f = _odf_args(odf_dirs)
+    pk = np.empty((nvert, nvox), np.float32)
+    isort = np.empty((nvert, nvox), np.int32)
+    nvalid = np.empty(nvox, np.int32)
+    _lib.check(_lib.lib().fib_find_peaks_work(device, planar.ctypes.data, nvox, v.ctypes.data, v.shape[0], f.ctypes.data,
+                                              f.shape[0], pk.ctypes.data, isort.ctypes.data, nvalid.ctypes.data))
+    return pk.T.reshape(lead + (nvert,)), isort.T.reshape(lead + (nvert,)), nvalid.reshape(lead)
+
+
 # ---------------------------------------------------------------------------------------------
 # device-resident form
 # ---------------------------------------------------------------------------------------------

@@ -133,11 +133,17 @@ int fibd_dti_last_partial_count(const fib_dti_plan *plan, void *stream, int64_t 
  *                      that ranks can all-reduce it and call fibd_qa_normalize;
  *   FIB_ODF_PREZEROED  the caller guarantees that every output is already 0 at the voxels outside
  *                      `mask` (e.g. buffers from a previous call with the same mask); otherwise they
- *                      are zero-filled here, like the reference's freshly allocated volumes.
+ *                      are zero-filled here, like the reference's freshly allocated volumes;
+ *   FIB_ODF_SEPARATE_PEAKS  run find_peaks! as its own kernel on the stored ODF instead of on the contraction
+ *                      kernel's accumulators (the fused form needs 16-byte aligned rows, nvox % 4 == 0, and
+ *                      computes two of the 321 rows of sphere_642 with a different rounding): a caller that
+ *                      cuts one volume into pieces sets it for ALL pieces when any piece is unaligned, so
+ *                      that the result does not depend on the cut (the host-buffer tier does).
  * Only voxels inside the mask are computed: the mask is compacted on the device into a voxel list
  * (reconstruction) and a list of 64-voxel tiles (peak finder), so cost scales with the mask. */
 #define FIB_ODF_NORMALIZE 1
 #define FIB_ODF_PREZEROED 2
+#define FIB_ODF_SEPARATE_PEAKS 4
 int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const uint8_t *mask, int64_t nvox,
                  float *pdf, float *odf, float *const peak[3], float *const qa[3],
                  float *odfmax_dev, int flags, void *stream);
@@ -151,6 +157,10 @@ int fibd_qa_normalize_dev(float *const qa[3], int64_t nvox, const float *odfmax_
  * isort_top [3*nvox] planar int32 (-1 where fewer than k+1 vertices exist). */
 int fibd_find_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox,
                     int32_t *isort_top, int32_t *nvalid, void *stream);
+/* .. with all of the work struct's outputs: odf_peak [nvert*nvox] planar (gqi.jl:184-196), isort [nvert*nvox] planar int32
+ * (the complete permutation, 0-based, gqi.jl:198), nvalid [nvox] (gqi.jl:200) */
+int fibd_find_peaks_work(const fib_odf_plan *plan, const float *odf, int64_t nvox,
+                         float *odf_peak, int32_t *isort, int32_t *nvalid, void *stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* RUMBA-SD (rusd.jl), SURVEY.md row N4                                                   */
@@ -317,6 +327,11 @@ int fib_rumba_rec(int device, const float *dwi, int nx, int ny, int nz, int nvol
  * of `isort` (0-based first-half vertex rows, -1 where the sphere has fewer vertices); nvalid [nvox] (gqi.jl:200). */
 int fib_find_peaks(int device, const float *odf, int64_t nvox, const float *verts, int nverts,
                    const int32_t *faces, int nfaces, int32_t *isort_top, int32_t *nvalid);
+/* find_peaks!(W) with every output the reference's work struct receives (gqi.jl:180-201): odf_peak [nvox x nvert] planar
+ * (W.odf_peak: the amplitudes of the local peaks, 0 elsewhere, :184-196), isort [nvox x nvert] planar (W.isort: the complete
+ * sortperm(odf_peak, rev=true), 0-based, :198) and nvalid [nvox] (the return value, :200). */
+int fib_find_peaks_work(int device, const float *odf, int64_t nvox, const float *verts, int nverts,
+                        const int32_t *faces, int nfaces, float *odf_peak, int32_t *isort, int32_t *nvalid);
 
 /* stream(ovec; f, f_thresh, fa, fa_thresh, mask, seed, ...)::Tract (stream.jl:730), non-LCM macro path.
  * ovec[k] [nx,ny,nz,3]; f[k] [nx,ny,nz] or f == NULL; fa / mask / seed may be NULL (mask == NULL:

@@ -25,6 +25,7 @@ function fib_check(rc::Cint)
   error(msg)                       # same strings as the reference's error() calls
 end
 
+# layout: fib_dti_out sizeof 80: s0@0 eigval1@8 eigval2@16 eigval3@24 eigvec1@32 eigvec2@40 eigvec3@48 rd@56 md@64 fa@72
 struct FibDtiOut
   s0::Ptr{Float32}; eigval1::Ptr{Float32}; eigval2::Ptr{Float32}; eigval3::Ptr{Float32}
   eigvec1::Ptr{Float32}; eigvec2::Ptr{Float32}; eigvec3::Ptr{Float32}
@@ -76,6 +77,31 @@ function find_peaks(odf::MRI, odf_dirs::ODF=sphere_642; device::Integer=0)
   return top .+ Int32(1), nvalid
 end
 
+"""
+    find_peaks!(W::Union{GQIwork, DSIwork})
+
+The reference's own surface (gqi.jl:180-201): reads `W.o[tid]` of the calling thread, fills `W.odf_peak[tid]` (amplitudes of the
+local peaks, 0 elsewhere) and `W.isort[tid]` (`sortperm(odf_peak, rev=true)`, 1-based), returns `count(odf_peak .> 0)`.
+`W.faces` is the FOLDED face table of the work struct (vertex indices 1..nvert); the library folds faces itself, so the
+unfolded tessellation is rebuilt by pairing every half-sphere vertex with a placeholder antipode that no face uses.
+One voxel per call, as in the reference; `gqi_rec` / `dsi_rec` do not come through here (they find the peaks on the GPU while
+the ODF is on chip) — this is for code that calls `find_peaks!` directly.
+"""
+function find_peaks!(W; device::Integer=0)
+  tid = Threads.threadid()
+  o = W.o[tid]::Vector{Float32}
+  nvert = W.nvert
+  faces = Int32.(W.faces)                                 # folded, 1-based, [nf x 3]
+  verts = zeros(Float32, 2 * nvert, 3)                    # coordinates are not used by find_peaks!
+  pk = Vector{Float32}(undef, nvert); isort = Vector{Int32}(undef, nvert); nvalid = Ref{Int32}(0)
+  GC.@preserve o pk isort faces verts fib_check(ccall((:fib_find_peaks_work, libfibers), Cint,
+      (Cint, Ptr{Float32}, Int64, Ptr{Float32}, Cint, Ptr{Int32}, Cint, Ptr{Float32}, Ptr{Int32}, Ref{Int32}),
+      device, o, 1, verts, 2 * nvert, faces, size(faces, 1), pk, isort, nvalid))
+  W.odf_peak[tid] .= pk
+  W.isort[tid] .= Int.(isort) .+ 1
+  return Int(nvalid[])
+end
+
 "gqi_rec(dwi, mask, odf_dirs, σ) — replaces gqi.jl:109-171 (and find_peaks! gqi.jl:180-201)"
 function gqi_rec(dwi::MRI, mask::MRI, odf_dirs::ODF=sphere_642, σ::Float32=Float32(1.25); device::Integer=0)
   isempty(dwi.bval) && error("Missing b-value table from input DWI structure")
@@ -112,6 +138,7 @@ function dsi_rec(dwi::MRI, mask::MRI, odf_dirs::ODF=sphere_642, hann_width::Int=
   return DSI(pdf, odf, peak, qa)
 end
 
+# layout: fib_rumba_out sizeof 80: fodf@0 fgm@8 fcsf@16 gfa@24 var@32 peak@40
 struct FibRumbaOut
   fodf::Ptr{Float32}; fgm::Ptr{Float32}; fcsf::Ptr{Float32}; gfa::Ptr{Float32}; var::Ptr{Float32}
   peak::NTuple{5, Ptr{Float32}}
@@ -153,6 +180,7 @@ function rumba_rec(dwi::MRI, mask::MRI, odf_dirs::ODF=sphere_724, niter::Integer
   return RUMBASD(fodf, fgm, fcsf, peak, gfa, var, snr[], snrsd[])
 end
 
+# layout: fib_stream_params sizeof 64: nx@0 ny@4 nz@8 nvec@12 len_min@16 len_max@20 cosang_thresh@24 step_size@28 smooth_coeff@32 search_dist@36 search_cosang@40 ws@48 interp@56
 struct FibStreamParams
   nx::Int32; ny::Int32; nz::Int32; nvec::Int32; len_min::Int32; len_max::Int32
   cosang_thresh::Float32; step_size::Float32; smooth_coeff::Float32
@@ -161,6 +189,7 @@ struct FibStreamParams
   interp::Int32                                       # 0: nearest voxel (stream.jl:514); 1: trilinear blend (not in the reference)
 end
 
+# layout: fib_tract_out sizeof 48: nlines@0 npoints@8 npts@16 seed_index@24 xyz@32 flags@40
 mutable struct FibTractOut
   nlines::Int64; npoints::Int64
   npts::Ptr{Int32}; seed_index::Ptr{Int64}; xyz::Ptr{Float32}; flags::Ptr{UInt8}

@@ -74,3 +74,44 @@ def test_sphere_tables(fj):
         assert s.vertices.shape == (nv, 3) and s.faces.shape == (nf, 3) and s.vertices.dtype == np.float32
         assert np.array_equal(s.vertices[nv // 2:], -s.vertices[: nv // 2])
         assert s.faces.min() == 1 and s.faces.max() == nv
+
+
+def test_struct_layouts_of_the_header_match_the_bindings(tmp_path):
+    """The four structs that cross the C ABI by pointer have hand-written mirrors (ctypes in fibers.jl_amd/_lib.py, Julia structs in
+    julia/FibersHIP.jl).  A C program compiled against include/fibers_hip.h prints sizeof and every offsetof; the ctypes mirrors
+    must agree field by field, and so must the numbers quoted in FibersHIP.jl's comments."""
+    import subprocess
+    from fibers_jl_amd import _lib
+    fields = {
+        "fib_dti_out": ["s0", "eigval1", "eigval2", "eigval3", "eigvec1", "eigvec2", "eigvec3", "rd", "md", "fa"],
+        "fib_rumba_out": ["fodf", "fgm", "fcsf", "gfa", "var", "peak"],
+        "fib_stream_params": ["nx", "ny", "nz", "nvec", "len_min", "len_max", "cosang_thresh", "step_size", "smooth_coeff", "search_dist",
+                              "search_cosang", "ws", "interp"],
+        "fib_tract_out": ["nlines", "npoints", "npts", "seed_index", "xyz", "flags"],
+    }
+    mirrors = {"fib_dti_out": _lib.DtiOut, "fib_rumba_out": _lib.RumbaOut, "fib_stream_params": _lib.StreamParams, "fib_tract_out": _lib.TractOut}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "fibers_hip.h"', 'int main(void) {']
+    for st, fl in fields.items():
+        src.append('  printf("%s sizeof %%zu\\n", sizeof(%s));' % (st, st))
+        for f in fl:
+            src.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (st, f, st, f))
+    src += ['  return 0;', '}']
+    cfile = tmp_path / "layout.c"
+    cfile.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(cfile), "-o", str(exe)])
+    got = {}
+    for ln in subprocess.check_output([str(exe)], text=True).splitlines():
+        st, f, v = ln.split()
+        got[(st, f)] = int(v)
+    for st, fl in fields.items():
+        m = mirrors[st]
+        assert C.sizeof(m) == got[(st, "sizeof")], (st, C.sizeof(m), got[(st, "sizeof")])
+        assert [n for n, _ in m._fields_] == fl, (st, [n for n, _ in m._fields_])
+        for f in fl:
+            assert getattr(m, f).offset == got[(st, f)], (st, f, getattr(m, f).offset, got[(st, f)])
+    # the Julia mirrors state their layout in comments of the form `# layout: <struct> sizeof N: field@offset ...` -- keep them true
+    jl = open(os.path.join(ROOT, "julia", "FibersHIP.jl")).read()
+    for st, fl in fields.items():
+        want = "# layout: %s sizeof %d: %s" % (st, got[(st, "sizeof")], " ".join("%s@%d" % (f, got[(st, f)]) for f in fl))
+        assert want in jl, "julia/FibersHIP.jl lacks or misstates: " + want

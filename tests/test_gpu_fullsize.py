@@ -80,11 +80,10 @@ def _check_odf_sample(fj, orc, kind, out, dwi, mask, bval, bvec, dev, nsamp, odf
         gpdf = out["pdf"][:, tidx].T.cpu().numpy().reshape(nsamp, 1, 1, -1)
         ps = np.abs(ref["pdf"]).max(axis=3, keepdims=True) + 1e-30
         assert (np.abs(gpdf - ref["pdf"]) / ps).max() <= 5e-5
-    nbad = 0
-    for k in range(3):
-        gp = out["peak"][k][:, tidx].T.cpu().numpy().reshape(nsamp, 1, 1, 3)
-        nbad += int((~np.all(gp == ref["peak"][k], axis=3)).sum())
-    assert nbad <= max(2, int(2e-3 * 3 * nsamp)), "%d peak mismatches in the sample" % nbad
+    # peaks: identical, or a tie at rounding level in the oracle's own ODF (margin <= 1e-4 of the maximum); no allowance by count
+    from util import peak_mismatches_are_ties
+    gps = [out["peak"][k][:, tidx].T.cpu().numpy().reshape(nsamp, 1, 1, 3) for k in range(3)]
+    peak_mismatches_are_ties(ref["odf"], ref["peak"], gps, np.asarray(sph.vertices, np.float32)[:sph.nvert])
     return ref
 
 
@@ -246,3 +245,27 @@ def test_c5_stream_three_peaks_10m(fj, dev, dsi_result):
     torch.cuda.synchronize()
     nl = _check_tract(res, 3, mout, int(seeds.numel()), 10)
     assert nl > 5_000_000
+    # oracle on the same three-peak field (f = qa, f_thresh = .03, stream.jl:135-139; first-max / NaN / sign rule of
+    # stream_pick_by_angle!, stream.jl:340-374) for 300 sampled seeds x the 10 offsets: identical lines, bit for bit
+    import fibers_jl_amd  # noqa: F401
+    from oracle import oracle as orc
+    rng = np.random.default_rng(7)
+    pick = np.sort(rng.choice(int(seeds.numel()), 300, replace=False))
+    vol = lambda t, c: t.reshape(c, NVOX).T.contiguous().cpu().numpy().reshape(140, 140, 140, c, order="F")
+    ovs = [np.asfortranarray(vol(out["peak"][k], 3)) for k in range(3)]
+    fs = [out["qa"][k].cpu().numpy().reshape(140, 140, 140, order="F") for k in range(3)]
+    mk = r["mask"].cpu().numpy().reshape(140, 140, 140, order="F")
+    seedvol = np.zeros(NVOX, np.uint8)
+    seedvol[seeds[torch.from_numpy(pick).to(dev)].cpu().numpy()] = 1
+    ref = orc.stream(ovs, sub.cpu().numpy(), f=fs, f_thresh=0.03, mask=mk, seed=seedvol.reshape(140, 140, 140, order="F"), nthreads=8)
+    sidx = res["seed_index"].cpu().numpy()
+    off = np.concatenate([[0], np.cumsum(res["npts"].cpu().numpy().astype(np.int64))])
+    pos = {int(s_): i for i, s_ in enumerate(sidx)}
+    roff = np.concatenate([[0], np.cumsum(ref["npts"].astype(np.int64))])
+    assert len(ref["npts"]) > 1500                            # most of the 3000 (seed, offset) pairs give a line of >= 3 points
+    xyz = res["xyz"]
+    for j, rs in enumerate(ref["seed_index"]):               # the oracle numbers its 300 seeds 0..299 in findall order, x 10 offsets
+        sd, so = divmod(int(rs), 10)
+        i = pos[int(pick[sd]) * 10 + so]
+        assert np.array_equal(xyz[off[i]:off[i + 1]].cpu().numpy(), ref["xyz"][roff[j]:roff[j + 1]]), (j, rs)
+    assert len(ref["npts"]) == sum(1 for sd in pick for so in range(10) if int(sd) * 10 + so in pos)   # and no line more or less

@@ -144,6 +144,49 @@ def test_concurrent_callers_on_two_workers_and_on_one(fj):
     assert _lib.lib().fib_last_error() is not None
 
 
+def test_many_concurrent_calls_of_different_sizes_on_one_worker(fj, monkeypatch):
+    """Stress of the qa hand-over between the two passes of fib_gqi_rec (the worker's lock is released in between): four threads
+    hammer ONE worker with volumes of different sizes and chunkings; a call must never see another call's qa (or a buffer the
+    other call reallocated): every result equals the single-threaded one, bit for bit."""
+    shapes = [(22, 18, 14), (9, 7, 5), (31, 12, 10), (16, 20, 12)]
+    cases = [_gqi_case(fj, shape=sh, seed=20 + i) for i, sh in enumerate(shapes)]
+    want = [fj.gqi_rec(d, m) for d, m in cases]
+    monkeypatch.setenv("FIBERS_HOST_CHUNK", "1024")              # several chunks per call: the passes interleave more
+    errs = []
+
+    def run(i):
+        try:
+            d, m = cases[i]
+            for _ in range(12):
+                _same_gqi(fj.gqi_rec(d, m), want[i])
+        except BaseException as e:                               # noqa: BLE001
+            errs.append((i, e))
+    th = [threading.Thread(target=run, args=(i,)) for i in range(len(cases))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+
+
+def test_gqi_unaligned_volume_does_not_depend_on_chunks_or_device_set(fj, orc, monkeypatch):
+    """nvox % 4 != 0 (13 x 11 x 9 = 1287): the same kernel choice for every chunk, so chunk size and device set do not change
+    a bit (the fused peak kernel needs 16-byte aligned rows; the choice is made from the whole volume, not per chunk)"""
+    dwi, mask = _gqi_case(fj, shape=(13, 11, 9), seed=31)
+    assert dwi.vol[..., 0].size % 4 != 0
+    one = fj.gqi_rec(dwi, mask)
+    ref = orc.gqi_rec(dwi.vol, mask.vol[..., 0], dwi.bval, dwi.bvec, fj.sphere_642.vertices, fj.sphere_642.faces, 1.25, nthreads=4)
+    assert np.abs(one.odf.vol - ref["odf"]).max() <= 2e-5 * np.abs(ref["odf"]).max()
+    try:
+        for chunk in ("1024", "2048"):
+            monkeypatch.setenv("FIBERS_HOST_CHUNK", chunk)
+            _same_gqi(fj.gqi_rec(dwi, mask), one)
+        fj.init([0, 0, 0])
+        _same_gqi(fj.gqi_rec(dwi, mask, device=fj.DEVICE_ALL), one)
+        monkeypatch.delenv("FIBERS_HOST_CHUNK")
+        _same_gqi(fj.gqi_rec(dwi, mask, device=fj.DEVICE_ALL), one)
+    finally:
+        fj.shutdown()
+
+
 def test_errors_come_back_as_codes_not_exceptions(fj):
     """invalid arguments through the multi-worker path: a status code and a message from the worker thread, the process
     lives on (no C++ exception crosses the ABI)"""

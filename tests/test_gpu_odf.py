@@ -15,6 +15,20 @@ def _gqi_case(shape, seed, nb0=3, ndir=20, shells=(1000.0, 2000.0, 3000.0), nonp
     return dwi, mask, bval, bvec
 
 
+def _verts_by_count():
+    import fibers_jl_amd as fj
+    return {s.nvert: np.asarray(s.vertices, np.float32) for s in (fj.sphere_362, fj.sphere_642, fj.sphere_724)}
+
+
+class _Lazy(dict):
+    def __missing__(self, k):
+        self.update(_verts_by_count())
+        return dict.__getitem__(self, k)
+
+
+_VERTS = _Lazy()
+
+
 def _check_odf_rec(got_odf, got_peak, got_qa, ref, mask, odf_rtol=2e-5, qa_atol=1e-5, label=""):
     m = mask.astype(bool)
     ro = ref["odf"]
@@ -22,15 +36,15 @@ def _check_odf_rec(got_odf, got_peak, got_qa, ref, mask, odf_rtol=2e-5, qa_atol=
     err = np.abs(got_odf - ro) / scale
     assert err.max() <= odf_rtol, "%s odf rel err %g" % (label, err.max())
     assert (got_odf[~m] == 0).all()
-    nbad = 0
     for k in range(3):
         rp, gp = ref["peak"][k], got_peak[k]
         same = np.all(rp == gp, axis=3)
-        nbad += (~same).sum()
         np.testing.assert_allclose(got_qa[k][same], ref["qa"][k][same], atol=qa_atol, rtol=1e-5)
-    # peak indices may legitimately differ only where two amplitudes are within rounding of each other
-    assert nbad <= max(1, int(2e-3 * m.sum())), "%s: %d peak mismatches" % (label, nbad)
-    return nbad
+    # peak vertices may differ only where the oracle's amplitudes of the two vertices are within 1e-4 of the voxel maximum of each
+    # other: every mismatch is checked, there is no allowance by count
+    from util import peak_mismatches_are_ties
+    nv = ref["odf"].shape[3]
+    return peak_mismatches_are_ties(ref["odf"], ref["peak"], got_peak, _VERTS[nv][:nv])
 
 
 @pytest.mark.parametrize("shape,sphere", [((8, 8, 8), "sphere_642"), ((9, 7, 5), "sphere_362"),
@@ -729,3 +743,31 @@ def test_qa_normalize_with_device_scalar(fj):
     torch.cuda.synchronize()
     two = torch.tensor(2.0, device="cuda")
     assert all(torch.equal(a, torch.div(b, two)) for a, b in zip(qa, ref))
+
+
+@pytest.mark.parametrize("sphere", ["sphere_642", "sphere_362", "sphere_724"])
+def test_find_peaks_work_fills_the_whole_work_struct(fj, sphere):
+    """fib_find_peaks_work = find_peaks!(W) with all its outputs (gqi.jl:180-201): odf_peak, the complete isort and the count,
+    against the independent NumPy restatement (the reference's face-mask formulation + sortperm by isless): exactly, on smooth
+    ODFs, exact ties, zeros, negative lobes, -0.0, NaN and +-Inf amplitudes"""
+    from oracle import oracle_np as onp
+    sph = getattr(fj, sphere)
+    nv = sph.nvert
+    rng = np.random.default_rng(17)
+    odf = rng.random((40, nv)).astype(np.float32)
+    odf[1] = np.round(odf[1] * 4) / 4                        # many exact ties
+    odf[2] = 0.0
+    odf[3] -= 0.5                                            # negative lobes
+    odf[4, ::7] = -0.0
+    odf[5, 10] = np.nan
+    odf[6, 3] = np.inf; odf[6, 40] = -np.inf
+    odf[7] = 1.0                                             # all equal: no peak
+    faces0 = onp.fold_faces(np.asarray(sph.faces), nv)
+    pk, isort, nvalid = fj.find_peaks_work(odf, sph)
+    for i in range(odf.shape[0]):
+        want_isort, want_n, want_pk = onp.find_peaks(odf[i], faces0)
+        assert np.array_equal(pk[i], want_pk, equal_nan=True), i
+        assert int(nvalid[i]) == want_n, i
+        assert np.array_equal(isort[i], want_isort), i
+    top, nv3 = fj.find_peaks(odf, sph)                       # the three-entry form agrees with the complete one
+    assert np.array_equal(top, isort[:, :3]) and np.array_equal(nv3, nvalid)

@@ -37,3 +37,30 @@ def assert_dti_close(got, ref, mask, label="", s0_rtol=1e-4, ev_atol=1e-7, ev_rt
         if dots.size:
             assert dots.min() >= 1 - vec_tol, "%s %s: min |dot| = %g" % (label, k, dots.min())
         assert (g[~m] == 0).all()
+
+
+def peak_mismatches_are_ties(ref_odf, ref_peaks, got_peaks, verts_half, tol=1e-4):
+    """peak vertices are identical "where the deciding amplitude margin > 1e-4 * max".  For every voxel and rank at
+    which the two peak vectors differ, the ORACLE's amplitudes of the two vertices involved (0 for "no peak at this rank") must
+    be within tol * the voxel's ODF maximum of each other: a mismatch has to be a rounding-level tie, not an error.
+    ref_odf [..., nvert]; ref_peaks / got_peaks: three arrays [..., 3]; verts_half [nvert, 3].  Returns the mismatch count."""
+    vh = np.ascontiguousarray(verts_half, np.float32)
+    index = {vh[i].tobytes(): i for i in range(vh.shape[0])}
+    odf = np.asarray(ref_odf).reshape(-1, vh.shape[0])
+    nbad = 0
+    for k in range(3):
+        rp = np.ascontiguousarray(np.asarray(ref_peaks[k], np.float32).reshape(-1, 3))
+        gp = np.ascontiguousarray(np.asarray(got_peaks[k], np.float32).reshape(-1, 3))
+        for i in np.flatnonzero(~np.all(rp == gp, axis=1)):
+            nbad += 1
+            col = odf[i]
+            amp = []
+            for vec in (rp[i], gp[i]):
+                if not vec.any():
+                    amp.append(0.0)                                   # no peak at this rank
+                else:
+                    assert vec.tobytes() in index, "peak %d of voxel %d is not a vertex of the tessellation" % (k, i)
+                    amp.append(float(col[index[vec.tobytes()]]))
+            gap, top = abs(amp[0] - amp[1]), float(np.abs(col).max())
+            assert gap <= tol * top, "voxel %d rank %d: peaks differ with an amplitude gap of %g = %.3g of the ODF maximum (not a tie)" % (i, k, gap, gap / max(top, 1e-30))
+    return nbad
