@@ -498,36 +498,13 @@ int launch_fit(const fib_dti_plan *plan, const float *dwi, const uint8_t *mask, 
     int rc = plan->partial_list.ensure((size_t)nvox);
     if (rc != FIB_OK) return rc;
     FIB_HIP(hipMemsetAsync(plan->partial_count.p, 0, 2 * sizeof(int), st));
-    // widest per-lane access that every frame base and every output base is aligned for
-    auto aligned = [&](int v) {
-        if (nvox % v) return false;
-        const uintptr_t m = (uintptr_t)(4 * v - 1);
-        const void *ptrs[] = {dwi, o.s0, o.l1, o.l2, o.l3, o.e1, o.e2, o.e3, o.rd, o.md, o.fa, adc};
-        for (const void *q : ptrs) if (q && ((uintptr_t)q & m)) return false;
-        return ((uintptr_t)mask & (uintptr_t)(v - 1)) == 0;
-    };
-    // measured on MI355X (140^3 x 64): 4 voxels/lane (16-B loads, 4 waves/SIMD) 0.185 ms; 2 -> 0.171 ms;
-    // 1 voxel/lane (4-B loads but 7 waves/SIMD and 16 frames in flight per lane) 0.165 ms = 5.3 TB/s
-    const int vmax = aligned(4) ? 4 : (aligned(2) ? 2 : 1);
-    int V = 1, unr = 16;
-    if (const char *e = getenv("FIBERS_DTI_VARIANT")) {          // tuning hook: "<V>x<UNR>"
-        int v = 0, u = 0;
-        if (sscanf(e, "%dx%d", &v, &u) == 2 && (v == 1 || v == 2 || v == 4) && v <= vmax && (u == 8 || u == 16 || u == 32)) { V = v; unr = u; }
-    }
+    // measured on MI355X (140^3 x 64): 4 voxels / lane (16-byte loads, 4 waves / SIMD) 0.185 ms; 2 -> 0.171 ms; 1 voxel / lane
+    // (4-byte loads but 7 waves / SIMD and 16 frames in flight per lane) 0.165 ms, 0.155 with non-temporal accesses: the only
+    // form that is built; block sizes 64-256 and 8-32 frames in flight made no difference
     { fib::ProfScope prof(NP == 7 ? "dti_fit" : "adc_fit", st);
-    int block = 256;
-    if (const char *e = getenv("FIBERS_DTI_BLOCK")) { const int b = atoi(e); if (b == 64 || b == 128 || b == 256) block = b; }   // tuning hook
-    const int64_t nthreads = nvox / V;
-    const unsigned grid = (unsigned)fib::cdiv(nthreads, block);
-#define FIB_FIT_LAUNCH(VV, UU) hipLaunchKernelGGL((fit_kernel<NP, VV, UU>), dim3(grid), dim3(block), 0, st, dwi, mask, plan->coef.p, plan->nvol, nvox, o, adc, plan->partial_list.p, plan->partial_count.p)
-    if (V == 4 && unr == 8) FIB_FIT_LAUNCH(4, 8);
-    else if (V == 4) FIB_FIT_LAUNCH(4, 16);
-    else if (V == 2 && unr == 8) FIB_FIT_LAUNCH(2, 8);
-    else if (V == 2) FIB_FIT_LAUNCH(2, 16);
-    else if (unr == 8) FIB_FIT_LAUNCH(1, 8);
-    else if (unr == 16) FIB_FIT_LAUNCH(1, 16);
-    else FIB_FIT_LAUNCH(1, 32);
-#undef FIB_FIT_LAUNCH
+    const int block = 256;
+    const unsigned grid = (unsigned)fib::cdiv(nvox, block);
+    hipLaunchKernelGGL((fit_kernel<NP, 1, 16>), dim3(grid), dim3(block), 0, st, dwi, mask, plan->coef.p, plan->nvol, nvox, o, adc, plan->partial_list.p, plan->partial_count.p);
     }
     FIB_HIP(hipGetLastError());
     fib::ProfScope prof2("fit_partial", st);

@@ -2093,12 +2093,6 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
             const int cost = nt * (64 * mb + 4 * nx);
             if (cost < best_cost) { best_cost = cost; p->MB = mb; p->NX = nx; p->ntile_m = nt; }
         }
-    if (const char *e = getenv("FIBERS_GEMM_TILE")) {        // tuning hook: "<MB>x<NX>"
-        int mb = 0, nx = 0;
-        if (sscanf(e, "%dx%d", &mb, &nx) == 2 && mb >= 5 && mb <= 11 && (nx == 0 || nx == 1) && !(nx > 0 && mb > 10)) {
-            p->MB = mb; p->NX = nx; p->ntile_m = (M + mb * 32 + nx - 1) / (mb * 32 + nx);
-        }
-    }
     p->Kpad = (K + KT - 1) / KT * KT;
     const int MW = gemm_row_stride(p->MB, p->NX), ROWS = p->MB * 32 + p->NX;
     std::vector<float> At((size_t)p->ntile_m * p->Kpad * MW, 0.0f);
@@ -2315,7 +2309,7 @@ extern "C" int fib_dsi_plan_create(int device, const float *bval, const float *b
     // ---- antipodal folding (see dsi_fold_kernel): every frame needs a partner at -q with an identical column ----
     {
         std::vector<int> partner(nvol, -1);
-        bool ok = !getenv("FIBERS_DSI_NOFOLD");
+        bool ok = true;
         for (int j = 0; j < nvol && ok; j++) if (eff[j] == 0.0f) ok = false;
         for (int j = 0; j < nvol && ok; j++) {
             for (int k = 0; k < nvol; k++)

@@ -355,173 +355,6 @@ def test_peak_kernels_agree_incl_nan_poisoned_voxels(fj, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "f32"])
-def test_gqi_both_matrix_core_paths_full_mask(fj, orc, mode, monkeypatch):
-    """the two contraction kernels (split-bf16 MFMA, f32 MFMA) against the oracle on an all-ones mask: contiguous voxel
-    runs take the LDS-transposed dwordx4 epilogue, the ragged last work item the scalar one"""
-    monkeypatch.setenv("FIBERS_ODF_GEMM", mode)
-    from fibers_jl_amd import phantom
-    shape = (12, 10, 9)                                    # 1080 voxels: a multiple of 4, not of 256
-    bval, bvec = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3)
-    dwi, _, _ = phantom.make_volume(shape, bval, bvec, seed=17, noise_frac=0.02, crossing=True)
-    mask = np.ones(shape, np.uint8)
-    sph = fj.sphere_642
-    ref = orc.gqi_rec(dwi, mask, bval, bvec, sph.vertices, sph.faces, 1.25, nthreads=4)
-    got = fj.gqi_rec(fj.MRI(dwi, bval, bvec), fj.MRI(mask), sph)
-    _check_odf_rec(got.odf.vol, [p.vol for p in got.peak], [q.vol[..., 0] for q in got.qa], ref, mask, label=mode)
-
-
-@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
-def test_dsi_both_matrix_core_paths_full_mask(fj, orc, mode, monkeypatch):
-    """DSI (folded lattice: mapped pdf rows, three M tiles per voxel group) on an all-ones mask, both kernels"""
-    monkeypatch.setenv("FIBERS_ODF_GEMM", mode)
-    dwi, _, bval, bvec = _dsi_case((8, 6, 2), seed=8)      # 96 voxels: one full 32-voxel wave run + ragged rest
-    mask = np.ones(dwi.shape[:3], np.uint8)
-    sph = fj.sphere_642
-    ref = orc.dsi_rec(dwi, mask, bval, bvec, sph.vertices, sph.faces, 32, nthreads=4)
-    got = fj.dsi_rec(fj.MRI(dwi, bval, bvec), fj.MRI(mask), sph, 32)
-    scale = np.abs(ref["pdf"]).max(axis=3, keepdims=True) + 1e-30
-    assert (np.abs(got.pdf.vol - ref["pdf"]) / scale).max() < 5e-5
-    _check_odf_rec(got.odf.vol, [p.vol for p in got.peak], [q.vol[..., 0] for q in got.qa], ref, mask,
-                   odf_rtol=1e-4, qa_atol=1e-4, label="dsi " + mode)
-
-
-def test_split_bf16_matches_f32_kernel_large(fj, monkeypatch):
-    """40^3 x 63 frames: the split-bf16 contraction agrees with the f32-MFMA chain to f32 rounding everywhere, with and
-    without a mask (the compacted voxel list changes which lanes / work items a voxel lands in)"""
-    import torch
-    from fibers_jl_amd import phantom
-    dev = torch.device("cuda", 0)
-    shape = (40, 40, 40)
-    nvox = 40 ** 3
-    bval, bvec = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3)
-    dwi, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=4, device=dev)
-    ball = phantom.ball_mask_torch(shape, dev, radius=17.3)
-    outs = {}
-    for mode in ("f32", "bf16x3"):
-        monkeypatch.setenv("FIBERS_ODF_GEMM", mode)
-        plan = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642)
-        for name, m in (("ones", torch.ones(nvox, dtype=torch.uint8, device=dev)), ("ball", ball)):
-            o = fj.odf_rec_device(plan, dwi, m)
-            outs[mode, name] = (o["odf"].clone(), o["peak"][0].clone())
-        plan.close()
-    for name in ("ones", "ball"):
-        a, b = outs["f32", name][0], outs["bf16x3", name][0]
-        vmax = a.abs().max(0).values.clamp_min(1e-30)
-        assert float(((a - b).abs() / vmax).max()) < 5e-6
-        differ = (outs["f32", name][1] != outs["bf16x3", name][1]).any(0).float().mean()
-        assert float(differ) < 1e-3                        # first-peak vertex: only amplitude ties at rounding level may flip
-    live = ball.bool()
-    assert torch.equal(outs["bf16x3", "ones"][0][:, live], outs["bf16x3", "ball"][0][:, live])
-    assert (outs["bf16x3", "ball"][0][:, ~live] == 0).all()
-
-
-def test_find_peaks_host_entry(fj, orc):
-    """fib_find_peaks (host buffers): the first three entries of isort and nvalid, for all three tessellations"""
-    rng = np.random.default_rng(9)
-    for sph in (fj.sphere_362, fj.sphere_642, fj.sphere_724):
-        odf = rng.random((7, 5, sph.nvert)).astype(np.float32)
-        odf[0, 0] = 0.0
-        odf[1, 1, :] = np.round(odf[1, 1, :] * 4) / 4            # ties
-        top, nvalid = fj.find_peaks(odf, sph)
-        faces0 = orc.fold_faces(sph.faces, sph.nvert)
-        for i in range(7):
-            for j in range(5):
-                isort, nv, _ = orc.find_peaks(odf[i, j], faces0)
-                assert nv == nvalid[i, j]
-                assert list(isort[:3]) == list(top[i, j])
-
-
-def test_peak_kernels_agree_incl_nan_poisoned_voxels(fj, monkeypatch):
-    """the peak finder fused into the contraction kernel (sphere_642 GQI default), the separate list-based sphere_642
-    kernel and the generic-table kernel give the same peaks / qa / odfmax, also when NaN samples poison whole voxels
-    (321 NaN "candidates": the fused scan hands such voxels to its redo kernel, the list kernel takes its overflow path).
-    The two separate kernels read the same ODF and must agree bit for bit; the fused kernel computes rows 46 and 320 of
-    the ODF with the roles of the MFMA and the f32 VALU row swapped (1e-6 relative), so a rounding-level tie may fall
-    differently there."""
-    import torch
-    from fibers_jl_amd import phantom
-    dev = torch.device("cuda", 0)
-    shape = (32, 24, 20)
-    nvox = shape[0] * shape[1] * shape[2]
-    bval, bvec = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3)
-    dwi, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=6, device=dev)
-    rng = np.random.default_rng(4)
-    bad = torch.from_numpy(rng.choice(nvox, 60, replace=False)).to(dev)
-    dwi[5, bad] = float("nan")
-    mask = torch.ones(nvox, dtype=torch.uint8, device=dev)
-    res = {}
-    for name, env in (("fused", {}), ("list", {"FIBERS_ODF_UNFUSED": "1"}), ("generic", {"FIBERS_PEAKS_GENERIC": "1"})):
-        for k in ("FIBERS_ODF_UNFUSED", "FIBERS_PEAKS_GENERIC"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        p = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642)
-        o = fj.odf_rec_device(p, dwi, mask, normalize=False)
-        torch.cuda.synchronize()
-        res[name] = dict(peak=[t.clone() for t in o["peak"]], qa=[t.clone() for t in o["qa"]], odfmax=o["odfmax"].clone(),
-                         odf=o["odf"].clone())
-    for name in res:
-        assert bool(torch.isnan(res[name]["odf"][:, bad]).all())
-        assert float(res[name]["odfmax"][1]) == 1.0              # NaN flag of the global maximum (gqi.jl:164)
-        assert float(res[name]["peak"][0][:, bad].abs().max()) == 0.0   # nvalid = 0 for an all-NaN ODF: no peaks (gqi.jl:151,200)
-    for k in range(3):
-        assert torch.equal(res["list"]["peak"][k], res["generic"]["peak"][k]), k
-        assert torch.equal(torch.nan_to_num(res["list"]["qa"][k], nan=-7.0), torch.nan_to_num(res["generic"]["qa"][k], nan=-7.0)), k
-        differ = (res["fused"]["peak"][k] != res["list"]["peak"][k]).any(0)
-        assert int(differ.sum()) <= 2, (k, int(differ.sum()))
-        same = ~differ
-        torch.testing.assert_close(torch.nan_to_num(res["fused"]["qa"][k][same], nan=-7.0), torch.nan_to_num(res["list"]["qa"][k][same], nan=-7.0),
-                                   rtol=2e-5, atol=1e-2)
-    assert torch.equal(torch.nan_to_num(res["list"]["odfmax"], nan=-7.0), torch.nan_to_num(res["generic"]["odfmax"], nan=-7.0))
-    rows = torch.ones(res["fused"]["odf"].shape[0], dtype=torch.bool, device=dev)
-    rows[46] = False; rows[320] = False
-    assert torch.equal(torch.nan_to_num(res["fused"]["odf"][rows], nan=-7.0), torch.nan_to_num(res["list"]["odf"][rows], nan=-7.0))
-    torch.testing.assert_close(torch.nan_to_num(res["fused"]["odf"][~rows], nan=-7.0), torch.nan_to_num(res["list"]["odf"][~rows], nan=-7.0), rtol=1e-5, atol=0)
-
-
-@pytest.mark.parametrize("case", ["full", "ball", "poison", "noisy"])
-def test_pipelined_gqi_kernel_is_bit_identical_to_the_fused_one(fj, case, monkeypatch):
-    """odf_pipe_kernel (FIBERS_ODF_PIPE=1: one wave per SIMD, the epilogue of work item i-1 issued between the MFMAs of item i)
-    against odf_gemm3_kernel<FUSE> on the same buffers: ODF rows, peaks, raw qa and odfmax bit for bit.  270-frame protocol
-    (17 contraction stages: the pipelined kernel needs 14), a voxel count that is not a multiple of the 128-voxel work item;
-    NaN / +Inf / all-zero / negative / identical voxels; uniform noise (tens of local maxima per voxel: list overflow and the
-    more-than-three-candidates-per-block path, both handed to odf_redo_kernel); a sparse mask."""
-    import torch
-    from fibers_jl_amd import phantom
-    dev = torch.device("cuda", 0)
-    shape = (37, 29, 23)
-    nvox = shape[0] * shape[1] * shape[2]
-    bval, bvec = phantom.scheme_gqi()
-    assert len(bval) >= 209
-    dwi, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=8, device=dev, noise_frac=0.1)
-    mask = torch.ones(nvox, dtype=torch.uint8, device=dev)
-    if case == "ball":
-        mask = phantom.ball_mask_torch(shape, dev)
-    if case == "poison":
-        dwi[5, 100] = float("nan"); dwi[7, 2000] = float("inf"); dwi[:, 3000] = 0.0; dwi[:, 3001] = -1.0
-        dwi[:, 5000:5064] = 1000.0
-        dwi[11, nvox - 1] = float("nan")
-    if case == "noisy":
-        g = torch.Generator(device=dev); g.manual_seed(11)
-        dwi = torch.rand(dwi.shape, generator=g, device=dev) * 100.0
-    plan = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642, sigma=1.25)
-    res = {}
-    for name, flag in (("pipe", "1"), ("fused", "0")):
-        monkeypatch.setenv("FIBERS_ODF_PIPE", flag)
-        o = fj.odf_rec_device(plan, dwi, mask, normalize=False)
-        torch.cuda.synchronize()
-        res[name] = dict(odf=o["odf"].clone(), peak=[t.clone() for t in o["peak"]], qa=[t.clone() for t in o["qa"]], odfmax=o["odfmax"].clone())
-    nn = lambda t: torch.nan_to_num(t, nan=-7.0, posinf=-8.0, neginf=-9.0)
-    assert torch.equal(nn(res["pipe"]["odf"]), nn(res["fused"]["odf"]))
-    for k in range(3):
-        assert torch.equal(nn(res["pipe"]["peak"][k]), nn(res["fused"]["peak"][k])), k
-        assert torch.equal(nn(res["pipe"]["qa"][k]), nn(res["fused"]["qa"][k])), k
-    assert torch.equal(nn(res["pipe"]["odfmax"]), nn(res["fused"]["odfmax"]))
-    assert int((res["pipe"]["peak"][0] != 0).any(0).sum()) > (0 if case == "ball" else nvox // 2)     # (it did find peaks)
-
-
-
-@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
 def test_gqi_nonfinite_samples_propagate_like_the_reference(fj, orc, mode, monkeypatch):
     """gqi.jl:139-144 on samples that are not finite: `s[s .< 0] .= 0` turns -Inf into 0 and keeps NaN; `maximum(s) == 0`
     does not skip a voxel with a NaN; mul!(o, A, s) makes a NaN sample a NaN column and a +Inf sample +-Inf rows (NaN where
@@ -771,3 +604,47 @@ def test_find_peaks_work_fills_the_whole_work_struct(fj, sphere):
         assert np.array_equal(isort[i], want_isort), i
     top, nv3 = fj.find_peaks(odf, sph)                       # the three-entry form agrees with the complete one
     assert np.array_equal(top, isort[:, :3]) and np.array_equal(nv3, nvalid)
+
+
+@pytest.mark.parametrize("case", ["full", "sparse", "poison"])
+def test_dsi_two_tile_kernel_against_the_three_tile_path(fj, case, monkeypatch):
+    """odf_dsi2_kernel (default for folded lattices on sphere_642: fused ODF tile + pdf tile in one launch, find_peaks! on the
+    accumulators) against the path it replaced (FIBERS_DSI_THREE_TILES=1: three M tiles, then odf_peaks642_kernel on the stored
+    ODF), same device buffers: peaks identical, qa / odfmax to rounding, ODF rows bit-identical except the three rows whose
+    role differs (the fused layout's pole row and the three-tile layout's two extra rows are f32 VALU rows), pdf to rounding."""
+    import torch
+    from fibers_jl_amd import phantom
+    dev = torch.device("cuda", 0)
+    shape = (21, 17, 11)
+    nvox = shape[0] * shape[1] * shape[2]
+    bval, bvec = phantom.scheme_dsi()
+    dwi, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=9, device=dev, noise_frac=0.05)
+    mask = torch.ones(nvox, dtype=torch.uint8, device=dev)
+    if case == "sparse":
+        mask = (torch.rand(nvox, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) < 0.4).to(torch.uint8)
+    if case == "poison":
+        dwi[5, 100] = float("nan"); dwi[7, 2000] = float("inf"); dwi[:, 3000] = 0.0; dwi[:, 3001] = -1.0; dwi[0, 3002] = 0.0
+    res = {}
+    for name, env in (("two", None), ("three", "1")):
+        if env:
+            monkeypatch.setenv("FIBERS_DSI_THREE_TILES", env)
+        else:
+            monkeypatch.delenv("FIBERS_DSI_THREE_TILES", raising=False)
+        plan = fj.OdfPlan("dsi", bval, bvec, fj.sphere_642, hann_width=32)
+        o = fj.odf_rec_device(plan, dwi, mask, normalize=True)
+        torch.cuda.synchronize()
+        res[name] = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in o.items()}
+    a, b = res["two"], res["three"]
+    nn = lambda t: torch.nan_to_num(t, nan=-7.0, posinf=-8.0, neginf=-9.0)
+    differing = (nn(a["odf"]) != nn(b["odf"])).any(1)
+    assert int(differing.sum()) <= 3
+    torch.testing.assert_close(nn(a["odf"]), nn(b["odf"]), rtol=2e-5, atol=1e-9)
+    torch.testing.assert_close(nn(a["pdf"]), nn(b["pdf"]), rtol=2e-5, atol=1e-9)
+    same = torch.ones(nvox, dtype=torch.bool, device=dev)
+    for k in range(3):
+        same &= (a["peak"][k] == b["peak"][k]).all(0)
+    assert float(same.float().mean()) > 0.999                 # (a tie decided by one of the three rows may fall the other way)
+    for k in range(3):
+        torch.testing.assert_close(nn(a["qa"][k])[same], nn(b["qa"][k])[same], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(nn(a["odfmax"]), nn(b["odfmax"]), rtol=1e-5, atol=0)
+    assert int((a["peak"][0] != 0).any(0).sum()) > int(mask.sum()) // 2
