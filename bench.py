@@ -170,8 +170,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    PRECOND_S = 0.15
+
     def timed(fn, steps, warmup):
-        """W untimed steps, then K steps bracketed by barrier + synchronize; max over ranks"""
+        """W untimed steps, then K steps bracketed by barrier + synchronize; max over ranks.
+        Before the W warm-up steps the same step runs untimed for PRECOND_S seconds: after the idle stretch that precedes every
+        section (plan set-up, input generation) the chip needs ~50 ms of load to leave its idle power state -- the step takes 3.1,
+        2.70, 2.63, 2.59 ms in its first four blocks of five steps and 2.58 ms from then on (tools/step_evolution.py,
+        profiles/r03/step_evolution.txt; extra.gqi_cold_start has this run's ramp) -- and W = 2..5 steps end inside that ramp.
+        What is timed is the steady state a stream of volumes sees; the line's `preconditioning` field says so."""
+        t_end = time.perf_counter() + PRECOND_S
+        while time.perf_counter() < t_end:
+            fn()
+            torch.cuda.synchronize()
         for _ in range(warmup):
             fn()
         sync()
@@ -207,6 +218,16 @@ def main():
         else:                                                              # slab + all-reduce(MAX) of {odfmax, NaN flag} + qa ./= odfmax
             fd.odf_rec_sharded(plan, dwi, mask, out=out)
 
+    # the ramp out of the idle power state, for the record (untimed as far as `value` goes): ms per step in blocks of five
+    cold = []
+    torch.cuda.synchronize()
+    time.sleep(0.5)
+    for _ in range(6):
+        t0 = time.perf_counter()
+        for _ in range(5):
+            gqi_step()
+        torch.cuda.synchronize()
+        cold.append((time.perf_counter() - t0) / 5 * 1e3)
     dt = timed(gqi_step, args.steps, args.warmup)
     gemm_ms, gemm_n = prof_get(L, "odf_gemm")
     peaks_ms, peaks_n = prof_get(L, "odf_peaks")
@@ -252,6 +273,8 @@ def main():
             pass
 
     extra = {}
+    extra["gqi_cold_start"] = dict(ms_per_step_blocks_of_5=cold, note="the headline step right after 0.5 s of idle, six blocks of five steps, before any "
+                                                                        "preconditioning: the ramp the `preconditioning` field refers to")
     if not args.no_extra and world == 1:
         # ---- in-kernel clock of the contraction kernels (MI355X_MICROARCH.md "DVFS give-back" item 6): a child process loads the
         # DIAGNOSTIC build (libfibers_hip_stamp.so: one s_memtime / s_memrealtime pair around each workgroup's work loop) and runs the
@@ -622,6 +645,8 @@ def main():
                                          "(18 x b=5 + 84 dirs x {1000,2000,3000}), sphere_642, mask = all ones" % shape,
                                 voxels=nvox, voxels_per_gpu=nloc, frames=nvol, odf_vertices=nvert,
                                 parallelism="contiguous z-slabs over the ranks (gqi.jl:132), 2-float all-reduce(MAX) of odfmax (gqi.jl:164)" if world > 1 else "single GPU"),
+                    preconditioning="every timed section is preceded by %.2f s of the same step, untimed, then the W warm-up steps, then exactly K timed steps "
+                                    "(the chip leaves its idle power state over ~50 ms of load; extra.gqi_cold_start, tools/step_evolution.py)" % PRECOND_S,
                     roofline=roofline, cpu_baseline=cpu, extra=extra)
         print(json.dumps(line))
     if world > 1:

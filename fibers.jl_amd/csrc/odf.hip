@@ -69,6 +69,8 @@ struct GemmArgs {
     const void *At3b;             // odf_dsi2_kernel: image of the pdf tile (At3 / Aextra = the ODF tile in the fused scan's row order)
     int one_slot, one_stride;     // .. its work list: voxel groups one_slot + i * one_stride of the workgroup's XCD (set by the kernel)
     int dsi_na;                   // .. workgroups per XCD that take the ODF tile (the others take the pdf tile)
+    unsigned *pair_flags;         // .. pairing (dsi_na = half the workgroups): [8 XCDs][32] item counters of the ODF-tile workgroups
+    int pair_role;                // 0: none; 1: publish my item number; 2: wait (bounded) until my partner has reached my item
 };
 
 // Diagnostic build only (make stamp -> libfibers_hip_stamp.so, -DFIB_CLOCK_STAMP; in the product library no stamp executes):
@@ -997,6 +999,26 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     int g = 0;                                           // stages done: ring position
     FIB_STAMP_BEGIN();
     for (;;) {
+        if constexpr (ONE) {
+            // The two tiles of a voxel group read the same samples.  With as many ODF-tile as pdf-tile workgroups, workgroup p of each
+            // kind walks the same groups; the pdf-tile workgroup (the faster one) starts an item only when its partner has started
+            // it, so that the second reader finds the samples in the XCD's L2.  A hint, not a protocol: the wait is bounded, and
+            // nothing but speed depends on it (relaxed agent-scope accesses of a counter, no data is handed over).
+            if (a.pair_role != 0) {
+                unsigned *flag = a.pair_flags + (blockIdx.x & 7) * 32 + a.one_slot;
+                const unsigned item = (unsigned)(g / ntiles) + 1u;
+                if (a.pair_role == 1) { if (tid == 0) __hip_atomic_store(flag, item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                else {
+                    if (tid == 0) {
+                        for (int spin = 0; spin < 4000; spin++) {
+                            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= item) break;
+                            __builtin_amdgcn_s_sleep(8);
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
         float sraw = 0.0f;                               // DSI: the sample that sum(p) is a multiple of (dsi.jl:224-225)
         if (a.scale_frame >= 0) sraw = *reinterpret_cast<const float *>(Sbase + (int64_t)a.scale_frame * a.stride * 4 + (uint32_t)(vox * 4));
         const bool lv = inb && a.mask[vox] != 0;         // voxels of a listed quad that are outside the mask: zeros
@@ -1106,11 +1128,14 @@ __global__ __launch_bounds__(512, 2) void odf_dsi2_kernel(const GemmArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[LA_ > LB_ ? LA_ : LB_];
     const int wslot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
     GemmArgs b = a;
+    const bool paired = a.pair_flags != nullptr && 2 * a.dsi_na == nslot && nslot <= 64;
     if (wslot < a.dsi_na) {
         b.one_slot = wslot; b.one_stride = a.dsi_na;
+        b.pair_role = paired ? 1 : 0;
         gemm3_body<10, 1, 8, true, true, true>(b, lds);
     } else {
         b.one_slot = wslot - a.dsi_na; b.one_stride = nslot - a.dsi_na;
+        b.pair_role = paired ? 2 : 0;
         b.At3 = a.At3b;
         b.M = a.nrow0;                                   // the pdf rows only (rows >= M are padding of the tile)
         gemm3_body<MBB, 0, 8, true, false, true>(b, lds);
@@ -1945,28 +1970,45 @@ __global__ __launch_bounds__(64) void odf_redo_kernel(const RedoArgs a) {
 // the sequential f32 sum over its stored column here (a handful of voxels unless many voxels hold the same ODF).
 struct RefineArgs { const float *odf; int64_t stride, nvox; int nvert; const int32_t *vidx, *nlive; const float *mean_hi; unsigned *maxenc; };
 __global__ __launch_bounds__(256) void odfmax_refine_kernel(const RefineArgs a) {
+    __shared__ float col[4][512];                               // a selected voxel's column, per wave
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nlive = a.nlive[0];
     // voxels of quads that are not listed have an all-zero ODF: their mean (0) takes part in the maximum
     if (blockIdx.x == 0 && threadIdx.x == 0 && nlive < a.nvox) atomicMax(&a.maxenc[0], enc_ordered(0.0f));
     const unsigned lo_e = a.maxenc[2];
     const float m_lo = lo_e ? dec_ordered(lo_e) : -INFINITY;
     const int64_t nround = ((int64_t)nlive + 63) / 64 * 64;
+    unsigned ebest = 0u;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nround; i += (int64_t)gridDim.x * 256) {
         int64_t vox = 0;
         bool sel = false;
         if (i < nlive) { vox = a.vidx[i]; sel = a.mean_hi[vox] >= m_lo; }
-        unsigned e = 0u;
-        if (sel) {
-            float sum = 0.0f;
-#pragma unroll 8
-            for (int r = 0; r < a.nvert; r++) sum += a.odf[(int64_t)r * a.stride + vox];
-            e = enc_ordered(sum / (float)a.nvert);      // finite columns only (the others are on the redo list)
-        }
-        if (__any(sel)) {
-            for (int off = 32; off >= 1; off >>= 1) { const unsigned oth = (unsigned)__shfl_xor((int)e, off); e = oth > e ? oth : e; }
-            if ((threadIdx.x & 63) == 0 && e) atomicMax(&a.maxenc[0], e);
+        // the few selected voxels of this wave, one after the other: the whole wave fetches the column (the loads of a lane that sums
+        // its own column one element after the other are 321 dependent round trips), lane 0 adds it up in the reference's order
+        unsigned long long todo = __ballot(sel);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const int64_t v = __shfl(vox, src);
+            if (a.nvert <= 512) {
+                for (int r = lane; r < a.nvert; r += 64) col[wv][r] = a.odf[(int64_t)r * a.stride + v];
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) {
+                    float sum = 0.0f;
+                    for (int r = 0; r < a.nvert; r++) sum += col[wv][r];      // mean(odf, dims=4): sequential over the vertices (gqi.jl:164)
+                    const unsigned e = enc_ordered(sum / (float)a.nvert);     // finite columns only (the others are on the redo list)
+                    ebest = e > ebest ? e : ebest;
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else if (lane == 0) {
+                float sum = 0.0f;
+                for (int r = 0; r < a.nvert; r++) sum += a.odf[(int64_t)r * a.stride + v];
+                const unsigned e = enc_ordered(sum / (float)a.nvert);
+                ebest = e > ebest ? e : ebest;
+            }
         }
     }
+    if (lane == 0 && ebest) atomicMax(&a.maxenc[0], ebest);
 }
 
 __global__ void odfmax_finalize_kernel(const unsigned *enc, float *out) {
@@ -2055,6 +2097,7 @@ struct fib_odf_plan {
     bool dsi2_shape = false, dsi2 = false;           // folded DSI plan on sphere_642: odf_dsi2_kernel (fused ODF tile + pdf tile of MBB blocks)
     int MBB = 0;
     fib::DevBuf<uint16_t> At3b;                      // image of the pdf tile (the ODF tile's image / pole row: At3f / Aextraf)
+    mutable fib::DevBuf<unsigned> pair_flags;        // item counters of the ODF-tile workgroups (odf_dsi2_kernel's pairing hint)
     fib::DevBuf<uint16_t> At3f;                      // split-bf16 image with the rows in the order of sphere642_fused.inc
     fib::DevBuf<float> Aextraf;                      // its extra row (the pole of the layout's rotation)
     mutable fib::DevBuf<float> mean_hi;              // [nvox] per-voxel upper bound of the mean (fused path)
@@ -2191,7 +2234,7 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
             FIB_HIP(hipMemcpy(p->At3f.p, A3.data(), A3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             FIB_HIP(hipMemcpy(p->Aextraf.p, AX.data(), AX.size() * sizeof(float), hipMemcpyHostToDevice));
             build_one(p->MBB, 0, [&](int r) { return r < r0 ? r : -1; }, A3, AX);
-            if ((rc3 = p->At3b.alloc(A3.size())) != FIB_OK) return rc3;
+            if ((rc3 = p->At3b.alloc(A3.size())) != FIB_OK || (rc3 = p->pair_flags.alloc(8 * 32)) != FIB_OK) return rc3;
             FIB_HIP(hipMemcpy(p->At3b.p, A3.data(), A3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         }
         p->fused_shape = faces && p->gRow0 == 0 && p->scale_frame < 0 && M == FQ_NV && p->MB == 10 && p->NX == 1 && p->ntile_m == 1 && p->Kpad <= 512;
@@ -2566,8 +2609,17 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
             // blocks; ~4.5 us per block): 17 of 32 workgroups per XCD for the 515-point lattice
             const double ca = 68.0, cb = 19.0 + 4.5 * plan->MBB;
             int na = (int)(nslot * ca / (ca + cb) + 0.5);
-            if (const char *e = getenv("FIBERS_DSI_NA")) na = atoi(e);
+            // Default: as many ODF-tile as pdf-tile workgroups, paired (see gemm3_body): the pdf tile waits ~12 % of its time for its
+            // partner, but the samples are fetched once -- measured at 140^3 x 515: kernel 5.54 ms, FETCH_SIZE 6.5 GB against 5.40 ms
+            // and 10.1 GB for the cost-balanced split without pairing (FIBERS_DSI_NA=<n> selects that, tools/dsi_na_sweep.py).
+            const char *ena = getenv("FIBERS_DSI_NA");
+            if (ena) na = atoi(ena);
             g.dsi_na = std::max(1, std::min(nslot - 1, na));
+            if (!ena && plan->pair_flags.p && nslot <= 64 && nslot % 2 == 0) {
+                g.dsi_na = nslot / 2;
+                g.pair_flags = plan->pair_flags.p;
+                FIB_HIP(hipMemsetAsync(plan->pair_flags.p, 0, 8 * 32 * sizeof(unsigned), s));
+            }
             switch (plan->MBB) {
                 case 5: hipLaunchKernelGGL(odf_dsi2_kernel<5>, dim3(pg), dim3(512), 0, s, g); break;
                 case 7: hipLaunchKernelGGL(odf_dsi2_kernel<7>, dim3(pg), dim3(512), 0, s, g); break;

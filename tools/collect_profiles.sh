@@ -3,7 +3,7 @@
 # counters in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc never together with tracing).
 # Output: gpurun_out/prof_<tag>/...; summarise with tools/summarise_profiles.py and copy into profiles/.
 set -u
-TAG=${1:-r01b}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -14,12 +14,14 @@ rocprofv3 --kernel-trace --stats -f csv -d $OUT/benchfull -o benchfull -- python
 for what in gqi dti stream dsi; do
   rocprofv3 --kernel-trace --stats -f csv -d $OUT/$what -o $what -- python3 tools/prof_step.py $what 5 > $OUT/$what.log 2>&1
 done
-for what in gqi dti; do
+for what in gqi dti dsi stream; do
   rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/${what}_fetch -o fetch -- python3 tools/prof_step.py $what 2 > $OUT/${what}_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/${what}_write -o write -- python3 tools/prof_step.py $what 2 > $OUT/${what}_write.log 2>&1
 done
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES -f csv -d $OUT/gqi_sq -o sq -- python3 tools/prof_step.py gqi 2 > $OUT/gqi_sq.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY -f csv -d $OUT/gqi_sq2 -o sq2 -- python3 tools/prof_step.py gqi 2 > $OUT/gqi_sq2.log 2>&1
+for what in gqi dsi; do
+  rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES -f csv -d $OUT/${what}_sq -o sq -- python3 tools/prof_step.py $what 2 > $OUT/${what}_sq.log 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY -f csv -d $OUT/${what}_sq2 -o sq2 -- python3 tools/prof_step.py $what 2 > $OUT/${what}_sq2.log 2>&1
+done
 # the raw traces are large (gpurun copies back at most 64 MiB): keep the stats and counter tables only
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*agent_info.csv" -delete

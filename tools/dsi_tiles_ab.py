@@ -1,5 +1,6 @@
+"""DSI at 140^3 x 515: odf_dsi2_kernel (two M tiles, peaks on chip) against the three-tile path + separate peak kernel (FIBERS_DSI_THREE_TILES=1): step and kernel times, agreement of the outputs."""
 import sys, os, time, ctypes as C
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import fibers_jl_amd as fj
 from fibers_jl_amd import phantom

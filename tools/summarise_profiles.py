@@ -6,7 +6,7 @@ import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01b"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
@@ -44,24 +44,24 @@ def pmc(sub):
 
 
 traffic = {}
-for what in ("gqi", "dti"):
+for what in ("gqi", "dti", "dsi", "stream"):
     fe, wr = pmc(what + "_fetch"), pmc(what + "_write")
     for k in sorted(set(fe) | set(wr)):
         f = fe.get(k, {}).get("FETCH_SIZE"); w = wr.get(k, {}).get("WRITE_SIZE")
         if f is None and w is None:
             continue
-        if (f or 0) + (w or 0) < 1000 or not re.match(r"(odf_|fit_|stream_|dsi_|mask_|zero_|qa_|scan_)", k):
+        if (f or 0) + (w or 0) < 1000 or not re.match(r"(odf_|fit_|stream_|dsi_|mask_|zero_|qa_|scan_)", k) or k in traffic:
             continue
         traffic[k] = dict(FETCH_SIZE_KB=f, WRITE_SIZE_KB=w, hbm_bytes_per_launch=(2.0 * (f or 0) + (w or 0)) * 1024.0)
 lines.append("== HBM traffic per launch (last dispatch; FETCH_SIZE x2 = gfx950 correction for wide coalesced reads) ==")
 for k, v in traffic.items():
     lines.append("  %-44s fetch(x2)=%8.3f GB  write=%8.3f GB  total=%8.3f GB" % (k[:44], 2 * (v["FETCH_SIZE_KB"] or 0) * 1024 / 1e9, (v["WRITE_SIZE_KB"] or 0) * 1024 / 1e9, v["hbm_bytes_per_launch"] / 1e9))
-for sub in ("gqi_sq", "gqi_sq2"):
+for sub in ("gqi_sq", "gqi_sq2", "dsi_sq", "dsi_sq2"):
     for k, v in pmc(sub).items():
-        if "gemm" in k or "peaks" in k:
+        if "gemm" in k or "peaks" in k or "dsi2" in k:
             lines.append("  PMC %-40s %s" % (k[:40], ", ".join("%s=%.4g" % kv for kv in sorted(v.items()))))
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
-gem = [v for k, v in traffic.items() if k.startswith("odf_gemm")]
+gem = [v for k, v in traffic.items() if k.startswith("odf_gemm3_kernel<10, 1, 8, false, true")] or [v for k, v in traffic.items() if k.startswith("odf_gemm")]
 if gem:   # what bench.py reports as roofline.traffic (per launch of the dominant kernel)
     json.dump({"odf_gemm_bytes_per_launch": gem[0]["hbm_bytes_per_launch"], "source": "profiles/%s/traffic.json" % tag,
                "note": "FETCH_SIZE*1024*2 (gfx950 correction for wide coalesced reads) + WRITE_SIZE*1024, separate --pmc passes; algorithmic = 6.63e9 (DWI + mask in, ODF + peaks + qa out)",
