@@ -174,15 +174,23 @@ def main():
 
     def timed(fn, steps, warmup):
         """W untimed steps, then K steps bracketed by barrier + synchronize; max over ranks.
-        Before the W warm-up steps the same step runs untimed for PRECOND_S seconds: after the idle stretch that precedes every
+        Before the W warm-up steps the same step runs untimed for about PRECOND_S seconds (a step count derived from the first step's
+        duration, identical on every rank): after the idle stretch that precedes every
         section (plan set-up, input generation) the chip needs ~50 ms of load to leave its idle power state -- the step takes 3.1,
         2.70, 2.63, 2.59 ms in its first four blocks of five steps and 2.58 ms from then on (tools/step_evolution.py,
         profiles/r03/step_evolution.txt; extra.gqi_cold_start has this run's ramp) -- and W = 2..5 steps end inside that ramp.
         What is timed is the steady state a stream of volumes sees; the line's `preconditioning` field says so."""
-        t_end = time.perf_counter() + PRECOND_S
-        while time.perf_counter() < t_end:
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        npre = max(5.0, min(2000.0, PRECOND_S / max(time.perf_counter() - t0, 1e-5)))   # (>= 5: the first call may carry one-off costs)
+        if world > 1:                                    # a step may hold a collective: the SAME number of steps on every rank
+            tn = torch.tensor([npre], device=dev, dtype=torch.float64)
+            dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+            npre = float(tn.item())
+        for _ in range(int(npre)):
             fn()
-            torch.cuda.synchronize()
+        torch.cuda.synchronize()
         for _ in range(warmup):
             fn()
         sync()
