@@ -66,7 +66,6 @@ struct GemmArgs {
     int32_t *redo_count, *redo_list;   // voxels the register scan could not finish (NaN / Inf columns, candidate-list overflow)
     int redo_cap;
     int anti;                     // fused kernel: anti-phase wave halves (see odf_gemm3_kernel)
-    int half_ring;                // fused GQI: At3 is in half-stage layout, launch two 4-wave workgroups per CU
     const void *At3b;             // odf_dsi2_kernel: image of the pdf tile (At3 / Aextra = the ODF tile in the fused scan's row order)
     int one_slot, one_stride;     // .. its work list: voxel groups one_slot + i * one_stride of the workgroup's XCD (set by the kernel)
     int dsi_na;                   // .. workgroups per XCD that take the ODF tile (the others take the pdf tile)
@@ -797,25 +796,19 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {      // ro
 // lowest frame that the stage touches on that side: one buffer resource per stage and side).
 constexpr int FKMAX = 512, FSMAX = FKMAX / KT;
 // LDS of one instantiation: stage ring + per-wave transposition tiles + extra-row table + fold tables + fused-scan lists / tables
-template <int MB, int NX, int NW, bool FOLD, bool FUSE, bool HALF = false>
+template <int MB, int NX, int NW, bool FOLD, bool FUSE>
 constexpr int gemm3_lds_bytes() {
-    return 2 * 3 * (HALF ? MB / 2 : MB) * 1024 + NW * (FUSE ? 4096 : 2048) + (NX > 0 ? (FUSE ? 2048 : 8192) : 0) +
+    return 2 * 3 * MB * 1024 + NW * (FUSE ? 4096 : 2048) + (NX > 0 ? (FUSE ? 2048 : 8192) : 0) +
            (FOLD ? 2 * FKMAX * 4 + 4 * FSMAX * 4 + (FUSE ? 0 : 2 * FKMAX * 4) : 0) + (FUSE ? NW * FQ_LIST + FQ_TABB : 0);
 }
 // ONE: the workgroup works on a single-tile image of its own (odf_dsi2_kernel: the DSI rows are cut into an ODF tile and a pdf tile
 // with images of different shapes); the work list still deals the items of both tiles (a.ntile_m = 2), and with an even number
 // of workgroups per XCD every workgroup keeps drawing items of its own tile
-// HALF: a ring buffer holds the fragments of HALF the row blocks of a stage (image layout [stage][half][piece][block]); a stage is
-// two sub-steps with a barrier each.  Half the ring (30 KB instead of 60 for sphere_642) lets TWO 4-wave workgroups share a CU:
-// they are independent (no common barrier), so one's epilogue -- a quarter of a work item's time with the matrix cores idle --
-// runs beside the other's MFMA blocks.
-template <int MB, int NX, int NW, bool FOLD = false, bool FUSE = false, bool ONE = false, bool HALF = false>
+template <int MB, int NX, int NW, bool FOLD = false, bool FUSE = false, bool ONE = false>
 __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     static_assert(!FUSE || (MB == 10 && NX == 1), "the fused peak scan is generated for 10 blocks + 1 extra row");
-    static_assert(!HALF || MB % 2 == 0, "half-stage ring buffers need an even number of row blocks");
-    constexpr int MBB = HALF ? MB / 2 : MB;             // row blocks per ring buffer
-    constexpr int NPIECE = 3 * MBB;                     // 1-KiB pieces per ring buffer
-    constexpr int TILEB = NPIECE * 1024;                // bytes per ring buffer
+    constexpr int NPIECE = 3 * MB;                      // 1-KiB pieces per stage
+    constexpr int TILEB = NPIECE * 1024;                // bytes per stage
     constexpr int NA = (NPIECE + NW - 1) / NW;          // direct-to-LDS loads per wave and stage (a surplus load repeats the last piece)
     constexpr int WGV = NW * 32;                        // voxels per work item
     constexpr int NXA = NX > 0 ? NX : 1;
@@ -823,7 +816,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     constexpr int FTAB = FOLD ? 2 * FKMAX * 4 + 4 * FSMAX * 4 + (FUSE ? 0 : 2 * FKMAX * 4) : 0;   // (a tile with pdf rows: + the row -> frame tables)
     constexpr int QTAB = FUSE ? NW * FQ_LIST + FQ_TABB : 0;   // fused peak scan: candidate lists + lookup tables
     constexpr int TRB = FUSE ? 4096 : 2048;                   // per-wave transposition tile(s) of the epilogue
-    static_assert(2 * TILEB + NW * TRB + XTAB + FTAB + QTAB == gemm3_lds_bytes<MB, NX, NW, FOLD, FUSE, HALF>(), "LDS carve-up");
+    static_assert(2 * TILEB + NW * TRB + XTAB + FTAB + QTAB == gemm3_lds_bytes<MB, NX, NW, FOLD, FUSE>(), "LDS carve-up");
     uint64_t *q_posoff = reinterpret_cast<uint64_t *>(lds + 2 * TILEB + NW * TRB + XTAB + FTAB + (FUSE ? NW * FQ_LIST : 0));   // [320] matrix row -> byte offset of its output row
     int *q_slotv = reinterpret_cast<int *>(q_posoff + FQ_NPOS);                                                                               // [2][161] (half, slot) -> vertex
     float *q_vl = reinterpret_cast<float *>(q_slotv + FQ_NSLOT);                                                   // [321][3]
@@ -894,8 +887,8 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     Work nxt = work_at(1);
     int32_t vraw_nxt = vidx_at(nxt);     // (clamped: always a valid address)
 
-    auto stage_A = [&](int tile_m, int t, int buf, int h = 0) {   // (HALF: half h of stage t)
-        const char *g = reinterpret_cast<const char *>(a.At3) + (((size_t)tile_m * ntiles + t) * (HALF ? 2 : 1) + h) * TILEB;
+    auto stage_A = [&](int tile_m, int t, int buf) {
+        const char *g = reinterpret_cast<const char *>(a.At3) + ((size_t)tile_m * ntiles + t) * TILEB;
         char *l = lds + buf * TILEB;
 #pragma unroll
         for (int i = 0; i < NA; i++) {
@@ -1003,8 +996,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();                                     // (also: the extra rows' table is complete)
     if (ANTI && early) split(cur.tile_m, 0);
-    int g = 0;                                           // ring buffers consumed: ring position
-    int items = 0;                                       // work items done
+    int g = 0;                                           // stages done: ring position
     FIB_STAMP_BEGIN();
     for (;;) {
         if constexpr (ONE) {
@@ -1014,7 +1006,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
             // nothing but speed depends on it (relaxed agent-scope accesses of a counter, no data is handed over).
             if (a.pair_role != 0) {
                 unsigned *flag = a.pair_flags + (blockIdx.x & 7) * 32 + a.one_slot;
-                const unsigned item = (unsigned)items + 1u;
+                const unsigned item = (unsigned)(g / ntiles) + 1u;
                 if (a.pair_role == 1) { if (tid == 0) __hip_atomic_store(flag, item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                 else {
                     if (tid == 0) {
@@ -1035,74 +1027,54 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
         // the middle of the stage loop, behind the next stage's loads: 11 % of the fused kernel, tools/check_loop_waits.py)
         bool inb_n = false; int64_t vox_n = 0; uint32_t s_off_n = 0;
         lane_state(nxt, vraw_nxt, inb_n, vox_n, s_off_n);
-        // the MFMAs of row blocks [m0, m0 + MBB) of a stage from ring buffer L.  The fragment reads are pinned (sched_barrier) 2-5 MFMAs
-        // ahead of their first use, each into the registers its predecessor has just left: left to itself hipcc sinks every
-        // ds_read to the MFMA that needs it.
-        auto mma_blocks = [&](auto m0_, const char *L) {
-            constexpr int m0 = decltype(m0_)::value;
-            const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, bp[0]), b1 = __builtin_bit_cast(bf16x8_t, bp[1]), b2 = __builtin_bit_cast(bf16x8_t, bp[2]);
-            const bf16x8_t *LA = reinterpret_cast<const bf16x8_t *>(L) + lane;
-            bf16x8_t a2 = LA[(2 * MBB) * 64], a1 = LA[(1 * MBB) * 64], a0 = LA[0];
-            if (prio) __builtin_amdgcn_s_setprio(2);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int m = 0; m < MBB; m++) {
-                bf16x8_t n2 = a2, n1 = a1, n0 = a0;
-                f32x16 &c = acc[m0 + m];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);     // smallest terms first
-                if (m + 1 < MBB) n2 = LA[(2 * MBB + m + 1) * 64];
-                __builtin_amdgcn_sched_barrier(0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
-                if (m + 1 < MBB) n0 = LA[(m + 1) * 64];
-                __builtin_amdgcn_sched_barrier(0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
-                if (m + 1 < MBB) n1 = LA[(1 * MBB + m + 1) * 64];
-                __builtin_amdgcn_sched_barrier(0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                a2 = n2; a1 = n1; a0 = n0;
-            }
-            if (prio) __builtin_amdgcn_s_setprio(0);
-        };
-        for (int t = 0; t < ntiles; t++) {
+        for (int t = 0; t < ntiles; t++, g++) {
+            const int cb = g & 1;
+            const char *L = lds + cb * TILEB;
             if (!(ANTI && early)) split(cur.tile_m, t);
             // the next stage (it may open the next work item): pieces into the other buffer, samples into braw
             const bool w1 = t + 1 < ntiles;
-            const int tm_n = w1 ? cur.tile_m : (nxt.valid ? nxt.tile_m : cur.tile_m);
-            if constexpr (HALF) {
-                stage_A(cur.tile_m, t, (g & 1) ^ 1, 1);  // this stage's second half of the row blocks
-                load_B(w1 ? t + 1 : 0, w1 ? s_off : s_off_n, w1 || nxt.valid);
-                __builtin_amdgcn_sched_barrier(0);      // the requests go out before the MFMA block, not after it
-                mma_blocks(std::integral_constant<int, 0>{}, lds + (g & 1) * TILEB);
-                __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
-                __syncthreads();
-                g++;
-                stage_A(tm_n, w1 ? t + 1 : 0, (g & 1) ^ 1, 0);
+            stage_A(w1 ? cur.tile_m : (nxt.valid ? nxt.tile_m : cur.tile_m), w1 ? t + 1 : 0, cb ^ 1);
+            load_B(w1 ? t + 1 : 0, w1 ? s_off : s_off_n, w1 || nxt.valid);
+            __builtin_amdgcn_sched_barrier(0);          // the requests go out before the MFMA block, not after it
+            const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, bp[0]), b1 = __builtin_bit_cast(bf16x8_t, bp[1]), b2 = __builtin_bit_cast(bf16x8_t, bp[2]);
+            const bf16x8_t *LA = reinterpret_cast<const bf16x8_t *>(L) + lane;
+            // The fragment reads are pinned (sched_barrier) 2-5 MFMAs ahead of their first use, each into the registers
+            // its predecessor has just left: left to itself hipcc sinks every ds_read to the MFMA that needs it.
+            bf16x8_t a2 = LA[(2 * MB) * 64], a1 = LA[(1 * MB) * 64], a0 = LA[0];
+            if (prio) __builtin_amdgcn_s_setprio(2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MB; m++) {
+                bf16x8_t n2 = a2, n1 = a1, n0 = a0;
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[m], 0, 0, 0);     // smallest terms first
+                if (m + 1 < MB) n2 = LA[(2 * MB + m + 1) * 64];
                 __builtin_amdgcn_sched_barrier(0);
-                mma_blocks(std::integral_constant<int, MBB>{}, lds + (g & 1) * TILEB);
-            } else {
-                stage_A(tm_n, w1 ? t + 1 : 0, (g & 1) ^ 1);
-                load_B(w1 ? t + 1 : 0, w1 ? s_off : s_off_n, w1 || nxt.valid);
-                __builtin_amdgcn_sched_barrier(0);      // the requests go out before the MFMA block, not after it
-                mma_blocks(std::integral_constant<int, 0>{}, lds + (g & 1) * TILEB);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[m], 0, 0, 0);
+                if (m + 1 < MB) n0 = LA[(m + 1) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[m], 0, 0, 0);
+                if (m + 1 < MB) n1 = LA[(1 * MB + m + 1) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                a2 = n2; a1 = n1; a0 = n0;
             }
             if constexpr (ANTI) {
+                if (prio) __builtin_amdgcn_s_setprio(0);
                 if (early) {                              // the samples requested above: the next stage's split, now
                     if (!w1) {                            // .. which opens the next work item: close this item's sums first
 #pragma unroll
                         for (int x = 0; x < NXA; x++) { xfin[x] = xacc[x]; xacc[x] = 0.0f; }
                         vmax_fin = vmax; vnf_fin = vnf; vmax = 0.0f; vnf = 0.0f;
                     }
-                    split(tm_n, w1 ? t + 1 : 0);
+                    split(w1 ? cur.tile_m : (nxt.valid ? nxt.tile_m : cur.tile_m), w1 ? t + 1 : 0);
                 }
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): the next stage's pieces and samples have landed
             __syncthreads();
-            g++;
         }
-        items++;
         {
             // the voxel's clamped-sample maximum over both k halves; vnf = NaN iff it is NaN or +Inf (the epilogues' "non-finite sample" flag)
             float vm = early ? vmax_fin : vmax;
@@ -1127,21 +1099,21 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
         }
         if (!nxt.valid) break;
         cur = nxt; inb = inb_n; vox = vox_n; s_off = s_off_n;
-        nxt = work_at(items + 1);
+        nxt = work_at(g / ntiles + 1);
         vraw_nxt = vidx_at(nxt);     // (clamped: always a valid address)
         clear(early);
     }
-    FIB_STAMP_END(ONE ? 8 : (HALF ? 9 : (FUSE ? 2 : (FOLD ? 3 : 1))), items);
+    FIB_STAMP_END(ONE ? 8 : (FUSE ? 2 : (FOLD ? 3 : 1)), g / ntiles);
     if constexpr (FUSE) {
         for (int off = 32; off >= 1; off >>= 1) { const unsigned oth = (unsigned)__shfl_xor((int)en_run, off); en_run = oth > en_run ? oth : en_run; }
         if (lane == 0 && en_run) atomicMax(&a.maxenc[2], en_run);
     }
 }
 
-template <int MB, int NX, int NW, bool FOLD = false, bool FUSE = false, bool HALF = false>
+template <int MB, int NX, int NW, bool FOLD = false, bool FUSE = false>
 __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) char lds[gemm3_lds_bytes<MB, NX, NW, FOLD, FUSE, HALF>()];
-    gemm3_body<MB, NX, NW, FOLD, FUSE, false, HALF>(a, lds);
+    __shared__ __attribute__((aligned(16))) char lds[gemm3_lds_bytes<MB, NX, NW, FOLD, FUSE>()];
+    gemm3_body<MB, NX, NW, FOLD, FUSE>(a, lds);
 }
 
 // ---- K5, DSI on sphere_642 with an antipodally symmetric lattice (config 5): dsi.jl:204-258 in ONE launch ------------------------------
@@ -2130,7 +2102,6 @@ struct fib_odf_plan {
     fib::DevBuf<uint16_t> At3b;                      // image of the pdf tile (the ODF tile's image / pole row: At3f / Aextraf)
     mutable fib::DevBuf<unsigned> pair_flags;        // item counters of the ODF-tile workgroups (odf_dsi2_kernel's pairing hint)
     fib::DevBuf<uint16_t> At3f;                      // split-bf16 image with the rows in the order of sphere642_fused.inc
-    fib::DevBuf<uint16_t> At3h;                      // .. in half-stage layout (gemm3_body HALF)
     fib::DevBuf<float> Aextraf;                      // its extra row (the pole of the layout's rotation)
     mutable fib::DevBuf<float> mean_hi;              // [nvox] per-voxel upper bound of the mean (fused path)
     mutable fib::DevBuf<int32_t> redo_list;          // [nvox] voxels left to odf_redo_kernel
@@ -2191,7 +2162,6 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
         };
         auto bf16_f = [](uint16_t h) -> float { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
         // image row `row` of the kernel holds row rowmap[row] of G (identity, or the layout of the fused peak scan)
-        bool half_layout = false;                              // [stage][half][piece][block of the half] instead of [stage][piece][block]
         auto build = [&](const short *rowmap, std::vector<uint16_t> &A3, std::vector<float> &AX) {
             A3.assign((size_t)p->ntile_m * nst * npiece * 512, 0);
             AX.assign((size_t)std::max(1, p->ntile_m * p->NX * p->Kpad), 0.0f);
@@ -2210,10 +2180,7 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
                                 const float r2 = r1 - bf16_f(h2);
                                 const uint16_t h3 = bf16_rn(r2);
                                 const uint16_t hs[3] = {h1, h2, h3};
-                                const int mbh = p->MB / 2, hf = half_layout && m >= mbh;
-                                for (int pc = 0; pc < 3; pc++)
-                                    st[half_layout ? (size_t)hf * 3 * mbh * 512 + ((size_t)(pc * mbh + (m - hf * mbh)) * 64 + l) * 8 + j
-                                                   : ((size_t)(pc * p->MB + m) * 64 + l) * 8 + j] = hs[pc];
+                                for (int pc = 0; pc < 3; pc++) st[((size_t)(pc * p->MB + m) * 64 + l) * 8 + j] = hs[pc];
                             }
                 }
                 for (int x = 0; x < p->NX; x++)
@@ -2279,11 +2246,6 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
             if ((rc3 = p->At3f.alloc(A3.size())) != FIB_OK || (rc3 = p->Aextraf.alloc(AX.size())) != FIB_OK) return rc3;
             FIB_HIP(hipMemcpy(p->At3f.p, A3.data(), A3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             FIB_HIP(hipMemcpy(p->Aextraf.p, AX.data(), AX.size() * sizeof(float), hipMemcpyHostToDevice));
-            half_layout = true;                                 // .. and the same in half-stage layout (two 4-wave workgroups per CU)
-            build(fib_f642_pos_vertex, A3, AX);
-            half_layout = false;
-            if ((rc3 = p->At3h.alloc(A3.size())) != FIB_OK) return rc3;
-            FIB_HIP(hipMemcpy(p->At3h.p, A3.data(), A3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         }
     }
     std::vector<int32_t> nbr32;
@@ -2475,13 +2437,6 @@ void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
             return;
         }
         if constexpr (MB == 10 && NX == 1) {
-            if (ga.mean_hi && ga.half_ring) {             // two independent 4-wave workgroups per CU on half-stage ring buffers
-                const int64_t items4 = fib::cdiv(ga.nvox, 4 * 32);
-                unsigned pg4 = (unsigned)std::min<int64_t>((int64_t)ncu * 2, items4);
-                pg4 = (pg4 + 7) / 8 * 8;
-                hipLaunchKernelGGL((odf_gemm3_kernel<10, 1, 4, false, true, true>), dim3(pg4), dim3(256), 0, st, g2);
-                return;
-            }
             if (ga.mean_hi) { hipLaunchKernelGGL((odf_gemm3_kernel<10, 1, 8, false, true>), dim3(pg), dim3(512), 0, st, g2); return; }
         }
         hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 8>), dim3(pg), dim3(512), 0, st, g2);
@@ -2608,14 +2563,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         { const char *pa = getenv("FIBERS_ODF_ANTI"); ga.anti = pa ? atoi(pa) : 3; }   // bit 0: anti-phase wave halves, bit 1: s_setprio around the MFMA block (default both; 0 = neither)
         return FIB_OK;
     };
-    if (fuse) {
-        int rcf = setup_fused();
-        if (rcf != FIB_OK) return rcf;
-        // default: two independent 4-wave workgroups per CU on half-stage ring buffers (one's epilogue beside the other's MFMA blocks:
-        // 11 % faster than one 8-wave workgroup, bit-identical, tools/half_ab.py); FIBERS_ODF_HALF=0 keeps the 8-wave kernel
-        const char *eh = getenv("FIBERS_ODF_HALF");
-        if (plan->At3h.p && !(eh && eh[0] == '0')) { ga.At3 = plan->At3h.p; ga.half_ring = 1; }
-    }
+    if (fuse) { int rcf = setup_fused(); if (rcf != FIB_OK) return rcf; }
     ga.K = plan->gK; ga.Kpad = plan->Kpad; ga.M = plan->gM; ga.nrow0 = plan->gRow0; ga.ntile_m = plan->ntile_m;
     const bool fold_ok = plan->folded && ga.At3 != nullptr && plan->Kpad <= FKMAX && plan->scale_frame_raw >= 0 &&
                          (int64_t)plan->fold_span_max * nvox * 4 < (int64_t)0xE0000000ll && !getenv("FIBERS_DSI_UNFUSED");

@@ -130,11 +130,9 @@ def test_c3_gqi_140cubed(fj, orc, dev):
     _odf_properties(fj, out, mask, plan, dwi, dev, 4.0)
 
 
-@pytest.mark.parametrize("env,val", [("FIBERS_ODF_HALF", "0"), ("FIBERS_ODF_ANTI", "0")])
+@pytest.mark.parametrize("env,val", [("FIBERS_ODF_ANTI", "0")])
 def test_c3_gqi_kernel_variants_bit_identical_140cubed(fj, dev, monkeypatch, env, val):
-    """the fused GQI kernel as one 8-wave workgroup per CU (FIBERS_ODF_HALF=0; with and without its anti-phase wave halves) against
-    the default form (two independent 4-wave workgroups per CU on half-stage ring buffers) on the full 140^3 x 270 volume (ball
-    mask: partial work items, workgroups with different item counts): every output bit"""
+    """the fused GQI kernel without its anti-phase wave halves against the default kernel on the full 140^3 x 270 volume (ball mask: partial work items, workgroups with different item counts): every output bit"""
     import torch
     from fibers_jl_amd import phantom
     bval, bvec = phantom.scheme_gqi()
@@ -145,7 +143,6 @@ def test_c3_gqi_kernel_variants_bit_identical_140cubed(fj, dev, monkeypatch, env
     for on in (False, True):
         if on:
             monkeypatch.setenv(env, val)
-            monkeypatch.setenv("FIBERS_ODF_HALF", "0")          # (the anti-phase switch belongs to the 8-wave kernel)
         o = fj.odf_rec_device(plan, dwi, mask)
         torch.cuda.synchronize()
         res.append([o["odf"].clone()] + [t.clone() for t in o["peak"]] + [t.clone() for t in o["qa"]] + [o["odfmax"].clone()])
