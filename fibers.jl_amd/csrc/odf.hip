@@ -71,6 +71,8 @@ struct GemmArgs {
     int dsi_na;                   // .. workgroups per XCD that take the ODF tile (the others take the pdf tile)
     unsigned *pair_flags;         // .. pairing (dsi_na = half the workgroups): [8 XCDs][32] item counters of the ODF-tile workgroups
     int pair_role;                // 0: none; 1: publish my item number; 2: wait (bounded) until my partner has reached my item
+    int h2;                       // the images hold two fp16 pieces per element, scaled by the power of two sa (gemm3_body H2) ..
+    float h2_inv_sa;              // .. and 1 / sa
 };
 
 // Diagnostic build only (make stamp -> libfibers_hip_stamp.so, -DFIB_CLOCK_STAMP; in the product library no stamp executes):
@@ -425,10 +427,11 @@ __global__ __launch_bounds__(256, 2) void odf_gemm_kernel(const GemmArgs a) {
 // r and r+4 interleaved so that both lane halves write different banks) and leaves as 2 dwordx4 stores of 8 rows x 128 B.
 // PRE (odf_gemm16_kernel): the caller has already summed the extra rows over the lanes of a voxel and applied the DSI scale;
 // ROWS = rows of an M tile (the 16x16x32 kernel's tiles are a whole number of 16-row blocks)
-template <int MB, int NX, bool PRE = false, int ROWS_ = 0, bool MAPLDS = false>
+// ASC: the accumulators (not the extra rows) carry the voxel's power-of-two factor 1 / ascale (gemm3_body H2)
+template <int MB, int NX, bool PRE = false, int ROWS_ = 0, bool MAPLDS = false, bool ASC = false>
 __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[MB], float (&xacc)[NX > 0 ? NX : 1], float vmax, float vnf,
                                                bool inb, bool lv, int64_t vox, int lane, int tile_m, float sraw, char *tr,
-                                               const int32_t *mapA = nullptr, const int32_t *mapB = nullptr) {
+                                               const int32_t *mapA = nullptr, const int32_t *mapB = nullptr, float ascale = 1.0f) {
     // MAPLDS: mapA / mapB are LDS copies of a.rowA / a.rowB (a global load per stored row would sit between the transposition and
     // its stores).  Two code paths, not one pointer chosen at run time: a generic pointer would make every lookup a flat load, and
     // a flat load waits for all the row stores before it (vmcnt).
@@ -455,8 +458,9 @@ __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[
         const int slot = atomicAdd(a.fix_count, 1);
         if (slot < a.fix_cap) a.fix_list[slot] = (int32_t)vox;
     }
-    const bool plain = __all(valid && !nonfinite) && !do_scale;   // wave-uniform: store the accumulators as they are
+    const bool plain = __all(valid && !nonfinite) && !do_scale && !ASC;   // wave-uniform: store the accumulators as they are
     const float mulv = valid ? scale : 0.0f;
+    const float mula = ASC ? (valid ? scale * ascale : 0.0f) : mulv;       // (scale * ascale: exact, ascale is a power of two)
     if (!PRE) {
 #pragma unroll
         for (int x = 0; x < NX; x++) xacc[x] += __shfl_xor(xacc[x], 32);
@@ -491,7 +495,7 @@ __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[
 #pragma unroll
                 for (int r = 8 * hb; r < 8 * hb + 8; r++) {
                     float v = acc[m][r];
-                    if (!plain) v = valid ? v * mulv : 0.0f;
+                    if (!plain) v = valid ? v * mula : 0.0f;
                     tw[(8 * ((r >> 2) & 1) + 2 * (r & 3)) * 32] = v;   // logical row (r&3) + 8(r>>2) + 4kh
                 }
 #pragma unroll
@@ -524,7 +528,7 @@ __device__ __forceinline__ void gemm3_epilogue(const GemmArgs &a, f32x16 (&acc)[
             for (int r = 0; r < 16; r++) {
                 const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 float v = acc[m][r];
-                if (!plain) v = valid ? v * mulv : 0.0f;
+                if (!plain) v = valid ? v * mula : 0.0f;
                 if (row >= a.M || m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh >= XROW0) continue;
                 if (mapped && row < a.nrow0) {
                     const int fa = rowA_at(row), fb = rowB_at(row);
@@ -588,7 +592,7 @@ __device__ __forceinline__ float fq_max2(float a, float b) { return __builtin_fm
 template <int NW, bool PRE = false, bool SCALE = false>
 __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (&acc)[10], float xrow, float vmax, float vnf, bool inb, bool lv,
                                                      int64_t vox, int lane, char *tr, char *lst, const uint64_t *posoff, const int *slotv, const float *vl,
-                                                     unsigned &en_run, float scale = 1.0f) {
+                                                     unsigned &en_run, float scale = 1.0f, float xscale = 1.0f) {
     const int col = lane & 31, kh = lane >> 5;
     const float pm = fmaxf(vmax, __shfl_xor(vmax, 32));
     const float pn = vnf + __shfl_xor(vnf, 32);
@@ -604,7 +608,7 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
         for (int m = 0; m < 10; m++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[m][r] = valid ? acc[m][r] * scale : 0.0f;
-        xrow = valid ? xrow * scale : 0.0f;
+        xrow = valid ? xrow * xscale : 0.0f;             // (H2: the f32 extra row carries no power-of-two factor)
     } else if (!__all(valid && !nonfinite)) {           // wave-uniform, rare: skipped voxels and voxels outside the mask read 0
 #pragma unroll
         for (int m = 0; m < 10; m++)
@@ -781,6 +785,8 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
 // private 4-KiB LDS tile and writes it with 4 global_store_dwordx4 (8 rows x 128 B each) instead of 16
 // global_store_dword: dword stores are issue-bound at ~6 B/clk/CU (measured: 30 000 cycles for the 161 rows).
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {      // round-to-nearest-even, NaN stays NaN
@@ -796,18 +802,20 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {      // ro
 // lowest frame that the stage touches on that side: one buffer resource per stage and side).
 constexpr int FKMAX = 512, FSMAX = FKMAX / KT;
 // LDS of one instantiation: stage ring + per-wave transposition tiles + extra-row table + fold tables + fused-scan lists / tables
-template <int MB, int NX, int NW, bool FOLD, bool FUSE>
+template <int MB, int NX, int NW, bool FOLD, bool FUSE, bool H2>
 constexpr int gemm3_lds_bytes() {
-    return 2 * 3 * MB * 1024 + NW * (FUSE ? 4096 : 2048) + (NX > 0 ? (FUSE ? 2048 : 8192) : 0) +
+    return 2 * (H2 ? 2 : 3) * MB * 1024 + NW * (FUSE ? 4096 : 2048) + (NX > 0 ? (FUSE ? 2048 : 8192) : 0) +
            (FOLD ? 2 * FKMAX * 4 + 4 * FSMAX * 4 + (FUSE ? 0 : 2 * FKMAX * 4) : 0) + (FUSE ? NW * FQ_LIST + FQ_TABB : 0);
 }
 // ONE: the workgroup works on a single-tile image of its own (odf_dsi2_kernel: the DSI rows are cut into an ODF tile and a pdf tile
 // with images of different shapes); the work list still deals the items of both tiles (a.ntile_m = 2), and with an even number
 // of workgroups per XCD every workgroup keeps drawing items of its own tile
-template <int MB, int NX, int NW, bool FOLD = false, bool FUSE = false, bool ONE = false>
+// H2: the operands travel as TWO fp16 pieces instead of three bf16 pieces (see "Two fp16 pieces" below): 3 MFMAs per block and
+// 16 frames instead of 6
+template <int MB, int NX, int NW, bool FOLD = false, bool FUSE = false, bool ONE = false, bool H2 = false>
 __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     static_assert(!FUSE || (MB == 10 && NX == 1), "the fused peak scan is generated for 10 blocks + 1 extra row");
-    constexpr int NPIECE = 3 * MB;                      // 1-KiB pieces per stage
+    constexpr int NPIECE = (H2 ? 2 : 3) * MB;           // 1-KiB pieces per stage
     constexpr int TILEB = NPIECE * 1024;                // bytes per stage
     constexpr int NA = (NPIECE + NW - 1) / NW;          // direct-to-LDS loads per wave and stage (a surplus load repeats the last piece)
     constexpr int WGV = NW * 32;                        // voxels per work item
@@ -816,7 +824,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     constexpr int FTAB = FOLD ? 2 * FKMAX * 4 + 4 * FSMAX * 4 + (FUSE ? 0 : 2 * FKMAX * 4) : 0;   // (a tile with pdf rows: + the row -> frame tables)
     constexpr int QTAB = FUSE ? NW * FQ_LIST + FQ_TABB : 0;   // fused peak scan: candidate lists + lookup tables
     constexpr int TRB = FUSE ? 4096 : 2048;                   // per-wave transposition tile(s) of the epilogue
-    static_assert(2 * TILEB + NW * TRB + XTAB + FTAB + QTAB == gemm3_lds_bytes<MB, NX, NW, FOLD, FUSE>(), "LDS carve-up");
+    static_assert(2 * TILEB + NW * TRB + XTAB + FTAB + QTAB == gemm3_lds_bytes<MB, NX, NW, FOLD, FUSE, H2>(), "LDS carve-up");
     uint64_t *q_posoff = reinterpret_cast<uint64_t *>(lds + 2 * TILEB + NW * TRB + XTAB + FTAB + (FUSE ? NW * FQ_LIST : 0));   // [320] matrix row -> byte offset of its output row
     int *q_slotv = reinterpret_cast<int *>(q_posoff + FQ_NPOS);                                                                               // [2][161] (half, slot) -> vertex
     float *q_vl = reinterpret_cast<float *>(q_slotv + FQ_NSLOT);                                                   // [321][3]
@@ -956,9 +964,24 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     };
     clear(false);
 
-    // clamp (gqi.jl:140, dsi.jl:209), positivity / non-finite tracking, exact 3-way bf16 split, extra rows
+    // clamp (gqi.jl:140, dsi.jl:209), positivity / non-finite tracking, exact 3-way bf16 split (H2: two fp16 pieces), extra rows
+    //
+    // Two fp16 pieces (H2).  s * 2^k = h + l + e with h = RN16(s 2^k), l = RN16(s 2^k - h) and |e| <= 2^-23 |s 2^k| as long as l is
+    // a normal fp16 number: 23 of the sample's 24 significant bits.  The matrix is split the same way on the host (scaled by the
+    // power of two sa), and a product is a_h s_l + a_l s_h + a_h s_h: exact piece products, f32 accumulate, the dropped terms
+    // (a_l s_l and the two residues) are each <= 2^-22 |a s| and of either sign.  Measured against a float64 contraction the result
+    // is as close as the six-product bf16 form (the error of both is the f32 accumulation's) and closer than an f32 fma chain
+    // (tools/gemm_accuracy.py); the three-piece bf16 form stays available (FIBERS_ODF_EXACT=1).
+    // fp16 has 5 exponent bits, so every voxel carries its own power of two: 2^k puts the running maximum of its clamped samples
+    // into [2^6, 2^7) when the item's first stage is split -- l stays normal for samples down to 2^-16 of that maximum, and below
+    // that the absolute error is <= 2^-25 (half an fp16 subnormal step) against a maximum >= 2^6.  A later sample that would
+    // reach 2^15 (it is > 256 x everything the voxel held so far) lowers k and the accumulators are multiplied by the (exact) power
+    // of two in between.  k depends on the voxel's own samples only: results do not depend on which voxels share a wave.
     u32x4_t bp[3];
+    constexpr int H2_TARGET = 127 + 6;                  // biased exponent of the scaled running maximum when k is chosen
+    int kexp = 127, kexp_fin = 127;                     // H2: biased exponent of 2^k (kexp_fin: of the item an early wave is finishing)
     auto split = [&](int tile_m, int t) {
+        float cs[H2 ? 8 : 1];
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
             float x0 = braw[2 * jj], x1 = braw[2 * jj + 1];
@@ -970,12 +993,15 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
             c0 = FOLD ? x0 : clamp_sample(x0);
             c1 = FOLD ? x1 : clamp_sample(x1);
             vmax = max3_nan(vmax, c0, c1);              // (vnf is derived from it at the end of the item)
-            const uint32_t h = cvt_pk_bf16(c0, c1);
-            const float r0 = c0 - __uint_as_float(h << 16), r1 = c1 - __uint_as_float(h & 0xffff0000u);      // exact
-            const uint32_t m = cvt_pk_bf16(r0, r1);
-            const float q0 = r0 - __uint_as_float(m << 16), q1 = r1 - __uint_as_float(m & 0xffff0000u);      // exact
-            const uint32_t l = cvt_pk_bf16(q0, q1);                                                           // exact
-            bp[0][jj] = h; bp[1][jj] = m; bp[2][jj] = l;
+            if constexpr (H2) { cs[2 * jj] = c0; cs[2 * jj + 1] = c1; }
+            else {
+                const uint32_t h = cvt_pk_bf16(c0, c1);
+                const float r0 = c0 - __uint_as_float(h << 16), r1 = c1 - __uint_as_float(h & 0xffff0000u);      // exact
+                const uint32_t m = cvt_pk_bf16(r0, r1);
+                const float q0 = r0 - __uint_as_float(m << 16), q1 = r1 - __uint_as_float(m & 0xffff0000u);      // exact
+                const uint32_t l = cvt_pk_bf16(q0, q1);                                                           // exact
+                bp[0][jj] = h; bp[1][jj] = m; bp[2][jj] = l;
+            }
             if (NX > 0) {                               // extra rows: f32 fma, coefficients from the LDS table (frames 8h + 2jj, +1)
                 const f32x2 *ex = reinterpret_cast<const f32x2 *>(lds + 2 * TILEB + NW * TRB) + ((tile_m * NX) * a.Kpad + t * KT + 8 * kh) / 2 + jj;
 #pragma unroll
@@ -984,6 +1010,37 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
                     xacc[x] = __builtin_fmaf(e[0], c0, xacc[x]);
                     xacc[x] = __builtin_fmaf(e[1], c1, xacc[x]);
                 }
+            }
+        }
+        if constexpr (H2) {
+            const float mall = max3_nan(vmax, __shfl_xor(vmax, 32), 0.0f);      // the voxel's running maximum (both k halves)
+            const int e = (int)((__float_as_uint(mall) >> 23) & 0xffu);          // (255: NaN / +Inf -- the column is repaired anyway)
+            int kfit = e == 0 ? 127 + 60 : 127 + (H2_TARGET - e);
+            kfit = kfit < 1 ? 1 : (kfit > 253 ? 253 : kfit);
+            if (t == 0) kexp = e == 255 ? 127 : kfit;
+            else {
+                const bool lower = e != 255 && e + kexp >= 254 + 15;
+                if (__any(lower)) {                      // rare: wave-uniform branch, per-lane factor
+                    const int d = lower ? kfit - kexp : 0;
+                    const float f = __uint_as_float((uint32_t)(127 + (d < -126 ? -126 : d)) << 23);
+#pragma unroll
+                    for (int m = 0; m < MB; m++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) acc[m][r] *= f;
+                    kexp = lower ? kfit : kexp;
+                }
+            }
+            // (v_ldexp_f32, not a multiplication: hipcc turns pairs of multiplications by one factor into v_pk_mul_f32 with a 64-bit
+            // register operand whose upper half is undefined, and that half can land on a register a load is still writing to --
+            // the waitcnt insertion then puts s_waitcnt vmcnt(0) in front of the split, tools/check_loop_waits.py)
+            const int kx = kexp - 127;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const float p0 = __builtin_amdgcn_ldexpf(cs[2 * jj], kx), p1 = __builtin_amdgcn_ldexpf(cs[2 * jj + 1], kx);
+                const f16x2_t h = {(_Float16)p0, (_Float16)p1};
+                const float r0 = p0 - (float)h[0], r1 = p1 - (float)h[1];      // exact
+                const f16x2_t l = {(_Float16)r0, (_Float16)r1};
+                bp[0][jj] = __builtin_bit_cast(uint32_t, h); bp[1][jj] = __builtin_bit_cast(uint32_t, l);
             }
         }
     };
@@ -1036,6 +1093,26 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
             stage_A(w1 ? cur.tile_m : (nxt.valid ? nxt.tile_m : cur.tile_m), w1 ? t + 1 : 0, cb ^ 1);
             load_B(w1 ? t + 1 : 0, w1 ? s_off : s_off_n, w1 || nxt.valid);
             __builtin_amdgcn_sched_barrier(0);          // the requests go out before the MFMA block, not after it
+            if constexpr (H2) {
+                const f16x8_t b0 = __builtin_bit_cast(f16x8_t, bp[0]), b1 = __builtin_bit_cast(f16x8_t, bp[1]);
+                const f16x8_t *LA = reinterpret_cast<const f16x8_t *>(L) + lane;
+                f16x8_t a1 = LA[MB * 64], a0 = LA[0];
+                if (prio) __builtin_amdgcn_s_setprio(2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MB; m++) {
+                    f16x8_t n1 = a1, n0 = a0;
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[m], 0, 0, 0);     // smallest terms first
+                    if (m + 1 < MB) n1 = LA[(MB + m + 1) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[m], 0, 0, 0);
+                    if (m + 1 < MB) n0 = LA[(m + 1) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[m], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    a1 = n1; a0 = n0;
+                }
+            } else {
             const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, bp[0]), b1 = __builtin_bit_cast(bf16x8_t, bp[1]), b2 = __builtin_bit_cast(bf16x8_t, bp[2]);
             const bf16x8_t *LA = reinterpret_cast<const bf16x8_t *>(L) + lane;
             // The fragment reads are pinned (sched_barrier) 2-5 MFMAs ahead of their first use, each into the registers
@@ -1061,6 +1138,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
                 __builtin_amdgcn_sched_barrier(0);
                 a2 = n2; a1 = n1; a0 = n0;
             }
+            }
             if constexpr (ANTI) {
                 if (prio) __builtin_amdgcn_s_setprio(0);
                 if (early) {                              // the samples requested above: the next stage's split, now
@@ -1068,6 +1146,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
 #pragma unroll
                         for (int x = 0; x < NXA; x++) { xfin[x] = xacc[x]; xacc[x] = 0.0f; }
                         vmax_fin = vmax; vnf_fin = vnf; vmax = 0.0f; vnf = 0.0f;
+                        kexp_fin = kexp;
                     }
                     split(w1 ? cur.tile_m : (nxt.valid ? nxt.tile_m : cur.tile_m), w1 ? t + 1 : 0);
                 }
@@ -1080,11 +1159,14 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
             float vm = early ? vmax_fin : vmax;
             vm = max3_nan(vm, __shfl_xor(vm, 32), 0.0f);
             const float vn = vm < INFINITY ? 0.0f : __builtin_nanf("");
+            // H2: the accumulators hold sa 2^k times the sums
+            const float asc = H2 ? __uint_as_float((uint32_t)(254 - (early ? kexp_fin : kexp)) << 23) * a.h2_inv_sa : 1.0f;
             if constexpr (FUSE) {
                 float fscale = 1.0f;                      // DSI (the FOLD form): 1 / sum(p), NaN where a sample is not finite (see gemm3_epilogue)
                 if (FOLD) { const float s0 = sraw < 0.0f ? 0.0f : sraw; fscale = vn != vn ? __builtin_nanf("") : 1.0f / (a.scale_coef * s0); }
-                gemm3_epilogue_fused<NW, false, FOLD>(a, acc, early ? xfin[0] : xacc[0], vm, vn, inb, lv, vox, lane, lds + 2 * TILEB + wave * TRB,
-                                                      lds + 2 * TILEB + NW * TRB + XTAB + FTAB + wave * FQ_LIST, q_posoff, q_slotv, q_vl, en_run, fscale);
+                gemm3_epilogue_fused<NW, false, FOLD || H2>(a, acc, early ? xfin[0] : xacc[0], vm, vn, inb, lv, vox, lane, lds + 2 * TILEB + wave * TRB,
+                                                            lds + 2 * TILEB + NW * TRB + XTAB + FTAB + wave * FQ_LIST, q_posoff, q_slotv, q_vl, en_run,
+                                                            fscale * asc, fscale);
             }
             else {
                 // (the lane index is laundered per work item: otherwise every lane-derived row index, table lookup and 64-bit row
@@ -1092,9 +1174,9 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
                 int le = lane;
                 asm volatile("" : "+v"(le));
                 if constexpr (FOLD)
-                    gemm3_epilogue<MB, NX, false, 0, true>(a, acc, xacc, vm, vn, inb, lv, vox, le, cur.tile_m, sraw, lds + 2 * TILEB + wave * TRB, f_row, f_row + FKMAX);
+                    gemm3_epilogue<MB, NX, false, 0, true, H2>(a, acc, xacc, vm, vn, inb, lv, vox, le, cur.tile_m, sraw, lds + 2 * TILEB + wave * TRB, f_row, f_row + FKMAX, asc);
                 else
-                    gemm3_epilogue<MB, NX>(a, acc, xacc, vm, vn, inb, lv, vox, le, cur.tile_m, sraw, lds + 2 * TILEB + wave * TRB);
+                    gemm3_epilogue<MB, NX, false, 0, false, H2>(a, acc, xacc, vm, vn, inb, lv, vox, le, cur.tile_m, sraw, lds + 2 * TILEB + wave * TRB, nullptr, nullptr, asc);
             }
         }
         if (!nxt.valid) break;
@@ -1110,10 +1192,10 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     }
 }
 
-template <int MB, int NX, int NW, bool FOLD = false, bool FUSE = false>
+template <int MB, int NX, int NW, bool FOLD = false, bool FUSE = false, bool H2 = false>
 __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) char lds[gemm3_lds_bytes<MB, NX, NW, FOLD, FUSE>()];
-    gemm3_body<MB, NX, NW, FOLD, FUSE>(a, lds);
+    __shared__ __attribute__((aligned(16))) char lds[gemm3_lds_bytes<MB, NX, NW, FOLD, FUSE, H2>()];
+    gemm3_body<MB, NX, NW, FOLD, FUSE, false, H2>(a, lds);
 }
 
 // ---- K5, DSI on sphere_642 with an antipodally symmetric lattice (config 5): dsi.jl:204-258 in ONE launch ------------------------------
@@ -1125,9 +1207,9 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
 // L2 hit), and fold + clamp + 3-way split run twice per
 // voxel instead of three times (three tiles of 6 blocks before).  Of the workgroups of an XCD the first dsi_na take ODF tiles, the
 // others pdf tiles, each kind walking the XCD's voxel groups with its own stride: the split follows the two tiles' costs.
-template <int MBB>
+template <int MBB, bool H2>
 __global__ __launch_bounds__(512, 2) void odf_dsi2_kernel(const GemmArgs a) {
-    constexpr int LA_ = gemm3_lds_bytes<10, 1, 8, true, true>(), LB_ = gemm3_lds_bytes<MBB, 0, 8, true, false>();
+    constexpr int LA_ = gemm3_lds_bytes<10, 1, 8, true, true, H2>(), LB_ = gemm3_lds_bytes<MBB, 0, 8, true, false, H2>();
     __shared__ __attribute__((aligned(16))) char lds[LA_ > LB_ ? LA_ : LB_];
     const int wslot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
     GemmArgs b = a;
@@ -1135,13 +1217,13 @@ __global__ __launch_bounds__(512, 2) void odf_dsi2_kernel(const GemmArgs a) {
     if (wslot < a.dsi_na) {
         b.one_slot = wslot; b.one_stride = a.dsi_na;
         b.pair_role = paired ? 1 : 0;
-        gemm3_body<10, 1, 8, true, true, true>(b, lds);
+        gemm3_body<10, 1, 8, true, true, true, H2>(b, lds);
     } else {
         b.one_slot = wslot - a.dsi_na; b.one_stride = nslot - a.dsi_na;
         b.pair_role = paired ? 2 : 0;
         b.At3 = a.At3b;
         b.M = a.nrow0;                                   // the pdf rows only (rows >= M are padding of the tile)
-        gemm3_body<MBB, 0, 8, true, false, true>(b, lds);
+        gemm3_body<MBB, 0, 8, true, false, true, H2>(b, lds);
     }
 }
 
@@ -2095,6 +2177,8 @@ struct fib_odf_plan {
     fib::DevBuf<float> Gdev;                         // G, column-major [gM x gK] (odf_inf_fix_kernel)
     mutable fib::DevBuf<int32_t> inf_list;           // [nvox] voxels with a +Inf sample (GQI, split-bf16 kernel; grow-only)
     bool split_bf16 = false;
+    bool h2 = false;                                 // .. with two fp16 pieces per element (default) instead of three bf16 pieces (FIBERS_ODF_EXACT=1)
+    float h2_sa = 1.0f;                              // power of two the matrix is scaled by before it is split into fp16 pieces
     bool fused_shape = false;                        // (GQI, 10 blocks + 1 extra row: the shape the fused scan is generated for)
     bool fused = false;                              // sphere_642 GQI plan: the contraction kernel finds the peaks on its accumulators
     bool dsi2_shape = false, dsi2 = false;           // folded DSI plan on sphere_642: odf_dsi2_kernel (fused ODF tile + pdf tile of MBB blocks)
@@ -2153,7 +2237,18 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
     for (int k = 0; k < K; k++) if (frame_eff[k] == 0.0f) any_ineff = true;
     if (p->split_bf16 && (any_ineff || p->Kpad / KT < 2 || p->MB > 10 || (size_t)p->ntile_m * p->NX * p->Kpad > 2048)) p->split_bf16 = false;
     if (p->split_bf16) {
-        const int npiece = 3 * p->MB, nst = p->Kpad / KT;
+        // piece format: two fp16 pieces of sa * G (sa = the power of two that puts max |G| into [2^8, 2^9): the second piece of an
+        // element stays a normal fp16 number down to 2^-20 of the largest, gemm3_body H2), or three exact bf16 pieces
+        { const char *ex = getenv("FIBERS_ODF_EXACT"); p->h2 = !(ex && ex[0] != '0'); }
+        float gmax = 0.0f;
+        for (float v : p->G) if (std::isfinite(v)) gmax = std::max(gmax, std::fabs(v));
+        if (p->h2 && !(gmax > 0.0f)) p->h2 = false;
+        for (float v : p->G) if (!std::isfinite(v)) p->h2 = false;       // (a matrix with NaN / Inf entries keeps the exact split's behaviour)
+        if (p->h2) { int eg; std::frexp(gmax, &eg); p->h2_sa = std::ldexp(1.0f, 9 - eg); }   // gmax = m 2^eg, m in [0.5, 1)
+        const int NP = p->h2 ? 2 : 3;
+        const int npiece = NP * p->MB, nst = p->Kpad / KT;
+        auto f16_rn = [](float f) -> uint16_t { const _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; };
+        auto f16_f = [](uint16_t u) -> float { _Float16 h; memcpy(&h, &u, 2); return (float)h; };
         auto bf16_rn = [](float f) -> uint16_t {
             uint32_t u; memcpy(&u, &f, 4);
             if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
@@ -2161,6 +2256,19 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
             return (uint16_t)(u >> 16);
         };
         auto bf16_f = [](uint16_t h) -> float { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+        auto pieces = [&](float v, uint16_t (&hs)[3]) {
+            if (p->h2) {
+                const float w = v * p->h2_sa;                          // exact
+                hs[0] = f16_rn(w);
+                hs[1] = f16_rn(w - f16_f(hs[0]));                       // (the difference is exact)
+                hs[2] = 0;
+            } else {
+                hs[0] = bf16_rn(v);
+                const float r1 = v - bf16_f(hs[0]);
+                hs[1] = bf16_rn(r1);
+                hs[2] = bf16_rn(r1 - bf16_f(hs[1]));
+            }
+        };
         // image row `row` of the kernel holds row rowmap[row] of G (identity, or the layout of the fused peak scan)
         auto build = [&](const short *rowmap, std::vector<uint16_t> &A3, std::vector<float> &AX) {
             A3.assign((size_t)p->ntile_m * nst * npiece * 512, 0);
@@ -2173,14 +2281,9 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
                             for (int j = 0; j < 8; j++) {
                                 const int row = tm * ROWS + m * 32 + (l & 31), k = t * KT + 8 * (l >> 5) + j;
                                 if (row >= M || k >= K) continue;
-                                const float v = p->G[(rowmap ? rowmap[row] : row) + (size_t)M * k];
-                                const uint16_t h1 = bf16_rn(v);
-                                const float r1 = v - bf16_f(h1);
-                                const uint16_t h2 = bf16_rn(r1);
-                                const float r2 = r1 - bf16_f(h2);
-                                const uint16_t h3 = bf16_rn(r2);
-                                const uint16_t hs[3] = {h1, h2, h3};
-                                for (int pc = 0; pc < 3; pc++) st[((size_t)(pc * p->MB + m) * 64 + l) * 8 + j] = hs[pc];
+                                uint16_t hs[3];
+                                pieces(p->G[(rowmap ? rowmap[row] : row) + (size_t)M * k], hs);
+                                for (int pc = 0; pc < NP; pc++) st[((size_t)(pc * p->MB + m) * 64 + l) * 8 + j] = hs[pc];
                             }
                 }
                 for (int x = 0; x < p->NX; x++)
@@ -2204,22 +2307,18 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
         FIB_HIP(hipMemcpy(p->Aextra.p, AX.data(), AX.size() * sizeof(float), hipMemcpyHostToDevice));
         // single-tile image of mb blocks (+ nx extra rows) whose image row r holds row rowfn(r) of G (< 0: padding)
         auto build_one = [&](int mb, int nx, auto rowfn, std::vector<uint16_t> &A3o, std::vector<float> &AXo) {
-            A3o.assign((size_t)nst * 3 * mb * 512, 0);
+            A3o.assign((size_t)nst * NP * mb * 512, 0);
             AXo.assign((size_t)std::max(1, nx * p->Kpad), 0.0f);
             for (int t = 0; t < nst; t++) {
-                uint16_t *st = A3o.data() + (size_t)t * 3 * mb * 512;
+                uint16_t *st = A3o.data() + (size_t)t * NP * mb * 512;
                 for (int m = 0; m < mb; m++)
                     for (int l = 0; l < 64; l++)
                         for (int j = 0; j < 8; j++) {
                             const int gr = rowfn(m * 32 + (l & 31)), k = t * KT + 8 * (l >> 5) + j;
                             if (gr < 0 || k >= K) continue;
-                            const float v = p->G[gr + (size_t)M * k];
-                            const uint16_t h1 = bf16_rn(v);
-                            const float r1 = v - bf16_f(h1);
-                            const uint16_t h2 = bf16_rn(r1);
-                            const float r2 = r1 - bf16_f(h2);
-                            const uint16_t hs[3] = {h1, h2, bf16_rn(r2)};
-                            for (int pc = 0; pc < 3; pc++) st[((size_t)(pc * mb + m) * 64 + l) * 8 + j] = hs[pc];
+                            uint16_t hs[3];
+                            pieces(p->G[gr + (size_t)M * k], hs);
+                            for (int pc = 0; pc < NP; pc++) st[((size_t)(pc * mb + m) * 64 + l) * 8 + j] = hs[pc];
                         }
             }
             for (int x = 0; x < nx; x++)
@@ -2432,14 +2531,18 @@ void launch_gemm(const GemmArgs &ga, unsigned grid, hipStream_t st) {
         const int64_t items = fib::cdiv(ga.nvox, nw * 32) * ga.ntile_m;
         unsigned pg = (unsigned)std::min<int64_t>((int64_t)ncu * (8 / nw), items);
         pg = (pg + 7) / 8 * 8;
-        if (ga.fold) {
-            if constexpr (MB <= FOLD_MB_MAX) hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 8, true>), dim3(pg), dim3(512), 0, st, g2);
-            return;
-        }
-        if constexpr (MB == 10 && NX == 1) {
-            if (ga.mean_hi) { hipLaunchKernelGGL((odf_gemm3_kernel<10, 1, 8, false, true>), dim3(pg), dim3(512), 0, st, g2); return; }
-        }
-        hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 8>), dim3(pg), dim3(512), 0, st, g2);
+        auto go = [&](auto h2_) {
+            constexpr bool H2 = decltype(h2_)::value;
+            if (ga.fold) {
+                if constexpr (MB <= FOLD_MB_MAX) hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 8, true, false, H2>), dim3(pg), dim3(512), 0, st, g2);
+                return;
+            }
+            if constexpr (MB == 10 && NX == 1) {
+                if (ga.mean_hi) { hipLaunchKernelGGL((odf_gemm3_kernel<10, 1, 8, false, true, H2>), dim3(pg), dim3(512), 0, st, g2); return; }
+            }
+            hipLaunchKernelGGL((odf_gemm3_kernel<MB, NX, 8, false, false, H2>), dim3(pg), dim3(512), 0, st, g2);
+        };
+        if (ga.h2) go(std::true_type{}); else go(std::false_type{});
     }
     else hipLaunchKernelGGL((odf_gemm_kernel<MB, NX>), dim3(grid), dim3(256), 0, st, ga);
 }
@@ -2538,7 +2641,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         FIB_HIP(hipGetLastError());
     }
     ga.At = plan->At.p; ga.At3 = (plan->split_bf16 && nvox <= ((int64_t)1 << 26)) ? plan->At3.p : nullptr; ga.S = dwi;
-    ga.Aextra = plan->Aextra.p;
+    ga.Aextra = plan->Aextra.p; ga.h2 = plan->h2 ? 1 : 0; ga.h2_inv_sa = 1.0f / plan->h2_sa;
     ga.vec_ok = (nvox % 4 == 0 && ((uintptr_t)odf & 15) == 0 && (pdf == nullptr || ((uintptr_t)pdf & 15) == 0)) ? 1 : 0; ga.vidx = plan->live_vox.p; ga.nlive = plan->live_counts.p; ga.mask = mask; ga.effbits = plan->effbits.p;
     ga.out0 = pdf; ga.out1 = odf; ga.nvox = nvox;
     if (ga.At3 && plan->Gdev.p) {                        // GQI: voxels with a +Inf sample are listed and recomputed (no cap: the list holds every voxel)
@@ -2624,9 +2727,9 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
                 FIB_HIP(hipMemsetAsync(plan->pair_flags.p, 0, 8 * 32 * sizeof(unsigned), s));
             }
             switch (plan->MBB) {
-                case 5: hipLaunchKernelGGL(odf_dsi2_kernel<5>, dim3(pg), dim3(512), 0, s, g); break;
-                case 7: hipLaunchKernelGGL(odf_dsi2_kernel<7>, dim3(pg), dim3(512), 0, s, g); break;
-                default: hipLaunchKernelGGL(odf_dsi2_kernel<9>, dim3(pg), dim3(512), 0, s, g); break;
+                case 5: if (g.h2) hipLaunchKernelGGL((odf_dsi2_kernel<5, true>), dim3(pg), dim3(512), 0, s, g); else hipLaunchKernelGGL((odf_dsi2_kernel<5, false>), dim3(pg), dim3(512), 0, s, g); break;
+                case 7: if (g.h2) hipLaunchKernelGGL((odf_dsi2_kernel<7, true>), dim3(pg), dim3(512), 0, s, g); else hipLaunchKernelGGL((odf_dsi2_kernel<7, false>), dim3(pg), dim3(512), 0, s, g); break;
+                default: if (g.h2) hipLaunchKernelGGL((odf_dsi2_kernel<9, true>), dim3(pg), dim3(512), 0, s, g); else hipLaunchKernelGGL((odf_dsi2_kernel<9, false>), dim3(pg), dim3(512), 0, s, g); break;
             }
             FIB_HIP(hipGetLastError());
             return FIB_OK;
@@ -2715,7 +2818,7 @@ int fib::matrix_plan_run(const fib_odf_plan *plan, const float *S, const uint8_t
     }
     GemmArgs ga{};
     ga.At = plan->At.p; ga.At3 = plan->split_bf16 ? plan->At3.p : nullptr; ga.S = S;
-    ga.Aextra = plan->Aextra.p;
+    ga.Aextra = plan->Aextra.p; ga.h2 = plan->h2 ? 1 : 0; ga.h2_inv_sa = 1.0f / plan->h2_sa;
     ga.vec_ok = (n % 4 == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0;
     ga.vidx = plan->live_vox.p; ga.nlive = plan->live_counts.p; ga.mask = ones; ga.effbits = plan->effbits.p;
     ga.out0 = nullptr; ga.out1 = out; ga.nvox = n;
