@@ -73,6 +73,7 @@ struct GemmArgs {
     int pair_role;                // 0: none; 1: publish my item number; 2: wait (bounded) until my partner has reached my item
     int h2;                       // the images hold two fp16 pieces per element, scaled by the power of two sa (gemm3_body H2) ..
     float h2_inv_sa;              // .. and 1 / sa
+    int phase_item;               // diagnostic build: the work item whose phases are stamped (FIB_PHASE)
 };
 
 // Diagnostic build only (make stamp -> libfibers_hip_stamp.so, -DFIB_CLOCK_STAMP; in the product library no stamp executes):
@@ -90,9 +91,24 @@ __device__ unsigned long long fib_clock_stamps[2048][4];        // per workgroup
             fib_clock_stamps[blockIdx.x][2] = (kid); fib_clock_stamps[blockIdx.x][3] = (unsigned long long)(items);                 \
         }                                                                                                                           \
     } while (0)
+// .. and the phases of ONE work item (GemmArgs::phase_item, FIBERS_PHASE_ITEM, default the third) of waves 0 and 4 of workgroup 8:
+// s_memtime at the marks below, 256 per wave (tools/phase_profile.py; a mark costs ~250 cycles)
+__device__ unsigned long long fib_phase_stamps[2][256];
+#define FIB_PHASE_VARS() int fps_n_ = 0
+#define FIB_PHASE(item_, wave_, id_)                                                                                                \
+    do {                                                                                                                            \
+        if (blockIdx.x == 8 && (item_) == a.phase_item && ((wave_) & 3) == 0 && fps_n_ < 256) {                                     \
+            unsigned long long t_;                                                                                                  \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                                          \
+            if ((threadIdx.x & 63) == 0) fib_phase_stamps[(wave_) >> 2][fps_n_] = (t_ << 8) | (unsigned)(id_);                      \
+            fps_n_++;                                                                                                               \
+        }                                                                                                                           \
+    } while (0)
 #else
 #define FIB_STAMP_BEGIN() do { } while (0)
 #define FIB_STAMP_END(kid, items) do { } while (0)
+#define FIB_PHASE_VARS() do { } while (0)
+#define FIB_PHASE(item_, wave_, id_) do { } while (0)
 #endif
 
 // scheduling hint: spread one k-step's fragment reads (ds_read2_b32 = 2 fragments) between the previous
@@ -735,7 +751,7 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
     const float vmin_t = fq_min3(vmin, __shfl_xor(vmin, 32), xrow);
     const float vsum_t = (vsum + __shfl_xor(vsum, 32)) + xrow;
     const bool finite = fabsf(vsum_t) < INFINITY;       // false for NaN / Inf columns
-    const bool redo = inb && (!finite || cnt > FQ_CAP || cnt_o > FQ_CAP);
+    const bool redo = inb && (!finite || nonfinite || cnt > FQ_CAP || cnt_o > FQ_CAP);   // (nonfinite: the column is recomputed after this kernel)
     const float mean = vsum_t / (float)FQ_NV;
     const float eps = (2.1f * 5.9604645e-8f) * (float)FQ_NV * (fabsf(mean) + 2.0f * fabsf(fminf(vmin_t, 0.0f)));   // see odfmax_contribute
     if (kh == 0 && inb) {
@@ -1013,7 +1029,9 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
             }
         }
         if constexpr (H2) {
-            const float mall = max3_nan(vmax, __shfl_xor(vmax, 32), 0.0f);      // the voxel's running maximum (both k halves)
+            // the voxel's running maximum over both k halves (v_permlane32_swap: no LDS round trip in the split)
+            const auto vsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(vmax), __float_as_uint(vmax), false, false);
+            const float mall = max3_nan(__uint_as_float(vsw[0]), __uint_as_float(vsw[1]), 0.0f);
             const int e = (int)((__float_as_uint(mall) >> 23) & 0xffu);          // (255: NaN / +Inf -- the column is repaired anyway)
             int kfit = e == 0 ? 127 + 60 : 127 + (H2_TARGET - e);
             kfit = kfit < 1 ? 1 : (kfit > 253 ? 253 : kfit);
@@ -1055,6 +1073,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     if (ANTI && early) split(cur.tile_m, 0);
     int g = 0;                                           // stages done: ring position
     FIB_STAMP_BEGIN();
+    FIB_PHASE_VARS();
     for (;;) {
         if constexpr (ONE) {
             // The two tiles of a voxel group read the same samples.  With as many ODF-tile as pdf-tile workgroups, workgroup p of each
@@ -1087,12 +1106,15 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
         for (int t = 0; t < ntiles; t++, g++) {
             const int cb = g & 1;
             const char *L = lds + cb * TILEB;
+            FIB_PHASE(g / ntiles, wave, 1);             // stage top
             if (!(ANTI && early)) split(cur.tile_m, t);
+            FIB_PHASE(g / ntiles, wave, 2);             // (late waves: split done)
             // the next stage (it may open the next work item): pieces into the other buffer, samples into braw
             const bool w1 = t + 1 < ntiles;
             stage_A(w1 ? cur.tile_m : (nxt.valid ? nxt.tile_m : cur.tile_m), w1 ? t + 1 : 0, cb ^ 1);
             load_B(w1 ? t + 1 : 0, w1 ? s_off : s_off_n, w1 || nxt.valid);
             __builtin_amdgcn_sched_barrier(0);          // the requests go out before the MFMA block, not after it
+            FIB_PHASE(g / ntiles, wave, 3);             // requests issued
             if constexpr (H2) {
                 const f16x8_t b0 = __builtin_bit_cast(f16x8_t, bp[0]), b1 = __builtin_bit_cast(f16x8_t, bp[1]);
                 const f16x8_t *LA = reinterpret_cast<const f16x8_t *>(L) + lane;
@@ -1139,6 +1161,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
                 a2 = n2; a1 = n1; a0 = n0;
             }
             }
+            FIB_PHASE(g / ntiles, wave, 4);             // MFMA block issued
             if constexpr (ANTI) {
                 if (prio) __builtin_amdgcn_s_setprio(0);
                 if (early) {                              // the samples requested above: the next stage's split, now
@@ -1151,13 +1174,20 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
                     split(w1 ? cur.tile_m : (nxt.valid ? nxt.tile_m : cur.tile_m), w1 ? t + 1 : 0);
                 }
             }
+            FIB_PHASE(g / ntiles, wave, 5);             // (early waves: next split done)
             __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): the next stage's pieces and samples have landed
+            FIB_PHASE(g / ntiles, wave, 6);             // loads landed
             __syncthreads();
+            FIB_PHASE(g / ntiles, wave, 7);             // barrier passed
         }
         {
             // the voxel's clamped-sample maximum over both k halves; vnf = NaN iff it is NaN or +Inf (the epilogues' "non-finite sample" flag)
             float vm = early ? vmax_fin : vmax;
             vm = max3_nan(vm, __shfl_xor(vm, 32), 0.0f);
+            // H2: a voxel whose largest sample is a denormal number has no power of two that brings it into fp16's range (2^k is a
+            // float here); where the repair list exists (GQI) it is handed over like a voxel with a +Inf sample and recomputed as a
+            // plain f32 chain.  (DSI divides by sum(p) ~ that sample: Inf / NaN in the reference as well.)
+            if (H2 && a.scale_frame < 0 && a.fix_list != nullptr && vm > 0.0f && vm < 1.17549435e-38f) vm = INFINITY;
             const float vn = vm < INFINITY ? 0.0f : __builtin_nanf("");
             // H2: the accumulators hold sa 2^k times the sums
             const float asc = H2 ? __uint_as_float((uint32_t)(254 - (early ? kexp_fin : kexp)) << 23) * a.h2_inv_sa : 1.0f;
@@ -1179,6 +1209,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
                     gemm3_epilogue<MB, NX, false, 0, false, H2>(a, acc, xacc, vm, vn, inb, lv, vox, le, cur.tile_m, sraw, lds + 2 * TILEB + wave * TRB, nullptr, nullptr, asc);
             }
         }
+        FIB_PHASE(g / ntiles - 1, wave, 8);             // epilogue done
         if (!nxt.valid) break;
         cur = nxt; inb = inb_n; vox = vox_n; s_off = s_off_n;
         nxt = work_at(g / ntiles + 1);
@@ -2642,6 +2673,9 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
     }
     ga.At = plan->At.p; ga.At3 = (plan->split_bf16 && nvox <= ((int64_t)1 << 26)) ? plan->At3.p : nullptr; ga.S = dwi;
     ga.Aextra = plan->Aextra.p; ga.h2 = plan->h2 ? 1 : 0; ga.h2_inv_sa = 1.0f / plan->h2_sa;
+#ifdef FIB_CLOCK_STAMP
+    { const char *pi = getenv("FIBERS_PHASE_ITEM"); ga.phase_item = pi ? atoi(pi) : 2; }
+#endif
     ga.vec_ok = (nvox % 4 == 0 && ((uintptr_t)odf & 15) == 0 && (pdf == nullptr || ((uintptr_t)pdf & 15) == 0)) ? 1 : 0; ga.vidx = plan->live_vox.p; ga.nlive = plan->live_counts.p; ga.mask = mask; ga.effbits = plan->effbits.p;
     ga.out0 = pdf; ga.out1 = odf; ga.nvox = nvox;
     if (ga.At3 && plan->Gdev.p) {                        // GQI: voxels with a +Inf sample are listed and recomputed (no cap: the list holds every voxel)
@@ -2867,6 +2901,13 @@ extern "C" int fib_debug_clock_stamps(unsigned long long *out, int cap) try {
     FIB_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(fib_clock_stamps), (size_t)cap * 4 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost));
     return FIB_OK;
 } FIB_API_CATCH
+extern "C" int fib_debug_phase_stamps(unsigned long long *out) try {      // [2][256]: (s_memtime << 8) | mark id
+    FIB_CHECK(out, FIB_ERR_INVALID, "invalid stamp buffer");
+    FIB_HIP(hipDeviceSynchronize());
+    FIB_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(fib_phase_stamps), sizeof(unsigned long long) * 512, 0, hipMemcpyDeviceToHost));
+    return FIB_OK;
+} FIB_API_CATCH
+
 extern "C" int fib_debug_clock_clear(void) try {
     static unsigned long long zeros[2048][4];
     FIB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(fib_clock_stamps), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice));

@@ -83,7 +83,7 @@ def _check_odf_sample(fj, orc, kind, out, dwi, mask, bval, bvec, dev, nsamp, odf
     # peaks: identical, or a tie at rounding level in the oracle's own ODF (margin <= 1e-4 of the maximum); no allowance by count
     from util import peak_mismatches_are_ties
     gps = [out["peak"][k][:, tidx].T.cpu().numpy().reshape(nsamp, 1, 1, 3) for k in range(3)]
-    peak_mismatches_are_ties(ref["odf"], ref["peak"], gps, np.asarray(sph.vertices, np.float32)[:sph.nvert])
+    peak_mismatches_are_ties(ref["odf"], ref["peak"], gps, np.asarray(sph.vertices, np.float32)[:sph.nvert], faces=np.asarray(sph.faces))
     return ref
 
 

@@ -29,6 +29,16 @@ class _Lazy(dict):
 _VERTS = _Lazy()
 
 
+class _LazyFaces(dict):
+    def __missing__(self, k):
+        import fibers_jl_amd as fj
+        self.update({s.nvert: np.asarray(s.faces) for s in (fj.sphere_362, fj.sphere_642, fj.sphere_724)})
+        return dict.__getitem__(self, k)
+
+
+_FACES = _LazyFaces()
+
+
 def _check_odf_rec(got_odf, got_peak, got_qa, ref, mask, odf_rtol=2e-5, qa_atol=1e-5, label=""):
     m = mask.astype(bool)
     ro = ref["odf"]
@@ -44,7 +54,7 @@ def _check_odf_rec(got_odf, got_peak, got_qa, ref, mask, odf_rtol=2e-5, qa_atol=
     # other: every mismatch is checked, there is no allowance by count
     from util import peak_mismatches_are_ties
     nv = ref["odf"].shape[3]
-    return peak_mismatches_are_ties(ref["odf"], ref["peak"], got_peak, _VERTS[nv][:nv])
+    return peak_mismatches_are_ties(ref["odf"], ref["peak"], got_peak, _VERTS[nv][:nv], faces=_FACES[nv])
 
 
 @pytest.mark.parametrize("shape,sphere", [((8, 8, 8), "sphere_642"), ((9, 7, 5), "sphere_362"),
@@ -648,3 +658,92 @@ def test_dsi_two_tile_kernel_against_the_three_tile_path(fj, case, monkeypatch):
         torch.testing.assert_close(nn(a["qa"][k])[same], nn(b["qa"][k])[same], rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(nn(a["odfmax"]), nn(b["odfmax"]), rtol=1e-5, atol=0)
     assert int((a["peak"][0] != 0).any(0).sum()) > int(mask.sum()) // 2
+
+
+# ---- the two operand formats of the contraction: two fp16 pieces (default) / three exact bf16 pieces (FIBERS_ODF_EXACT=1) ----------
+def _rec_both_formats(fj, monkeypatch, kind, dwi, mask, bval, bvec, sph):
+    """device tier with explicitly built plans (the host tier caches its plans; the format is chosen when a plan builds its matrix
+    image): dict(odf [nvox, nvert], peak 3 x [nvox, 3], pdf) per format"""
+    import torch
+    nvol = dwi.shape[3]
+    d = torch.from_numpy(np.ascontiguousarray(dwi.reshape(-1, nvol, order="F").T)).cuda()     # planar [nvol, nvox], x fastest
+    m = torch.from_numpy(np.ascontiguousarray(mask.reshape(-1, order="F"))).cuda()
+    res = {}
+    for exact in (False, True):
+        if exact:
+            monkeypatch.setenv("FIBERS_ODF_EXACT", "1")
+        else:
+            monkeypatch.delenv("FIBERS_ODF_EXACT", raising=False)
+        plan = fj.OdfPlan(kind, bval, bvec, sph, sigma=1.25, hann_width=32)
+        o = fj.odf_rec_device(plan, d, m)
+        torch.cuda.synchronize()
+        res[exact] = dict(odf=o["odf"].cpu().numpy().T.copy(), peak=[p.cpu().numpy().T.copy() for p in o["peak"]],
+                          pdf=o["pdf"].cpu().numpy().T.copy() if kind == "dsi" else None)
+        plan.close()
+    monkeypatch.delenv("FIBERS_ODF_EXACT", raising=False)
+    return res[False], res[True]
+
+
+def _formats_agree(a, b, tol, nvert):
+    """a: default (fp16 x 2), b: exact split (bf16 x 3).  ODF within tol of the voxel maximum (the exact split's own distance from a
+    float64 contraction is ~1e-6: f32 accumulation), peaks identical except rounding-level ties"""
+    from util import peak_mismatches_are_ties
+    oa, ob = a["odf"], b["odf"]
+    assert not np.array_equal(oa, ob), "the two operand formats gave identical bits: the switch did not reach the plan"
+    scale = np.abs(ob).max(axis=1, keepdims=True) + 1e-30
+    assert np.array_equal(np.isnan(oa), np.isnan(ob))
+    err = np.nanmax(np.abs(oa - ob) / scale)
+    assert err <= tol, "odf differs by %g of the voxel maximum between the two operand formats" % err
+    return peak_mismatches_are_ties(ob, b["peak"], a["peak"], _VERTS[nvert][:nvert], faces=_FACES[nvert])
+
+
+def test_fp16_pieces_agree_with_the_exact_split_gqi(fj, monkeypatch):
+    dwi, mask, bval, bvec = _gqi_case((16, 16, 12), seed=21)
+    a, b = _rec_both_formats(fj, monkeypatch, "gqi", dwi, mask, bval, bvec, fj.sphere_642)
+    _formats_agree(a, b, 3e-6, fj.sphere_642.nvert)
+
+
+def test_fp16_pieces_agree_with_the_exact_split_dsi(fj, monkeypatch):
+    dwi, mask, bval, bvec = _dsi_case((8, 8, 8), seed=22)
+    a, b = _rec_both_formats(fj, monkeypatch, "dsi", dwi, mask, bval, bvec, fj.sphere_642)
+    _formats_agree(a, b, 3e-6, fj.sphere_642.nvert)
+    pa, pb = a["pdf"], b["pdf"]
+    assert np.nanmax(np.abs(pa - pb) / (np.abs(pb).max(axis=1, keepdims=True) + 1e-30)) <= 3e-6
+
+
+@pytest.mark.parametrize("k", [-60, -17, 23, 60])
+def test_scaling_the_samples_by_a_power_of_two_scales_the_odf_exactly(fj, k):
+    """every voxel carries its own power-of-two sample scale (fp16 pieces have 5 exponent bits): the result must not depend on the
+    magnitude of the data -- ODF x 2^k bit for bit, same peaks, same qa (which is a ratio)"""
+    dwi, mask, bval, bvec = _gqi_case((8, 8, 8), seed=31)
+    sph = fj.sphere_642
+    a = fj.gqi_rec(fj.MRI(dwi, bval, bvec), fj.MRI(mask), sph)
+    b = fj.gqi_rec(fj.MRI(np.ldexp(dwi, k).astype(np.float32), bval, bvec), fj.MRI(mask), sph)
+    assert np.array_equal(np.ldexp(a.odf.vol.astype(np.float64), k), b.odf.vol.astype(np.float64))
+    for p, q in zip(a.peak, b.peak):
+        assert np.array_equal(p.vol, q.vol)
+    for p, q in zip(a.qa, b.qa):
+        assert np.array_equal(p.vol, q.vol)
+
+
+def test_late_large_samples_lower_the_sample_scale(fj, orc):
+    """the scale is chosen from the first 16 frames; frames that come later and are > 256 x larger make the kernel lower it and
+    rescale the accumulators on the way: first stage tiny, first stage all zero, one huge frame at the very end, denormal samples"""
+    dwi, mask, bval, bvec = _gqi_case((8, 8, 8), seed=41)
+    sph = fj.sphere_642
+    nf = dwi.shape[3]
+    cases = {}
+    d = dwi.copy(); d[..., :16] = np.ldexp(d[..., :16], -14); cases["tiny first stage"] = d
+    d = dwi.copy(); d[..., :16] = 0.0; cases["zero first stage"] = d
+    d = dwi.copy(); d[..., nf - 1] = np.ldexp(d[..., nf - 1], 20); cases["huge last frame"] = d
+    d = dwi.copy(); d[..., :32] = 1e-41; d[..., 40] = np.ldexp(d[..., 40], 12); cases["denormal samples, then two steps up"] = d
+    d = np.ldexp(dwi, -140).astype(np.float32); cases["all samples denormal"] = d
+    for label, d in cases.items():
+        ref = orc.gqi_rec(d, mask, bval, bvec, sph.vertices, sph.faces, 1.25, nthreads=2)
+        got = fj.gqi_rec(fj.MRI(d, bval, bvec), fj.MRI(mask), sph)
+        # (relative to the voxel maximum itself -- _check_odf_rec's 1e-30 floor would hide the denormal case)
+        m = mask.astype(bool)
+        top = np.abs(ref["odf"][m]).max(axis=1, keepdims=True)
+        err = np.abs(got.odf.vol[m] - ref["odf"][m]) / top
+        assert err.max() <= (2e-5 if label != "all samples denormal" else 2e-2), "%s: odf rel err %g" % (label, err.max())   # (a denormal sum carries a few bits)
+        _check_odf_rec(got.odf.vol, [p.vol for p in got.peak], [q.vol[..., 0] for q in got.qa], ref, mask, label=label)

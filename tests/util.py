@@ -39,28 +39,80 @@ def assert_dti_close(got, ref, mask, label="", s0_rtol=1e-4, ev_atol=1e-7, ev_rt
         assert (g[~m] == 0).all()
 
 
-def peak_mismatches_are_ties(ref_odf, ref_peaks, got_peaks, verts_half, tol=1e-4):
-    """peak vertices are identical "where the deciding amplitude margin > 1e-4 * max".  For every voxel and rank at
-    which the two peak vectors differ, the ORACLE's amplitudes of the two vertices involved (0 for "no peak at this rank") must
-    be within tol * the voxel's ODF maximum of each other: a mismatch has to be a rounding-level tie, not an error.
+def _half_sphere_neighbours(faces, nvert):
+    """neighbour lists of the folded tessellation: faces[faces .> nvert] .-= nvert (gqi.jl:63-64); faces 1-based [nfaces, 3]"""
+    f = np.array(faces, dtype=np.int64, copy=True)
+    f[f > nvert] -= nvert
+    f -= 1
+    nb = [set() for _ in range(nvert)]
+    for a, b, c in f:
+        nb[a].update((b, c)); nb[b].update((a, c)); nb[c].update((a, b))
+    return [np.array(sorted(x - {v}), dtype=np.int64) for v, x in enumerate(nb)]
+
+
+def _lists_match_up_to_ties(col, want, got, slack):
+    """two ranked vertex lists (-1 = no peak) agree if at every rank the amplitudes agree within slack (0 for "no peak")"""
+    for w, g in zip(want, got):
+        if w == g:
+            continue
+        aw = float(col[w]) if w >= 0 else 0.0
+        ag = float(col[g]) if g >= 0 else 0.0
+        if abs(aw - ag) > slack:
+            return False
+    return True
+
+
+def peak_mismatches_are_ties(ref_odf, ref_peaks, got_peaks, verts_half, tol=1e-4, faces=None):
+    """peak vertices are identical "where the deciding amplitude margin > 1e-4 * max".  A voxel whose peak vectors
+    differ must be explained by margins of at most tol * the voxel's ODF maximum IN THE ORACLE'S ODF -- either
+      * the amplitudes of the two vertices at the differing rank are that close (a tie in the ranking), or
+      * (faces given) the peak test itself is that close for some vertices: find_peaks! keeps a vertex that is > all its neighbours
+        and > 0 (gqi.jl:185-200); vertices whose margin over their largest neighbour (or over 0) is within tol may flip, and the
+        kernel's list must be the top three of the certain peaks plus SOME subset of the marginal ones, again up to ranking ties.
     ref_odf [..., nvert]; ref_peaks / got_peaks: three arrays [..., 3]; verts_half [nvert, 3].  Returns the mismatch count."""
+    import itertools
     vh = np.ascontiguousarray(verts_half, np.float32)
-    index = {vh[i].tobytes(): i for i in range(vh.shape[0])}
-    odf = np.asarray(ref_odf).reshape(-1, vh.shape[0])
-    nbad = 0
+    nvert = vh.shape[0]
+    index = {vh[i].tobytes(): i for i in range(nvert)}
+    odf = np.asarray(ref_odf).reshape(-1, nvert)
+    rp = [np.ascontiguousarray(np.asarray(ref_peaks[k], np.float32).reshape(-1, 3)) for k in range(3)]
+    gp = [np.ascontiguousarray(np.asarray(got_peaks[k], np.float32).reshape(-1, 3)) for k in range(3)]
+    differ = np.zeros(odf.shape[0], bool)
     for k in range(3):
-        rp = np.ascontiguousarray(np.asarray(ref_peaks[k], np.float32).reshape(-1, 3))
-        gp = np.ascontiguousarray(np.asarray(got_peaks[k], np.float32).reshape(-1, 3))
-        for i in np.flatnonzero(~np.all(rp == gp, axis=1)):
-            nbad += 1
-            col = odf[i]
-            amp = []
-            for vec in (rp[i], gp[i]):
-                if not vec.any():
-                    amp.append(0.0)                                   # no peak at this rank
-                else:
-                    assert vec.tobytes() in index, "peak %d of voxel %d is not a vertex of the tessellation" % (k, i)
-                    amp.append(float(col[index[vec.tobytes()]]))
-            gap, top = abs(amp[0] - amp[1]), float(np.abs(col).max())
-            assert gap <= tol * top, "voxel %d rank %d: peaks differ with an amplitude gap of %g = %.3g of the ODF maximum (not a tie)" % (i, k, gap, gap / max(top, 1e-30))
+        differ |= ~np.all(rp[k] == gp[k], axis=1)
+    nbrs = _half_sphere_neighbours(faces, nvert) if faces is not None else None
+
+    def vertex_of(vec, i, k):
+        if not vec.any():
+            return -1                                             # no peak at this rank
+        assert vec.tobytes() in index, "peak %d of voxel %d is not a vertex of the tessellation" % (k, i)
+        return index[vec.tobytes()]
+
+    nbad = 0
+    for i in np.flatnonzero(differ):
+        nbad += 1
+        col = odf[i].astype(np.float64)
+        top = float(np.abs(col).max())
+        slack = tol * top
+        want = [vertex_of(rp[k][i], i, k) for k in range(3)]
+        got = [vertex_of(gp[k][i], i, k) for k in range(3)]
+        if _lists_match_up_to_ties(col, want, got, slack):
+            continue
+        msg = "voxel %d: peaks %s (oracle) vs %s differ by more than a tie of %.3g of the ODF maximum" % (i, want, got, tol)
+        assert nbrs is not None, msg
+        margin = np.array([min(col[v] - col[nbrs[v]].max(), col[v]) for v in range(nvert)])   # > 0: a peak (strictly above neighbours and 0)
+        certain = [v for v in range(nvert) if margin[v] > slack]
+        marginal = [v for v in range(nvert) if abs(margin[v]) <= slack]
+        assert len(marginal) <= 12, msg + " (and %d vertices with a marginal peak test)" % len(marginal)
+        ok = False
+        for n in range(len(marginal) + 1):
+            for sub in itertools.combinations(marginal, n):
+                cand = sorted(certain + list(sub), key=lambda v: (-col[v], v))[:3]
+                cand += [-1] * (3 - len(cand))
+                if _lists_match_up_to_ties(col, cand, got, slack):
+                    ok = True
+                    break
+            if ok:
+                break
+        assert ok, msg + "; marginal vertices %s do not explain it" % marginal
     return nbad
