@@ -252,20 +252,36 @@ def main():
                 algorithmic_bytes=gemm_bytes, frac=gemm_bytes / (gemm_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if gemm_n else 0.0)
     pk = dict(avg_kernel_ms=peaks_ms / max(peaks_n, 1), refine_ms=refine_ms / max(refine_n, 1),
               note="fused: what is left outside the contraction kernel (redo list + exact odfmax)" if fused else "separate peak kernel (ODF re-read)")
+    exact = os.environ.get("FIBERS_ODF_EXACT", "0") not in ("", "0")
+    nprod = 6 if exact else 3
     if split:
-        # every f32 product = 6 exact bf16 piece products -> the matrix cores execute 6 x the algorithmic flops (320 of the
-        # 321 rows; K padded 270 -> 272); the binding roof is the BF16 MFMA peak / 6 for the algorithmic f32 flops
-        peak_eff = PEAK_BF16_TFLOPS / 6.0
-        roofline = dict(bound="mfma", kernel="odf_gemm3_kernel<MB=10,NX=1,NW=8%s> (v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 splits of both f32 "
-                                             "operands: 6 piece products per f32 product; 320 rows on MFMA + 1 row on VALU%s)"
-                                             % (",FUSE" if fused else "", "; find_peaks! + peak/qa extraction on the accumulators" if fused else ""),
-                        achieved=achieved, peak=peak_eff, unit="TFLOP/s", frac=achieved / peak_eff,
-                        note="achieved = algorithmic f32 flops (2*321*270 per voxel) / kernel time (the fused kernel's time includes the peak finder); "
-                             "peak = 2500 TFLOP/s dense BF16 / 6 piece products; executed BF16 MFMA rate = %.0f TFLOP/s of 2500; the chip holds "
-                             "1.8-1.9 GHz of the nominal 2.4 inside this kernel (in_kernel_clock_ghz: s_memtime / s_memrealtime, diagnostic build); the "
-                             "16x16x32 MFMA shape holds 2.16 GHz but costs 27 %% more cycles (DESIGN.md K2/K5)"
-                             % (6.0 * 2.0 * 320 * 272 * nloc / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0),
-                        avg_kernel_ms=gemm_avg_ms, launches=gemm_n, traffic=None, hbm_secondary=hbm2, peaks_kernel=pk)
+        # every f32 product = 3 piece products of two fp16 pieces per operand (default; FIBERS_ODF_EXACT=1: 6 products of three
+        # bf16 pieces): the matrix cores execute nprod x the algorithmic flops of 320 of the 321 rows (K padded 270 -> 272).  Two
+        # floors: executed flops / 2500 TFLOP/s and algorithmic bytes / 8 TB/s; the line's roofline is the larger one (with
+        # 3 products: HBM, 0.83 ms against 0.57 ms), the other is reported beside it
+        exec_flops = nprod * 2.0 * 320 * 272 * nloc
+        t_mfma, t_hbm = exec_flops / (PEAK_BF16_TFLOPS * 1e12), gemm_bytes / (PEAK_HBM_GBS * 1e9)
+        mfma2 = dict(achieved=achieved, peak=PEAK_BF16_TFLOPS / nprod, unit="TFLOP/s", frac=achieved / (PEAK_BF16_TFLOPS / nprod),
+                     executed_tflops=exec_flops / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0, floor_ms=t_mfma * 1e3,
+                     note="algorithmic f32 flops (2*321*270 per voxel) / kernel time against 2500 TFLOP/s dense / %d piece products per f32 product" % nprod)
+        kname = ("odf_gemm3_kernel<MB=10,NX=1,NW=8%s,%s> (%s; 320 rows on MFMA + 1 row on VALU%s)"
+                 % (",FUSE" if fused else "", "bf16x3" if exact else "H2",
+                    "v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 splits of both f32 operands: 6 piece products per f32 product" if exact else
+                    "v_mfma_f32_32x32x16_f16 on two fp16 pieces per f32 operand (23 significant bits, per-voxel power-of-two sample scale): 3 piece products per f32 product",
+                    "; find_peaks! + peak/qa extraction on the accumulators" if fused else ""))
+        if t_hbm >= t_mfma:
+            roofline = dict(bound="hbm", kernel=kname, achieved=hbm2["achieved"], peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm2["frac"],
+                            algorithmic_bytes=gemm_bytes, floor_ms=t_hbm * 1e3,
+                            note="achieved = algorithmic bytes per launch (4*270 + 1 in, 4*321 + 48 out per voxel: SURVEY 8d) / the kernel's mean duration "
+                                 "(hipEvents on the launch stream); the kernel's time includes the peak finder.  Which roof binds: bytes / 8 TB/s = %.2f ms "
+                                 "against executed MFMA flops / 2500 TFLOP/s = %.2f ms -> HBM" % (t_hbm * 1e3, t_mfma * 1e3),
+                            avg_kernel_ms=gemm_avg_ms, launches=gemm_n, traffic=None, mfma_secondary=mfma2, peaks_kernel=pk)
+        else:
+            roofline = dict(bound="mfma", kernel=kname, achieved=achieved, peak=PEAK_BF16_TFLOPS / nprod, unit="TFLOP/s", frac=achieved / (PEAK_BF16_TFLOPS / nprod),
+                            note="achieved = algorithmic f32 flops (2*321*270 per voxel) / kernel time (the fused kernel's time includes the peak finder); "
+                                 "peak = 2500 TFLOP/s dense / %d piece products; executed MFMA rate = %.0f TFLOP/s of 2500 (floors: MFMA %.2f ms, HBM %.2f ms)"
+                                 % (nprod, mfma2["executed_tflops"], t_mfma * 1e3, t_hbm * 1e3),
+                            avg_kernel_ms=gemm_avg_ms, launches=gemm_n, traffic=None, hbm_secondary=hbm2, peaks_kernel=pk)
     else:
         roofline = dict(bound="mfma", kernel="odf_gemm_kernel<MB=10,NX=1> (v_mfma_f32_32x32x2_f32; 320 rows on MFMA + 1 row on VALU)", achieved=achieved,
                         peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_F32_TFLOPS,
@@ -297,7 +313,8 @@ def main():
                 if "gqi_fused" in kc and kc["gqi_fused"].get("clock_ghz_median"):
                     ghz = kc["gqi_fused"]["clock_ghz_median"]
                     roofline["in_kernel_clock_ghz"] = ghz
-                    roofline["frac_of_clock_adjusted_peak"] = roofline["frac"] * 2.4 / ghz if split else None
+                    if roofline.get("bound") == "mfma" and split:
+                        roofline["frac_of_clock_adjusted_peak"] = roofline["frac"] * 2.4 / ghz
         except Exception as e:                                                      # noqa: BLE001
             extra["in_kernel_clock"] = dict(error=str(e))
         # ---- the same step on the less flattering inputs of SURVEY §8d: ball mask (36 % of the volume inside) and ~1 % of the
@@ -316,6 +333,35 @@ def main():
                                                   mvoxels_of_volume_per_s=nvox / t_b / 1e6, gemm_kernel_ms=gb_ms / max(gb_n, 1),
                                                   note="ball mask r = 62 (998 592 voxels), 1 % of the samples set to 0 or -3; cost scales with the mask")
         del dwi_np, out_b, bm_h
+        # ---- the headline step with the other operand format (a plan built under FIBERS_ODF_EXACT picks it up): the exact 3 x bf16 split
+        # when the line runs the default, the two-piece fp16 form when the line itself was run with FIBERS_ODF_EXACT=1 ------------------
+        try:
+            prev = os.environ.get("FIBERS_ODF_EXACT")
+            if exact:
+                os.environ.pop("FIBERS_ODF_EXACT", None)
+            else:
+                os.environ["FIBERS_ODF_EXACT"] = "1"
+            plan_x = fj.OdfPlan("gqi", bval, bvec, sph, sigma=1.25, device=dev.index)
+            if prev is None:
+                os.environ.pop("FIBERS_ODF_EXACT", None)
+            else:
+                os.environ["FIBERS_ODF_EXACT"] = prev
+            out_x = fj.odf_rec_device(plan_x, dwi, mask, normalize=True)
+            t_x = timed(lambda: fj.odf_rec_device(plan_x, dwi, mask, out=out_x, normalize=True), args.steps, 1) / args.steps
+            gx_ms, gx_n = prof_get(L, "odf_gemm")
+            den = out["odf"].abs().amax(dim=0).clamp_min(1e-30)
+            dmax = float(((out_x["odf"] - out["odf"]).abs().amax(dim=0) / den).max())
+            same_pk = float((out_x["peak"][0] == out["peak"][0]).all(dim=0).float().mean())
+            extra["gqi_exact_split" if not exact else "gqi_fp16_pieces"] = dict(
+                ms_per_step=t_x * 1e3, mvoxels_per_s=nvox / t_x / 1e6, gemm_kernel_ms=gx_ms / max(gx_n, 1),
+                odf_max_difference_of_voxel_max=dmax, first_peak_identical_fraction=same_pk,
+                note="the same step, same inputs, with %s; differences between the two formats' outputs relative to each voxel's ODF maximum "
+                     "(tests: <= 3e-6, peaks identical except ties; both are ~1e-6 from a float64 contraction, tools/gemm_accuracy.py)"
+                     % ("three exact bf16 pieces per operand, 6 MFMAs per block and 16 frames (FIBERS_ODF_EXACT=1)" if not exact else "two fp16 pieces per operand, 3 MFMAs per block and 16 frames (the default)"))
+            del out_x
+            plan_x.close()
+        except Exception as e:                                                      # noqa: BLE001
+            extra["gqi_exact_split"] = dict(error=str(e))
     if not args.no_extra:
         # ---- weak-scaling figure of the same step: one whole volume per rank, odfmax all-reduced -----------------------------
         if world > 1:
@@ -537,14 +583,21 @@ def main():
         n5 = len(b5)
         dsi_bytes = (4.0 * n5 + 1 + 4.0 * n5 + 4.0 * nvert + 48) * nloc          # 5 456 B / voxel (DWI + mask in; pdf, odf, peaks, qa out)
         dsi_k_ms = g_ms / max(g_n, 1)
-        dsi_exec = 6.0 * 2.0 * (320 + 288) * 272 * nloc                          # executed bf16 flops: 6 piece products x (10 + 9 blocks) x 32 rows x 17 stages x 16
+        nprod5 = 6 if os.environ.get("FIBERS_ODF_EXACT", "0") not in ("", "0") else 3
+        dsi_exec = nprod5 * 2.0 * (320 + 288) * 272 * nloc                       # executed MFMA flops: piece products x (10 + 9 blocks) x 32 rows x 17 stages x 16
         extra["dsi_rec_140x515"] = dict(mvoxels_per_s=nvox / t_dsi / 1e6, ms_per_step=t_dsi * 1e3,
                                         gemm_kernel_ms=dsi_k_ms, fold_kernel_ms=f_ms / max(f_n, 1), peaks_kernel_ms=q_ms / max(q_n, 1),
-                                        roofline=dict(bound="mfma", kernel="odf_dsi2_kernel<9>: fused ODF tile (10 blocks + pole row, find_peaks on the accumulators) + pdf tile "
-                                                                            "(9 blocks) per voxel group, antipodal fold inside the sample load",
-                                                      achieved=dsi_exec / (dsi_k_ms * 1e-3) / 1e12 if g_n else 0.0, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                                                      frac=dsi_exec / (dsi_k_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if g_n else 0.0,
-                                                      note="executed dense-bf16 flops of the kernel / its hipEvent time, against 2500 TFLOP/s",
+                                        roofline=dict(bound="hbm" if nprod5 == 3 else "mfma",
+                                                      kernel="odf_dsi2_kernel<9>: fused ODF tile (10 blocks + pole row, find_peaks on the accumulators) + pdf tile "
+                                                             "(9 blocks) per voxel group, antipodal fold inside the sample load, %d piece products per f32 product" % nprod5,
+                                                      achieved=(dsi_bytes / (dsi_k_ms * 1e-3) / 1e9 if nprod5 == 3 else dsi_exec / (dsi_k_ms * 1e-3) / 1e12) if g_n else 0.0,
+                                                      peak=PEAK_HBM_GBS if nprod5 == 3 else PEAK_BF16_TFLOPS, unit="GB/s" if nprod5 == 3 else "TFLOP/s",
+                                                      frac=(dsi_bytes / (dsi_k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if nprod5 == 3 else dsi_exec / (dsi_k_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if g_n else 0.0,
+                                                      note="floors: algorithmic bytes / 8 TB/s = %.2f ms, executed MFMA flops / 2500 TFLOP/s = %.2f ms; achieved = the binding "
+                                                           "quantity / the kernel's hipEvent time" % (dsi_bytes / (PEAK_HBM_GBS * 1e9) * 1e3, dsi_exec / (PEAK_BF16_TFLOPS * 1e12) * 1e3),
+                                                      mfma_secondary=dict(achieved=dsi_exec / (dsi_k_ms * 1e-3) / 1e12 if g_n else 0.0, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                                                                          frac=dsi_exec / (dsi_k_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if g_n else 0.0,
+                                                                          note="executed dense MFMA flops of the kernel / its hipEvent time"),
                                                       hbm_secondary=dict(algorithmic_bytes=dsi_bytes, achieved=dsi_bytes / t_dsi / 1e9 if t_dsi else 0.0,
                                                                          peak=PEAK_HBM_GBS, unit="GB/s", frac=dsi_bytes / t_dsi / 1e9 / PEAK_HBM_GBS,
                                                                          note="algorithmic bytes of the whole step / step wall time")),
@@ -648,7 +701,11 @@ def main():
         line = dict(metric="Mvoxels/s fit (GQI ODF + peaks, 140^3 x 270-dir); Mpoints/s streamline in extra",
                     value=value, unit="Mvoxels/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None,
-                    dtype="f32" if not split else "f32 (exact 3xbf16 operand splits on the bf16 matrix cores, f32 accumulate)", data="synthetic",
+                    dtype="f32" if not split else ("f32 (exact 3xbf16 operand splits on the bf16 matrix cores, f32 accumulate)" if exact else
+                                                   "f32 (f32 in, f32 accumulate, f32 out; inside the contraction every operand travels as two fp16 pieces = 23 significant "
+                                                   "bits with a per-voxel power-of-two scale, 3 exact piece products per f32 product on the f16 matrix cores; measured "
+                                                   "against a float64 contraction the result is closer than the exact 3xbf16 split's and than an f32 fma chain's: "
+                                                   "profiles/r03/gemm_accuracy.txt; FIBERS_ODF_EXACT=1 selects the exact split, timed in extra.gqi_exact_split)"), data="synthetic",
                     config=dict(workload="gqi_rec + find_peaks + qa normalisation, ONE %dx%dx%d x 270-frame volume "
                                          "(18 x b=5 + 84 dirs x {1000,2000,3000}), sphere_642, mask = all ones" % shape,
                                 voxels=nvox, voxels_per_gpu=nloc, frames=nvol, odf_vertices=nvert,
