@@ -605,7 +605,9 @@ __device__ __forceinline__ float fq_max3z(float a, float b) { return __builtin_f
 __device__ __forceinline__ float fq_min3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 __device__ __forceinline__ float fq_max2(float a, float b) { return __builtin_fmaxf(a, b); }
 
-template <int NW, bool PRE = false, bool SCALE = false>
+// POW2: `scale` is a finite power of two for every voxel (H2 without the DSI factor): one legacy multiplication per value does the
+// scaling and the zeroing of voxels that are skipped or outside the mask
+template <int NW, bool PRE = false, bool SCALE = false, bool POW2 = false>
 __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (&acc)[10], float xrow, float vmax, float vnf, bool inb, bool lv,
                                                      int64_t vox, int lane, char *tr, char *lst, const uint64_t *posoff, const int *slotv, const float *vl,
                                                      unsigned &en_run, float scale = 1.0f, float xscale = 1.0f) {
@@ -623,7 +625,10 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
 #pragma unroll
         for (int m = 0; m < 10; m++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[m][r] = valid ? acc[m][r] * scale : 0.0f;
+            for (int r = 0; r < 16; r++) {
+                if constexpr (POW2) asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(acc[m][r]) : "v"(acc[m][r]), "v"(valid ? scale : 0.0f));   // (x * 0 = 0 for every x, NaN and Inf included)
+                else acc[m][r] = valid ? acc[m][r] * scale : 0.0f;
+            }
         xrow = valid ? xrow * xscale : 0.0f;             // (H2: the f32 extra row carries no power-of-two factor)
     } else if (!__all(valid && !nonfinite)) {           // wave-uniform, rare: skipped voxels and voxels outside the mask read 0
 #pragma unroll
@@ -890,14 +895,16 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
 
     // ---- work list of this workgroup ---------------------------------------------------------------------------
     const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
-    const int nlive = a.nlive[0];
+    const int nlive = __builtin_amdgcn_readfirstlane(a.nlive[0]);
     const int ntile_n = (nlive + WGV - 1) / WGV;
     struct Work { int tile_m; int tile_n; bool valid; };
     auto work_at = [&](int i) {
         const int w = wslot + i * nslot;
         Work r;
-        r.tile_m = ONE ? 0 : w % a.ntile_m;
-        r.tile_n = ONE ? (a.one_slot + i * a.one_stride) * 8 + xcd : (w / a.ntile_m) * 8 + xcd;
+        // (wave-uniform by construction; told to the compiler so that the stage loop's piece addresses are scalar arithmetic -- ntile_n
+        // comes from a vector load and would otherwise drag 64-bit multiplications onto the VALU in every stage)
+        r.tile_m = ONE ? 0 : __builtin_amdgcn_readfirstlane(w % a.ntile_m);
+        r.tile_n = __builtin_amdgcn_readfirstlane(ONE ? (a.one_slot + i * a.one_stride) * 8 + xcd : (w / a.ntile_m) * 8 + xcd);
         r.valid = r.tile_n < ntile_n;
         return r;
     };
@@ -1194,7 +1201,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
             if constexpr (FUSE) {
                 float fscale = 1.0f;                      // DSI (the FOLD form): 1 / sum(p), NaN where a sample is not finite (see gemm3_epilogue)
                 if (FOLD) { const float s0 = sraw < 0.0f ? 0.0f : sraw; fscale = vn != vn ? __builtin_nanf("") : 1.0f / (a.scale_coef * s0); }
-                gemm3_epilogue_fused<NW, false, FOLD || H2>(a, acc, early ? xfin[0] : xacc[0], vm, vn, inb, lv, vox, lane, lds + 2 * TILEB + wave * TRB,
+                gemm3_epilogue_fused<NW, false, FOLD || H2, H2 && !FOLD>(a, acc, early ? xfin[0] : xacc[0], vm, vn, inb, lv, vox, lane, lds + 2 * TILEB + wave * TRB,
                                                             lds + 2 * TILEB + NW * TRB + XTAB + FTAB + wave * FQ_LIST, q_posoff, q_slotv, q_vl, en_run,
                                                             fscale * asc, fscale);
             }
