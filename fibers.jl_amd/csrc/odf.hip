@@ -592,7 +592,7 @@ __device__ const short fib_f642_slot_vertex_dev[2 * 161] = {
     FIB_F642_SLOT_LIST(FIB_F642_COPY)
 #undef FIB_F642_COPY
 };
-constexpr int FQ_CAP = 12;                       // candidates per lane half that the list holds
+constexpr int FQ_CAP = 10;                       // candidates per lane half that the list holds (a longer list: odf_redo_kernel)
 constexpr int FQ_LIST = FQ_CAP * 512;            // bytes per wave: [FQ_CAP][2][64] dwords
 constexpr int FQ_NPOS = 320, FQ_NSLOT = 2 * 161, FQ_NV = 321;
 constexpr int FQ_TABB = (2 * FQ_NPOS + FQ_NSLOT + 3 * FQ_NV) * 4 + 12;   // byte offset of each position's output row, vertex-of-slot, vertex coordinates (16-byte multiple)
@@ -826,7 +826,8 @@ constexpr int FKMAX = 512, FSMAX = FKMAX / KT;
 template <int MB, int NX, int NW, bool FOLD, bool FUSE, bool H2>
 constexpr int gemm3_lds_bytes() {
     return 2 * (H2 ? 2 : 3) * MB * 1024 + NW * (FUSE ? 4096 : 2048) + (NX > 0 ? (FUSE ? 2048 : 8192) : 0) +
-           (FOLD ? 2 * FKMAX * 4 + 4 * FSMAX * 4 + (FUSE ? 0 : 2 * FKMAX * 4) : 0) + (FUSE ? NW * FQ_LIST + FQ_TABB : 0);
+           (FOLD ? 2 * FKMAX * 4 + 4 * FSMAX * 4 + (FUSE ? 0 : 2 * FKMAX * 4) : 0) + (FUSE ? NW * FQ_LIST + FQ_TABB : 0) +
+           (H2 && FUSE && !FOLD ? NW * 4096 : 0);       // (SLDS: two sample tiles per wave)
 }
 // ONE: the workgroup works on a single-tile image of its own (odf_dsi2_kernel: the DSI rows are cut into an ODF tile and a pdf tile
 // with images of different shapes); the work list still deals the items of both tiles (a.ntile_m = 2), and with an even number
@@ -845,7 +846,14 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     constexpr int FTAB = FOLD ? 2 * FKMAX * 4 + 4 * FSMAX * 4 + (FUSE ? 0 : 2 * FKMAX * 4) : 0;   // (a tile with pdf rows: + the row -> frame tables)
     constexpr int QTAB = FUSE ? NW * FQ_LIST + FQ_TABB : 0;   // fused peak scan: candidate lists + lookup tables
     constexpr int TRB = FUSE ? 4096 : 2048;                   // per-wave transposition tile(s) of the epilogue
-    static_assert(2 * TILEB + NW * TRB + XTAB + FTAB + QTAB == gemm3_lds_bytes<MB, NX, NW, FOLD, FUSE, H2>(), "LDS carve-up");
+    // SLDS (fused GQI on fp16 pieces): the samples travel through LDS -- two tiles [16 frames][32 voxels] per wave, filled by
+    // range-checked `buffer_load_dwordx4 .. lds` (a lane = 4 consecutive voxels of one frame: the voxel list is made of aligned quads),
+    // two stages ahead of the split that reads them.  With the samples in registers a wave can have ONE stage in flight, a request
+    // can precede its use by at most a stage, and a stage had settled at the ~1.5 us a sample load takes under load (twice what its
+    // MFMAs need); requests in LDS cost no registers, so they also cross an item's epilogue.
+    constexpr bool SLDS = H2 && FUSE && !FOLD;
+    constexpr int STILE = SLDS ? NW * 4096 : 0;
+    static_assert(2 * TILEB + NW * TRB + XTAB + FTAB + QTAB + STILE == gemm3_lds_bytes<MB, NX, NW, FOLD, FUSE, H2>(), "LDS carve-up");
     uint64_t *q_posoff = reinterpret_cast<uint64_t *>(lds + 2 * TILEB + NW * TRB + XTAB + FTAB + (FUSE ? NW * FQ_LIST : 0));   // [320] matrix row -> byte offset of its output row
     int *q_slotv = reinterpret_cast<int *>(q_posoff + FQ_NPOS);                                                                               // [2][161] (half, slot) -> vertex
     float *q_vl = reinterpret_cast<float *>(q_slotv + FQ_NSLOT);                                                   // [321][3]
@@ -925,8 +933,16 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
         for (int i = 0; i < NA; i++) {
             int p = wave + i * NW;
             p = p < NPIECE ? p : NPIECE - 1;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + p * 1024 + a_off),
-                                             (__attribute__((address_space(3))) void *)(l + p * 1024), 16, 0, 0);
+            if constexpr (H2 && FUSE && !FOLD) {
+                // (SLDS: as inline assembly, like the sample requests -- a builtin LDS-DMA in flight makes hipcc close every barrier with
+                // s_waitcnt vmcnt(0), and that would wait for the sample request that is meant to stay in flight across it)
+                const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char *)(l + p * 1024)));
+                const char *src = g + p * 1024 + a_off;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(d), "v"(src) : "memory");
+            } else {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + p * 1024 + a_off),
+                                                 (__attribute__((address_space(3))) void *)(l + p * 1024), 16, 0, 0);
+            }
         }
     };
     float braw[8], brawb[FOLD ? 8 : 1];
@@ -955,6 +971,25 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
 #pragma unroll
         for (int j = 0; j < 8; j++)
             braw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)s_off, (int)(j * row_bytes), FUSE ? 2 : 0));   // (aux 2 = nt: the samples are read once)
+    };
+    // SLDS: samples of stage t (frames 16 t ..) of the voxel quads at byte offsets qoff into this wave's sample tile `slot`.  Inline
+    // assembly: hipcc treats its own LDS-DMA builtins as stores that a later LDS read may depend on
+    char *stile = lds + 2 * TILEB + NW * TRB + XTAB + FTAB + QTAB + wave * 4096;
+    const uint32_t stile_l = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char *)stile);
+    auto load_S = [&](int t, uint32_t qoff, bool live, int slot) {
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        const int rem = live ? a.K - t * KT : 0;
+        const uint64_t span = (uint64_t)(rem > 0 ? rem : 0) * row_bytes;
+        const uint64_t b = reinterpret_cast<uint64_t>(rem > 0 ? Sbase + (int64_t)t * KT * row_bytes : Sbase);
+        i32x4_t r;
+        r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+        r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((b >> 32) & 0xffffu));
+        r[2] = __builtin_amdgcn_readfirstlane((int)(span > 0xffffffffull ? 0xffffffffu : (uint32_t)span));
+        r[3] = 0x00020000;
+        const uint32_t v0 = qoff + (uint32_t)(lane >> 3) * row_bytes, v1 = v0 + 8u * row_bytes;   // (in the vector offset: that is what the range check sees)
+        const uint32_t d0 = __builtin_amdgcn_readfirstlane(stile_l + (uint32_t)slot * 2048u);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" :: "s"(d0), "v"(v0), "s"(r) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" :: "s"(d0 + 1024u), "v"(v1), "s"(r) : "memory");
     };
     auto lane_state = [&](const Work &w, int32_t vr, bool &inb, int64_t &vox, uint32_t &s_off) {
         inb = (int64_t)w.tile_n * WGV + wave * 32 + col < nlive;
@@ -1003,8 +1038,14 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     u32x4_t bp[3];
     constexpr int H2_TARGET = 127 + 6;                  // biased exponent of the scaled running maximum when k is chosen
     int kexp = 127, kexp_fin = 127;                     // H2: biased exponent of 2^k (kexp_fin: of the item an early wave is finishing)
-    auto split = [&](int tile_m, int t) {
+    // (SLDS: reads the stage's samples from sample tile `slot` and, when done, requests stage tn of the quads at qo into that tile)
+    auto split = [&](int tile_m, int t, int slot = 0, int tn = 0, uint32_t qo = 0, bool live = false) {
         float cs[H2 ? 8 : 1];
+        if constexpr (SLDS) {
+            const float *sp = reinterpret_cast<const float *>(stile + slot * 2048) + (8 * kh) * 32 + col;
+#pragma unroll
+            for (int j = 0; j < 8; j++) braw[j] = sp[j * 32];
+        }
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
             float x0 = braw[2 * jj], x1 = braw[2 * jj + 1];
@@ -1067,17 +1108,20 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
                 const f16x2_t l = {(_Float16)r0, (_Float16)r1};
                 bp[0][jj] = __builtin_bit_cast(uint32_t, h); bp[1][jj] = __builtin_bit_cast(uint32_t, l);
             }
+            if constexpr (SLDS) load_S(tn, qo, live, slot);
         }
     };
 
     bool inb; int64_t vox; uint32_t s_off;
     lane_state(cur, vraw, inb, vox, s_off);
-    // ---- ring prologue: stage 0's pieces into LDS, its samples into registers ------------------------------------
+    uint32_t qoff = SLDS ? (uint32_t)__shfl((int)vox, 4 * (lane & 7)) * 4u : 0u, qoff_n = 0u;   // SLDS: byte offset of the voxel quad this lane requests
+    // ---- ring prologue: stage 0's pieces into LDS, its samples into registers (SLDS: stages 0 and 1 into the sample tiles) ----------
     stage_A(cur.tile_m, 0, 0);
-    load_B(0, s_off, true);
+    if constexpr (SLDS) { load_S(0, qoff, true, 0); load_S(1, qoff, true, 1); }
+    else load_B(0, s_off, true);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();                                     // (also: the extra rows' table is complete)
-    if (ANTI && early) split(cur.tile_m, 0);
+    if (ANTI && early) split(cur.tile_m, 0, 0, 2, qoff, true);
     int g = 0;                                           // stages done: ring position
     FIB_STAMP_BEGIN();
     FIB_PHASE_VARS();
@@ -1110,16 +1154,29 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
         // the middle of the stage loop, behind the next stage's loads: 11 % of the fused kernel, tools/check_loop_waits.py)
         bool inb_n = false; int64_t vox_n = 0; uint32_t s_off_n = 0;
         lane_state(nxt, vraw_nxt, inb_n, vox_n, s_off_n);
+        if constexpr (SLDS) qoff_n = (uint32_t)__shfl((int)vox_n, 4 * (lane & 7)) * 4u;
         for (int t = 0; t < ntiles; t++, g++) {
             const int cb = g & 1;
             const char *L = lds + cb * TILEB;
             FIB_PHASE(g / ntiles, wave, 1);             // stage top
+            const bool w1 = t + 1 < ntiles;
+            const int tm_n = w1 ? cur.tile_m : (nxt.valid ? nxt.tile_m : cur.tile_m);
+            if constexpr (SLDS) {
+                // pieces first, the sample request (at the end of the split) last: the stage's closing wait leaves exactly that request
+                // in flight.  A wave that splits first takes stage t (ring position g) and asks for position g + 2
+                stage_A(tm_n, w1 ? t + 1 : 0, cb ^ 1);
+                if (!(ANTI && early)) {
+                    const bool in = t + 2 < ntiles;
+                    split(cur.tile_m, t, g & 1, in ? t + 2 : t + 2 - ntiles, in ? qoff : qoff_n, in || nxt.valid);
+                }
+                FIB_PHASE(g / ntiles, wave, 2);
+            } else {
             if (!(ANTI && early)) split(cur.tile_m, t);
             FIB_PHASE(g / ntiles, wave, 2);             // (late waves: split done)
             // the next stage (it may open the next work item): pieces into the other buffer, samples into braw
-            const bool w1 = t + 1 < ntiles;
-            stage_A(w1 ? cur.tile_m : (nxt.valid ? nxt.tile_m : cur.tile_m), w1 ? t + 1 : 0, cb ^ 1);
+            stage_A(tm_n, w1 ? t + 1 : 0, cb ^ 1);
             load_B(w1 ? t + 1 : 0, w1 ? s_off : s_off_n, w1 || nxt.valid);
+            }
             __builtin_amdgcn_sched_barrier(0);          // the requests go out before the MFMA block, not after it
             FIB_PHASE(g / ntiles, wave, 3);             // requests issued
             if constexpr (H2) {
@@ -1178,12 +1235,21 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
                         vmax_fin = vmax; vnf_fin = vnf; vmax = 0.0f; vnf = 0.0f;
                         kexp_fin = kexp;
                     }
-                    split(w1 ? cur.tile_m : (nxt.valid ? nxt.tile_m : cur.tile_m), w1 ? t + 1 : 0);
+                    if constexpr (SLDS) {                // stage t + 1 (position g + 1), then the request for position g + 3
+                        if (w1) { const bool in = t + 3 < ntiles; split(cur.tile_m, t + 1, (g + 1) & 1, in ? t + 3 : t + 3 - ntiles, in ? qoff : qoff_n, in || nxt.valid); }
+                        else split(tm_n, 0, (g + 1) & 1, 2, qoff_n, nxt.valid);
+                    } else {
+                        split(tm_n, w1 ? t + 1 : 0);
+                    }
                 }
             }
             FIB_PHASE(g / ntiles, wave, 5);             // (early waves: next split done)
+            if constexpr (SLDS) __builtin_amdgcn_s_waitcnt(0x0F72);   // vmcnt(2): everything but the sample request just issued (2 instructions) has landed
+            else
             __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): the next stage's pieces and samples have landed
             FIB_PHASE(g / ntiles, wave, 6);             // loads landed
+            if constexpr (SLDS) __builtin_amdgcn_s_barrier();   // (no fence: this wave's LDS traffic of the stage is reads that its MFMAs have consumed)
+            else
             __syncthreads();
             FIB_PHASE(g / ntiles, wave, 7);             // barrier passed
         }
@@ -1218,11 +1284,12 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
         }
         FIB_PHASE(g / ntiles - 1, wave, 8);             // epilogue done
         if (!nxt.valid) break;
-        cur = nxt; inb = inb_n; vox = vox_n; s_off = s_off_n;
+        cur = nxt; inb = inb_n; vox = vox_n; s_off = s_off_n; qoff = qoff_n;
         nxt = work_at(g / ntiles + 1);
         vraw_nxt = vidx_at(nxt);     // (clamped: always a valid address)
         clear(early);
     }
+    if constexpr (SLDS) __builtin_amdgcn_s_waitcnt(0x0F70);   // (the last stages' requests -- empty ones -- must not outlive the workgroup)
     FIB_STAMP_END(ONE ? 8 : (FUSE ? 2 : (FOLD ? 3 : 1)), g / ntiles);
     if constexpr (FUSE) {
         for (int off = 32; off >= 1; off >>= 1) { const unsigned oth = (unsigned)__shfl_xor((int)en_run, off); en_run = oth > en_run ? oth : en_run; }
@@ -2377,7 +2444,8 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
             if ((rc3 = p->At3b.alloc(A3.size())) != FIB_OK || (rc3 = p->pair_flags.alloc(8 * 32)) != FIB_OK) return rc3;
             FIB_HIP(hipMemcpy(p->At3b.p, A3.data(), A3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         }
-        p->fused_shape = faces && p->gRow0 == 0 && p->scale_frame < 0 && M == FQ_NV && p->MB == 10 && p->NX == 1 && p->ntile_m == 1 && p->Kpad <= 512;
+        p->fused_shape = faces && p->gRow0 == 0 && p->scale_frame < 0 && M == FQ_NV && p->MB == 10 && p->NX == 1 && p->ntile_m == 1 && p->Kpad <= 512 &&
+                         nst >= 3;                              // (the sample tiles are requested two stages ahead)
         if (p->fused_shape) {                                   // second image in the row order of sphere642_fused.inc
             build(fib_f642_pos_vertex, A3, AX);
             if ((rc3 = p->At3f.alloc(A3.size())) != FIB_OK || (rc3 = p->Aextraf.alloc(AX.size())) != FIB_OK) return rc3;

@@ -7,7 +7,8 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 
 def _bf16(x):
@@ -40,7 +41,7 @@ def _contract(prods, shape, accum=np.float32):
 def _case():
     import fibers_jl_amd as fj
     from fibers_jl_amd import phantom
-    import oracle_np as onp
+    from oracle import oracle_np as onp
     bval, bvec = phantom.scheme_gqi()
     sph = fj.sphere_642
     W = onp.gqi_work(bval, bvec, np.asarray(sph.vertices), np.asarray(sph.faces), 1.25)
