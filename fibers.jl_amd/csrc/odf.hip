@@ -827,7 +827,7 @@ template <int MB, int NX, int NW, bool FOLD, bool FUSE, bool H2>
 constexpr int gemm3_lds_bytes() {
     return 2 * (H2 ? 2 : 3) * MB * 1024 + NW * (FUSE ? 4096 : 2048) + (NX > 0 ? (FUSE ? 2048 : 8192) : 0) +
            (FOLD ? 2 * FKMAX * 4 + 4 * FSMAX * 4 + (FUSE ? 0 : 2 * FKMAX * 4) : 0) + (FUSE ? NW * FQ_LIST + FQ_TABB : 0) +
-           (H2 && FUSE && !FOLD ? NW * 4096 : 0);       // (SLDS: two sample tiles per wave)
+           (H2 && FUSE && !FOLD ? NW * (4096 + 512) : 0);   // (SLDS: two sample tiles + the next items' mask bytes and list entries, per wave)
 }
 // ONE: the workgroup works on a single-tile image of its own (odf_dsi2_kernel: the DSI rows are cut into an ODF tile and a pdf tile
 // with images of different shapes); the work list still deals the items of both tiles (a.ntile_m = 2), and with an even number
@@ -852,7 +852,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     // can precede its use by at most a stage, and a stage had settled at the ~1.5 us a sample load takes under load (twice what its
     // MFMAs need); requests in LDS cost no registers, so they also cross an item's epilogue.
     constexpr bool SLDS = H2 && FUSE && !FOLD;
-    constexpr int STILE = SLDS ? NW * 4096 : 0;
+    constexpr int STILE = SLDS ? NW * (4096 + 512) : 0;
     static_assert(2 * TILEB + NW * TRB + XTAB + FTAB + QTAB + STILE == gemm3_lds_bytes<MB, NX, NW, FOLD, FUSE, H2>(), "LDS carve-up");
     uint64_t *q_posoff = reinterpret_cast<uint64_t *>(lds + 2 * TILEB + NW * TRB + XTAB + FTAB + (FUSE ? NW * FQ_LIST : 0));   // [320] matrix row -> byte offset of its output row
     int *q_slotv = reinterpret_cast<int *>(q_posoff + FQ_NPOS);                                                                               // [2][161] (half, slot) -> vertex
@@ -991,6 +991,19 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" :: "s"(d0), "v"(v0), "s"(r) : "memory");
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" :: "s"(d0 + 1024u), "v"(v1), "s"(r) : "memory");
     };
+    // SLDS: the NEXT item's mask byte (book[lane]) and the list entry of the item after it (book[64 + lane]) also come by LDS-DMA, one
+    // item ahead: a plain load at the top of an item would wait (vmcnt, in issue order) until the epilogue's row stores have drained
+    uint32_t *book = reinterpret_cast<uint32_t *>(lds + 2 * TILEB + NW * TRB + XTAB + FTAB + QTAB + NW * 4096 + wave * 512);
+    const uint32_t book_l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char *)book));
+    auto book_mask = [&](int64_t voxn) {
+        const uint8_t *mp = a.mask + voxn;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, off" :: "s"(book_l), "v"(mp) : "memory");
+    };
+    auto book_vidx = [&](const Work &w) {
+        const int64_t sl = (int64_t)w.tile_n * WGV + wave * 32 + col;
+        const int32_t *vp = a.vidx + (sl < a.nvox ? sl : a.nvox - 1);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(book_l + 256u), "v"(vp) : "memory");
+    };
     auto lane_state = [&](const Work &w, int32_t vr, bool &inb, int64_t &vox, uint32_t &s_off) {
         inb = (int64_t)w.tile_n * WGV + wave * 32 + col < nlive;
         vox = inb ? vr : 0;
@@ -1117,7 +1130,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     uint32_t qoff = SLDS ? (uint32_t)__shfl((int)vox, 4 * (lane & 7)) * 4u : 0u, qoff_n = 0u;   // SLDS: byte offset of the voxel quad this lane requests
     // ---- ring prologue: stage 0's pieces into LDS, its samples into registers (SLDS: stages 0 and 1 into the sample tiles) ----------
     stage_A(cur.tile_m, 0, 0);
-    if constexpr (SLDS) { load_S(0, qoff, true, 0); load_S(1, qoff, true, 1); }
+    if constexpr (SLDS) { load_S(0, qoff, true, 0); load_S(1, qoff, true, 1); book_mask(vox); }
     else load_B(0, s_off, true);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();                                     // (also: the extra rows' table is complete)
@@ -1148,13 +1161,19 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
         }
         float sraw = 0.0f;                               // DSI: the sample that sum(p) is a multiple of (dsi.jl:224-225)
         if (a.scale_frame >= 0) sraw = *reinterpret_cast<const float *>(Sbase + (int64_t)a.scale_frame * a.stride * 4 + (uint32_t)(vox * 4));
-        const bool lv = inb && a.mask[vox] != 0;         // voxels of a listed quad that are outside the mask: zeros
+        bool lv;                                         // voxels of a listed quad that are outside the mask: zeros
+        if constexpr (SLDS) lv = inb && (book[lane] & 0xffu) != 0u;
+        else lv = inb && a.mask[vox] != 0;
         // (unconditionally: vraw_nxt is a load, and a load whose only use sits behind a branch stays "in flight" for hipcc's waitcnt
         // insertion on the other path -- it then guards the first overwrite of a register near it with an s_waitcnt vmcnt(0) in
         // the middle of the stage loop, behind the next stage's loads: 11 % of the fused kernel, tools/check_loop_waits.py)
         bool inb_n = false; int64_t vox_n = 0; uint32_t s_off_n = 0;
         lane_state(nxt, vraw_nxt, inb_n, vox_n, s_off_n);
-        if constexpr (SLDS) qoff_n = (uint32_t)__shfl((int)vox_n, 4 * (lane & 7)) * 4u;
+        if constexpr (SLDS) {
+            qoff_n = (uint32_t)__shfl((int)vox_n, 4 * (lane & 7)) * 4u;
+            book_mask(vox_n);                            // (behind the read of book[lane] above)
+            book_vidx(work_at(g / ntiles + 2));
+        }
         for (int t = 0; t < ntiles; t++, g++) {
             const int cb = g & 1;
             const char *L = lds + cb * TILEB;
@@ -1286,7 +1305,8 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
         if (!nxt.valid) break;
         cur = nxt; inb = inb_n; vox = vox_n; s_off = s_off_n; qoff = qoff_n;
         nxt = work_at(g / ntiles + 1);
-        vraw_nxt = vidx_at(nxt);     // (clamped: always a valid address)
+        if constexpr (SLDS) vraw_nxt = (int32_t)book[64 + lane];   // (requested at the top of the item that has just ended)
+        else vraw_nxt = vidx_at(nxt);     // (clamped: always a valid address)
         clear(early);
     }
     if constexpr (SLDS) __builtin_amdgcn_s_waitcnt(0x0F70);   // (the last stages' requests -- empty ones -- must not outlive the workgroup)
