@@ -607,7 +607,9 @@ __device__ __forceinline__ float fq_max2(float a, float b) { return __builtin_fm
 
 // POW2: `scale` is a finite power of two for every voxel (H2 without the DSI factor): one legacy multiplication per value does the
 // scaling and the zeroing of voxels that are skipped or outside the mask
-template <int NW, bool PRE = false, bool SCALE = false, bool POW2 = false>
+// DRAIN: wait for the caller's requests in flight (the next item's first pieces and samples, issued a scan ago) right before the first
+// row store goes out -- after the stores no wait can tell those requests from the stores (gemm3_body SLDS)
+template <int NW, bool PRE = false, bool SCALE = false, bool POW2 = false, bool DRAIN = false>
 __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (&acc)[10], float xrow, float vmax, float vnf, bool inb, bool lv,
                                                      int64_t vox, int lane, char *tr, char *lst, const uint64_t *posoff, const int *slotv, const float *vl,
                                                      unsigned &en_run, float scale = 1.0f, float xscale = 1.0f) {
@@ -720,6 +722,7 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
                 }
             }
         };
+        if constexpr (DRAIN) __builtin_amdgcn_s_waitcnt(0x0F70);
         if (__all(qinb)) rows_out(std::false_type{}); else rows_out(std::true_type{});   // (the guarded copy: ragged end of the voxel list)
         if (inb && kh == 0) a.out1[(int64_t)FIB_F642_POLE * a.stride + vox] = xrow;
         if (cpole) { if (cnt < FQ_CAP) { lw[cnt * 128] = __float_as_uint(xrow); lw[cnt * 128 + 64] = 160u; } cnt++; }
@@ -1130,7 +1133,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     uint32_t qoff = SLDS ? (uint32_t)__shfl((int)vox, 4 * (lane & 7)) * 4u : 0u, qoff_n = 0u;   // SLDS: byte offset of the voxel quad this lane requests
     // ---- ring prologue: stage 0's pieces into LDS, its samples into registers (SLDS: stages 0 and 1 into the sample tiles) ----------
     stage_A(cur.tile_m, 0, 0);
-    if constexpr (SLDS) { load_S(0, qoff, true, 0); load_S(1, qoff, true, 1); book_mask(vox); }
+    if constexpr (SLDS) { stage_A(cur.tile_m, 1, 1); load_S(0, qoff, true, 0); load_S(1, qoff, true, 1); book_mask(vox); }
     else load_B(0, s_off, true);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();                                     // (also: the extra rows' table is complete)
@@ -1183,7 +1186,9 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
             if constexpr (SLDS) {
                 // pieces first, the sample request (at the end of the split) last: the stage's closing wait leaves exactly that request
                 // in flight.  A wave that splits first takes stage t (ring position g) and asks for position g + 2
-                stage_A(tm_n, w1 ? t + 1 : 0, cb ^ 1);
+                // (an item's second stage was requested before the previous item's row stores went out -- below -- and the epilogue has
+                // waited for it: stage 0 asks for no pieces and closes without a wait)
+                if (t > 0) stage_A(tm_n, w1 ? t + 1 : 0, cb ^ 1);
                 if (!(ANTI && early)) {
                     const bool in = t + 2 < ntiles;
                     split(cur.tile_m, t, g & 1, in ? t + 2 : t + 2 - ntiles, in ? qoff : qoff_n, in || nxt.valid);
@@ -1263,7 +1268,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
                 }
             }
             FIB_PHASE(g / ntiles, wave, 5);             // (early waves: next split done)
-            if constexpr (SLDS) __builtin_amdgcn_s_waitcnt(0x0F72);   // vmcnt(2): everything but the sample request just issued (2 instructions) has landed
+            if constexpr (SLDS) { if (t > 0) __builtin_amdgcn_s_waitcnt(0x0F72); }   // vmcnt(2): everything but the sample request just issued (2 instructions) has landed
             else
             __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): the next stage's pieces and samples have landed
             FIB_PHASE(g / ntiles, wave, 6);             // loads landed
@@ -1272,6 +1277,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
             __syncthreads();
             FIB_PHASE(g / ntiles, wave, 7);             // barrier passed
         }
+        if constexpr (SLDS) stage_A(nxt.valid ? nxt.tile_m : cur.tile_m, 1, (g & 1) ^ 1);   // the next item's second stage: the buffer the last stage has just left
         {
             // the voxel's clamped-sample maximum over both k halves; vnf = NaN iff it is NaN or +Inf (the epilogues' "non-finite sample" flag)
             float vm = early ? vmax_fin : vmax;
@@ -1286,7 +1292,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
             if constexpr (FUSE) {
                 float fscale = 1.0f;                      // DSI (the FOLD form): 1 / sum(p), NaN where a sample is not finite (see gemm3_epilogue)
                 if (FOLD) { const float s0 = sraw < 0.0f ? 0.0f : sraw; fscale = vn != vn ? __builtin_nanf("") : 1.0f / (a.scale_coef * s0); }
-                gemm3_epilogue_fused<NW, false, FOLD || H2, H2 && !FOLD>(a, acc, early ? xfin[0] : xacc[0], vm, vn, inb, lv, vox, lane, lds + 2 * TILEB + wave * TRB,
+                gemm3_epilogue_fused<NW, false, FOLD || H2, H2 && !FOLD, SLDS>(a, acc, early ? xfin[0] : xacc[0], vm, vn, inb, lv, vox, lane, lds + 2 * TILEB + wave * TRB,
                                                             lds + 2 * TILEB + NW * TRB + XTAB + FTAB + wave * FQ_LIST, q_posoff, q_slotv, q_vl, en_run,
                                                             fscale * asc, fscale);
             }
