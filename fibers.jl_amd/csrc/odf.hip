@@ -914,8 +914,9 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
         Work r;
         // (wave-uniform by construction; told to the compiler so that the stage loop's piece addresses are scalar arithmetic -- ntile_n
         // comes from a vector load and would otherwise drag 64-bit multiplications onto the VALU in every stage)
-        r.tile_m = ONE ? 0 : __builtin_amdgcn_readfirstlane(w % a.ntile_m);
-        r.tile_n = __builtin_amdgcn_readfirstlane(ONE ? (a.one_slot + i * a.one_stride) * 8 + xcd : (w / a.ntile_m) * 8 + xcd);
+        constexpr bool ONE_M = ONE || (FUSE && !FOLD);   // (the fused GQI form exists for single-tile matrices only: finish_plan)
+        r.tile_m = ONE_M ? 0 : __builtin_amdgcn_readfirstlane(w % a.ntile_m);
+        r.tile_n = __builtin_amdgcn_readfirstlane(ONE ? (a.one_slot + i * a.one_stride) * 8 + xcd : (ONE_M ? w : w / a.ntile_m) * 8 + xcd);
         r.valid = r.tile_n < ntile_n;
         return r;
     };
@@ -929,6 +930,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     Work nxt = work_at(1);
     int32_t vraw_nxt = vidx_at(nxt);     // (clamped: always a valid address)
 
+    const uint32_t lds_l = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char *)lds);
     auto stage_A = [&](int tile_m, int t, int buf) {
         const char *g = reinterpret_cast<const char *>(a.At3) + ((size_t)tile_m * ntiles + t) * TILEB;
         char *l = lds + buf * TILEB;
@@ -939,7 +941,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
             if constexpr (H2 && FUSE && !FOLD) {
                 // (SLDS: as inline assembly, like the sample requests -- a builtin LDS-DMA in flight makes hipcc close every barrier with
                 // s_waitcnt vmcnt(0), and that would wait for the sample request that is meant to stay in flight across it)
-                const uint32_t d = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char *)(l + p * 1024)));
+                const uint32_t d = __builtin_amdgcn_readfirstlane(lds_l + (uint32_t)(buf * TILEB + p * 1024));   // (integer arithmetic on the LDS address: a pointer cast per piece is a null check per piece)
                 const char *src = g + p * 1024 + a_off;
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(d), "v"(src) : "memory");
             } else {
@@ -1061,6 +1063,9 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
             const float *sp = reinterpret_cast<const float *>(stile + slot * 2048) + (8 * kh) * 32 + col;
 #pragma unroll
             for (int j = 0; j < 8; j++) braw[j] = sp[j * 32];
+            // (all eight reads before the first use: left alone hipcc reads a pair, waits, clamps it, reads the next pair into the same
+            // registers -- four LDS round trips in a row at the top of every split, and a wave issues one instruction per ~4 cycles)
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
