@@ -1121,6 +1121,21 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
             // register operand whose upper half is undefined, and that half can land on a register a load is still writing to --
             // the waitcnt insertion then puts s_waitcnt vmcnt(0) in front of the split, tools/check_loop_waits.py)
             const int kx = kexp - 127;
+            if constexpr (SLDS) {
+                // four instructions per sample pair: h = RN16(c 2^k) and l = RN16(fma(c, 2^k, -h)), each one v_fma_mix{lo,hi}_f16 (the
+                // product and the difference are exact in f32, the instruction rounds once to fp16: the same bits as the
+                // multiply / convert / subtract / convert sequence below, which costs seven)
+                const float sc = __uint_as_float((uint32_t)kexp << 23);
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    uint32_t h, l;
+                    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(cs[2 * jj]), "v"(sc));
+                    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(cs[2 * jj + 1]), "v"(sc));
+                    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(cs[2 * jj]), "v"(sc), "v"(h));
+                    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(cs[2 * jj + 1]), "v"(sc), "v"(h));
+                    bp[0][jj] = h; bp[1][jj] = l;
+                }
+            } else
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) {
                 const float p0 = __builtin_amdgcn_ldexpf(cs[2 * jj], kx), p1 = __builtin_amdgcn_ldexpf(cs[2 * jj + 1], kx);
