@@ -1098,33 +1098,36 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
             }
         }
         if constexpr (H2) {
-            // the voxel's running maximum over both k halves (v_permlane32_swap: no LDS round trip in the split)
-            const auto vsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(vmax), __float_as_uint(vmax), false, false);
-            const float mall = max3_nan(__uint_as_float(vsw[0]), __uint_as_float(vsw[1]), 0.0f);
-            const int e = (int)((__float_as_uint(mall) >> 23) & 0xffu);          // (255: NaN / +Inf -- the column is repaired anyway)
-            int kfit = e == 0 ? 127 + 60 : 127 + (H2_TARGET - e);
-            kfit = kfit < 1 ? 1 : (kfit > 253 ? 253 : kfit);
-            if (t == 0) kexp = e == 255 ? 127 : kfit;
-            else {
-                const bool lower = e != 255 && e + kexp >= 254 + 15;
-                if (__any(lower)) {                      // rare: wave-uniform branch, per-lane factor
-                    const int d = lower ? kfit - kexp : 0;
-                    const float f = __uint_as_float((uint32_t)(127 + (d < -126 ? -126 : d)) << 23);
+            // The exchange between the two k halves of a voxel is needed when an item opens (k is chosen) and when a sample would reach
+            // 2^15 after scaling (k is lowered: rare): a lane-local test and a wave-uniform branch decide, everything else is behind it
+            const float sck = __uint_as_float((uint32_t)kexp << 23);
+            if (t == 0 || __any(vmax * sck >= 32768.0f)) {       // (NaN: false -- the column is repaired anyway)
+                // the voxel's running maximum over both k halves (v_permlane32_swap: no LDS round trip in the split)
+                const auto vsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(vmax), __float_as_uint(vmax), false, false);
+                const float mall = max3_nan(__uint_as_float(vsw[0]), __uint_as_float(vsw[1]), 0.0f);
+                const int e = (int)((__float_as_uint(mall) >> 23) & 0xffu);          // (255: NaN / +Inf)
+                int kfit = e == 0 ? 127 + 60 : 127 + (H2_TARGET - e);
+                kfit = kfit < 1 ? 1 : (kfit > 253 ? 253 : kfit);
+                if (t == 0) kexp = e == 255 ? 127 : kfit;
+                else {
+                    const bool lower = e != 255 && e + kexp >= 254 + 15;
+                    if (__any(lower)) {                      // per-lane factor
+                        const int d = lower ? kfit - kexp : 0;
+                        const float f = __uint_as_float((uint32_t)(127 + (d < -126 ? -126 : d)) << 23);
 #pragma unroll
-                    for (int m = 0; m < MB; m++)
+                        for (int m = 0; m < MB; m++)
 #pragma unroll
-                        for (int r = 0; r < 16; r++) acc[m][r] *= f;
-                    kexp = lower ? kfit : kexp;
+                            for (int r = 0; r < 16; r++) acc[m][r] *= f;
+                        kexp = lower ? kfit : kexp;
+                    }
                 }
             }
-            // (v_ldexp_f32, not a multiplication: hipcc turns pairs of multiplications by one factor into v_pk_mul_f32 with a 64-bit
-            // register operand whose upper half is undefined, and that half can land on a register a load is still writing to --
-            // the waitcnt insertion then puts s_waitcnt vmcnt(0) in front of the split, tools/check_loop_waits.py)
-            const int kx = kexp - 127;
-            if constexpr (SLDS) {
-                // four instructions per sample pair: h = RN16(c 2^k) and l = RN16(fma(c, 2^k, -h)), each one v_fma_mix{lo,hi}_f16 (the
-                // product and the difference are exact in f32, the instruction rounds once to fp16: the same bits as the
-                // multiply / convert / subtract / convert sequence below, which costs seven)
+            // four instructions per sample pair: h = RN16(c 2^k) and l = RN16(fma(c, 2^k, -h)), each one v_fma_mix{lo,hi}_f16 -- the
+            // product and the difference are exact in f32 and the instruction rounds once to fp16.  (Written out in C++ hipcc makes it
+            // seven, or pairs the multiplications into v_pk_mul_f32 with a 64-bit register operand whose upper half is undefined: that
+            // half can land on a register a load is still writing to, and the waitcnt insertion then puts s_waitcnt vmcnt(0) in
+            // front of the split, tools/check_loop_waits.py.)
+            {
                 const float sc = __uint_as_float((uint32_t)kexp << 23);
 #pragma unroll
                 for (int jj = 0; jj < 4; jj++) {
@@ -1135,14 +1138,6 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
                     asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(cs[2 * jj + 1]), "v"(sc), "v"(h));
                     bp[0][jj] = h; bp[1][jj] = l;
                 }
-            } else
-#pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
-                const float p0 = __builtin_amdgcn_ldexpf(cs[2 * jj], kx), p1 = __builtin_amdgcn_ldexpf(cs[2 * jj + 1], kx);
-                const f16x2_t h = {(_Float16)p0, (_Float16)p1};
-                const float r0 = p0 - (float)h[0], r1 = p1 - (float)h[1];      // exact
-                const f16x2_t l = {(_Float16)r0, (_Float16)r1};
-                bp[0][jj] = __builtin_bit_cast(uint32_t, h); bp[1][jj] = __builtin_bit_cast(uint32_t, l);
             }
             if constexpr (SLDS) load_S(tn, qo, live, slot);
         }
