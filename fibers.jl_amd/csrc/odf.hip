@@ -1283,7 +1283,11 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
                 }
             }
             FIB_PHASE(g / ntiles, wave, 5);             // (early waves: next split done)
-            if constexpr (SLDS) { if (t > 0) __builtin_amdgcn_s_waitcnt(0x0F72); }   // vmcnt(2): everything but the sample request just issued (2 instructions) has landed
+            // vmcnt(2): everything but the sample request just issued (2 instructions) has landed.  Stage 0 of an item closes without a
+            // wait -- all it and stage 1 need was requested before the previous item's stores and the epilogue has waited for it --
+            // EXCEPT in a workgroup's first item: there an early wave's request for stage 2 went out behind the prologue's wait
+            // (a stale sample tile in stage 1 otherwise: seen as a rare wrong ODF under concurrent launches, tests/test_gpu_hosttier.py)
+            if constexpr (SLDS) { if (t > 0 || g == 0) __builtin_amdgcn_s_waitcnt(0x0F72); }
             else
             __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): the next stage's pieces and samples have landed
             FIB_PHASE(g / ntiles, wave, 6);             // loads landed
