@@ -931,6 +931,15 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     int32_t vraw_nxt = vidx_at(nxt);     // (clamped: always a valid address)
 
     const uint32_t lds_l = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char *)lds);
+    // (SLDS: the pieces through ONE buffer resource over the image -- per piece a scalar offset and the LDS address, nothing else: a
+    // wave issues one instruction per ~4 cycles, and 64-bit address arithmetic per piece was 45 of a stage's ~250 instructions)
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    i32x4_t rsrcA;
+    {
+        const uint64_t b = reinterpret_cast<uint64_t>(a.At3);
+        rsrcA[0] = (int)(uint32_t)b; rsrcA[1] = (int)(uint32_t)((b >> 32) & 0xffffu);
+        rsrcA[2] = (int)((uint32_t)(ONE ? 1 : a.ntile_m) * (uint32_t)ntiles * (uint32_t)TILEB); rsrcA[3] = 0x00020000;
+    }
     auto stage_A = [&](int tile_m, int t, int buf) {
         const char *g = reinterpret_cast<const char *>(a.At3) + ((size_t)tile_m * ntiles + t) * TILEB;
         char *l = lds + buf * TILEB;
@@ -941,9 +950,9 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
             if constexpr (H2 && FUSE && !FOLD) {
                 // (SLDS: as inline assembly, like the sample requests -- a builtin LDS-DMA in flight makes hipcc close every barrier with
                 // s_waitcnt vmcnt(0), and that would wait for the sample request that is meant to stay in flight across it)
-                const uint32_t d = __builtin_amdgcn_readfirstlane(lds_l + (uint32_t)(buf * TILEB + p * 1024));   // (integer arithmetic on the LDS address: a pointer cast per piece is a null check per piece)
-                const char *src = g + p * 1024 + a_off;
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(d), "v"(src) : "memory");
+                const uint32_t d = lds_l + (uint32_t)(buf * TILEB + p * 1024);   // (integer arithmetic on the LDS address: a pointer cast per piece is a null check per piece)
+                const uint32_t so = (uint32_t)((tile_m * ntiles + t) * TILEB + p * 1024);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(d), "v"(a_off), "s"(rsrcA), "s"(so) : "memory");
             } else {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + p * 1024 + a_off),
                                                  (__attribute__((address_space(3))) void *)(l + p * 1024), 16, 0, 0);
@@ -981,18 +990,18 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     // assembly: hipcc treats its own LDS-DMA builtins as stores that a later LDS read may depend on
     char *stile = lds + 2 * TILEB + NW * TRB + XTAB + FTAB + QTAB + wave * 4096;
     const uint32_t stile_l = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char *)stile);
+    const uint32_t lane_rows = (uint32_t)(lane >> 3) * row_bytes;
     auto load_S = [&](int t, uint32_t qoff, bool live, int slot) {
-        typedef int i32x4_t __attribute__((ext_vector_type(4)));
         const int rem = live ? a.K - t * KT : 0;
         const uint64_t span = (uint64_t)(rem > 0 ? rem : 0) * row_bytes;
-        const uint64_t b = reinterpret_cast<uint64_t>(rem > 0 ? Sbase + (int64_t)t * KT * row_bytes : Sbase);
+        const uint64_t b = reinterpret_cast<uint64_t>(Sbase) + (rem > 0 ? (uint64_t)(uint32_t)(t * KT) * row_bytes : 0ull);
         i32x4_t r;
-        r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
-        r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((b >> 32) & 0xffffu));
-        r[2] = __builtin_amdgcn_readfirstlane((int)(span > 0xffffffffull ? 0xffffffffu : (uint32_t)span));
+        r[0] = (int)(uint32_t)b;
+        r[1] = (int)(uint32_t)((b >> 32) & 0xffffu);
+        r[2] = (int)(span > 0xffffffffull ? 0xffffffffu : (uint32_t)span);
         r[3] = 0x00020000;
-        const uint32_t v0 = qoff + (uint32_t)(lane >> 3) * row_bytes, v1 = v0 + 8u * row_bytes;   // (in the vector offset: that is what the range check sees)
-        const uint32_t d0 = __builtin_amdgcn_readfirstlane(stile_l + (uint32_t)slot * 2048u);
+        const uint32_t v0 = qoff + lane_rows, v1 = v0 + 8u * row_bytes;   // (in the vector offset: that is what the range check sees)
+        const uint32_t d0 = stile_l + (uint32_t)slot * 2048u;
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" :: "s"(d0), "v"(v0), "s"(r) : "memory");
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" :: "s"(d0 + 1024u), "v"(v1), "s"(r) : "memory");
     };
