@@ -1035,7 +1035,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     constexpr bool ANTI = FUSE && NW == 8;
     const bool early = ANTI && (a.anti & 1) != 0 && wave < NW / 2;
     const bool prio = ANTI && (a.anti & 2) != 0;
-    float xfin[NXA], vmax_fin = 0.0f, vnf_fin = 0.0f;    // early waves: the sums of the item being accumulated (its last split is one stage ahead)
+    float xfin[NXA], vmax_fin = 0.0f;                   // early waves: the sums of the item being accumulated (its last split is one stage ahead)
 #pragma unroll
     for (int x = 0; x < NXA; x++) xfin[x] = 0.0f;
     auto clear = [&](bool keep_sums) {
@@ -1280,7 +1280,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
                     if (!w1) {                            // .. which opens the next work item: close this item's sums first
 #pragma unroll
                         for (int x = 0; x < NXA; x++) { xfin[x] = xacc[x]; xacc[x] = 0.0f; }
-                        vmax_fin = vmax; vnf_fin = vnf; vmax = 0.0f; vnf = 0.0f;
+                        vmax_fin = vmax; vmax = 0.0f; vnf = 0.0f;
                         kexp_fin = kexp;
                     }
                     if constexpr (SLDS) {                // stage t + 1 (position g + 1), then the request for position g + 3
