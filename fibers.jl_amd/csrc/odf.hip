@@ -600,6 +600,15 @@ static_assert(FQ_TABB % 16 == 0, "table block keeps the LDS carve-up 16-byte ali
 
 // (plain fmaxf / fminf chains: hipcc folds them into v_max3_f32 / v_min3_f32 and knows MFMA results are canonical; inline asm
 // would cost an s_nop per statement)
+// the value the other lane half holds / the maximum over both halves, by v_permlane32_swap (VALU) instead of ds_bpermute (an LDS round trip)
+__device__ __forceinline__ float fq_xhalf(float x, int kh) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);   // r[0]: the lower half's value in every lane, r[1]: the upper half's
+    return __uint_as_float(kh ? r[0] : r[1]);
+}
+__device__ __forceinline__ float fq_xhalf_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 __device__ __forceinline__ float fq_max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 __device__ __forceinline__ float fq_max3z(float a, float b) { return __builtin_fmaxf(__builtin_fmaxf(a, b), 0.0f); }
 __device__ __forceinline__ float fq_min3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
@@ -649,10 +658,10 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
 #define X(j) fx##j
 #define Z 0.0f
 #define FQ_FLAG(sid, t_, x_) asm("v_cmp_nge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"((sid) < 32 ? cw0 : (sid) < 64 ? cw1 : (sid) < 96 ? cw2 : (sid) < 128 ? cw3 : cw4) : "v"(t_), "v"(x_) : "vcc");
-#define FQ_FDEF(i, m, r) const float ff##i = __shfl_xor(acc[m][r], 32);
+#define FQ_FDEF(i, m, r) const float ff##i = fq_xhalf(acc[m][r], kh);
 #define FQ_SLOT(sid, m, r, n0, n1, n2, n3, n4, n5) { const float t_ = fq_max3z(fq_max3(fq_max3(n0, n1, n2), n3, n4), n5); FQ_FLAG(sid, t_, acc[m][r]) }
-#define FQ_XDEF(ja, jb, m, r) const float fo##ja = __shfl_xor(acc[m][r], 32); const float fx##ja = kh ? fo##ja : acc[m][r], fx##jb = kh ? acc[m][r] : fo##ja;
-#define FQ_FMAX(o0, o1, o2, x0, x1, x2, out) float out; { float p_ = fq_max3(o0, o1, o2); p_ = fq_max2(p_, __shfl_xor(p_, 32)); out = fq_max3z(fq_max3(p_, x0, x1), x2); }
+#define FQ_XDEF(ja, jb, m, r) const float fo##ja = fq_xhalf(acc[m][r], kh); const float fx##ja = kh ? fo##ja : acc[m][r], fx##jb = kh ? acc[m][r] : fo##ja;
+#define FQ_FMAX(o0, o1, o2, x0, x1, x2, out) float out; { float p_ = fq_max3(o0, o1, o2); p_ = fq_xhalf_max(p_); out = fq_max3z(fq_max3(p_, x0, x1), x2); }
 #define FQ_FTEST2(sid, ja, oa0, oa1, oa2, xa0, xa1, xa2, jb, ob0, ob1, ob2, xb0, xb1, xb2) { FQ_FMAX(oa0, oa1, oa2, xa0, xa1, xa2, ta_) FQ_FMAX(ob0, ob1, ob2, xb0, xb1, xb2, tb_) \
         const float t_ = kh ? tb_ : ta_, x_ = kh ? fx##jb : fx##ja; FQ_FLAG(sid, t_, x_) }
 #define FQ_FPOLE(j, o0, o1, o2, x0, x1, x2) { FQ_FMAX(o0, o1, o2, x0, x1, x2, t_) cpole = kh == 0 && !(t_ >= fx##j); }
