@@ -141,16 +141,23 @@ def main():
     shape = tuple(int(v) for v in os.environ.get("FIBERS_BENCH_SHAPE", "140,140,140").split(","))   # (tests shrink the volume)
     if os.environ.get("FIBERS_BENCH_ONE_DEVICE"):
         local = 0
-    if world > 1:
+    # FIBERS_BENCH_FORCE_PG=1 (test hook, 1-GPU box): with ONE rank still create the process group (backend nccl = RCCL) and take
+    # every multi-rank branch below -- barrier, all-reduces, the sharded drivers, the field all-gather, the object gather -- so that
+    # this file's RCCL code has run on hardware before its first 8-GPU launch
+    force_pg = os.environ.get("FIBERS_BENCH_FORCE_PG", "0") not in ("", "0")
+    multi = world > 1 or force_pg
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         torch.cuda.set_device(local)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local if world > 1 else 0)
+    dev = torch.device("cuda", local if multi else 0)
 
     import fibers_jl_amd as fj
     from fibers_jl_amd import dist as fd, phantom
@@ -166,7 +173,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -184,7 +191,7 @@ def main():
         fn()
         torch.cuda.synchronize()
         npre = max(5.0, min(2000.0, PRECOND_S / max(time.perf_counter() - t0, 1e-5)))   # (>= 5: the first call may carry one-off costs)
-        if world > 1:                                    # a step may hold a collective: the SAME number of steps on every rank
+        if multi:                                        # a step may hold a collective: the SAME number of steps on every rank
             tn = torch.tensor([npre], device=dev, dtype=torch.float64)
             dist.all_reduce(tn, op=dist.ReduceOp.MAX)
             npre = float(tn.item())
@@ -202,7 +209,7 @@ def main():
         sync()
         dt = time.perf_counter() - t0
         L.fib_profile_enable(0)
-        if world > 1:
+        if multi:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -221,10 +228,10 @@ def main():
     out = fj.odf_rec_device(plan, dwi, mask, normalize=False)
 
     def gqi_step():
-        if world == 1:                                                     # one GPU: qa ./= odfmax inside the library call
+        if not multi:                                                      # one GPU: qa ./= odfmax inside the library call
             fj.odf_rec_device(plan, dwi, mask, out=out, normalize=True)
-        else:                                                              # slab + all-reduce(MAX) of {odfmax, NaN flag} + qa ./= odfmax
-            fd.odf_rec_sharded(plan, dwi, mask, out=out)
+        else:                                                              # slab + ONE all-reduce(MAX) of {odfmax, NaN flag} + qa ./= odfmax
+            fd.odf_rec_sharded(plan, dwi, mask, out=out, counts=counts, always=force_pg)
 
     # the ramp out of the idle power state, for the record (untimed as far as `value` goes): ms per step in blocks of five
     cold = []
@@ -238,8 +245,10 @@ def main():
         cold.append((time.perf_counter() - t0) / 5 * 1e3)
     dt = timed(gqi_step, args.steps, args.warmup)
     gemm_ms, gemm_n = prof_get(L, "odf_gemm")
-    peaks_ms, peaks_n = prof_get(L, "odf_peaks")
-    refine_ms, refine_n = prof_get(L, "odfmax_refine")
+    peaks_ms, peaks_n = prof_get(L, "odf_peaks")              # (the separate peak kernel: not launched by the fused path)
+    post_ms, post_n = prof_get(L, "odf_post")                 # redo list + exact odfmax + its two floats: one launch
+    mc_ms, mc_n = prof_get(L, "mask_compact")
+    qn_ms, qn_n = prof_get(L, "qa_normalize")
     value = nvox * args.steps / dt / 1e6
 
     fused = os.environ.get("FIBERS_ODF_UNFUSED") is None and os.environ.get("FIBERS_ODF_GEMM", "bf16x3").lower() != "f32"
@@ -250,8 +259,10 @@ def main():
     split = os.environ.get("FIBERS_ODF_GEMM", "bf16x3").lower() != "f32"
     hbm2 = dict(achieved=gemm_bytes / (gemm_avg_ms * 1e-3) / 1e9 if gemm_n else 0.0, peak=PEAK_HBM_GBS, unit="GB/s",
                 algorithmic_bytes=gemm_bytes, frac=gemm_bytes / (gemm_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if gemm_n else 0.0)
-    pk = dict(avg_kernel_ms=peaks_ms / max(peaks_n, 1), refine_ms=refine_ms / max(refine_n, 1),
-              note="fused: what is left outside the contraction kernel (redo list + exact odfmax)" if fused else "separate peak kernel (ODF re-read)")
+    pk = dict(avg_kernel_ms=peaks_ms / max(peaks_n, 1), post_ms=post_ms / max(post_n, 1), mask_compact_ms=mc_ms / max(mc_n, 1),
+              qa_normalize_ms=qn_ms / max(qn_n, 1), launches_per_step=4 if fused else 6,
+              note=("fused: a step is 4 launches -- mask_compact (voxel list by decoupled look-back + outputs outside the mask), the contraction "
+                    "kernel, odf_post (redo list + exact odfmax), qa_normalize") if fused else "separate peak kernel (ODF re-read)")
     exact = os.environ.get("FIBERS_ODF_EXACT", "0") not in ("", "0")
     nprod = 6 if exact else 3
     if split:
@@ -333,6 +344,27 @@ def main():
                                                   mvoxels_of_volume_per_s=nvox / t_b / 1e6, gemm_kernel_ms=gb_ms / max(gb_n, 1),
                                                   note="ball mask r = 62 (998 592 voxels), 1 % of the samples set to 0 or -3; cost scales with the mask")
         del dwi_np, out_b, bm_h
+        # ---- what ONE of eight ranks would run per step, timed alone on this GPU: rank 0's z-slab of the same volume (nz = 18 of 140),
+        # the step of odf_rec_sharded without its collective (mask_compact, contraction, odf_post with the raw {max, flag} pair,
+        # qa_normalize from the pair).  No 8-GPU node has run this bench: this bounds the strong-scaling efficiency from the fixed
+        # per-step cost alone (ideal = the N = 1 step / 8) ------------------------------------------------------------------------
+        try:
+            zs0, zs1 = fd.slab_bounds(nz, 8, 0)
+            ns = (zs1 - zs0) * nxy
+            counts8 = [(b - a) * nxy for a, b in (fd.slab_bounds(nz, 8, r) for r in range(8))]
+            dwi_s = dwi[:, :ns].contiguous()
+            mask_s = torch.ones(ns, dtype=torch.uint8, device=dev)
+            out_s = fj.odf_rec_device(plan, dwi_s, mask_s, normalize=False)
+            nss = max(4, args.steps)
+            t_s = timed(lambda: fd.odf_rec_sharded(plan, dwi_s, mask_s, out=out_s, counts=counts8), nss, 2) / nss
+            gs_ms, gs_n = prof_get(L, "odf_gemm")
+            extra["gqi_slab_1of8"] = dict(voxels=ns, nz=zs1 - zs0, ms_per_step=t_s * 1e3, gemm_kernel_ms=gs_ms / max(gs_n, 1),
+                                          ideal_ms=dt / args.steps * 1e3 * ns / nvox,
+                                          efficiency_before_collectives=(dt / args.steps * ns / nvox) / t_s,
+                                          note="rank 0 of 8's slab timed alone on one GPU (no collective): ideal = N=1 ms_per_step x slab share")
+            del dwi_s, mask_s, out_s
+        except Exception as e:                                                      # noqa: BLE001
+            extra["gqi_slab_1of8"] = dict(error=str(e))
         # ---- the headline step with the other operand format (a plan built under FIBERS_ODF_EXACT picks it up): the exact 3 x bf16 split
         # when the line runs the default, the two-piece fp16 form when the line itself was run with FIBERS_ODF_EXACT=1 ------------------
         try:
@@ -364,14 +396,14 @@ def main():
             extra["gqi_exact_split"] = dict(error=str(e))
     if not args.no_extra:
         # ---- weak-scaling figure of the same step: one whole volume per rank, odfmax all-reduced -----------------------------
-        if world > 1:
+        if multi:
             del out, dwi
             torch.cuda.empty_cache()
             dwi_w, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=3 + rank, device=dev)
             mask_w = torch.ones(nvox, dtype=torch.uint8, device=dev)
             out_w = fj.odf_rec_device(plan, dwi_w, mask_w, normalize=False)
             nst = max(2, args.steps // 2)
-            t_w = timed(lambda: fd.odf_rec_sharded(plan, dwi_w, mask_w, out=out_w), nst, 1)
+            t_w = timed(lambda: fd.odf_rec_sharded(plan, dwi_w, mask_w, out=out_w, counts=[nvox] * world, always=force_pg), nst, 1)
             extra["gqi_weak_scaling"] = dict(mvoxels_per_s=world * nvox * nst / t_w / 1e6, ms_per_step=t_w / nst * 1e3,
                                              note="one whole 140^3 x 270 volume per rank, 2-float all-reduce(MAX) inside the step")
             del dwi_w, out_w, mask_w
@@ -397,7 +429,7 @@ def main():
         # the timed step (the path's only bulk collective: 16 B/voxel), seeds round-robin, no collective after ----------------------
         bm_full = phantom.ball_mask_torch(shape, dev)
         field_loc, mout_loc = fj.stream_field_device([o2["eigvec1"]], fa=o2["fa"], fa_thresh=0.1, mask=bm_full[v0:v1].contiguous())
-        mout = fd.allgather_slabs(mout_loc, counts)
+        mout = fd.allgather_slabs(mout_loc, counts, always=force_pg)
         seeds_all = torch.nonzero(mout).flatten()
         sub = torch.tensor([[0.1, -0.2, 0.3]], dtype=torch.float32, device=dev)
         xyz_buf = {}
@@ -409,13 +441,13 @@ def main():
         res = {}
 
         def stream_step():
-            field = fd.allgather_slabs(field_loc, counts)                    # shared peak field over xGMI
+            field = fd.allgather_slabs(field_loc, counts, always=force_pg)   # shared peak field over xGMI
             res["r"] = fd.stream_sharded(field, shape, seeds_all, sub, xyz_out=xyz_out)
         nst = max(2, args.steps // 2)
         t_st = timed(stream_step, nst, 2)
         r = res["r"]
         cnt = torch.tensor([float(r["xyz"].shape[0]), float(r["npts"].numel())], device=dev, dtype=torch.float64)
-        if world > 1:
+        if multi:
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         npoints, nlines, t_st = int(cnt[0].item()), int(cnt[1].item()), t_st / nst
         tr_ms, tr_n = prof_get(L, "stream_trace")
@@ -572,14 +604,14 @@ def main():
         nd = max(2, args.steps // 2)
 
         def dsi_step():
-            if world == 1:
+            if not multi:
                 fj.odf_rec_device(p5, d5, mask, out=o5, normalize=True)
             else:
-                fd.odf_rec_sharded(p5, d5, mask, out=o5)
+                fd.odf_rec_sharded(p5, d5, mask, out=o5, counts=counts, always=force_pg)
         t_dsi = timed(dsi_step, nd, 1) / nd
         g_ms, g_n = prof_get(L, "odf_gemm")
         f_ms, f_n = prof_get(L, "dsi_fold")
-        q_ms, q_n = prof_get(L, "odf_peaks")
+        q_ms, q_n = prof_get(L, "odf_post")
         n5 = len(b5)
         dsi_bytes = (4.0 * n5 + 1 + 4.0 * n5 + 4.0 * nvert + 48) * nloc          # 5 456 B / voxel (DWI + mask in; pdf, odf, peaks, qa out)
         dsi_k_ms = g_ms / max(g_n, 1)
@@ -606,7 +638,7 @@ def main():
         del d5
         bm_full5 = phantom.ball_mask_torch(shape, dev)
         f3_loc, m3_loc = fj.stream_field_device(o5["peak"], f=o5["qa"], f_thresh=0.03, mask=bm_full5[v0:v1].contiguous())
-        mout3 = fd.allgather_slabs(m3_loc, counts)
+        mout3 = fd.allgather_slabs(m3_loc, counts, always=force_pg)
         seeds3 = torch.nonzero(mout3).flatten()
         sub10 = torch.from_numpy(fj.make_sublist(10, np.random.default_rng(5))).to(dev)
         xyz5 = {}
@@ -618,14 +650,14 @@ def main():
         r3 = {}
 
         def c5_step():
-            field3 = fd.allgather_slabs(f3_loc, counts)                         # the shared 3-peak field over xGMI (48 B / voxel)
+            field3 = fd.allgather_slabs(f3_loc, counts, always=force_pg)       # the shared 3-peak field over xGMI (48 B / voxel)
             r3["r"] = fd.stream_sharded(field3, shape, seeds3, sub10, xyz_out=xyz_out5)
         t3 = timed(c5_step, 3, 2) / 3
         tr_ms, tr_n = prof_get(L, "stream_trace")
         pk_ms, pk_n = prof_get(L, "stream_pack")
         sc_ms, sc_n = prof_get(L, "stream_scan")
         cnt3 = torch.tensor([float(r3["r"]["xyz"].shape[0]), float(r3["r"]["npts"].numel())], device=dev, dtype=torch.float64)
-        if world > 1:
+        if multi:
             dist.all_reduce(cnt3, op=dist.ReduceOp.SUM)
         np3, nl3 = int(cnt3[0].item()), int(cnt3[1].item())
         ksum3 = (tr_ms + pk_ms + sc_ms) / max(tr_n, 1)
@@ -714,7 +746,7 @@ def main():
                                     "(the chip leaves its idle power state over ~50 ms of load; extra.gqi_cold_start, tools/step_evolution.py)" % PRECOND_S,
                     roofline=roofline, cpu_baseline=cpu, extra=extra)
         print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.barrier()                                   # (rank 0 may still have been timing the CPU baseline)
         dist.destroy_process_group()
 

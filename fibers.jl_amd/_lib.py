@@ -57,6 +57,10 @@ _PROTOS = {
     "fib_dti_plan_tables": (i32, [vp, vp, vp, C.POINTER(i32)]),
     "fib_gqi_plan_create": (i32, [i32, vp, vp, i32, vp, i32, vp, i32, f32, C.POINTER(vp)]),
     "fib_dsi_plan_create": (i32, [i32, vp, vp, i32, vp, i32, vp, i32, i32, C.POINTER(vp)]),
+    "fib_gqi_plan_create_fmt": (i32, [i32, vp, vp, i32, vp, i32, vp, i32, f32, i32, C.POINTER(vp)]),
+    "fib_dsi_plan_create_fmt": (i32, [i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, C.POINTER(vp)]),
+    "fib_odf_plan_format": (i32, [vp]),
+    "fib_odf_default_format": (i32, []),
     "fib_odf_plan_destroy": (None, [vp]),
     "fib_odf_plan_matrix": (i32, [vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "fibd_dti_fit": (i32, [vp, vp, vp, i64, C.POINTER(DtiOut), vp]),
@@ -67,6 +71,7 @@ _PROTOS = {
     "fibd_odf_rec": (i32, [vp, vp, vp, i64, vp, vp, P3, P3, vp, i32, vp]),
     "fibd_qa_normalize": (i32, [P3, i64, f32, vp]),
     "fibd_qa_normalize_dev": (i32, [P3, i64, vp, vp]),
+    "fibd_qa_normalize_pair": (i32, [P3, i64, vp, vp]),
     "fibd_find_peaks": (i32, [vp, vp, i64, vp, vp, vp]),
     "fibd_stream_field": (i32, [i32, i64, vp, vp, f32, vp, f32, vp, vp, vp, vp]),
     "fibd_stream_trace": (i32, [C.POINTER(StreamParams), vp, vp, i64, vp, i32, vp,

@@ -496,11 +496,13 @@ int odf_plan_for(DevState &d, const OdfSpec &s, fib_odf_plan **plan) {
     key_add(key, s.verts, sizeof(float) * 3 * s.nverts);
     key_add(key, s.faces, sizeof(int32_t) * 3 * s.nfaces);
     key_add(key, s.dsi ? (const void *)&s.hann_width : (const void *)&s.sigma, 4);
+    const int fmt = fib_odf_default_format();            // the operand format is part of a plan's identity (it may change with the environment)
+    key_add(key, &fmt, sizeof(fmt));
     void *p = nullptr;
     RC(cached_plan(d, 1, key, [&](void **out) {
         fib_odf_plan *q = nullptr;
-        const int rc = s.dsi ? fib_dsi_plan_create(d.device, s.bval, s.bvec, s.nvol, s.verts, s.nverts, s.faces, s.nfaces, s.hann_width, &q)
-                             : fib_gqi_plan_create(d.device, s.bval, s.bvec, s.nvol, s.verts, s.nverts, s.faces, s.nfaces, s.sigma, &q);
+        const int rc = s.dsi ? fib_dsi_plan_create_fmt(d.device, s.bval, s.bvec, s.nvol, s.verts, s.nverts, s.faces, s.nfaces, s.hann_width, fmt, &q)
+                             : fib_gqi_plan_create_fmt(d.device, s.bval, s.bvec, s.nvol, s.verts, s.nverts, s.faces, s.nfaces, s.sigma, fmt, &q);
         *out = q;
         return rc;
     }, &p));

@@ -6,7 +6,7 @@
 //          odf_gemm_kernel   the same contraction on v_mfma_f32_32x32x2_f32 (FIBERS_ODF_GEMM=f32 and every plan the
 //                            split kernel does not take)
 //                            (gqi.jl:139-145 `mul!(o, A, s)`; dsi.jl:204-246 recast as two dense maps)
-//          mask_*_kernel, zero_dead_kernel, odf_inf_fix_kernel: voxel-list compaction, outputs outside the mask,
+//          mask_compact_kernel, odf_post_kernel, odf_inf_fix_kernel: voxel-list compaction + outputs outside the mask (one launch),
 //                            columns of voxels with a +Inf sample
 //   K3     odf_peaks642_kernel (sphere_642, specialised scan + candidate lists), odf_peaks64_kernel (any tessellation),
 //          odf_peaks_kernel (32-voxel tiles): find_peaks! + peak/qa extraction (gqi.jl:147-159,180-201; dsi.jl:244-258)
@@ -627,10 +627,8 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
     const float pn = vnf + __shfl_xor(vnf, 32);
     const bool nonfinite = pn != pn;                    // the voxel holds a NaN or +Inf sample (after the clamp)
     const bool valid = lv && (pm > 0.0f || nonfinite);  // gqi.jl:142
-    if (a.fix_list != nullptr && kh == 0 && lv && pm == INFINITY) {      // +Inf sample: column recomputed by odf_inf_fix_kernel
-        const int slot = atomicAdd(a.fix_count, 1);
-        if (slot < a.fix_cap) a.fix_list[slot] = (int32_t)vox;
-    }
+    // (a +Inf sample where the repair exists, GQI: the voxel goes to the redo list with bit 31 set and odf_post_kernel recomputes its column)
+    const bool refix = a.fix_list != nullptr && lv && pm == INFINITY;
     if (!PRE) xrow += __shfl_xor(xrow, 32);
     if constexpr (SCALE) {                              // DSI: p ./ sum(p) (dsi.jl:225) before the radial sums are looked at
 #pragma unroll
@@ -774,7 +772,7 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
     if (kh == 0 && inb) {
         if (redo) {
             const int slot = atomicAdd(a.redo_count, 1);
-            if (slot < a.redo_cap) a.redo_list[slot] = (int32_t)vox;
+            if (slot < a.redo_cap) a.redo_list[slot] = (int32_t)((unsigned)vox | (refix ? 0x80000000u : 0u));
         }
         a.mean_hi[vox] = redo ? __builtin_nanf("") : mean + eps;
         const int n = npos < 3 ? npos : 3;              // gqi.jl:151
@@ -1401,124 +1399,173 @@ __global__ __launch_bounds__(512, 2) void odf_dsi2_kernel(const GemmArgs a) {
 // that every four consecutive list entries are four consecutive, 16-byte aligned voxels (dwordx4 row stores in the
 // GEMM epilogue; the GEMM re-tests the mask per voxel and writes zeros for the group's voxels outside it: at most 3
 // wasted columns per run end).  tiles = ascending list of the 64-voxel tiles that hold at least one voxel of the
-// mask; both counts stay on the device (no host round trip).  Three small launches: per-block counts,
-// one-block exclusive scan, ordered write.  A block covers 1024 voxels as 4 passes x 4 waves x 64 lanes, so a
-// wave-pass is exactly one tile and a ballot gives both counts.
-constexpr int CB = 1024;
+// mask; both counts stay on the device (no host round trip).
+// [r4] ONE launch (it was three: per-block counts, one-block scan, ordered write -- plus a fourth for the outputs outside the
+// mask): a workgroup draws a chunk (a whole number of 4096-voxel sub-chunks: 4 passes x 16 waves x 64 lanes, so that a wave-pass
+// is exactly one tile and a ballot gives both counts; at most 1024 chunks per volume) from a ticket counter, publishes the
+// chunk's two counts as ONE 8-byte granule {epoch, tiles, voxels}, adds up the granules of all chunks before it (every thread
+// polls one: a single round; a chunk number is drawn before anything is waited for, so every chunk a workgroup waits for
+// belongs to a workgroup that is already running -- no assumption on dispatch order or residency), writes its part of the two
+// lists and clears the chunk's output voxels outside the mask.  Granules are written and read with agent-scope atomics (the
+// data is the flag: no fence); the epoch is the plan's call counter, so nothing has to be cleared between calls.  The
+// workgroup with the last chunk writes the totals, clears the peak finder's running maximum and resets the ticket.
+constexpr int CB = 4096;                             // voxels per sub-chunk
+constexpr int CB_ITERS_MAX = 32;                     // sub-chunks per chunk (2^27 voxels / 4096 / 1024 chunks)
 // lanes of the quads (aligned groups of 4 lanes = voxels) in which at least one lane's bit is set
 __device__ __forceinline__ unsigned long long quad_expand(unsigned long long b) {
     unsigned long long q = (b | (b >> 1) | (b >> 2) | (b >> 3)) & 0x1111111111111111ull;
     return q | (q << 1) | (q << 2) | (q << 3);
 }
-__global__ __launch_bounds__(256) void mask_count_kernel(const uint8_t *__restrict__ mask, int64_t nvox, int2 *__restrict__ blockcnt) {
-    __shared__ int cv[4], ct[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int nv = 0, nt = 0;
-    for (int i = 0; i < 4; i++) {
-        const int64_t vx = (int64_t)blockIdx.x * CB + i * 256 + tid;
-        const unsigned long long b = __ballot(vx < nvox && mask[vx] != 0);
-        nv += __popcll(quad_expand(b) & __ballot(vx < nvox));
-        nt += b != 0ull;
-    }
-    if (lane == 0) { cv[wave] = nv; ct[wave] = nt; }
-    __syncthreads();
-    if (tid == 0) blockcnt[blockIdx.x] = make_int2(cv[0] + cv[1] + cv[2] + cv[3], ct[0] + ct[1] + ct[2] + ct[3]);
-}
-// in-place exclusive scan of blockcnt[nb]; totals -> {nlive, ntiles_live}
-__global__ __launch_bounds__(1024) void mask_scan_kernel(int2 *__restrict__ blockcnt, int nb, int32_t *__restrict__ totals, unsigned *__restrict__ maxenc) {
-    __shared__ int2 part[1024];
-    const int tid = threadIdx.x;
-    const int per = (nb + 1023) / 1024;
-    const int lo = tid * per, hi = lo + per < nb ? lo + per : nb;
-    int2 sum = make_int2(0, 0);
-    for (int i = lo; i < hi; i++) { sum.x += blockcnt[i].x; sum.y += blockcnt[i].y; }
-    part[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan of the 1024 segment sums
-        int2 add = make_int2(0, 0);
-        if (tid >= off) add = part[tid - off];
-        __syncthreads();
-        part[tid].x += add.x; part[tid].y += add.y;
-        __syncthreads();
-    }
-    int2 run = tid ? part[tid - 1] : make_int2(0, 0);
-    for (int i = lo; i < hi; i++) { const int2 c = blockcnt[i]; blockcnt[i] = run; run.x += c.x; run.y += c.y; }
-    if (tid == 1023) { totals[0] = part[1023].x; totals[1] = part[1023].y; totals[2] = 0; totals[3] = 0; }   // [2]: length of the +Inf voxel list, [3]: of the redo list
-    if (tid < 4 && maxenc) maxenc[tid] = 0u;                // (the peak finder's running odfmax: one memset launch less)
-}
-__global__ __launch_bounds__(256) void mask_write_kernel(const uint8_t *__restrict__ mask, int64_t nvox, const int2 *__restrict__ blockoff,
-                                                        int32_t *__restrict__ vidx, int32_t *__restrict__ tiles) {
-    __shared__ int cv[16], ct[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long b[4], e[4];
-    for (int i = 0; i < 4; i++) {
-        const int64_t vx = (int64_t)blockIdx.x * CB + i * 256 + tid;
-        b[i] = __ballot(vx < nvox && mask[vx] != 0);
-        e[i] = quad_expand(b[i]) & __ballot(vx < nvox);
-        if (lane == 0) { cv[i * 4 + wave] = __popcll(e[i]); ct[i * 4 + wave] = b[i] != 0ull; }
-    }
-    __syncthreads();
-    const int2 off = blockoff[blockIdx.x];
-    for (int i = 0; i < 4; i++) {
-        int pv = off.x, pt = off.y;
-        for (int c = 0; c < i * 4 + wave; c++) { pv += cv[c]; pt += ct[c]; }
-        const int64_t vx = (int64_t)blockIdx.x * CB + i * 256 + tid;
-        if ((e[i] >> lane) & 1ull) vidx[pv + __popcll(e[i] & ((1ull << lane) - 1ull))] = (int32_t)vx;
-        if (lane == 0 && b[i]) tiles[pt] = (int32_t)(vx >> 6);
-    }
-}
 // outputs of voxels outside the mask are zero (the reference's output volumes start zero-filled): every output
 // row of the GEMM plus the 9 peak components and 3 qa volumes
-struct ZeroArgs { float *out0, *out1, *peak[3], *qa[3]; int n0, n1; int64_t nvox, stride; const uint8_t *mask; const int32_t *nlive; };
-constexpr int ZROWS = 8;       // row groups (blockIdx.y)
-__global__ __launch_bounds__(256) void zero_dead_kernel(const ZeroArgs z) {
-    // A thread owns 4 consecutive voxels: it reads their mask bytes once and then walks the output rows of its row group
-    // (blockIdx.y), one 16-byte store per row when all four are outside the mask (scalar stores for mixed groups): pure
-    // streaming stores with no load in the loop (the earlier row-major version re-read the mask for every row: 0.67-0.87
-    // ms on the ball mask, i.e. half the fill rate).
-    if (z.nlive[0] == z.nvox) return;                       // nothing outside the mask
-    const int64_t v0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    const int nr = z.n0 + z.n1 + 12;
-    const int per = (nr + ZROWS - 1) / ZROWS;
-    const int r0 = blockIdx.y * per, r1 = r0 + per < nr ? r0 + per : nr;
-    const bool full = v0 + 4 <= z.nvox;
-    // Whole-line stores run at the fill rate (6.7 TB/s), the ragged ends of the runs outside a mask at well under half of it
-    // (ball mask: 0.90 ms selective, 0.54 ms for everything): once a quarter of the volume is outside the mask, clear it all
-    // and let the GEMM / peak kernels overwrite the voxels inside.
-    const bool everything = (int64_t)z.nlive[0] * 4 < z.nvox * 3;
-    if (everything && z.stride == z.nvox && (z.nvox & 3) == 0) {
-        // every output is one contiguous array (rows follow each other): each block clears one contiguous span of each
-        const int64_t nb = (int64_t)gridDim.x * gridDim.y, b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-        auto clear = [&](float *p, int64_t nfl) {
-            if (!p || nfl <= 0) return;
-            if (reinterpret_cast<uintptr_t>(p) & 15) { for (int64_t i = b * 256 + threadIdx.x; i < nfl; i += nb * 256) p[i] = 0.0f; return; }
-            const int64_t nq = nfl >> 2;
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
-            v4f *d = reinterpret_cast<v4f *>(p);
-            int64_t q = b * 1024 + threadIdx.x;
-            for (; q + 768 < nq; q += nb * 1024) { d[q] = zero4; d[q + 256] = zero4; d[q + 512] = zero4; d[q + 768] = zero4; }
-            for (int i = 0; i < 4; i++) if (q + 256 * i < nq) d[q + 256 * i] = zero4;
-        };
-        clear(z.out0, (int64_t)z.n0 * z.nvox);
-        clear(z.out1, (int64_t)z.n1 * z.nvox);
-        for (int k = 0; k < 3; k++) { clear(z.peak[k], 3 * z.nvox); clear(z.qa[k], z.nvox); }
+struct ZeroArgs { float *out0, *out1, *peak[3], *qa[3]; int n0, n1; int64_t nvox, stride; };
+struct CompactArgs {
+    const uint8_t *mask; int64_t nvox;
+    int32_t *vidx, *tiles;
+    unsigned long long *state;    // [nchunks] granules: epoch << 32 | tiles of the chunk << 18 | listed voxels of the chunk
+    unsigned *ticket;             // [4]: chunk dispenser, the post kernel's arrival counter, -, -
+    int32_t *totals;              // [4]: {listed voxels, listed tiles, length of the +Inf list, length of the redo list}
+    unsigned *maxenc;             // [4] (may be NULL)
+    unsigned epoch;
+    int nchunks, iters, zero;     // iters: sub-chunks per chunk; zero: workgroups nchunks.. of the grid clear the outputs outside the mask (z)
+    unsigned *clear; int nclear;  // words the call needs zeroed before its next launch (odf_dsi2_kernel's pairing counters)
+    ZeroArgs z;
+};
+typedef __attribute__((address_space(1))) unsigned long long fib_gu64;
+__global__ __launch_bounds__(1024) void mask_compact_kernel(const CompactArgs c) {
+    __shared__ int cv[CB_ITERS_MAX][64], ct[CB_ITERS_MAX][64];
+    __shared__ int s_chunk, s_base[2], s_agg[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool compacts = (int)blockIdx.x < c.nchunks;        // (the other workgroups only help to clear outputs)
+    if (compacts) {
+        if (tid == 0) { s_chunk = (int)atomicAdd(c.ticket, 1u); s_base[0] = 0; s_base[1] = 0; }
+        __syncthreads();
+        const int t = s_chunk;
+        const int64_t base = (int64_t)t * c.iters * CB;
+        for (int it = 0; it < c.iters; it++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int64_t vx = base + (int64_t)it * CB + i * 1024 + tid;
+                const unsigned long long inr = __ballot(vx < c.nvox);
+                const unsigned long long b = __ballot(vx < c.nvox && c.mask[vx] != 0);
+                const unsigned long long e = quad_expand(b) & inr;
+                if (lane == 0) { cv[it][i * 16 + wave] = __popcll(e); ct[it][i * 16 + wave] = b != 0ull; }   // entry = wave-pass in voxel order
+            }
+        __syncthreads();
+        if (wave == 0) {                                         // exclusive prefix over the chunk's wave-passes, and its two totals
+            int runv = 0, runt = 0;
+            for (int it = 0; it < c.iters; it++) {
+                const int v = cv[it][lane], tl = ct[it][lane];
+                int sv = v, stl = tl;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int ov = __shfl_up(sv, off), ot = __shfl_up(stl, off);
+                    if (lane >= off) { sv += ov; stl += ot; }
+                }
+                cv[it][lane] = runv + sv - v; ct[it][lane] = runt + stl - tl;
+                runv += __shfl(sv, 63); runt += __shfl(stl, 63);
+            }
+            if (lane == 0) {
+                s_agg[0] = runv; s_agg[1] = runt;
+                __hip_atomic_store((fib_gu64 *)(c.state + t), ((unsigned long long)c.epoch << 32) | ((unsigned long long)runt << 18) | (unsigned long long)runv,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        {                                                        // the sum over the chunks before this one: thread i polls chunk i (nchunks <= 1024)
+            int pv = 0, pt = 0;
+            if (tid < t) {
+                unsigned long long g;
+                for (;;) {
+                    g = __hip_atomic_load((fib_gu64 *)(c.state + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(g >> 32) == c.epoch) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                pv = (int)(g & 0x3ffffull); pt = (int)((g >> 18) & 0x3fffull);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { pv += __shfl_xor(pv, off); pt += __shfl_xor(pt, off); }
+            if (lane == 0 && (pv | pt)) { atomicAdd(&s_base[0], pv); atomicAdd(&s_base[1], pt); }
+        }
+        __syncthreads();
+        if (t == c.nchunks - 1 && wave == 0) {                   // every chunk has been drawn: totals, and the state of the next call
+            if (lane == 0) {
+                c.totals[0] = s_base[0] + s_agg[0]; c.totals[1] = s_base[1] + s_agg[1]; c.totals[2] = 0; c.totals[3] = 0;
+                if (c.maxenc) { c.maxenc[0] = 0u; c.maxenc[1] = 0u; c.maxenc[2] = 0u; c.maxenc[3] = 0u; }
+                c.ticket[0] = 0u; c.ticket[1] = 0u;
+            }
+            for (int i = lane; i < c.nclear; i += 64) c.clear[i] = 0u;
+        }
+        for (int it = 0; it < c.iters; it++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int64_t vx = base + (int64_t)it * CB + i * 1024 + tid;
+                const unsigned long long b = __ballot(vx < c.nvox && c.mask[vx] != 0);
+                const unsigned long long e = quad_expand(b) & __ballot(vx < c.nvox);
+                const int pv = s_base[0] + cv[it][i * 16 + wave], pt = s_base[1] + ct[it][i * 16 + wave];
+                if ((e >> lane) & 1ull) c.vidx[pv + __popcll(e & ((1ull << lane) - 1ull))] = (int32_t)vx;
+                if (lane == 0 && b) c.tiles[pt] = (int32_t)(vx >> 6);
+            }
         return;
     }
-    if (v0 >= z.nvox) return;
-    bool dead[4];
+    // ---- outputs outside the mask: the job of the helper workgroups behind the compacting ones (they wait for nothing, and the
+    // compacting workgroups' chain is not lengthened).  The (span of 8 sub-chunks, group of 16 rows) items are dealt out
+    // round-robin: a thread owns 4 consecutive voxels of each sub-chunk and walks the rows, one 16-byte store per row and
+    // sub-chunk when all four are outside (scalar stores for mixed groups); a sub-chunk with more than a quarter of its voxels
+    // outside is cleared as a whole -- whole-line stores run at the fill rate, the ragged ends of the runs outside a mask at well
+    // under half of it -- and the GEMM / peak kernels overwrite the voxels inside.  A workgroup writes 128 KiB of a row before it
+    // moves to the next row (16 KiB pieces of 83 rows, 11 MB apart, ran at 4.4 TB/s).  With everything inside the mask an item is
+    // one look at 32 KiB of mask.
+    const ZeroArgs &z = c.z;
+    constexpr int ZS = 8, ZR = 16;                               // an item = 8 consecutive sub-chunks (128 KiB of every row) x 16 rows
+    __shared__ int s_nd[ZS];
+    const int nr = z.n0 + z.n1 + 12, ngrp = (nr + ZR - 1) / ZR;
+    const int64_t nsub = (c.nvox + CB - 1) / CB, nspan = (nsub + ZS - 1) / ZS;
+    for (int64_t item = (int64_t)blockIdx.x - c.nchunks; item < nspan * ngrp; item += (int64_t)gridDim.x - c.nchunks) {
+        const int64_t span = item / ngrp;                        // (neighbouring workgroups share a span: its mask bytes come from L2)
+        const int g = (int)(item % ngrp);
+        __syncthreads();                                         // (s_nd of the previous item has been read)
+        if (tid < ZS) s_nd[tid] = 0;
+        __syncthreads();
+        unsigned deadb = 0u, inrb = 0u;                          // 4 bits per sub-chunk: my voxels outside the mask / inside the volume
 #pragma unroll
-    for (int i = 0; i < 4; i++) dead[i] = v0 + i < z.nvox && (everything || z.mask[v0 + i] == 0);
-    const bool all = full && dead[0] && dead[1] && dead[2] && dead[3];
-    if (!(dead[0] || dead[1] || dead[2] || dead[3])) return;
-    for (int r = r0; r < r1; r++) {
-        float *row;
-        if (r < z.n0) row = z.out0 + (int64_t)r * z.stride;
-        else if (r < z.n0 + z.n1) row = z.out1 + (int64_t)(r - z.n0) * z.stride;
-        else { const int q = r - z.n0 - z.n1; row = q < 9 ? z.peak[q / 3] + (int64_t)(q % 3) * z.stride : z.qa[q - 9]; }
-        if (all && (reinterpret_cast<uintptr_t>(row) & 15) == 0) { *reinterpret_cast<float4 *>(row + v0) = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+        for (int k = 0; k < ZS; k++) {
+            const int64_t v0 = (span * ZS + k) * CB + (int64_t)tid * 4;
+            int nd = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) if (dead[i]) row[v0 + i] = 0.0f;
+            for (int i = 0; i < 4; i++) {
+                const bool in = v0 + i < c.nvox, dd = in && c.mask[v0 + i] == 0;
+                inrb |= (unsigned)in << (4 * k + i); deadb |= (unsigned)dd << (4 * k + i); nd += dd;
+            }
+            for (int off = 32; off >= 1; off >>= 1) nd += __shfl_xor(nd, off);
+            if (lane == 0 && nd) atomicAdd(&s_nd[k], nd);
+        }
+        __syncthreads();
+        unsigned clr = 0u;                                       // what this thread clears
+#pragma unroll
+        for (int k = 0; k < ZS; k++) {
+            const int64_t sb = (span * ZS + k) * CB;
+            const int64_t len = c.nvox - sb < CB ? c.nvox - sb : CB;
+            const unsigned m = 0xFu << (4 * k);
+            clr |= ((int64_t)s_nd[k] * 4 > len ? inrb : deadb) & m;
+        }
+        if (__syncthreads_or(clr != 0u) == 0) continue;
+        const int r1 = (g + 1) * ZR < nr ? (g + 1) * ZR : nr;
+        for (int r = g * ZR; r < r1; r++) {
+            float *row;
+            if (r < z.n0) row = z.out0 + (int64_t)r * z.stride;
+            else if (r < z.n0 + z.n1) row = z.out1 + (int64_t)(r - z.n0) * z.stride;
+            else { const int q = r - z.n0 - z.n1; row = q < 9 ? z.peak[q / 3] + (int64_t)(q % 3) * z.stride : z.qa[q - 9]; }
+            const bool al = (reinterpret_cast<uintptr_t>(row) & 15) == 0;
+#pragma unroll
+            for (int k = 0; k < ZS; k++) {
+                const unsigned bk = (clr >> (4 * k)) & 0xFu;
+                if (bk == 0u) continue;
+                float *d = row + (span * ZS + k) * CB + (int64_t)tid * 4;
+                if (bk == 0xFu && al) { *reinterpret_cast<float4 *>(d) = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+#pragma unroll
+                for (int i = 0; i < 4; i++) if ((bk >> i) & 1u) d[i] = 0.0f;
+            }
+        }
     }
 }
 
@@ -2154,126 +2201,192 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
     }
     return k;
 }
-// Voxels the register scan left alone (NaN / Inf columns, candidate-list overflow): one wave per listed voxel reads the
-// stored column and runs find_peaks! + peak / qa extraction with the generic semantics of odf_peaks_kernel (NaN
-// amplitudes lead the sort order, `NaN >= x` kills nothing), and the reference's sequential mean (gqi.jl:164).
+// [r4] What follows the contraction kernel, in ONE launch (it was five: +Inf repair, redo list, exact odfmax, its finalisation):
+//  * voxels the register scan left alone (NaN / Inf columns, candidate-list overflow): one wave per listed voxel reads the
+//    stored column and runs find_peaks! + peak / qa extraction with the generic semantics of odf_peaks_kernel (NaN amplitudes
+//    lead the sort order, `NaN >= x` kills nothing), and the reference's sequential mean (gqi.jl:164).  An entry with bit 31
+//    set is a voxel with a +Inf (or, fp16 pieces, denormal-maximum) sample: its column is first recomputed as a plain f32 fma
+//    chain over the frames (the reference's mul!(o, A, s): Inf * a = +-Inf, Inf * 0 = NaN, +Inf - Inf = NaN) and stored;
+//  * maximum(mean(odf, dims=4)) (gqi.jl:164) with the reference's arithmetic: the fused epilogue only bounds each voxel's mean
+//    (mean_hi) and the maximum (maxenc[2]); every listed voxel whose upper bound reaches the lower bound of the maximum gets
+//    the sequential f32 sum over its stored column here (a handful of voxels unless many voxels hold the same ODF).  Voxels on
+//    the redo list carry mean_hi = NaN and are never selected, so the two parts do not depend on each other;
+//  * the workgroup that arrives last (agent-scope release before the arrival ticket, acquire after it) turns the ordered-uint
+//    maximum and the NaN flag into the two floats the caller gets.
 struct RedoArgs { const float *odf; int64_t stride; const int32_t *count, *list; int cap; const float *verts; float *peak[3], *qa[3]; unsigned *maxenc; };
-__global__ __launch_bounds__(64) void odf_redo_kernel(const RedoArgs a) {
-    constexpr int NV = FIB_S642_NVERT;
-    __shared__ float o[NV + 1];
-    const int lane = threadIdx.x;
-    const int n = a.count[0] < a.cap ? a.count[0] : a.cap;
-    for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        const int64_t vox = a.list[i];
-        __syncthreads();
-        for (int v = lane; v < NV; v += 64) o[v] = a.odf[(int64_t)v * a.stride + vox];
-        if (lane == 0) o[NV] = __builtin_nanf("");      // unused neighbour slots
-        __syncthreads();
-        Top3 t;
-        top3_clear(t);
-        int npos = 0;
-        float vmin = INFINITY;
-        bool hasnan = false;
-        for (int v = lane; v < NV; v += 64) {
-            const float x = o[v];
-            bool killed = false;
-#pragma unroll
-            for (int d = 0; d < FIB_S642_DEG; d++) killed |= o[fib_s642_nbr_dev[v][d]] >= x;   // gqi.jl:185-196
-            const float pk = killed ? 0.0f : x;
-            if (pk > 0.0f) npos++;                      // gqi.jl:200
-            if (!(pk <= 0.0f)) top3_insert(t, pk, v);
-            hasnan |= x != x;
-            vmin = x < vmin ? x : vmin;
-        }
-        Top3 best;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {                   // keys are unique (vertex index in the low word): one lane pops per round
-            const unsigned long long m = wave_max_u64(t.k[0]);
-            best.k[k] = m;
-            if (m != 0ull && t.k[0] == m) { t.k[0] = t.k[1]; t.k[1] = t.k[2]; t.k[2] = 0ull; }
-        }
-        for (int off = 32; off >= 1; off >>= 1) {
-            npos += __shfl_xor(npos, off);
-            const float om = __shfl_xor(vmin, off);
-            vmin = om < vmin ? om : vmin;
-        }
-        if (__any(hasnan)) vmin = __builtin_nanf("");   // minimum() propagates NaN (gqi.jl:147)
-        if (lane == 0) {
-            float sum = 0.0f;
-            for (int v = 0; v < NV; v++) sum += o[v];   // mean(odf, dims=4): sequential over the vertices, then ./ n (gqi.jl:164)
-            const float mean = sum / (float)NV;
-            if (mean != mean) atomicOr(&a.maxenc[1], 1u); else atomicMax(&a.maxenc[0], enc_ordered(mean));
-            const int n3 = npos < 3 ? npos : 3;         // gqi.jl:151
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                float px = 0.0f, py = 0.0f, pz = 0.0f, q = 0.0f;
-                if (k < n3) {
-                    const int iv = top3_index(best, k);
-                    px = a.verts[3 * iv]; py = a.verts[3 * iv + 1]; pz = a.verts[3 * iv + 2];
-                    q = o[iv] - vmin;
-                }
-                a.peak[k][vox] = px; a.peak[k][a.stride + vox] = py; a.peak[k][2 * a.stride + vox] = pz;
-                a.qa[k][vox] = q;
-            }
-        }
-    }
-}
-// maximum(mean(odf, dims=4)) (gqi.jl:164) with the reference's arithmetic: the fused epilogue only bounds each voxel's mean
-// (mean_hi) and the maximum (maxenc[2]); every listed voxel whose upper bound reaches the lower bound of the maximum gets
-// the sequential f32 sum over its stored column here (a handful of voxels unless many voxels hold the same ODF).
 struct RefineArgs { const float *odf; int64_t stride, nvox; int nvert; const int32_t *vidx, *nlive; const float *mean_hi; unsigned *maxenc; };
-__global__ __launch_bounds__(256) void odfmax_refine_kernel(const RefineArgs a) {
-    __shared__ float col[4][512];                               // a selected voxel's column, per wave
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nlive = a.nlive[0];
-    // voxels of quads that are not listed have an all-zero ODF: their mean (0) takes part in the maximum
-    if (blockIdx.x == 0 && threadIdx.x == 0 && nlive < a.nvox) atomicMax(&a.maxenc[0], enc_ordered(0.0f));
-    const unsigned lo_e = a.maxenc[2];
-    const float m_lo = lo_e ? dec_ordered(lo_e) : -INFINITY;
-    const int64_t nround = ((int64_t)nlive + 63) / 64 * 64;
-    unsigned ebest = 0u;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nround; i += (int64_t)gridDim.x * 256) {
-        int64_t vox = 0;
-        bool sel = false;
-        if (i < nlive) { vox = a.vidx[i]; sel = a.mean_hi[vox] >= m_lo; }
-        // the few selected voxels of this wave, one after the other: the whole wave fetches the column (the loads of a lane that sums
-        // its own column one element after the other are 321 dependent round trips), lane 0 adds it up in the reference's order
-        unsigned long long todo = __ballot(sel);
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1ull;
-            const int64_t v = __shfl(vox, src);
-            if (a.nvert <= 512) {
-                for (int r = lane; r < a.nvert; r += 64) col[wv][r] = a.odf[(int64_t)r * a.stride + v];
-                __builtin_amdgcn_wave_barrier();
-                if (lane == 0) {
-                    float sum = 0.0f;
-                    for (int r = 0; r < a.nvert; r++) sum += col[wv][r];      // mean(odf, dims=4): sequential over the vertices (gqi.jl:164)
-                    const unsigned e = enc_ordered(sum / (float)a.nvert);     // finite columns only (the others are on the redo list)
-                    ebest = e > ebest ? e : ebest;
-                }
-                __builtin_amdgcn_wave_barrier();
-            } else if (lane == 0) {
-                float sum = 0.0f;
-                for (int r = 0; r < a.nvert; r++) sum += a.odf[(int64_t)r * a.stride + v];
-                const unsigned e = enc_ordered(sum / (float)a.nvert);
-                ebest = e > ebest ? e : ebest;
+struct PostArgs {
+    RedoArgs redo;                    // count == NULL: no redo list (the separate peak kernels have done everything)
+    const float *G, *S; float *out; int M, K;   // the matrix, column-major [M x K], the samples and the ODF rows of the flagged entries' recompute
+    RefineArgs refine;
+    unsigned *arrive;                 // arrival counter (0 at launch, left 0)
+    float *odfmax;                    // [2]
+    int raw;                          // 0: {maximum (NaN if any mean is NaN), NaN flag}; 1: {maximum of the means that are not NaN or -Inf, NaN flag}
+};
+__device__ __forceinline__ void redo_voxel(const RedoArgs &a, float *o, int64_t vox, int lane) {
+    constexpr int NV = FIB_S642_NVERT;
+    Top3 t;
+    top3_clear(t);
+    int npos = 0;
+    float vmin = INFINITY;
+    bool hasnan = false;
+    for (int v = lane; v < NV; v += 64) {
+        const float x = o[v];
+        bool killed = false;
+#pragma unroll
+        for (int d = 0; d < FIB_S642_DEG; d++) killed |= o[fib_s642_nbr_dev[v][d]] >= x;   // gqi.jl:185-196
+        const float pk = killed ? 0.0f : x;
+        if (pk > 0.0f) npos++;                      // gqi.jl:200
+        if (!(pk <= 0.0f)) top3_insert(t, pk, v);
+        hasnan |= x != x;
+        vmin = x < vmin ? x : vmin;
+    }
+    Top3 best;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {                   // keys are unique (vertex index in the low word): one lane pops per round
+        const unsigned long long m = wave_max_u64(t.k[0]);
+        best.k[k] = m;
+        if (m != 0ull && t.k[0] == m) { t.k[0] = t.k[1]; t.k[1] = t.k[2]; t.k[2] = 0ull; }
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        npos += __shfl_xor(npos, off);
+        const float om = __shfl_xor(vmin, off);
+        vmin = om < vmin ? om : vmin;
+    }
+    if (__any(hasnan)) vmin = __builtin_nanf("");   // minimum() propagates NaN (gqi.jl:147)
+    if (lane == 0) {
+        float sum = 0.0f;
+        for (int v = 0; v < NV; v++) sum += o[v];   // mean(odf, dims=4): sequential over the vertices, then ./ n (gqi.jl:164)
+        const float mean = sum / (float)NV;
+        if (mean != mean) atomicOr(&a.maxenc[1], 1u); else atomicMax(&a.maxenc[0], enc_ordered(mean));
+        const int n3 = npos < 3 ? npos : 3;         // gqi.jl:151
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float px = 0.0f, py = 0.0f, pz = 0.0f, q = 0.0f;
+            if (k < n3) {
+                const int iv = top3_index(best, k);
+                px = a.verts[3 * iv]; py = a.verts[3 * iv + 1]; pz = a.verts[3 * iv + 2];
+                q = o[iv] - vmin;
             }
+            a.peak[k][vox] = px; a.peak[k][a.stride + vox] = py; a.peak[k][2 * a.stride + vox] = pz;
+            a.qa[k][vox] = q;
         }
     }
-    if (lane == 0 && ebest) atomicMax(&a.maxenc[0], ebest);
+}
+__global__ __launch_bounds__(256) void odf_post_kernel(const PostArgs p) {
+    __shared__ float col[4][512];                               // a voxel's column, per wave
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // ---- the redo list (sphere_642 only: the fused paths) ---------------------------------------------------------------------
+    if (p.redo.count) {
+        constexpr int NV = FIB_S642_NVERT;
+        const RedoArgs &a = p.redo;
+        float *o = col[wv];
+        const int n = a.count[0] < a.cap ? a.count[0] : a.cap;
+        for (int i = blockIdx.x * 4 + wv; i < n; i += gridDim.x * 4) {
+            const unsigned ent = (unsigned)a.list[i];
+            const int64_t vox = (int64_t)(ent & 0x7fffffffu);
+            __builtin_amdgcn_wave_barrier();
+            if ((ent >> 31) && p.G) {
+                for (int row = lane; row < p.M; row += 64) {
+                    float acc = 0.0f;
+                    for (int k = 0; k < p.K; k++) acc = __builtin_fmaf(p.G[row + (size_t)p.M * k], clamp_sample(p.S[(int64_t)k * a.stride + vox]), acc);
+                    p.out[(int64_t)row * a.stride + vox] = acc;
+                    if (row < NV) o[row] = acc;
+                }
+            } else {
+                for (int v = lane; v < NV; v += 64) o[v] = a.odf[(int64_t)v * a.stride + vox];
+            }
+            if (lane == 0) o[NV] = __builtin_nanf("");      // unused neighbour slots
+            __builtin_amdgcn_wave_barrier();
+            redo_voxel(a, o, vox, lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- the exact maximum of the means -----------------------------------------------------------------------------------------
+    {
+        const RefineArgs &a = p.refine;
+        const int nlive = a.nlive[0];
+        // voxels of quads that are not listed have an all-zero ODF: their mean (0) takes part in the maximum
+        if (blockIdx.x == 0 && threadIdx.x == 0 && nlive < a.nvox) atomicMax(&a.maxenc[0], enc_ordered(0.0f));
+        const unsigned lo_e = a.maxenc[2];                      // (final: written by the kernels before this one)
+        const float m_lo = lo_e ? dec_ordered(lo_e) : -INFINITY;
+        // a thread tests one listed quad (four consecutive list entries = four consecutive, 16-byte aligned voxels): one index load
+        // and one 16-byte load of the four upper bounds per trip (a trip costs two dependent load latencies whatever it fetches)
+        const int64_t nquad = ((int64_t)nlive + 3) / 4, nround = (nquad + 63) / 64 * 64;
+        unsigned ebest = 0u;
+        for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nround; q += (int64_t)gridDim.x * 256) {
+            int64_t vox0 = 0;
+            float mh[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (q < nquad) {
+                vox0 = a.vidx[4 * q];
+                if (4 * q + 4 <= nlive && (vox0 & 3) == 0) {
+                    const float4 m4 = *reinterpret_cast<const float4 *>(a.mean_hi + vox0);
+                    mh[0] = m4.x; mh[1] = m4.y; mh[2] = m4.z; mh[3] = m4.w;
+                } else {
+                    for (int j = 0; j < 4; j++) if (4 * q + j < nlive) mh[j] = a.mean_hi[a.vidx[4 * q + j]];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool sel = mh[j] >= m_lo;
+                const int64_t vox = (4 * q + 4 <= nlive && (vox0 & 3) == 0) ? vox0 + j : (sel ? (int64_t)a.vidx[4 * q + j] : 0);
+                // the few selected voxels of this wave, one after the other: the whole wave fetches the column (the loads of a lane that sums
+                // its own column one element after the other are 321 dependent round trips), lane 0 adds it up in the reference's order
+                unsigned long long todo = __ballot(sel);
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ull;
+                    const int64_t v = __shfl(vox, src);
+                    if (a.nvert <= 512) {
+                        for (int r = lane; r < a.nvert; r += 64) col[wv][r] = a.odf[(int64_t)r * a.stride + v];
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane == 0) {
+                            float sum = 0.0f;
+                            for (int r = 0; r < a.nvert; r++) sum += col[wv][r];      // mean(odf, dims=4): sequential over the vertices (gqi.jl:164)
+                            const unsigned e = enc_ordered(sum / (float)a.nvert);     // finite columns only (the others are on the redo list)
+                            ebest = e > ebest ? e : ebest;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    } else if (lane == 0) {
+                        float sum = 0.0f;
+                        for (int r = 0; r < a.nvert; r++) sum += a.odf[(int64_t)r * a.stride + v];
+                        const unsigned e = enc_ordered(sum / (float)a.nvert);
+                        ebest = e > ebest ? e : ebest;
+                    }
+                }
+            }
+        }
+        if (lane == 0 && ebest) atomicMax(&a.maxenc[0], ebest);
+    }
+    // ---- the last workgroup to arrive publishes the result: everything it reads was written by agent-scope atomics, which are
+    // performed at the device's coherence point; a workgroup's arrival follows its atomics (vmcnt(0) in every wave, then the
+    // barrier, then the ticket), and the last arriver reads with agent-scope atomic loads: no cache has to be written back or dropped
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(p.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == gridDim.x - 1) {
+            const unsigned e0 = __hip_atomic_load(&p.refine.maxenc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned e1 = __hip_atomic_load(&p.refine.maxenc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool nan = e1 != 0;
+            const float m = e0 ? dec_ordered(e0) : -INFINITY;
+            p.odfmax[0] = (nan && !p.raw) ? NAN : m;             // maximum() propagates NaN
+            p.odfmax[1] = nan ? 1.0f : 0.0f;
+            __hip_atomic_store(p.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
-__global__ void odfmax_finalize_kernel(const unsigned *enc, float *out) {
-    const bool nan = enc[1] != 0;
-    const float m = enc[0] ? dec_ordered(enc[0]) : -INFINITY;
-    out[0] = nan ? NAN : m;                                     // maximum() propagates NaN
-    out[1] = nan ? 1.0f : 0.0f;
-}
-
+// qa[k] ./= odfmax (gqi.jl:166-168).  pair != 0: odfmax_dev = {maximum of the means that are not NaN, NaN flag} as it comes out of
+// the all-reduce of the multi-rank flow: the divisor is NaN when the flag is set, and the first element becomes what
+// maximum() returns.
 __global__ __launch_bounds__(256) void qa_normalize_kernel(float *q0, float *q1, float *q2, int64_t nvox,
-                                                          const float *odfmax_dev, float odfmax_val) {
-    const float d = odfmax_dev ? odfmax_dev[0] : odfmax_val;
+                                                          float *odfmax_dev, float odfmax_val, int pair) {
+    float d = odfmax_dev ? odfmax_dev[0] : odfmax_val;
+    if (pair) {                                                 // (the flag never changes; the first element may already be NaN: same d)
+        d = odfmax_dev[1] > 0.0f ? NAN : d;
+        if (blockIdx.x == 0 && threadIdx.x == 0) odfmax_dev[0] = d;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvox; i += (int64_t)gridDim.x * blockDim.x) {
         q0[i] = q0[i] / d;                                      // qa[ipeak].vol /= odfmax, gqi.jl:167
         q1[i] = q1[i] / d;
@@ -2363,23 +2476,32 @@ struct fib_odf_plan {
     bool is_s642 = false;                            // neighbour table == the compiled-in sphere_642 table (specialised scan)
     mutable fib::DevBuf<unsigned> maxenc;
     mutable fib::DevBuf<int32_t> live_vox, live_tiles, live_counts;   // mask compaction scratch (grow-only), counts = {voxels, tiles, +Inf voxels}
-    mutable fib::DevBuf<int2> live_blocks;
+    mutable fib::DevBuf<unsigned long long> compact_state;   // the chunk granules of mask_compact_kernel [1024]
+    mutable unsigned compact_epoch = 0;              // .. and the call counter they are tagged with
+    fib::DevBuf<unsigned> tickets;                   // [4]: chunk dispenser of mask_compact_kernel, arrival counter of odf_post_kernel (both 0 between calls)
     mutable fib::DevBuf<float> odfmax;
 };
 
 namespace {
 
 
+// FIB_ODF_FORMAT_DEFAULT -> what the environment asks for (FIBERS_ODF_GEMM=f32, FIBERS_ODF_EXACT=1), else two fp16 pieces
+int resolve_format(int format) {
+    if (format != FIB_ODF_FORMAT_DEFAULT) return format;
+    const char *e = getenv("FIBERS_ODF_GEMM");
+    if (e && (!strcmp(e, "f32") || !strcmp(e, "F32"))) return FIB_ODF_FORMAT_F32;
+    const char *ex = getenv("FIBERS_ODF_EXACT");
+    return (ex && ex[0] != '0' && ex[0] != 0) ? FIB_ODF_FORMAT_BF16X3 : FIB_ODF_FORMAT_FP16X2;
+}
+
 int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *faces, int nfaces,
-                const std::vector<float> &frame_eff) {
+                const std::vector<float> &frame_eff, int format = FIB_ODF_FORMAT_DEFAULT) {
     if (p->G.empty()) { p->G = p->A; p->gM = p->nrows; p->gK = p->nvol; p->gRow0 = p->nrow0; }
     const int M = p->gM, K = p->gK;
-    // which matrix-core path runs the contraction: "bf16x3" (default; f32-exact products from three bf16 pieces per
-    // operand) or "f32" (v_mfma_f32_32x32x2_f32: a k-ordered f32 fma chain, bit-identical to the oracle's loop)
-    {
-        const char *e = getenv("FIBERS_ODF_GEMM");
-        p->split_bf16 = !(e && (!strcmp(e, "f32") || !strcmp(e, "F32")));
-    }
+    // the operand format of the contraction (header: FIB_ODF_FORMAT_*): two fp16 pieces per f32 operand (default), three exact
+    // bf16 pieces, or v_mfma_f32_32x32x2_f32 (a k-ordered f32 fma chain, bit-identical to the oracle's loop)
+    format = resolve_format(format);
+    p->split_bf16 = format != FIB_ODF_FORMAT_F32;
     // pick (MB, NX) minimising the per-k-step issue cost ntile*(64*MB + 4*NX) cycles (MFMA block = 64, v_fmac = 4)
     int best_cost = INT32_MAX;
     const int nxs[] = {0, 1};                            // (tiles with 2 or 4 VALU rows never won for a shape in use: 13 variants instead of 25)
@@ -2407,7 +2529,7 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
     if (p->split_bf16) {
         // piece format: two fp16 pieces of sa * G (sa = the power of two that puts max |G| into [2^8, 2^9): the second piece of an
         // element stays a normal fp16 number down to 2^-20 of the largest, gemm3_body H2), or three exact bf16 pieces
-        { const char *ex = getenv("FIBERS_ODF_EXACT"); p->h2 = !(ex && ex[0] != '0'); }
+        p->h2 = format == FIB_ODF_FORMAT_FP16X2;
         float gmax = 0.0f;
         for (float v : p->G) if (std::isfinite(v)) gmax = std::max(gmax, std::fabs(v));
         if (p->h2 && !(gmax > 0.0f)) p->h2 = false;
@@ -2560,6 +2682,8 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
     if ((rc = p->nbr.alloc(nbr.size())) != FIB_OK) return rc;
     if ((rc = p->maxenc.alloc(4)) != FIB_OK) return rc;
     if ((rc = p->live_counts.alloc(4)) != FIB_OK) return rc;
+    if ((rc = p->tickets.alloc(4)) != FIB_OK) return rc;
+    FIB_HIP(hipMemset(p->tickets.p, 0, 4 * sizeof(unsigned)));
     if ((rc = p->odfmax.alloc(2)) != FIB_OK) return rc;
     FIB_HIP(hipMemcpy(p->At.p, At.data(), At.size() * sizeof(float), hipMemcpyHostToDevice));
     FIB_HIP(hipMemcpy(p->effbits.p, effbits.data(), effbits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -2583,9 +2707,23 @@ int check_plan_args(const float *bval, const float *bvec, int nvol, const float 
 
 extern "C" int fib_gqi_plan_create(int device, const float *bval, const float *bvec, int nvol,
                                    const float *verts, int nverts, const int32_t *faces, int nfaces,
-                                   float sigma, fib_odf_plan **plan) try {
+                                   float sigma, fib_odf_plan **plan) {
+    return fib_gqi_plan_create_fmt(device, bval, bvec, nvol, verts, nverts, faces, nfaces, sigma, FIB_ODF_FORMAT_DEFAULT, plan);
+}
+
+extern "C" int fib_odf_default_format(void) try { return resolve_format(FIB_ODF_FORMAT_DEFAULT); } FIB_API_CATCH
+
+extern "C" int fib_odf_plan_format(const fib_odf_plan *plan) try {
+    FIB_CHECK(plan != nullptr, FIB_ERR_INVALID, "plan is NULL");
+    return !plan->split_bf16 ? FIB_ODF_FORMAT_F32 : (plan->h2 ? FIB_ODF_FORMAT_FP16X2 : FIB_ODF_FORMAT_BF16X3);
+} FIB_API_CATCH
+
+extern "C" int fib_gqi_plan_create_fmt(int device, const float *bval, const float *bvec, int nvol,
+                                       const float *verts, int nverts, const int32_t *faces, int nfaces,
+                                       float sigma, int format, fib_odf_plan **plan) try {
     int rc = check_plan_args(bval, bvec, nvol, verts, nverts, faces, nfaces, plan);
     if (rc != FIB_OK) return rc;
+    FIB_CHECK(format >= FIB_ODF_FORMAT_DEFAULT && format <= FIB_ODF_FORMAT_F32, FIB_ERR_INVALID, "unknown operand format %d", format);
     fib::DeviceGuard guard;
     if ((rc = fib::use_device(device)) != FIB_OK) return rc;
     fib_odf_plan *p = new (std::nothrow) fib_odf_plan();
@@ -2594,7 +2732,7 @@ extern "C" int fib_gqi_plan_create(int device, const float *bval, const float *b
     p->A.resize((size_t)p->nrows * nvol);
     fib::host_gqi_matrix(bval, bvec, nvol, verts, nverts, sigma, p->A.data());
     std::vector<float> eff((size_t)nvol, 1.0f);
-    rc = finish_plan(p, verts, nverts, faces, nfaces, eff);
+    rc = finish_plan(p, verts, nverts, faces, nfaces, eff, format);
     if (rc != FIB_OK) { delete p; return rc; }
     *plan = p;
     return FIB_OK;
@@ -2602,9 +2740,16 @@ extern "C" int fib_gqi_plan_create(int device, const float *bval, const float *b
 
 extern "C" int fib_dsi_plan_create(int device, const float *bval, const float *bvec, int nvol,
                                    const float *verts, int nverts, const int32_t *faces, int nfaces,
-                                   int hann_width, fib_odf_plan **plan) try {
+                                   int hann_width, fib_odf_plan **plan) {
+    return fib_dsi_plan_create_fmt(device, bval, bvec, nvol, verts, nverts, faces, nfaces, hann_width, FIB_ODF_FORMAT_DEFAULT, plan);
+}
+
+extern "C" int fib_dsi_plan_create_fmt(int device, const float *bval, const float *bvec, int nvol,
+                                       const float *verts, int nverts, const int32_t *faces, int nfaces,
+                                       int hann_width, int format, fib_odf_plan **plan) try {
     int rc = check_plan_args(bval, bvec, nvol, verts, nverts, faces, nfaces, plan);
     if (rc != FIB_OK) return rc;
+    FIB_CHECK(format >= FIB_ODF_FORMAT_DEFAULT && format <= FIB_ODF_FORMAT_F32, FIB_ERR_INVALID, "unknown operand format %d", format);
     FIB_CHECK(hann_width >= 0, FIB_ERR_INVALID, "hann_width must be >= 0");
     fib::DeviceGuard guard;
     if ((rc = fib::use_device(device)) != FIB_OK) return rc;
@@ -2659,7 +2804,7 @@ extern "C" int fib_dsi_plan_create(int device, const float *bval, const float *b
             eff.assign((size_t)nrep, 1.0f);
         }
     }
-    rc = finish_plan(p, verts, nverts, faces, nfaces, eff);
+    rc = finish_plan(p, verts, nverts, faces, nfaces, eff, format);
     if (rc != FIB_OK) { delete p; return rc; }
     *plan = p;
     return FIB_OK;
@@ -2784,6 +2929,37 @@ int launch_peaks(const fib_odf_plan *plan, const float *odf, int64_t nvox, int64
 
 }  // namespace
 
+namespace {
+// the one-launch mask compaction (mask_compact_kernel) on the plan's scratch; z != NULL: also clear those outputs outside the mask
+int launch_mask_compact(const fib_odf_plan *plan, const uint8_t *mask, int64_t nvox, unsigned *maxenc, const ZeroArgs *z, hipStream_t st) {
+    // at most 256 chunks (one ticket each: returning atomics on one address are served at ~90 per microsecond), all resident at once
+    int iters = (int)std::max<int64_t>(1, fib::cdiv(fib::cdiv(nvox, CB), 256));
+    if (iters > CB_ITERS_MAX) iters = CB_ITERS_MAX;
+    const int nchunks = (int)fib::cdiv(nvox, (int64_t)CB * iters);                      // <= 1024 (2^27 voxels)
+    FIB_CHECK(nchunks <= 1024, FIB_ERR_UNSUPPORTED, "volume too large for the mask compaction");
+    int rc;
+    if ((rc = plan->live_vox.ensure((size_t)nvox)) != FIB_OK) return rc;
+    if ((rc = plan->live_tiles.ensure((size_t)fib::cdiv(nvox, 64))) != FIB_OK) return rc;
+    if (!plan->compact_state.p) {                                                       // fresh granules carry epoch 0 = "never written"
+        if ((rc = plan->compact_state.alloc(1024 + 2)) != FIB_OK) return rc;
+        FIB_HIP(hipMemsetAsync(plan->compact_state.p, 0, (1024 + 2) * sizeof(unsigned long long), st));
+    }
+    if (++plan->compact_epoch == 0u) plan->compact_epoch = 1u;
+    CompactArgs c{};
+    c.mask = mask; c.nvox = nvox; c.vidx = plan->live_vox.p; c.tiles = plan->live_tiles.p; c.state = plan->compact_state.p;
+    c.ticket = plan->tickets.p; c.totals = plan->live_counts.p; c.maxenc = maxenc; c.epoch = plan->compact_epoch; c.nchunks = nchunks; c.iters = iters;
+    c.zero = z != nullptr;
+    if (z) c.z = *z;
+    c.clear = plan->pair_flags.p; c.nclear = plan->pair_flags.p ? 8 * 32 : 0;
+    fib::ProfScope prof("mask_compact", st);
+    // with outputs to clear: helpers behind the compacting workgroups, so that a volume that is mostly outside the mask is cleared by the whole chip
+    const int grid = nchunks + (z ? 768 : 0);
+    hipLaunchKernelGGL(mask_compact_kernel, dim3(grid), dim3(1024), 0, st, c);
+    FIB_HIP(hipGetLastError());
+    return FIB_OK;
+}
+}  // namespace
+
 extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const uint8_t *mask, int64_t nvox,
                             float *pdf, float *odf, float *const peak[3], float *const qa[3],
                             float *odfmax_dev, int flags, void *stream) try {
@@ -2796,18 +2972,14 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
     FIB_HIP(hipSetDevice(plan->device));
     hipStream_t st = (hipStream_t)stream;
     GemmArgs ga{};
-    // compact the mask: voxel list for the GEMM, 64-voxel tile list for the peak finder (counts stay on the device)
+    // launch 1: compact the mask -- voxel list for the GEMM, 64-voxel tile list for the peak finder (counts stay on the device) -- and
+    // clear the outputs outside it
     {
-        const int nb = (int)fib::cdiv(nvox, CB);
-        int rcc;
-        if ((rcc = plan->live_vox.ensure((size_t)nvox)) != FIB_OK) return rcc;
-        if ((rcc = plan->live_tiles.ensure((size_t)fib::cdiv(nvox, 64))) != FIB_OK) return rcc;
-        if ((rcc = plan->live_blocks.ensure((size_t)nb)) != FIB_OK) return rcc;
-        fib::ProfScope prof("mask_compact", st);
-        hipLaunchKernelGGL(mask_count_kernel, dim3(nb), dim3(256), 0, st, mask, nvox, plan->live_blocks.p);
-        hipLaunchKernelGGL(mask_scan_kernel, dim3(1), dim3(1024), 0, st, plan->live_blocks.p, nb, plan->live_counts.p, plan->maxenc.p);
-        hipLaunchKernelGGL(mask_write_kernel, dim3(nb), dim3(256), 0, st, mask, nvox, plan->live_blocks.p, plan->live_vox.p, plan->live_tiles.p);
-        FIB_HIP(hipGetLastError());
+        ZeroArgs z{};
+        z.out0 = pdf; z.out1 = odf; z.n0 = plan->nrow0; z.n1 = plan->nrows - plan->nrow0; z.nvox = nvox; z.stride = nvox;
+        for (int k = 0; k < 3; k++) { z.peak[k] = peak[k]; z.qa[k] = qa[k]; }
+        int rcc = launch_mask_compact(plan, mask, nvox, plan->maxenc.p, !(flags & FIB_ODF_PREZEROED) ? &z : nullptr, st);
+        if (rcc != FIB_OK) return rcc;
     }
     ga.At = plan->At.p; ga.At3 = (plan->split_bf16 && nvox <= ((int64_t)1 << 26)) ? plan->At3.p : nullptr; ga.S = dwi;
     ga.Aextra = plan->Aextra.p; ga.h2 = plan->h2 ? 1 : 0; ga.h2_inv_sa = 1.0f / plan->h2_sa;
@@ -2825,7 +2997,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
     const bool sep = (flags & FIB_ODF_SEPARATE_PEAKS) != 0 || getenv("FIBERS_ODF_UNFUSED") != nullptr;
     const bool fuse = plan->fused && ga.At3 != nullptr && ga.vec_ok && !sep;
     {
-        int rcm = plan->mean_hi.ensure((size_t)nvox);
+        int rcm = plan->mean_hi.ensure((size_t)nvox + 4);
         if (rcm != FIB_OK) return rcm;
     }
     auto setup_fused = [&]() -> int {                   // the arguments of gemm3_epilogue_fused
@@ -2896,7 +3068,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
             if (!ena && plan->pair_flags.p && nslot <= 64 && nslot % 2 == 0) {
                 g.dsi_na = nslot / 2;
                 g.pair_flags = plan->pair_flags.p;
-                FIB_HIP(hipMemsetAsync(plan->pair_flags.p, 0, 8 * 32 * sizeof(unsigned), s));
+                // (the counters were cleared by mask_compact_kernel: one memset launch less)
             }
             switch (plan->MBB) {
                 case 5: if (g.h2) hipLaunchKernelGGL((odf_dsi2_kernel<5, true>), dim3(pg), dim3(512), 0, s, g); else hipLaunchKernelGGL((odf_dsi2_kernel<5, false>), dim3(pg), dim3(512), 0, s, g); break;
@@ -2916,41 +3088,31 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         return FIB_OK;
     };
 
-    if (!(flags & FIB_ODF_PREZEROED)) {
-        ZeroArgs z{};
-        z.out0 = pdf; z.out1 = odf; z.n0 = plan->nrow0; z.n1 = plan->nrows - plan->nrow0; z.nvox = nvox; z.stride = nvox; z.mask = mask; z.nlive = plan->live_counts.p;
-        for (int k = 0; k < 3; k++) { z.peak[k] = peak[k]; z.qa[k] = qa[k]; }
-        fib::ProfScope prof("zero_dead", st);
-        hipLaunchKernelGGL(zero_dead_kernel, dim3((unsigned)fib::cdiv(nvox, 1024), ZROWS), dim3(256), 0, st, z);
-        FIB_HIP(hipGetLastError());
-    }
-    int rc = run_gemm(ga, st);
+    int rc = run_gemm(ga, st);                           // launch 2
     if (rc != FIB_OK) return rc;
-    if (ga.fix_list) {
-        InfFixArgs fx{plan->Gdev.p, dwi, odf, ga.fix_count, ga.fix_list, ga.fix_cap, plan->gM, plan->gK, nvox};
-        hipLaunchKernelGGL(odf_inf_fix_kernel, dim3(64), dim3(256), 0, st, fx);
-    }
-    if (fuse || dsi2) {
-        fib::ProfScope prof("odf_peaks", st);           // what is left of the peak finder: the redo list and the exact odfmax
-        RedoArgs ra{odf, nvox, ga.redo_count, ga.redo_list, ga.redo_cap, plan->verts.p, {peak[0], peak[1], peak[2]}, {qa[0], qa[1], qa[2]}, plan->maxenc.p};
-        hipLaunchKernelGGL(odf_redo_kernel, dim3(256), dim3(64), 0, st, ra);
-        FIB_HIP(hipGetLastError());
-    } else {
+    const bool fused_scan = fuse || dsi2;
+    if (!fused_scan) {                                  // separate peak finder on the stored ODF (other tessellations, unaligned pieces, FIB_ODF_SEPARATE_PEAKS)
+        if (ga.fix_list) {
+            InfFixArgs fx{plan->Gdev.p, dwi, odf, ga.fix_count, ga.fix_list, ga.fix_cap, plan->gM, plan->gK, nvox};
+            hipLaunchKernelGGL(odf_inf_fix_kernel, dim3(64), dim3(256), 0, st, fx);
+        }
         rc = launch_peaks(plan, odf, nvox, nvox, peak, qa, nullptr, nullptr, true, st, false, plan->live_tiles.p, plan->live_counts.p + 1);
         if (rc != FIB_OK) return rc;
     }
-    {
-        fib::ProfScope prof("odfmax_refine", st);
-        RefineArgs rf{odf, nvox, nvox, plan->nvert, plan->live_vox.p, plan->live_counts.p, plan->mean_hi.p, plan->maxenc.p};
-        hipLaunchKernelGGL(odfmax_refine_kernel, dim3(1024), dim3(256), 0, st, rf);
+    float *om = odfmax_dev ? odfmax_dev : plan->odfmax.p;
+    {                                                   // launch 3: redo list (+ column repair), exact odfmax, its two floats
+        fib::ProfScope prof("odf_post", st);
+        PostArgs pa{};
+        pa.redo = RedoArgs{odf, nvox, fused_scan ? ga.redo_count : nullptr, ga.redo_list, ga.redo_cap, plan->verts.p, {peak[0], peak[1], peak[2]}, {qa[0], qa[1], qa[2]}, plan->maxenc.p};
+        pa.G = (fused_scan && ga.fix_list) ? plan->Gdev.p : nullptr; pa.S = dwi; pa.out = odf; pa.M = plan->gM; pa.K = plan->gK;
+        pa.refine = RefineArgs{odf, nvox, nvox, plan->nvert, plan->live_vox.p, plan->live_counts.p, plan->mean_hi.p, plan->maxenc.p};
+        pa.arrive = plan->tickets.p + 1; pa.odfmax = om; pa.raw = (flags & FIB_ODF_RAW_ODFMAX) ? 1 : 0;
+        hipLaunchKernelGGL(odf_post_kernel, dim3(384), dim3(256), 0, st, pa);
         FIB_HIP(hipGetLastError());
     }
-    float *om = odfmax_dev ? odfmax_dev : plan->odfmax.p;
-    hipLaunchKernelGGL(odfmax_finalize_kernel, dim3(1), dim3(1), 0, st, plan->maxenc.p, om);
-    FIB_HIP(hipGetLastError());
     if (flags & FIB_ODF_NORMALIZE) {
         fib::ProfScope prof("qa_normalize", st);
-        hipLaunchKernelGGL(qa_normalize_kernel, dim3(2048), dim3(256), 0, st, qa[0], qa[1], qa[2], nvox, om, 0.0f);
+        hipLaunchKernelGGL(qa_normalize_kernel, dim3(2048), dim3(256), 0, st, qa[0], qa[1], qa[2], nvox, om, 0.0f, (flags & FIB_ODF_RAW_ODFMAX) ? 1 : 0);   // launch 4
         FIB_HIP(hipGetLastError());
     }
     return FIB_OK;
@@ -2979,14 +3141,8 @@ int fib::matrix_plan_run(const fib_odf_plan *plan, const float *S, const uint8_t
     FIB_CHECK(n <= ((int64_t)1 << 26), FIB_ERR_UNSUPPORTED, "more than 2^26 columns");
     hipStream_t st = (hipStream_t)stream;
     if (recompact) {                                    // the column list of an all-ones mask: kept in the plan between calls
-        const int nb = (int)fib::cdiv(n, CB);
-        int rcc;
-        if ((rcc = plan->live_vox.ensure((size_t)n)) != FIB_OK) return rcc;
-        if ((rcc = plan->live_tiles.ensure((size_t)fib::cdiv(n, 64))) != FIB_OK) return rcc;
-        if ((rcc = plan->live_blocks.ensure((size_t)nb)) != FIB_OK) return rcc;
-        hipLaunchKernelGGL(mask_count_kernel, dim3(nb), dim3(256), 0, st, ones, n, plan->live_blocks.p);
-        hipLaunchKernelGGL(mask_scan_kernel, dim3(1), dim3(1024), 0, st, plan->live_blocks.p, nb, plan->live_counts.p, (unsigned *)nullptr);
-        hipLaunchKernelGGL(mask_write_kernel, dim3(nb), dim3(256), 0, st, ones, n, plan->live_blocks.p, plan->live_vox.p, plan->live_tiles.p);
+        int rcc = launch_mask_compact(plan, ones, n, nullptr, nullptr, st);
+        if (rcc != FIB_OK) return rcc;
     }
     GemmArgs ga{};
     ga.At = plan->At.p; ga.At3 = plan->split_bf16 ? plan->At3.p : nullptr; ga.S = S;
@@ -3011,14 +3167,21 @@ int fib::matrix_plan_run(const fib_odf_plan *plan, const float *S, const uint8_t
 extern "C" int fibd_qa_normalize(float *const qa[3], int64_t nvox, float odfmax, void *stream) try {
     FIB_CHECK(qa && qa[0] && qa[1] && qa[2] && nvox > 0, FIB_ERR_INVALID, "NULL argument");
     hipLaunchKernelGGL(qa_normalize_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, qa[0], qa[1], qa[2], nvox,
-                       (const float *)nullptr, odfmax);
+                       (float *)nullptr, odfmax, 0);
     FIB_HIP(hipGetLastError());
     return FIB_OK;
 } FIB_API_CATCH
 
 extern "C" int fibd_qa_normalize_dev(float *const qa[3], int64_t nvox, const float *odfmax_dev, void *stream) try {
     FIB_CHECK(qa && qa[0] && qa[1] && qa[2] && odfmax_dev && nvox > 0, FIB_ERR_INVALID, "NULL argument");
-    hipLaunchKernelGGL(qa_normalize_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, qa[0], qa[1], qa[2], nvox, odfmax_dev, 0.0f);
+    hipLaunchKernelGGL(qa_normalize_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, qa[0], qa[1], qa[2], nvox, const_cast<float *>(odfmax_dev), 0.0f, 0);
+    FIB_HIP(hipGetLastError());
+    return FIB_OK;
+} FIB_API_CATCH
+
+extern "C" int fibd_qa_normalize_pair(float *const qa[3], int64_t nvox, float *odfmax_pair_dev, void *stream) try {
+    FIB_CHECK(qa && qa[0] && qa[1] && qa[2] && odfmax_pair_dev && nvox > 0, FIB_ERR_INVALID, "NULL argument");
+    hipLaunchKernelGGL(qa_normalize_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, qa[0], qa[1], qa[2], nvox, odfmax_pair_dev, 0.0f, 1);
     FIB_HIP(hipGetLastError());
     return FIB_OK;
 } FIB_API_CATCH

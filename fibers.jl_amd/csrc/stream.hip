@@ -72,11 +72,12 @@ struct TraceArgs {
     const float4 *field;        // [nvox][nvec]
     const int64_t *seeds;       // [nseed] 0-based linear voxel index
     const float *sublist;       // [nsub][3]
-    float *scratch;             // [nlines/16 tiles][2*stride slots][16 lines][3]: forward step i -> slot i, backward step j -> slot stride+j
-                                // (a tile is one contiguous run that the pack kernel streams; a wave of the trace kernel writes 4 x 192 B per step)
-    int32_t *npts, *nfwd;       // [nlines]
+    float *scratch;             // [nlines/16 tiles][nslots][16 lines][3]: the point a line emits at loop trip t -> slot t: forward point i in slot i,
+                                // backward point j in slot nf + gap + j (a tile is one contiguous run that the pack kernel streams; a wave of the
+                                // trace kernel writes 4 x 192 B per trip)
+    int32_t *npts, *nfwd;       // [nlines]; nfwd = forward points | gap << 30 (gap = 1: the forward pass ended on a trip that emitted nothing)
     int64_t line0, nlines;      // this batch covers global lines [line0, line0+nlines)
-    int nx, ny, nz, nvec, nsub, len_max, stride;
+    int nx, ny, nz, nvec, nsub, len_max, stride, nslots;
     float cosang, step, smooth;
     // microscopy regime (stream.jl:252-287, 547-619)
     // LCM-guided tracking (stream.jl:200-236, 380-495)
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
     if (MODE == 2) {
         const int n = a.npts[li];
         if (n < a.len_min) return;                                // stream.jl:769
-        const int nf0 = a.nfwd[li];
+        const int nf0 = a.nfwd[li] & 0x3fffffff;
         const Pair e = a.excl[li], bo = a.block_off[li / TRACE_SCAN_B];
         const int64_t pt = e.pts + bo.pts, l0 = e.lines + bo.lines;
         int64_t p0;
@@ -172,22 +173,26 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
     const float p0y = (float)(sy + 1) + a.sublist[3 * isub + 1];
     const float p0z = (float)(sz + 1) + a.sublist[3 * isub + 2];
     constexpr int64_t slot_floats = SCR_TILE * 3;
-    float *dfw = a.scratch + (li / SCR_TILE) * ((int64_t)2 * a.stride * slot_floats) + (li % SCR_TILE) * 3;   // next forward slot of this line
-    float *dbw = dfw + (int64_t)a.stride * slot_floats;         // next backward slot
+    float *dcur = a.scratch + (li / SCR_TILE) * ((int64_t)a.nslots * slot_floats) + (li % SCR_TILE) * 3;   // this line's place in the slot of the current trip
     const char *fbase = reinterpret_cast<const char *>(a.field);   // wave-uniform base; per-lane offsets are 32-bit
     const float fnx = (float)a.nx, fny = (float)a.ny, fnz = (float)a.nz;
     const float omc = 1.0f - a.smooth;
-    int ivec = 0, npts = 0, nf = 0;
+    int ivec = 0, npts = 0, nf = 0, pass = 0, gap = 0;
     unsigned ndraw = 0;                                           // uniforms consumed by this line (LCM)
-    for (int pass = 0; pass < 2; pass++) {
-        const float fwd = pass == 0 ? 1.0f : -1.0f;
-        float px = p0x, py = p0y, pz = p0z;
-        const float4 s = a.field[lin * nvec + ivec];              // view(W.ovecs, :, ivec_next, seed...), stream.jl:650
-        float vx = s.x * fwd, vy = s.y * fwd, vz = s.z * fwd;
-        for (;;) {
+    float px = p0x, py = p0y, pz = p0z;
+    float vx, vy, vz;
+    {
+        const float4 s = a.field[lin * nvec];                     // view(W.ovecs, :, ivec_next, seed...), stream.jl:650 (ivec_next = 1)
+        vx = s.x * 1.0f; vy = s.y * 1.0f; vz = s.z * 1.0f;
+    }
+    // One trip of the loop = one step of whichever pass the lane is in.  true: the pass ended at this trip (stream.jl:657, :670, :674).
+    bool emitted = false;
+    auto step = [&]() -> bool {
+        emitted = false;
+        {
             const float nxp = px + vx * a.step, nyp = py + vy * a.step, nzp = pz + vz * a.step;   // stream.jl:512
             const float rx = rintf(nxp), ry = rintf(nyp), rz = rintf(nzp);                        // stream.jl:514
-            if (!(rx >= 1.0f && rx <= fnx && ry >= 1.0f && ry <= fny && rz >= 1.0f && rz <= fnz)) break;   // :517
+            if (!(rx >= 1.0f && rx <= fnx && ry >= 1.0f && ry <= fny && rz >= 1.0f && rz <= fnz)) return true;   // :517
             const uint32_t vox = (uint32_t)(((int)rx - 1) + a.nx * (((int)ry - 1) + a.ny * ((int)rz - 1)));   // nvox < 2^28 / nvec
             const float4 *cand = reinterpret_cast<const float4 *>(fbase + (size_t)(vox * (uint32_t)(nvec * 16)));
             float bx = 0.0f, by = 0.0f, bz = 0.0f, bestc = 0.0f, besta = 0.0f;
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
                     best = k; besta = ca; bestc = c; bx = w.x; by = w.y; bz = w.z;
                 }
             }
-            if (!(fabsf(bestc) < INFINITY)) break;                // !isfinite -> false, stream.jl:363
+            if (!(fabsf(bestc) < INFINITY)) return true;          // !isfinite -> false, stream.jl:363
             float wx, wy, wz;
             if (bestc > 0.0f) { wx = bx; wy = by; wz = bz; } else { wx = -bx; wy = -by; wz = -bz; }   // :365-369
             ivec = best;                                          // stream.jl:371
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
                     sx = sx + sg * ux; sy = sy + sg * uy; sz = sz + sg * uz;
                 }
                 const float m = fmaxf(fabsf(sx), fmaxf(fabsf(sy), fabsf(sz)));
-                if (m == 0.0f || !(m < INFINITY)) break;
+                if (m == 0.0f || !(m < INFINITY)) return true;
                 double acc = (double)(sx * sx);
                 acc += (double)(sy * sy);
                 acc += (double)(sz * sz);
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
                         lcm[j] = (e0 == entry || e1 == entry) ? lp[j] : 0.0f;
                         any |= lcm[j] != 0.0f;
                     }
-                    if (!any) break;                              // :448, :492
+                    if (!any) return true;                        // :448, :492
                     float sum = lcm[0];
 #pragma unroll
                     for (int j = 1; j < 10; j++) sum += lcm[j];
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
                         else { c = dot3(ex, ey, ez, w.x, w.y, w.z); ca = fabsf(c); }
                         if (k == 0 || (!(la != la) && ((ca != ca) || ca > la))) { lb = k; la = ca; lc = c; lx = w.x; ly = w.y; lz = w.z; }
                     }
-                    if (!(fabsf(lc) < INFINITY)) break;           // :476
+                    if (!(fabsf(lc) < INFINITY)) return true;     // :476
                     if (lc > 0.0f) { wx = lx; wy = ly; wz = lz; } else { wx = -lx; wy = -ly; wz = -lz; }   // :480-484
                     ivec = lb;                                    // :486
                 }
@@ -320,16 +325,15 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
                     d[2] = (float)(((double)pz + 0.5) * (double)a.vs[2]);
                 } else { d[0] = px; d[1] = py; d[2] = pz; }
                 if (pass == 0) ofw -= 3; else obw += 3;
-            } else if (MODE == 0) {   // push!/prepend! of pos_now (stream.jl:660): slot = step index within this pass
-                float *d = pass == 0 ? dfw : dbw;
+            } else if (MODE == 0) {   // push!/prepend! of pos_now (stream.jl:660): the slot of this trip
                 // LCM runs: the method-difference flag of the point (stream.jl:666) rides in the sign bit of x (x > 0)
-                d[0] = (LCM && isdiff) ? -px : px; d[1] = py; d[2] = pz;
-                if (pass == 0) dfw += slot_floats; else dbw += slot_floats;
+                dcur[0] = (LCM && isdiff) ? -px : px; dcur[1] = py; dcur[2] = pz;
             }
+            emitted = true;
             npts++;
             if (pass == 0) nf++;
-            if (!LCM && dot3(vx, vy, vz, wx, wy, wz) < a.cosang) break;   // stream.jl:670 (not used with LCMs, :668)
-            if (npts > a.len_max) break;                          // stream.jl:674
+            if (!LCM && dot3(vx, vy, vz, wx, wy, wz) < a.cosang) return true;   // stream.jl:670 (not used with LCMs, :668)
+            if (npts > a.len_max) return true;                    // stream.jl:674
             if (a.smooth != 0.0f) {                               // stream.jl:677-681
                 wx = a.smooth * vx + omc * wx;
                 wy = a.smooth * vy + omc * wy;
@@ -349,8 +353,27 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
             px = nxp; py = nyp; pz = nzp;                         // stream.jl:684-685
             vx = wx; vy = wy; vz = wz;
         }
+        return false;
+    };
+    // [r4] ONE loop for both passes: a lane whose forward pass ends turns round on the spot (back to the seed, opposite direction,
+    // stream.jl:649-650 with dir = -1) while its neighbours go on, so a wave runs max(forward + backward trips) over its lanes --
+    // with one loop per pass it ran max(forward) + max(backward): 1.5 x the trips on the benchmark field, whose lines all use up
+    // len_max but split it differently between the two directions.  The trip counter is wave-uniform, and so is the scratch slot
+    // a trip writes (all 64 lanes store into the same 4 x 192-byte rows, as before): forward point i sits in slot i, backward
+    // point j in slot nf + gap + j, gap = 1 if the forward pass ended on a trip that emitted nothing (a failed step).
+    for (;;) {
+        const bool ended = step();
+        if (MODE == 0) dcur += slot_floats;
+        if (ended) {
+            if (pass == 1) break;
+            pass = 1;
+            gap = emitted ? 0 : 1;
+            px = p0x; py = p0y; pz = p0z;
+            const float4 s = a.field[lin * nvec + ivec];          // view(W.ovecs, :, ivec_next, seed...), stream.jl:650
+            vx = s.x * -1.0f; vy = s.y * -1.0f; vz = s.z * -1.0f;
+        }
     }
-    if (MODE != 2) { a.npts[li] = npts; a.nfwd[li] = nf; }
+    if (MODE != 2) { a.npts[li] = npts; a.nfwd[li] = nf | (gap << 30); }
 }
 
 // Divergent termination (lines of a wave end at different steps: 30-53 % of the lane-steps idle on a phantom with a broad length
@@ -400,8 +423,7 @@ __global__ __launch_bounds__(1024) void stream_trace_micro_kernel(const TraceArg
         const float p0x = (float)(sx + 1) + a.sublist[3 * isub];
         const float p0y = (float)(sy + 1) + a.sublist[3 * isub + 1];
         const float p0z = (float)(sz + 1) + a.sublist[3 * isub + 2];
-        float *dfw = a.scratch + (li / SCR_TILE) * ((int64_t)2 * a.stride * slot_floats) + (li % SCR_TILE) * 3;
-        float *dbw = dfw + (int64_t)a.stride * slot_floats;
+        float *dcur = a.scratch + (li / SCR_TILE) * ((int64_t)a.nslots * slot_floats) + (li % SCR_TILE) * 3;   // next slot: the line's points one after the other (gap 0)
         int npts = 0, nf = 0;
         for (int pass = 0; pass < 2; pass++) {
             const float fwd = pass == 0 ? 1.0f : -1.0f;
@@ -471,11 +493,8 @@ __global__ __launch_bounds__(1024) void stream_trace_micro_kernel(const TraceArg
                 if (!(fabsf(bc) < INFINITY)) break;               // !isfinite, :609
                 float wx, wy, wz;
                 if (bc > 0.0f) { wx = fb.x; wy = fb.y; wz = fb.z; } else { wx = -fb.x; wy = -fb.y; wz = -fb.z; }   // :616-620
-                if (lane == 0) {                                  // addpt!(strline, pos_now), stream.jl:660
-                    float *dp = pass == 0 ? dfw : dbw;
-                    dp[0] = px; dp[1] = py; dp[2] = pz;
-                }
-                if (pass == 0) dfw += slot_floats; else dbw += slot_floats;
+                if (lane == 0) { dcur[0] = px; dcur[1] = py; dcur[2] = pz; }   // addpt!(strline, pos_now), stream.jl:660
+                dcur += slot_floats;
                 npts++;
                 if (pass == 0) nf++;
                 if (dot3(vx, vy, vz, wx, wy, wz) < a.cosang) break;   // :670
@@ -571,7 +590,7 @@ struct PackArgs {
     int64_t *out_seed;
     float *out_xyz;
     int64_t nlines, line0, out_line0, out_pt0;
-    int stride, len_min;
+    int stride, nslots, len_min;
     int trk;                    // 1: out_xyz is a .trk body: [Int32 npts, npts x 3 Float32 ((xyz+.5)*voxel_size)] per line
     float vs[3];
 };
@@ -590,14 +609,15 @@ __global__ __launch_bounds__(PK_WAVES * 64) void stream_pack_kernel(const PackAr
     const int64_t line0 = tix * PK_LINES;
     if (line0 >= a.nlines) return;
     // lanes 0..15: the tile's lines
-    int nf = 0, nb = 0;
+    int nf = 0, nb = 0, bs = 0;
     int64_t p0 = 0;
     {
         const int64_t li = line0 + (lane & 15);
         if (lane < PK_LINES && li < a.nlines) {
             const int n = a.npts[li];
             if (n >= a.len_min) {                               // stream.jl:769
-                nf = a.nfwd[li]; nb = n - nf;
+                const int nfr = a.nfwd[li];
+                nf = nfr & 0x3fffffff; nb = n - nf; bs = nf + (nfr >> 30);
                 const Pair e = a.excl[li], bo = a.block_off[li / SCAN_B];
                 const int64_t pt = a.out_pt0 + e.pts + bo.pts, l0 = a.out_line0 + e.lines + bo.lines;
                 if (a.trk) {
@@ -610,27 +630,26 @@ __global__ __launch_bounds__(PK_WAVES * 64) void stream_pack_kernel(const PackAr
             }
         }
     }
-    int cnt0 = nf, cnt1 = nb;
+    int cnt = nb > 0 ? bs + nb : nf;                            // slots of the tile that hold points of kept lines
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) { cnt0 = max(cnt0, __shfl_xor(cnt0, o)); cnt1 = max(cnt1, __shfl_xor(cnt1, o)); }
-    cnt0 = __builtin_amdgcn_readfirstlane(cnt0); cnt1 = __builtin_amdgcn_readfirstlane(cnt1);
-    const int nch0 = (cnt0 + PK_SLOTS - 1) / PK_SLOTS, nch = nch0 + (cnt1 + PK_SLOTS - 1) / PK_SLOTS;
+    for (int o = 1; o < 16; o <<= 1) cnt = max(cnt, __shfl_xor(cnt, o));
+    cnt = __builtin_amdgcn_readfirstlane(cnt);
+    const int nch = (cnt + PK_SLOTS - 1) / PK_SLOTS;
     // write-out mapping: lane = (line group lg, point pt); line tl = lg + 4 j
     const int lg = lane >> 4, pt = lane & 15;
-    int wnf[4], wnb[4];
+    int wnf[4], wnb[4], wbs[4];
     int64_t wp0[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        wnf[j] = __shfl(nf, lg + 4 * j); wnb[j] = __shfl(nb, lg + 4 * j);
+        wnf[j] = __shfl(nf, lg + 4 * j); wnb[j] = __shfl(nb, lg + 4 * j); wbs[j] = __shfl(bs, lg + 4 * j);
         wp0[j] = ((int64_t)__shfl((int)(p0 >> 32), lg + 4 * j) << 32) | (uint32_t)__shfl((int)(uint32_t)p0, lg + 4 * j);
     }
-    const float4 *tbase = reinterpret_cast<const float4 *>(a.scratch + tix * ((int64_t)2 * a.stride * PK_LINES * 3));
+    const float4 *tbase = reinterpret_cast<const float4 *>(a.scratch + tix * ((int64_t)a.nslots * PK_LINES * 3));
     float4 v[3];
-    auto fetch = [&](int c) {                                   // 3 KiB of contiguous scratch
-        const int region = c < nch0 ? 0 : 1;
-        const int s0 = (region == 0 ? c : c - nch0) * PK_SLOTS;
-        const float4 *src = tbase + ((int64_t)(region == 0 ? 0 : a.stride) + s0) * (PK_LINES * 3 / 4) + lane;
-        const int live = (region == 0 ? cnt0 : cnt1) - s0;     // live slots of the chunk (the scratch ends with the last slot)
+    auto fetch = [&](int c) {                                   // 3 KiB of contiguous scratch: 16 slots
+        const int s0 = c * PK_SLOTS;
+        const float4 *src = tbase + (int64_t)s0 * (PK_LINES * 3 / 4) + lane;
+        const int live = cnt - s0;                              // live slots of the chunk
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             const int f = lane + 64 * i;                        // float4 index within the chunk: slot f / 12
@@ -647,13 +666,14 @@ __global__ __launch_bounds__(PK_WAVES * 64) void stream_pack_kernel(const PackAr
         }
         __builtin_amdgcn_wave_barrier();
         if (c + 1 < nch) fetch(c + 1);                          // next chunk's loads fly during the write-out
-        const int region = c < nch0 ? 0 : 1;
-        const int sidx = (region == 0 ? c : c - nch0) * PK_SLOTS + pt;
+        const int sidx = c * PK_SLOTS + pt;                     // the slot = the loop trip that emitted the point
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int tl = lg + 4 * j;
-            if (sidx < (region == 0 ? wnf[j] : wnb[j])) {
-                const int64_t p = region == 0 ? (int64_t)(wnf[j] - 1 - sidx) : (int64_t)wnf[j] + sidx;
+            int64_t p = -1;                                     // forward points reversed, backward points behind them (stream.jl:652)
+            if (sidx < wnf[j]) p = (int64_t)(wnf[j] - 1 - sidx);
+            else if (sidx >= wbs[j] && sidx - wbs[j] < wnb[j]) p = (int64_t)wnf[j] + (sidx - wbs[j]);
+            if (p >= 0) {
                 struct P3 { float x, y, z; };
                 const float *t = T + pt * PK_ROW + tl * 3;
                 float *d = a.out_xyz + wp0[j] + p * 3;
@@ -677,19 +697,20 @@ __global__ __launch_bounds__(PK_WAVES * 64) void stream_pack_kernel(const PackAr
 // holds go through stream_pack_kernel above.
 __global__ __launch_bounds__(256) void stream_pack_tile_kernel(const PackArgs a) {
     extern __shared__ __attribute__((aligned(16))) float obuf[];
-    __shared__ int s_nf[PK_LINES], s_nb[PK_LINES], s_o[PK_LINES];   // per line: forward / backward counts (0 if dropped), offset in obuf
-    __shared__ int s_cnt[4];                                        // max forward, max backward, range length (floats), misalignment
+    __shared__ int s_nf[PK_LINES], s_nb[PK_LINES], s_bs[PK_LINES], s_o[PK_LINES];   // per line: forward / backward counts (0 if dropped), first backward slot, offset in obuf
+    __shared__ int s_cnt[4];                                        // slots in use, -, range length (floats), misalignment
     __shared__ int64_t s_g0;                                        // first float of the range in out_xyz
     const int tid = threadIdx.x;
     const int64_t line0 = (int64_t)blockIdx.x * PK_LINES;
     if (tid < 64) {
         const int64_t li = line0 + tid;
-        int nf = 0, nb = 0, n = 0;
+        int nf = 0, nb = 0, bs = 0, n = 0;
         int64_t p0 = 0, gs = INT64_MAX, ge = -1;
         if (tid < PK_LINES && li < a.nlines) {
             n = a.npts[li];
             if (n >= a.len_min) {                               // stream.jl:769
-                nf = a.nfwd[li]; nb = n - nf;
+                const int nfr = a.nfwd[li];
+                nf = nfr & 0x3fffffff; nb = n - nf; bs = nf + (nfr >> 30);
                 const Pair e = a.excl[li], bo = a.block_off[li / SCAN_B];
                 const int64_t pt = a.out_pt0 + e.pts + bo.pts, l0 = a.out_line0 + e.lines + bo.lines;
                 if (a.trk) { p0 = pt * 3 + l0 + 1; gs = p0 - 1; }   // the Int32 point count precedes the points (trk.jl:472)
@@ -697,41 +718,43 @@ __global__ __launch_bounds__(256) void stream_pack_tile_kernel(const PackArgs a)
                 ge = p0 + (int64_t)n * 3;
             } else n = 0;
         }
-        int mf = nf, mb = nb;
+        int mf = nb > 0 ? bs + nb : nf;                        // slots of the tile that hold points of kept lines
         int64_t g0 = gs, g1 = ge;
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) {
-            mf = max(mf, __shfl_xor(mf, o)); mb = max(mb, __shfl_xor(mb, o));
+            mf = max(mf, __shfl_xor(mf, o));
             const int64_t og0 = ((int64_t)__shfl_xor((int)(g0 >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)g0, o);
             const int64_t og1 = ((int64_t)__shfl_xor((int)(g1 >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)g1, o);
             g0 = og0 < g0 ? og0 : g0; g1 = og1 > g1 ? og1 : g1;
         }
         const int mis = g1 >= 0 ? (int)((reinterpret_cast<uintptr_t>(a.out_xyz + g0) >> 2) & 3) : 0;
         if (tid < PK_LINES) {
-            s_nf[tid] = nf; s_nb[tid] = nb; s_o[tid] = n > 0 ? (int)(p0 - g0) + mis : 0;
+            s_nf[tid] = nf; s_nb[tid] = nb; s_bs[tid] = bs; s_o[tid] = n > 0 ? (int)(p0 - g0) + mis : 0;
             if (a.trk && n > 0) obuf[(int)(p0 - g0) + mis - 1] = __int_as_float(n);
         }
-        if (tid == 0) { s_cnt[0] = mf; s_cnt[1] = mb; s_cnt[2] = g1 >= 0 ? (int)(g1 - g0) : 0; s_cnt[3] = mis; s_g0 = g0; }
+        if (tid == 0) { s_cnt[0] = mf; s_cnt[1] = 0; s_cnt[2] = g1 >= 0 ? (int)(g1 - g0) : 0; s_cnt[3] = mis; s_g0 = g0; }
     }
     __syncthreads();
-    const int cnt0 = s_cnt[0], cnt1 = s_cnt[1], len = s_cnt[2], mis = s_cnt[3];
+    const int cnt = s_cnt[0], len = s_cnt[2], mis = s_cnt[3];
     if (len == 0) return;
-    const int nch0 = (cnt0 + 15) >> 4, nch = nch0 + ((cnt1 + 15) >> 4);
+    const int nch = (cnt + 15) >> 4;
     const int l = tid & 15, sl = tid >> 4;                      // thread = (line, slot within the 16-slot chunk)
-    const int nf = s_nf[l], nb = s_nb[l], o = s_o[l];
+    const int nf = s_nf[l], nb = s_nb[l], bs = s_bs[l], o = s_o[l];
     struct P3 { float x, y, z; };
-    const P3 *tbase = reinterpret_cast<const P3 *>(a.scratch + (int64_t)blockIdx.x * ((int64_t)2 * a.stride * PK_LINES * 3)) + tid;
+    const P3 *tbase = reinterpret_cast<const P3 *>(a.scratch + (int64_t)blockIdx.x * ((int64_t)a.nslots * PK_LINES * 3)) + tid;
     for (int c0 = 0; c0 < nch; c0 += 4) {
         P3 v[4];
         int pos[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int c = c0 + i;
-            const int region = c < nch0 ? 0 : 1;
-            const int s = ((region == 0 ? c : c - nch0) << 4) + sl;
-            const bool ok = c < nch && s < (region == 0 ? nf : nb);
-            pos[i] = ok ? (region == 0 ? nf - 1 - s : nf + s) : -1;
-            if (ok) v[i] = tbase[((int64_t)(region == 0 ? 0 : a.stride) + s - sl) * PK_LINES];
+            const int t = (c << 4) + sl;                        // the slot = the loop trip that emitted the point
+            pos[i] = -1;                                        // forward points reversed, backward points behind them (stream.jl:652)
+            if (c < nch) {
+                if (t < nf) pos[i] = nf - 1 - t;
+                else if (t >= bs && t - bs < nb) pos[i] = nf + (t - bs);
+            }
+            if (pos[i] >= 0) v[i] = tbase[(int64_t)c * (16 * PK_LINES)];
             else v[i] = P3{0.f, 0.f, 0.f};
         }
 #pragma unroll
@@ -811,7 +834,7 @@ struct fib_stream_job {
     hipStream_t last_stream = nullptr;   // stream of the job's latest launch (trace or pack)
     fib_stream_params prm{};
     int64_t nseed = 0, nlines = 0;
-    int nsub = 1, stride = 0;
+    int nsub = 1, stride = 0, nslots = 0;
     float *scratch = nullptr;
     // carved out of the same (cached) arena as the scratch: no hipMalloc/hipFree per call
     struct View32 { int32_t *p = nullptr; } npts, nfwd;
@@ -905,6 +928,7 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
     FIB_CHECK(job != nullptr, FIB_ERR_NOMEM, "out of host memory");
     job->device = device; job->prm = *prm; job->nseed = nseed; job->nsub = nsub;
     job->nlines = nseed * nsub; job->stride = prm->len_max + 2;
+    job->nslots = prm->len_max + 4;                     // trips of a line's loop: <= len_max + 1 points + two failed steps
     const int64_t nl = job->nlines;
     *nlines_out = 0; *npoints_out = 0;
     if (nl == 0) { *job_out = job; return FIB_OK; }
@@ -916,7 +940,7 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
         const char *e = getenv("FIBERS_STREAM_TWOPASS");
         job->two_pass = prm->search_dist == 0 && !lin.lcms && e && e[0] == '1';
     }
-    const size_t b_scratch = job->two_pass ? 0 : up((size_t)fib::cdiv(nl, SCR_TILE) * SCR_TILE * job->stride * 2 * 3 * sizeof(float));
+    const size_t b_scratch = job->two_pass ? 0 : up((size_t)fib::cdiv(nl, SCR_TILE) * SCR_TILE * job->nslots * 3 * sizeof(float));
     const size_t b_i32 = up((size_t)nl * sizeof(int32_t)), b_excl = up((size_t)nl * sizeof(Pair));
     const size_t b_btot = up((size_t)nblocks * sizeof(Pair)), b_tot = 256;
     const size_t sbytes = b_scratch + 2 * b_i32 + b_excl + b_btot + b_tot;
@@ -955,7 +979,7 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
     ta.scratch = job->scratch; ta.npts = job->npts.p; ta.nfwd = job->nfwd.p;
     ta.line0 = 0; ta.nlines = nl;
     ta.nx = prm->nx; ta.ny = prm->ny; ta.nz = prm->nz; ta.nvec = prm->nvec; ta.nsub = nsub;
-    ta.len_max = prm->len_max; ta.stride = job->stride;
+    ta.len_max = prm->len_max; ta.stride = job->stride; ta.nslots = job->nslots;
     ta.cosang = prm->cosang_thresh; ta.step = prm->step_size; ta.smooth = prm->smooth_coeff;
     const unsigned grid = (unsigned)fib::cdiv(nl, 256);
     fib::DevBuf<float4> d_search;
@@ -1133,7 +1157,7 @@ static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, f
     pa.excl = job->excl.p; pa.block_off = job->block_tot.p;
     pa.out_npts = npts; pa.out_seed = seed_index; pa.out_xyz = xyz;
     pa.nlines = job->nlines; pa.line0 = 0; pa.out_line0 = 0; pa.out_pt0 = 0;
-    pa.stride = job->stride; pa.len_min = job->prm.len_min;
+    pa.stride = job->stride; pa.nslots = job->nslots; pa.len_min = job->prm.len_min;
     fib::ProfScope prof("stream_pack", (hipStream_t)stream);
     { const int rcl = launch_pack(job, pa, (hipStream_t)stream); if (rcl != FIB_OK) return rcl; }
     FIB_HIP(hipGetLastError());
@@ -1153,7 +1177,7 @@ extern "C" int fibd_stream_pack_trk(fib_stream_job *job, const float voxel_size[
     pa.excl = job->excl.p; pa.block_off = job->block_tot.p;
     pa.out_npts = nullptr; pa.out_seed = nullptr; pa.out_xyz = reinterpret_cast<float *>(body);
     pa.nlines = job->nlines; pa.line0 = 0; pa.out_line0 = 0; pa.out_pt0 = 0;
-    pa.stride = job->stride; pa.len_min = job->prm.len_min;
+    pa.stride = job->stride; pa.nslots = job->nslots; pa.len_min = job->prm.len_min;
     pa.trk = 1; pa.vs[0] = voxel_size[0]; pa.vs[1] = voxel_size[1]; pa.vs[2] = voxel_size[2];
     fib::ProfScope prof("stream_pack_trk", (hipStream_t)stream);
     { const int rcl = launch_pack(job, pa, (hipStream_t)stream); if (rcl != FIB_OK) return rcl; }

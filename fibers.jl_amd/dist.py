@@ -44,23 +44,28 @@ def _torch_stream(stream):
     import torch
     if stream is None or isinstance(stream, torch.cuda.Stream):
         return stream
-    return torch.cuda.ExternalStream(int(stream))
+    handle = int(getattr(stream, "value", stream) or 0)        # ctypes.c_void_p (the package's own handle type) or a plain integer
+    if handle == 0:                                             # the null stream: torch's default stream
+        return torch.cuda.default_stream()
+    return torch.cuda.ExternalStream(handle)
 
 
 def allreduce_odfmax(odfmax, group=None, always=False):
-    """odfmax: tensor [2] = {local max of per-voxel ODF means, nan flag}; in-place MAX over ranks.
-    A NaN anywhere must win (Julia's maximum propagates NaN): the flag is reduced too.
+    """odfmax: tensor [2] = {local max of the per-voxel ODF means that are not NaN (-Inf if there is none), NaN flag} as
+    fibd_odf_rec writes it with FIB_ODF_RAW_ODFMAX; in-place MAX over ranks: ONE 2-float all-reduce.  A NaN anywhere must win
+    (Julia's maximum propagates NaN, gqi.jl:164): the flag is reduced with the maximum, and the consumers
+    (fibd_qa_normalize_dev, odfmax_value) turn {m, flag > 0} into NaN.
     always: run the collective even in a one-rank group (tests: exercises the RCCL path on a 1-GPU box)."""
-    import torch
     import torch.distributed as dist
     if dist.is_initialized() and (dist.get_world_size(group) > 1 or always):
-        m = torch.nan_to_num(odfmax[:1], nan=float("-inf"))
-        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
-        fl = odfmax[1:2].clone()
-        dist.all_reduce(fl, op=dist.ReduceOp.MAX, group=group)
-        odfmax[0] = torch.where(fl[0] > 0, torch.full_like(m[0], float("nan")), m[0])
-        odfmax[1] = fl[0]
+        dist.all_reduce(odfmax, op=dist.ReduceOp.MAX, group=group)
     return odfmax
+
+
+def odfmax_value(odfmax):
+    """{max, NaN flag} -> maximum(mean(odf, dims=4)) as the reference computes it (NaN if any voxel's mean is NaN)"""
+    import torch
+    return torch.where(odfmax[1] > 0, torch.full_like(odfmax[0], float("nan")), odfmax[0])
 
 
 def allgather_slabs(local, counts: Sequence[int], group=None, always=False):
@@ -109,9 +114,9 @@ def merge_tracts(parts: List[dict]) -> dict:
                 xyz=np.concatenate(pieces) if pieces else np.zeros((0, 3), np.float32))
 
 
-def gather_objects(obj, group=None):
+def gather_objects(obj, group=None, always=False):
     import torch.distributed as dist
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not (dist.is_initialized() and (dist.get_world_size(group) > 1 or always)):
         return [obj]
     out = [None] * dist.get_world_size(group)
     dist.all_gather_object(out, obj, group=group)
@@ -121,19 +126,41 @@ def gather_objects(obj, group=None):
 # ---------------------------------------------------------------------------------------------
 # sharded drivers (device tier)
 # ---------------------------------------------------------------------------------------------
-def odf_rec_sharded(plan, dwi_local, mask_local, group=None, stream=None, out=None):
+def any_unaligned(counts: Sequence[int]) -> bool:
+    """FIB_ODF_SEPARATE_PEAKS contract (include/fibers_hip.h): when ONE volume is cut into pieces and any piece's voxel count is
+    not a multiple of 4, EVERY piece runs find_peaks! as its own kernel (an unaligned piece cannot run the fused scan, and the
+    two forms differ in two ODF rows at rounding level).  counts = every rank's slab voxel count (slab_bounds: the same on every
+    rank, no collective)."""
+    return any(int(c) % 4 != 0 for c in counts)
+
+
+def odf_rec_sharded(plan, dwi_local, mask_local, group=None, stream=None, out=None, counts: Sequence[int] = None,
+                    out_prezeroed: bool = False, always: bool = False):
     """gqi_rec / dsi_rec on this rank's z-slab + the global QA normalisation across ranks (gqi.jl:164-168): the slab's
-    {odfmax, NaN flag} pair is all-reduced with MAX, the divisor never leaves the device."""
+    {odfmax, NaN flag} pair is all-reduced with MAX (one collective), the divisor never leaves the device.
+    counts: the voxel counts of ALL ranks' slabs (e.g. nx*ny*(z1-z0) from slab_bounds); they decide, identically on every rank,
+    whether every slab takes the separate peak finder (any_unaligned).  Without them the ranks agree through one extra 1-int
+    all-reduce per call.  always: run the collectives in a one-rank group too (tests on a 1-GPU box)."""
     import contextlib
     import torch
+    import torch.distributed as dist
     from .gqi import odf_rec_device, qa_normalize_device
-    out = odf_rec_device(plan, dwi_local, mask_local, out=out, normalize=False, stream=stream)
+    if counts is not None:
+        sep = any_unaligned(counts)
+    elif dist.is_initialized() and (dist.get_world_size(group) > 1 or always):
+        fl = torch.tensor([int(mask_local.numel() % 4 != 0)], dtype=torch.int32, device=mask_local.device)
+        dist.all_reduce(fl, op=dist.ReduceOp.MAX, group=group)
+        sep = bool(fl.item())
+    else:
+        sep = False                                             # one piece: the library picks by the piece's own alignment
+    out = odf_rec_device(plan, dwi_local, mask_local, out=out, normalize=False, stream=stream, separate_peaks=sep,
+                         out_prezeroed=out_prezeroed, raw_odfmax=True)
     # the collective runs on the stream the kernels run on: it follows the kernel that writes out["odfmax"] and precedes the
     # normalisation in stream order, whatever torch's current stream is
     ts = _torch_stream(stream)
     with (torch.cuda.stream(ts) if ts is not None else contextlib.nullcontext()):
-        allreduce_odfmax(out["odfmax"], group)
-    qa_normalize_device(out["qa"], out["odfmax"], stream=stream)
+        allreduce_odfmax(out["odfmax"], group, always=always)
+    qa_normalize_device(out["qa"], out["odfmax"], stream=stream, raw=True)   # {max, flag} -> NaN divisor if any rank saw a NaN mean
     return out
 
 

@@ -118,11 +118,19 @@ def find_peaks_work(odf, odf_dirs: ODF = sphere_642, device: int = 0):
 # ---------------------------------------------------------------------------------------------
 # device-resident form
 # ---------------------------------------------------------------------------------------------
+ODF_FORMATS = {"default": 0, "fp16x2": 1, "bf16x3": 2, "f32": 3}      # FIB_ODF_FORMAT_* (include/fibers_hip.h)
+
+
 class OdfPlan:
-    """GQIwork (gqi.jl:32-82) or DSIwork (dsi.jl:41-143) resident on one GPU."""
+    """GQIwork (gqi.jl:32-82) or DSIwork (dsi.jl:41-143) resident on one GPU.  `format`: the operand format of the contraction
+    (include/fibers_hip.h FIB_ODF_FORMAT_*): "fp16x2" (two fp16 pieces per f32 operand, the default), "bf16x3" (three exact bf16
+    pieces), "f32" (f32 MFMA chain) or "default" (the environment's choice); `plan.format` is what the kernels actually run."""
 
     def __init__(self, kind: str, bval, bvec, odf_dirs: ODF = sphere_642, sigma: float = 1.25,
-                 hann_width: int = 32, device: int = 0):
+                 hann_width: int = 32, device: int = 0, format: str = "default"):
+        if format not in ODF_FORMATS:
+            raise ValueError("format must be one of %s" % sorted(ODF_FORMATS))
+        fmt = ODF_FORMATS[format]
         self._h = C.c_void_p()
         self.kind, self.device = kind, device
         bval = np.ascontiguousarray(bval, np.float32)
@@ -131,13 +139,21 @@ class OdfPlan:
         L = _lib.lib()
         self.nvol, self.nvert = int(bval.shape[0]), odf_dirs.nvert
         if kind == "gqi":
-            _lib.check(L.fib_gqi_plan_create(device, bval.ctypes.data, bvec.ctypes.data, self.nvol, v.ctypes.data,
-                                             v.shape[0], f.ctypes.data, f.shape[0], float(sigma), C.byref(self._h)))
+            _lib.check(L.fib_gqi_plan_create_fmt(device, bval.ctypes.data, bvec.ctypes.data, self.nvol, v.ctypes.data,
+                                                 v.shape[0], f.ctypes.data, f.shape[0], float(sigma), fmt, C.byref(self._h)))
         elif kind == "dsi":
-            _lib.check(L.fib_dsi_plan_create(device, bval.ctypes.data, bvec.ctypes.data, self.nvol, v.ctypes.data,
-                                             v.shape[0], f.ctypes.data, f.shape[0], int(hann_width), C.byref(self._h)))
+            _lib.check(L.fib_dsi_plan_create_fmt(device, bval.ctypes.data, bvec.ctypes.data, self.nvol, v.ctypes.data,
+                                                 v.shape[0], f.ctypes.data, f.shape[0], int(hann_width), fmt, C.byref(self._h)))
         else:
             raise ValueError("kind must be 'gqi' or 'dsi'")
+
+    @property
+    def format(self) -> str:
+        """the operand format the plan's contraction kernels run (a plan falls back to a wider one when its matrix needs it)"""
+        code = _lib.lib().fib_odf_plan_format(self._h)
+        if code <= 0:
+            _lib.check(code if code < 0 else -1)
+        return {v: k for k, v in ODF_FORMATS.items()}[code]
 
     def matrix(self):
         nr, nv, nt = C.c_int(0), C.c_int(0), C.c_int(0)
@@ -160,9 +176,12 @@ class OdfPlan:
 
 
 def odf_rec_device(plan: OdfPlan, dwi, mask, out: Optional[dict] = None, normalize: bool = True, stream=None,
-                   out_prezeroed: bool = False):
+                   out_prezeroed: bool = False, separate_peaks: bool = False, raw_odfmax: bool = False):
     """dwi: float32 CUDA tensor [nvol, nvox]; mask uint8 [nvox].  Returns dict(odf [nvert,nvox],
-    pdf [nvol,nvox] (DSI), peak [3][3,nvox], qa [3][nvox], odfmax float32[2] = {max, nan flag})."""
+    pdf [nvol,nvox] (DSI), peak [3][3,nvox], qa [3][nvox], odfmax float32[2] = {max, nan flag}).
+    separate_peaks = FIB_ODF_SEPARATE_PEAKS: a caller that cuts ONE volume into pieces sets it for every piece when any piece's
+    voxel count is not a multiple of 4 (such a piece cannot run the fused peak scan, and the two forms differ at rounding level).
+    raw_odfmax = FIB_ODF_RAW_ODFMAX: odfmax = {maximum of the means that are not NaN, NaN flag}, the form a MAX all-reduce takes."""
     import torch
     _chk_dev(dwi, torch.float32, "dwi")
     _chk_dev(mask, torch.uint8, "mask")
@@ -181,15 +200,20 @@ def odf_rec_device(plan: OdfPlan, dwi, mask, out: Optional[dict] = None, normali
     _lib.check(_lib.lib().fibd_odf_rec(plan._h, dwi.data_ptr(), mask.data_ptr(), nvox, pdf_ptr, out["odf"].data_ptr(),
                                        _lib.P3(*[t.data_ptr() for t in out["peak"]]),
                                        _lib.P3(*[t.data_ptr() for t in out["qa"]]),
-                                       out["odfmax"].data_ptr(), (1 if normalize else 0) | (2 if out_prezeroed else 0), _stream_ptr(stream)))
+                                       out["odfmax"].data_ptr(),
+                                       (1 if normalize else 0) | (2 if out_prezeroed else 0) | (4 if separate_peaks else 0) | (8 if raw_odfmax else 0),
+                                       _stream_ptr(stream)))
     return out
 
 
-def qa_normalize_device(qa, odfmax, stream=None):
+def qa_normalize_device(qa, odfmax, stream=None, raw=False):
     """qa[k] ./= odfmax (gqi.jl:166-168).  odfmax: a float, or a float32 CUDA tensor whose first element is the divisor (e.g.
-    the all-reduced `out["odfmax"]`: it never leaves the device)."""
+    the all-reduced `out["odfmax"]`: it never leaves the device).  raw: the tensor is the pair {maximum of the non-NaN means, NaN
+    flag} (odf_rec_device(raw_odfmax=True), all-reduced): the divisor is NaN if the flag is set, and odfmax[0] becomes the divisor."""
     nvox = qa[0].numel()
-    if hasattr(odfmax, "data_ptr"):
+    if raw:
+        _lib.check(_lib.lib().fibd_qa_normalize_pair(_lib.P3(*[t.data_ptr() for t in qa]), nvox, odfmax.data_ptr(), _stream_ptr(stream)))
+    elif hasattr(odfmax, "data_ptr"):
         _lib.check(_lib.lib().fibd_qa_normalize_dev(_lib.P3(*[t.data_ptr() for t in qa]), nvox, odfmax.data_ptr(), _stream_ptr(stream)))
     else:
         _lib.check(_lib.lib().fibd_qa_normalize(_lib.P3(*[t.data_ptr() for t in qa]), nvox, float(odfmax), _stream_ptr(stream)))

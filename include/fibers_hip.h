@@ -92,6 +92,26 @@ int fib_gqi_plan_create(int device, const float *bval, const float *bvec, int nv
 int fib_dsi_plan_create(int device, const float *bval, const float *bvec, int nvol,
                         const float *verts, int nverts, const int32_t *faces, int nfaces,
                         int hann_width, fib_odf_plan **plan);
+/* The same with the operand format of the contraction A*s chosen per plan.  The reference runs an f32 sgemv (gqi.jl:144);
+ * the kernels run it on the matrix cores in one of three forms, all f32 in / f32 accumulate / f32 out:
+ *   FIB_ODF_FORMAT_FP16X2  two fp16 pieces per f32 operand (23 of 24 significant bits, three piece products; the default)
+ *   FIB_ODF_FORMAT_BF16X3  three bf16 pieces per operand, six piece products: every f32 product exact
+ *   FIB_ODF_FORMAT_F32     v_mfma_f32_32x32x2_f32: a k-ordered f32 fma chain
+ *   FIB_ODF_FORMAT_DEFAULT what the environment selects (FIBERS_ODF_GEMM=f32, FIBERS_ODF_EXACT=1), else FP16X2.
+ * A plan may fall back to a wider form when its matrix does not fit a narrower one (non-finite entries, < 2 stages):
+ * fib_odf_plan_format reports what the plan's kernels actually run; fib_odf_default_format what DEFAULT resolves to now. */
+#define FIB_ODF_FORMAT_DEFAULT 0
+#define FIB_ODF_FORMAT_FP16X2 1
+#define FIB_ODF_FORMAT_BF16X3 2
+#define FIB_ODF_FORMAT_F32 3
+int fib_gqi_plan_create_fmt(int device, const float *bval, const float *bvec, int nvol,
+                            const float *verts, int nverts, const int32_t *faces, int nfaces,
+                            float sigma, int format, fib_odf_plan **plan);
+int fib_dsi_plan_create_fmt(int device, const float *bval, const float *bvec, int nvol,
+                            const float *verts, int nverts, const int32_t *faces, int nfaces,
+                            int hann_width, int format, fib_odf_plan **plan);
+int fib_odf_plan_format(const fib_odf_plan *plan);   /* FIB_ODF_FORMAT_* (> 0) or a negative error code */
+int fib_odf_default_format(void);
 void fib_odf_plan_destroy(fib_odf_plan *plan);
 /* host copy of the reconstruction matrix [nrows x nvol] column-major (GQI: nrows = nvert;
  * DSI: nrows = nvol + nvert, pdf rows first); pass NULL to query sizes only. */
@@ -139,11 +159,15 @@ int fibd_dti_last_partial_count(const fib_dti_plan *plan, void *stream, int64_t 
  *                      computes two of the 321 rows of sphere_642 with a different rounding): a caller that
  *                      cuts one volume into pieces sets it for ALL pieces when any piece is unaligned, so
  *                      that the result does not depend on the cut (the host-buffer tier does).
+ *   FIB_ODF_RAW_ODFMAX the form of *odfmax_dev a MAX all-reduce can take as it is: {maximum of the voxel means that
+ *                      are not NaN (-Inf if there is none), nan-flag}.  Without it the first element is NaN when the
+ *                      flag is set (what maximum() returns, gqi.jl:164).  fibd_qa_normalize_pair consumes the raw form.
  * Only voxels inside the mask are computed: the mask is compacted on the device into a voxel list
  * (reconstruction) and a list of 64-voxel tiles (peak finder), so cost scales with the mask. */
 #define FIB_ODF_NORMALIZE 1
 #define FIB_ODF_PREZEROED 2
 #define FIB_ODF_SEPARATE_PEAKS 4
+#define FIB_ODF_RAW_ODFMAX 8
 int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const uint8_t *mask, int64_t nvox,
                  float *pdf, float *odf, float *const peak[3], float *const qa[3],
                  float *odfmax_dev, int flags, void *stream);
@@ -151,6 +175,9 @@ int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const uint8_t *mask
 int fibd_qa_normalize(float *const qa[3], int64_t nvox, float odfmax, void *stream);
 /* same with the divisor read from device memory (the all-reduced odfmax stays on the device: no host round trip) */
 int fibd_qa_normalize_dev(float *const qa[3], int64_t nvox, const float *odfmax_dev, void *stream);
+/* .. from the raw pair {maximum of the non-NaN means, nan-flag} (FIB_ODF_RAW_ODFMAX, MAX-all-reduced over the ranks): the
+ * divisor is NaN when the flag is set, and odfmax_pair_dev[0] is rewritten to that divisor (what maximum() returns) */
+int fibd_qa_normalize_pair(float *const qa[3], int64_t nvox, float *odfmax_pair_dev, void *stream);
 
 /* find_peaks!(W) (gqi.jl:180-201) on a planar ODF volume [nvox*nvert]: for every voxel the
  * indices (0-based, first-half vertex rows) of the first 3 entries of `isort` and `nvalid`.

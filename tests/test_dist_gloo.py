@@ -54,10 +54,14 @@ def _worker(rank, world, port, q):
             assert np.array_equal(loc["peak"][k], full["peak"][k][:, :, z0:z1])
         assert np.array_equal(loc["odf"], full["odf"][:, :, z0:z1])
 
-        # NaN in one rank's maximum must win everywhere (Julia maximum propagates NaN)
-        om2 = torch.tensor([float("nan") if rank == 1 else 3.0, 1.0 if rank == 1 else 0.0])
+        # NaN in one rank's maximum must win everywhere (Julia maximum propagates NaN): the raw pair {maximum of the means that
+        # are not NaN, NaN flag} goes through ONE all-reduce(MAX); the flag turns the result into NaN
+        om2 = torch.tensor([2.0 if rank == 1 else 3.0, 1.0 if rank == 1 else 0.0])
         fd.allreduce_odfmax(om2)
-        assert torch.isnan(om2[0])
+        assert om2.tolist() == [3.0, 1.0] and torch.isnan(fd.odfmax_value(om2))
+        om3 = torch.tensor([float("-inf") if rank == 1 else 3.0, 0.0])        # a rank with no voxel at all
+        fd.allreduce_odfmax(om3)
+        assert om3.tolist() == [3.0, 0.0] and float(fd.odfmax_value(om3)) == 3.0
 
         # ---- field all-gather from ragged slabs ------------------------------------------------
         nxy = shape[0] * shape[1]

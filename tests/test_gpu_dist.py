@@ -52,7 +52,7 @@ def _worker(rank, world, port, q):
             full = fj.odf_rec_device(plan, d, mask, normalize=True)
             torch.cuda.synchronize()
             full = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in full.items()}
-            loc = fd.odf_rec_sharded(plan, d[:, v0:v1].contiguous(), mask[v0:v1].contiguous())
+            loc = fd.odf_rec_sharded(plan, d[:, v0:v1].contiguous(), mask[v0:v1].contiguous(), counts=counts)
             torch.cuda.synchronize()
             assert torch.equal(loc["odfmax"].nan_to_num(nan=-7.0), full["odfmax"].nan_to_num(nan=-7.0)), (rank, poison, loc["odfmax"], full["odfmax"])
             assert torch.equal(loc["odf"].nan_to_num(nan=-7.0), full["odf"][:, v0:v1].nan_to_num(nan=-7.0))
@@ -117,6 +117,28 @@ def _worker(rank, world, port, q):
         assert np.array_equal(merged["npts"], one["npts"].cpu().numpy())
         assert np.array_equal(merged["seed_index"], one["seed_index"].cpu().numpy())
         assert np.array_equal(merged["xyz"], one["xyz"].cpu().numpy())
+        # ---- a cut that leaves ONE slab unaligned (13 x 11 x 9: slabs of 715 and 572 voxels; 715 % 4 = 3): the unaligned slab cannot
+        # run the fused peak scan, so EVERY slab must take the separate peak finder (FIB_ODF_SEPARATE_PEAKS contract) -- with the
+        # slab counts given (no collective) and without them (the ranks agree through one 1-int all-reduce) ---------------------------
+        shape_u = (13, 11, 9)
+        nx, ny, nz = shape_u
+        nxy, nvox = nx * ny, nx * ny * nz
+        du, _ = phantom.make_dwi_torch(shape_u, bval, bvec, seed=9, device=dev, noise_frac=0.05)
+        mu = torch.from_numpy((np.random.default_rng(4).random(nvox) < 0.9).astype(np.uint8)).to(dev)
+        z0, z1 = fd.slab_bounds(nz, world, rank)
+        v0, v1 = z0 * nxy, z1 * nxy
+        counts = [(b - a) * nxy for a, b in (fd.slab_bounds(nz, world, r) for r in range(world))]
+        assert counts == [715, 572] and fd.any_unaligned(counts)
+        full = fj.odf_rec_device(plan, du, mu, normalize=True)          # 1287 voxels: unaligned as a whole as well
+        torch.cuda.synchronize()
+        full = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in full.items()}
+        for cnts in (counts, None):
+            loc = fd.odf_rec_sharded(plan, du[:, v0:v1].contiguous(), mu[v0:v1].contiguous(), counts=cnts)
+            torch.cuda.synchronize()
+            assert torch.equal(loc["odfmax"], full["odfmax"]), (rank, loc["odfmax"], full["odfmax"])
+            assert torch.equal(loc["odf"], full["odf"][:, v0:v1]), "unaligned cut: the ODF depends on the cut (rank %d)" % rank
+            for k in range(3):
+                assert torch.equal(loc["peak"][k], full["peak"][k][:, v0:v1]) and torch.equal(loc["qa"][k], full["qa"][k][v0:v1])
         q.put((rank, "ok"))
     except Exception as e:                                     # noqa: BLE001
         import traceback
@@ -142,10 +164,10 @@ def _rccl_worker(port, q):
         fd.allreduce_odfmax(om, always=True)
         torch.cuda.synchronize()
         assert om.tolist() == [0.25, 0.0]
-        om = torch.tensor([float("nan"), 1.0], device=dev)
+        om = torch.tensor([0.5, 1.0], device=dev)              # raw pair: {maximum of the non-NaN means, NaN flag}
         fd.allreduce_odfmax(om, always=True)
         torch.cuda.synchronize()
-        assert bool(torch.isnan(om[0])) and float(om[1]) == 1.0
+        assert om.tolist() == [0.5, 1.0] and bool(torch.isnan(fd.odfmax_value(om)))
         # slab all-gather of a float4 field (all_gather_into_tensor) and of a mask
         g = torch.Generator(device=dev); g.manual_seed(3)
         f = torch.rand((4096, 3, 4), device=dev, generator=g)
@@ -171,6 +193,13 @@ def _rccl_worker(port, q):
         side.synchronize()
         for k in range(3):
             assert torch.equal(got["qa"][k], ref["qa"][k])
+        got = fd.odf_rec_sharded(plan, dwi, mask, stream=side, always=True)    # .. and with the collectives taken (one-rank group)
+        side.synchronize()
+        assert torch.equal(got["odfmax"], ref["odfmax"])
+        for k in range(3):
+            assert torch.equal(got["qa"][k], ref["qa"][k])
+        objs = fd.gather_objects({"rank": 0, "n": 3}, always=True)             # all_gather_object through RCCL
+        assert objs == [{"rank": 0, "n": 3}]
         q.put("ok")
     except Exception as e:                                     # noqa: BLE001
         import traceback
@@ -203,6 +232,23 @@ def test_two_ranks_with_device_kernels_match_one_rank_bit_for_bit():
     res = [q.get(timeout=600) for _ in range(world)]
     [p.join(timeout=60) for p in procs]
     assert all(r[1] == "ok" for r in res), res
+
+
+def test_bench_rccl_branch_with_one_rank():
+    """bench.py's backend-nccl branch (init_process_group("nccl", device_id=...), barrier, float64 all-reduces, the sharded drivers with
+    their all-reduce, the field all-gather) executed on the GPU box: FIBERS_BENCH_FORCE_PG=1 takes every multi-rank branch with ONE
+    rank -- what a 1-GPU box allows; the first 8-GPU launch is then not this code's first execution"""
+    import json
+    import subprocess
+    env = dict(os.environ, FIBERS_BENCH_FORCE_PG="1", FIBERS_BENCH_SHAPE="40,36,30", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.pop("FIBERS_BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert line["extra"]["gqi_weak_scaling"]["mvoxels_per_s"] > 0                  # (only the multi-rank branch produces it)
+    assert line["extra"]["stream_dti_ball"]["points"] > 0 and line["extra"]["stream_dsi_3peaks_10M"]["points"] > 0
 
 
 def test_bench_multi_rank_control_flow_on_one_device():

@@ -239,11 +239,29 @@ def test_mask_compaction_device_tier(fj):
     assert all(float(q.abs().max()) == 0.0 for q in empty["qa"])
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
-def test_gqi_both_matrix_core_paths_full_mask(fj, orc, mode, monkeypatch):
-    """the two contraction kernels (split-bf16 MFMA, f32 MFMA) against the oracle on an all-ones mask: contiguous voxel
-    runs take the LDS-transposed dwordx4 epilogue, the ragged last work item the scalar one"""
-    monkeypatch.setenv("FIBERS_ODF_GEMM", mode)
+FORMATS = ["fp16x2", "bf16x3", "f32"]        # the operand formats of the contraction (include/fibers_hip.h FIB_ODF_FORMAT_*)
+
+
+def _use_format(monkeypatch, fmt):
+    """make `fmt` the default operand format of the plans built from here on (the host tier builds its plans with the default
+    format and keys its plan cache on it): fp16x2 = no switch, bf16x3 = FIBERS_ODF_EXACT=1, f32 = FIBERS_ODF_GEMM=f32"""
+    import fibers_jl_amd as fj
+    from fibers_jl_amd import _lib
+    monkeypatch.delenv("FIBERS_ODF_EXACT", raising=False)
+    monkeypatch.delenv("FIBERS_ODF_GEMM", raising=False)
+    if fmt == "bf16x3":
+        monkeypatch.setenv("FIBERS_ODF_EXACT", "1")
+    elif fmt == "f32":
+        monkeypatch.setenv("FIBERS_ODF_GEMM", "f32")
+    assert _lib.lib().fib_odf_default_format() == fj.gqi.ODF_FORMATS[fmt]
+
+
+@pytest.mark.parametrize("mode", FORMATS)
+def test_gqi_all_operand_formats_full_mask(fj, orc, mode, monkeypatch):
+    """the three operand formats of the contraction (two fp16 pieces, three exact bf16 pieces, f32 MFMA chain), each directly
+    against the oracle on an all-ones mask: contiguous voxel runs take the LDS-transposed dwordx4 epilogue, the ragged last work
+    item the scalar one"""
+    _use_format(monkeypatch, mode)
     from fibers_jl_amd import phantom
     shape = (12, 10, 9)                                    # 1080 voxels: a multiple of 4, not of 256
     bval, bvec = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3)
@@ -255,10 +273,11 @@ def test_gqi_both_matrix_core_paths_full_mask(fj, orc, mode, monkeypatch):
     _check_odf_rec(got.odf.vol, [p.vol for p in got.peak], [q.vol[..., 0] for q in got.qa], ref, mask, label=mode)
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
-def test_dsi_both_matrix_core_paths_full_mask(fj, orc, mode, monkeypatch):
-    """DSI (folded lattice: mapped pdf rows, three M tiles per voxel group) on an all-ones mask, both kernels"""
-    monkeypatch.setenv("FIBERS_ODF_GEMM", mode)
+@pytest.mark.parametrize("mode", FORMATS)
+def test_dsi_all_operand_formats_full_mask(fj, orc, mode, monkeypatch):
+    """DSI (folded lattice: mapped pdf rows, ODF tile + pdf tile per voxel group) on an all-ones mask, every operand format
+    directly against the oracle"""
+    _use_format(monkeypatch, mode)
     dwi, _, bval, bvec = _dsi_case((8, 6, 2), seed=8)      # 96 voxels: one full 32-voxel wave run + ragged rest
     mask = np.ones(dwi.shape[:3], np.uint8)
     sph = fj.sphere_642
@@ -270,8 +289,8 @@ def test_dsi_both_matrix_core_paths_full_mask(fj, orc, mode, monkeypatch):
                    odf_rtol=1e-4, qa_atol=1e-4, label="dsi " + mode)
 
 
-def test_split_bf16_matches_f32_kernel_large(fj, monkeypatch):
-    """40^3 x 63 frames: the split-bf16 contraction agrees with the f32-MFMA chain to f32 rounding everywhere, with and
+def test_split_formats_match_f32_kernel_large(fj):
+    """40^3 x 63 frames: each piece-split contraction (three bf16 pieces, two fp16 pieces) agrees with the f32-MFMA chain to f32 rounding everywhere, with and
     without a mask (the compacted voxel list changes which lanes / work items a voxel lands in)"""
     import torch
     from fibers_jl_amd import phantom
@@ -282,94 +301,31 @@ def test_split_bf16_matches_f32_kernel_large(fj, monkeypatch):
     dwi, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=4, device=dev)
     ball = phantom.ball_mask_torch(shape, dev, radius=17.3)
     outs = {}
-    for mode in ("f32", "bf16x3"):
-        monkeypatch.setenv("FIBERS_ODF_GEMM", mode)
-        plan = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642)
+    for mode in FORMATS:
+        plan = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642, format=mode)
+        assert plan.format == mode
         for name, m in (("ones", torch.ones(nvox, dtype=torch.uint8, device=dev)), ("ball", ball)):
             o = fj.odf_rec_device(plan, dwi, m)
             outs[mode, name] = (o["odf"].clone(), o["peak"][0].clone())
         plan.close()
-    for name in ("ones", "ball"):
-        a, b = outs["f32", name][0], outs["bf16x3", name][0]
-        vmax = a.abs().max(0).values.clamp_min(1e-30)
-        assert float(((a - b).abs() / vmax).max()) < 5e-6
-        differ = (outs["f32", name][1] != outs["bf16x3", name][1]).any(0).float().mean()
-        assert float(differ) < 1e-3                        # first-peak vertex: only amplitude ties at rounding level may flip
     live = ball.bool()
-    assert torch.equal(outs["bf16x3", "ones"][0][:, live], outs["bf16x3", "ball"][0][:, live])
-    assert (outs["bf16x3", "ball"][0][:, ~live] == 0).all()
+    for split in ("bf16x3", "fp16x2"):
+        for name in ("ones", "ball"):
+            a, b = outs["f32", name][0], outs[split, name][0]
+            vmax = a.abs().max(0).values.clamp_min(1e-30)
+            assert float(((a - b).abs() / vmax).max()) < 5e-6, split
+            differ = (outs["f32", name][1] != outs[split, name][1]).any(0).float().mean()
+            assert float(differ) < 1e-3                    # first-peak vertex: only amplitude ties at rounding level may flip
+        assert torch.equal(outs[split, "ones"][0][:, live], outs[split, "ball"][0][:, live])
+        assert (outs[split, "ball"][0][:, ~live] == 0).all()
 
 
-def test_find_peaks_host_entry(fj, orc):
-    """fib_find_peaks (host buffers): the first three entries of isort and nvalid, for all three tessellations"""
-    rng = np.random.default_rng(9)
-    for sph in (fj.sphere_362, fj.sphere_642, fj.sphere_724):
-        odf = rng.random((7, 5, sph.nvert)).astype(np.float32)
-        odf[0, 0] = 0.0
-        odf[1, 1, :] = np.round(odf[1, 1, :] * 4) / 4            # ties
-        top, nvalid = fj.find_peaks(odf, sph)
-        faces0 = orc.fold_faces(sph.faces, sph.nvert)
-        for i in range(7):
-            for j in range(5):
-                isort, nv, _ = orc.find_peaks(odf[i, j], faces0)
-                assert nv == nvalid[i, j]
-                assert list(isort[:3]) == list(top[i, j])
-
-
-def test_peak_kernels_agree_incl_nan_poisoned_voxels(fj, monkeypatch):
-    """the peak finder fused into the contraction kernel (sphere_642 GQI default), the separate list-based sphere_642
-    kernel and the generic-table kernel give the same peaks / qa / odfmax, also when NaN samples poison whole voxels
-    (321 NaN "candidates": the fused scan hands such voxels to its redo kernel, the list kernel takes its overflow path).
-    The two separate kernels read the same ODF and must agree bit for bit; the fused kernel computes rows 46 and 320 of
-    the ODF with the roles of the MFMA and the f32 VALU row swapped (1e-6 relative), so a rounding-level tie may fall
-    differently there."""
-    import torch
-    from fibers_jl_amd import phantom
-    dev = torch.device("cuda", 0)
-    shape = (32, 24, 20)
-    nvox = shape[0] * shape[1] * shape[2]
-    bval, bvec = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3)
-    dwi, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=6, device=dev)
-    rng = np.random.default_rng(4)
-    bad = torch.from_numpy(rng.choice(nvox, 60, replace=False)).to(dev)
-    dwi[5, bad] = float("nan")
-    mask = torch.ones(nvox, dtype=torch.uint8, device=dev)
-    res = {}
-    for name, env in (("fused", {}), ("list", {"FIBERS_ODF_UNFUSED": "1"}), ("generic", {"FIBERS_PEAKS_GENERIC": "1"})):
-        for k in ("FIBERS_ODF_UNFUSED", "FIBERS_PEAKS_GENERIC"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        p = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642)
-        o = fj.odf_rec_device(p, dwi, mask, normalize=False)
-        torch.cuda.synchronize()
-        res[name] = dict(peak=[t.clone() for t in o["peak"]], qa=[t.clone() for t in o["qa"]], odfmax=o["odfmax"].clone(),
-                         odf=o["odf"].clone())
-    for name in res:
-        assert bool(torch.isnan(res[name]["odf"][:, bad]).all())
-        assert float(res[name]["odfmax"][1]) == 1.0              # NaN flag of the global maximum (gqi.jl:164)
-        assert float(res[name]["peak"][0][:, bad].abs().max()) == 0.0   # nvalid = 0 for an all-NaN ODF: no peaks (gqi.jl:151,200)
-    for k in range(3):
-        assert torch.equal(res["list"]["peak"][k], res["generic"]["peak"][k]), k
-        assert torch.equal(torch.nan_to_num(res["list"]["qa"][k], nan=-7.0), torch.nan_to_num(res["generic"]["qa"][k], nan=-7.0)), k
-        differ = (res["fused"]["peak"][k] != res["list"]["peak"][k]).any(0)
-        assert int(differ.sum()) <= 2, (k, int(differ.sum()))
-        same = ~differ
-        torch.testing.assert_close(torch.nan_to_num(res["fused"]["qa"][k][same], nan=-7.0), torch.nan_to_num(res["list"]["qa"][k][same], nan=-7.0),
-                                   rtol=2e-5, atol=1e-2)
-    assert torch.equal(torch.nan_to_num(res["list"]["odfmax"], nan=-7.0), torch.nan_to_num(res["generic"]["odfmax"], nan=-7.0))
-    rows = torch.ones(res["fused"]["odf"].shape[0], dtype=torch.bool, device=dev)
-    rows[46] = False; rows[320] = False
-    assert torch.equal(torch.nan_to_num(res["fused"]["odf"][rows], nan=-7.0), torch.nan_to_num(res["list"]["odf"][rows], nan=-7.0))
-    torch.testing.assert_close(torch.nan_to_num(res["fused"]["odf"][~rows], nan=-7.0), torch.nan_to_num(res["list"]["odf"][~rows], nan=-7.0), rtol=1e-5, atol=0)
-
-
-@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+@pytest.mark.parametrize("mode", FORMATS)
 def test_gqi_nonfinite_samples_propagate_like_the_reference(fj, orc, mode, monkeypatch):
     """gqi.jl:139-144 on samples that are not finite: `s[s .< 0] .= 0` turns -Inf into 0 and keeps NaN; `maximum(s) == 0`
     does not skip a voxel with a NaN; mul!(o, A, s) makes a NaN sample a NaN column and a +Inf sample +-Inf rows (NaN where
     the coefficient is 0 or where both signs meet).  Nothing is trapped."""
-    monkeypatch.setenv("FIBERS_ODF_GEMM", mode)
+    _use_format(monkeypatch, mode)
     from fibers_jl_amd import phantom
     shape = (8, 6, 5)
     bval, bvec = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3)
@@ -406,11 +362,11 @@ def test_gqi_nonfinite_samples_propagate_like_the_reference(fj, orc, mode, monke
         assert (~same).sum() <= 2
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+@pytest.mark.parametrize("mode", FORMATS)
 def test_dsi_nonfinite_samples_propagate_like_the_reference(fj, orc, mode, monkeypatch):
     """dsi.jl:205-225 on samples that are not finite: max.(X, 0) turns -Inf into 0 and keeps NaN; the FFT smears a NaN or
     +Inf sample over the whole grid and p ./ sum(p) leaves NaN everywhere in that voxel's pdf and odf."""
-    monkeypatch.setenv("FIBERS_ODF_GEMM", mode)
+    _use_format(monkeypatch, mode)
     dwi, mask, bval, bvec = _dsi_case((5, 4, 3), seed=6)
     mask[:, 0, 0] = 1
     dwi[0, 0, 0, 100] = np.inf
@@ -543,7 +499,7 @@ def test_gqi_and_dsi_randomised_configurations(fj, orc, case, monkeypatch):
     non-positive samples, and which contraction kernel runs."""
     from fibers_jl_amd import phantom
     rng = np.random.default_rng(900 + case)
-    monkeypatch.setenv("FIBERS_ODF_GEMM", "f32" if case % 4 == 3 else "bf16x3")
+    _use_format(monkeypatch, FORMATS[[0, 1, 0, 2, 1, 0, 1, 2][case]])
     sph = getattr(fj, ["sphere_642", "sphere_362", "sphere_724"][case % 3])
     shape = tuple(int(x) for x in rng.integers(3, 9, 3))
     mask = (rng.random(shape) < rng.uniform(0.5, 1.0)).astype(np.uint8)
@@ -670,17 +626,13 @@ def _rec_both_formats(fj, monkeypatch, kind, dwi, mask, bval, bvec, sph):
     m = torch.from_numpy(np.ascontiguousarray(mask.reshape(-1, order="F"))).cuda()
     res = {}
     for exact in (False, True):
-        if exact:
-            monkeypatch.setenv("FIBERS_ODF_EXACT", "1")
-        else:
-            monkeypatch.delenv("FIBERS_ODF_EXACT", raising=False)
-        plan = fj.OdfPlan(kind, bval, bvec, sph, sigma=1.25, hann_width=32)
+        plan = fj.OdfPlan(kind, bval, bvec, sph, sigma=1.25, hann_width=32, format="bf16x3" if exact else "fp16x2")
+        assert plan.format == ("bf16x3" if exact else "fp16x2")      # what the plan's kernels run, read back from the library
         o = fj.odf_rec_device(plan, d, m)
         torch.cuda.synchronize()
         res[exact] = dict(odf=o["odf"].cpu().numpy().T.copy(), peak=[p.cpu().numpy().T.copy() for p in o["peak"]],
                           pdf=o["pdf"].cpu().numpy().T.copy() if kind == "dsi" else None)
         plan.close()
-    monkeypatch.delenv("FIBERS_ODF_EXACT", raising=False)
     return res[False], res[True]
 
 
