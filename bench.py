@@ -538,8 +538,10 @@ def main():
             # ---- LCM-guided tracking (stream.jl:380-495) on a synthetic 2-D section: 2048^2 pixels, 3 orientations each ----
             n2 = 2048
             g = torch.Generator(device=dev); g.manual_seed(11)
-            ang = [torch.rand(n2 * n2, device=dev, generator=g) - 0.5 + k * 3.14159265 / 3 for k in range(3)]
-            ov2 = [torch.stack([torch.cos(a_), torch.sin(a_), torch.zeros_like(a_)]) for a_ in ang]
+            # 2-D orientation ANGLES, as the reference's microscopy data come (stream.jl:147-172): three per pixel, radians in
+            # [-pi/2, pi/2]; the through-plane dimension is the one with the largest voxel size (z)
+            ang = [((torch.rand(n2 * n2, device=dev, generator=g) - 0.5 + k * 3.14159265 / 3 + 1.5707963) % 3.14159265) - 1.5707963 for k in range(3)]
+            ov2 = [fj.angles_to_vectors_device(a_.clamp(-1.5707963, 1.5707963), volres=(0.5, 0.5, 2.0))[0] for a_ in ang]
             lc = torch.rand((10, n2 * n2), device=dev, generator=g)
             fld, mo = fj.stream_field_device(ov2, mask=torch.ones(n2 * n2, dtype=torch.uint8, device=dev))
             sd2 = torch.nonzero(mo).flatten()
@@ -558,7 +560,7 @@ def main():
             extra["stream_lcm_2d"] = dict(seeds=int(sd2.numel()), lines=int(rl["npts"].numel()), points=npl,
                                           mpoints_per_s=npl / t_l / 1e6, ms_per_step=t_l * 1e3,
                                           trace_kernel_ms=lk_ms / max(lk_n, 1), flagged_fraction=float(rl["flags"].float().mean()),
-                                          note="2048x2048x1 pixels, 3 orientations + one 10-element LCM per pixel, len_max 140")
+                                          note="2048x2048x1 pixels, 3 orientation ANGLES (radians, expanded as stream.jl:147-172 does) + one 10-element LCM per pixel, len_max 140")
             del rl, fld, lc, ov2, ang
             # ---- RUMBA-SD (rusd.jl, row N4): 140^3 x 270 frames, ball mask, sphere_724 (364 compartments), 10 iterations ----
             torch.cuda.empty_cache()

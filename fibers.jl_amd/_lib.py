@@ -27,7 +27,8 @@ class StreamParams(C.Structure):
     _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("nvec", C.c_int32),
                 ("len_min", C.c_int32), ("len_max", C.c_int32),
                 ("cosang_thresh", C.c_float), ("step_size", C.c_float), ("smooth_coeff", C.c_float),
-                ("search_dist", C.c_int32), ("search_cosang", C.c_float), ("ws", C.c_void_p), ("interp", C.c_int32)]
+                ("search_dist", C.c_int32), ("search_cosang", C.c_float), ("ws", C.c_void_p), ("interp", C.c_int32),
+                ("search_flat_axis", C.c_int32)]
 
 
 class RumbaOut(C.Structure):

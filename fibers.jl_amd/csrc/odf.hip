@@ -1429,29 +1429,39 @@ struct CompactArgs {
     unsigned epoch;
     int nchunks, iters, zero;     // iters: sub-chunks per chunk; zero: workgroups nchunks.. of the grid clear the outputs outside the mask (z)
     unsigned *clear; int nclear;  // words the call needs zeroed before its next launch (odf_dsi2_kernel's pairing counters)
+    unsigned long long *sub_state;   // [sub-chunks] granules: epoch << 32 | voxels of the sub-chunk outside the mask (zero != 0 only)
     ZeroArgs z;
 };
 typedef __attribute__((address_space(1))) unsigned long long fib_gu64;
 __global__ __launch_bounds__(1024) void mask_compact_kernel(const CompactArgs c) {
     __shared__ int cv[CB_ITERS_MAX][64], ct[CB_ITERS_MAX][64];
-    __shared__ int s_chunk, s_base[2], s_agg[2];
+    __shared__ int s_chunk, s_base[2], s_agg[2], s_ndead[CB_ITERS_MAX];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool compacts = (int)blockIdx.x < c.nchunks;        // (the other workgroups only help to clear outputs)
     if (compacts) {
         if (tid == 0) { s_chunk = (int)atomicAdd(c.ticket, 1u); s_base[0] = 0; s_base[1] = 0; }
+        if (tid < CB_ITERS_MAX) s_ndead[tid] = 0;
         __syncthreads();
         const int t = s_chunk;
         const int64_t base = (int64_t)t * c.iters * CB;
-        for (int it = 0; it < c.iters; it++)
+        for (int it = 0; it < c.iters; it++) {
+            int nd = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int64_t vx = base + (int64_t)it * CB + i * 1024 + tid;
                 const unsigned long long inr = __ballot(vx < c.nvox);
                 const unsigned long long b = __ballot(vx < c.nvox && c.mask[vx] != 0);
                 const unsigned long long e = quad_expand(b) & inr;
+                nd += __popcll(inr & ~b);
                 if (lane == 0) { cv[it][i * 16 + wave] = __popcll(e); ct[it][i * 16 + wave] = b != 0ull; }   // entry = wave-pass in voxel order
             }
+            if (c.zero && lane == 0 && nd) atomicAdd(&s_ndead[it], nd);
+        }
         __syncthreads();
+        // (for the helpers below: how many voxels of each sub-chunk lie outside the mask -- a hint that saves them the look at the mask)
+        if (c.zero && tid < c.iters && (int64_t)(t * c.iters + tid) * CB < c.nvox)
+            __hip_atomic_store((fib_gu64 *)(c.sub_state + (size_t)t * c.iters + tid), ((unsigned long long)c.epoch << 32) | (unsigned)s_ndead[tid],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (wave == 0) {                                         // exclusive prefix over the chunk's wave-passes, and its two totals
             int runv = 0, runt = 0;
             for (int it = 0; it < c.iters; it++) {
@@ -1507,46 +1517,71 @@ __global__ __launch_bounds__(1024) void mask_compact_kernel(const CompactArgs c)
             }
         return;
     }
-    // ---- outputs outside the mask: the job of the helper workgroups behind the compacting ones (they wait for nothing, and the
-    // compacting workgroups' chain is not lengthened).  The (span of 8 sub-chunks, group of 16 rows) items are dealt out
-    // round-robin: a thread owns 4 consecutive voxels of each sub-chunk and walks the rows, one 16-byte store per row and
-    // sub-chunk when all four are outside (scalar stores for mixed groups); a sub-chunk with more than a quarter of its voxels
-    // outside is cleared as a whole -- whole-line stores run at the fill rate, the ragged ends of the runs outside a mask at well
-    // under half of it -- and the GEMM / peak kernels overwrite the voxels inside.  A workgroup writes 128 KiB of a row before it
-    // moves to the next row (16 KiB pieces of 83 rows, 11 MB apart, ran at 4.4 TB/s).  With everything inside the mask an item is
-    // one look at 32 KiB of mask.
+    // ---- outputs outside the mask: the job of the helper workgroups behind the compacting ones (so that the compacting
+    // workgroups' chain is not lengthened).  The (span of 8 sub-chunks, group of 16 rows) items are dealt out round-robin: a
+    // thread owns 4 consecutive voxels of each sub-chunk and walks the rows, one 16-byte store per row and sub-chunk when all
+    // four are to be cleared (scalar stores for mixed groups).  With everything inside the mask an item is eight granule loads.
     const ZeroArgs &z = c.z;
     constexpr int ZS = 8, ZR = 16;                               // an item = 8 consecutive sub-chunks (128 KiB of every row) x 16 rows
-    __shared__ int s_nd[ZS];
+    __shared__ int s_nd[ZS], s_known;
     const int nr = z.n0 + z.n1 + 12, ngrp = (nr + ZR - 1) / ZR;
     const int64_t nsub = (c.nvox + CB - 1) / CB, nspan = (nsub + ZS - 1) / ZS;
     for (int64_t item = (int64_t)blockIdx.x - c.nchunks; item < nspan * ngrp; item += (int64_t)gridDim.x - c.nchunks) {
-        const int64_t span = item / ngrp;                        // (neighbouring workgroups share a span: its mask bytes come from L2)
+        const int64_t span = item / ngrp;
         const int g = (int)(item % ngrp);
         __syncthreads();                                         // (s_nd of the previous item has been read)
-        if (tid < ZS) s_nd[tid] = 0;
+        // The compacting workgroups publish every sub-chunk's count of voxels outside the mask; a helper waits for them a bounded
+        // time (they were dispatched first, but nothing here depends on that: after the time-out the helper counts for itself)
+        if (wave == 0) {
+            int nd = -1;
+            if (lane < ZS && span * ZS + lane < nsub) {
+                for (int spin = 0; spin < 400; spin++) {
+                    const unsigned long long w = __hip_atomic_load((fib_gu64 *)(c.sub_state + span * ZS + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(w >> 32) == c.epoch) { nd = (int)(unsigned)w; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            } else if (lane < ZS) nd = 0;                        // past the end of the volume
+            if (lane < ZS) s_nd[lane] = nd < 0 ? 0 : nd;
+            const unsigned long long miss = __ballot(lane < ZS && nd < 0);
+            if (lane == 0) s_known = miss == 0ull;
+        }
         __syncthreads();
+        const bool known = s_known != 0;
         unsigned deadb = 0u, inrb = 0u;                          // 4 bits per sub-chunk: my voxels outside the mask / inside the volume
+        bool need_bits = !known;
+        if (known) {
+#pragma unroll
+            for (int k = 0; k < ZS; k++) {                       // the mask itself is needed for the sub-chunks that are cleared voxel by voxel only
+                const int64_t sb = (span * ZS + k) * CB;
+                const int64_t len = c.nvox - sb < CB ? c.nvox - sb : CB;
+                need_bits |= s_nd[k] != 0 && !((int64_t)s_nd[k] * 16 > len);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < ZS; k++) {
             const int64_t v0 = (span * ZS + k) * CB + (int64_t)tid * 4;
             int nd = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const bool in = v0 + i < c.nvox, dd = in && c.mask[v0 + i] == 0;
+                const bool in = v0 + i < c.nvox;
+                const bool dd = need_bits && in && c.mask[v0 + i] == 0;
                 inrb |= (unsigned)in << (4 * k + i); deadb |= (unsigned)dd << (4 * k + i); nd += dd;
             }
-            for (int off = 32; off >= 1; off >>= 1) nd += __shfl_xor(nd, off);
-            if (lane == 0 && nd) atomicAdd(&s_nd[k], nd);
+            if (!known) {
+                for (int off = 32; off >= 1; off >>= 1) nd += __shfl_xor(nd, off);
+                if (lane == 0 && nd) atomicAdd(&s_nd[k], nd);
+            }
         }
-        __syncthreads();
+        if (!known) __syncthreads();
         unsigned clr = 0u;                                       // what this thread clears
 #pragma unroll
         for (int k = 0; k < ZS; k++) {
             const int64_t sb = (span * ZS + k) * CB;
             const int64_t len = c.nvox - sb < CB ? c.nvox - sb : CB;
             const unsigned m = 0xFu << (4 * k);
-            clr |= ((int64_t)s_nd[k] * 4 > len ? inrb : deadb) & m;
+            // a sub-chunk with more than 1/16 of its voxels outside is cleared as a whole: ragged runs of 4-byte stores cost more
+            // than the lines of the voxels inside (which the contraction kernel overwrites)
+            clr |= (s_nd[k] == 0 ? 0u : ((int64_t)s_nd[k] * 16 > len ? inrb : deadb)) & m;
         }
         if (__syncthreads_or(clr != 0u) == 0) continue;
         const int r1 = (g + 1) * ZR < nr ? (g + 1) * ZR : nr;
@@ -2477,6 +2512,7 @@ struct fib_odf_plan {
     mutable fib::DevBuf<unsigned> maxenc;
     mutable fib::DevBuf<int32_t> live_vox, live_tiles, live_counts;   // mask compaction scratch (grow-only), counts = {voxels, tiles, +Inf voxels}
     mutable fib::DevBuf<unsigned long long> compact_state;   // the chunk granules of mask_compact_kernel [1024]
+    mutable fib::DevBuf<unsigned long long> compact_sub;     // .. and its per-sub-chunk hints for the workgroups that clear outputs
     mutable unsigned compact_epoch = 0;              // .. and the call counter they are tagged with
     fib::DevBuf<unsigned> tickets;                   // [4]: chunk dispenser of mask_compact_kernel, arrival counter of odf_post_kernel (both 0 between calls)
     mutable fib::DevBuf<float> odfmax;
@@ -2941,8 +2977,13 @@ int launch_mask_compact(const fib_odf_plan *plan, const uint8_t *mask, int64_t n
     if ((rc = plan->live_vox.ensure((size_t)nvox)) != FIB_OK) return rc;
     if ((rc = plan->live_tiles.ensure((size_t)fib::cdiv(nvox, 64))) != FIB_OK) return rc;
     if (!plan->compact_state.p) {                                                       // fresh granules carry epoch 0 = "never written"
-        if ((rc = plan->compact_state.alloc(1024 + 2)) != FIB_OK) return rc;
-        FIB_HIP(hipMemsetAsync(plan->compact_state.p, 0, (1024 + 2) * sizeof(unsigned long long), st));
+        if ((rc = plan->compact_state.alloc(1024)) != FIB_OK) return rc;
+        FIB_HIP(hipMemsetAsync(plan->compact_state.p, 0, 1024 * sizeof(unsigned long long), st));
+    }
+    const size_t nsub = (size_t)fib::cdiv(nvox, CB);
+    if (z && plan->compact_sub.n < nsub) {
+        if ((rc = plan->compact_sub.alloc(nsub)) != FIB_OK) return rc;
+        FIB_HIP(hipMemsetAsync(plan->compact_sub.p, 0, nsub * sizeof(unsigned long long), st));
     }
     if (++plan->compact_epoch == 0u) plan->compact_epoch = 1u;
     CompactArgs c{};
@@ -2951,9 +2992,10 @@ int launch_mask_compact(const fib_odf_plan *plan, const uint8_t *mask, int64_t n
     c.zero = z != nullptr;
     if (z) c.z = *z;
     c.clear = plan->pair_flags.p; c.nclear = plan->pair_flags.p ? 8 * 32 : 0;
+    c.sub_state = plan->compact_sub.p;
     fib::ProfScope prof("mask_compact", st);
     // with outputs to clear: helpers behind the compacting workgroups, so that a volume that is mostly outside the mask is cleared by the whole chip
-    const int grid = nchunks + (z ? 768 : 0);
+    const int grid = nchunks + (z ? 256 : 0);
     hipLaunchKernelGGL(mask_compact_kernel, dim3(grid), dim3(1024), 0, st, c);
     FIB_HIP(hipGetLastError());
     return FIB_OK;

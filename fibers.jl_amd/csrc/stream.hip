@@ -86,6 +86,7 @@ struct TraceArgs {
     unsigned long long rng_seed;
     const float4 *search;       // half of the search cube's cells with rho < 1, column-major order: {unit vector, bits of (kx | ky<<8 | kz<<16)} (0-based cell)
     int nsearch, search_dist;
+    int sdx, sdy, sdz;          // .. per axis: search_dist, or 0 along the through-plane axis of 2-D angle inputs (stream.jl:153-155)
     float search_cosang;
     const int32_t *cell_start;  // [G^3 + 1]: the table is sorted by direction cell (x fastest); entries of cell i = [cell_start[i], cell_start[i+1])
     int G;                      // direction grid: cell (floor((v + 1) / h)) per axis, h = 2 / G
@@ -409,8 +410,8 @@ __global__ __launch_bounds__(1024) void stream_trace_micro_kernel(const TraceArg
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int d = a.search_dist, S = 2 * d + 1;
-    const unsigned lin_centre = (unsigned)(d + S * (d + S * d)), lin_last = (unsigned)(S * S * S - 1);
+    const int dx = a.sdx, dy = a.sdy, dz = a.sdz, Sx = 2 * dx + 1, Sy = 2 * dy + 1, Sz = 2 * dz + 1;
+    const unsigned lin_centre = (unsigned)(dx + Sx * (dy + Sy * dz)), lin_last = (unsigned)(Sx * Sy * Sz - 1);
     constexpr int64_t slot_floats = SCR_TILE * 3;
     const float fnx = (float)a.nx, fny = (float)a.ny, fnz = (float)a.nz;
     const float omc = 1.0f - a.smooth;
@@ -453,12 +454,12 @@ __global__ __launch_bounds__(1024) void stream_trace_micro_kernel(const TraceArg
                     if (dv <= a.search_cosang) return;                                                // :597-598
                     const unsigned cell = __float_as_uint(t.w);
                     const int kx = (int)(cell & 255u), ky = (int)((cell >> 8) & 255u), kz = (int)(cell >> 16);
-                    const int ox = sg ? d - kx : kx - d, oy = sg ? d - ky : ky - d, oz = sg ? d - kz : kz - d;
+                    const int ox = sg ? dx - kx : kx - dx, oy = sg ? dy - ky : ky - dy, oz = sg ? dz - kz : kz - dz;
                     const int ix = cx + ox, iy = cy + oy, iz = cz + oz;
                     if (ix < 0 || ix >= a.nx || iy < 0 || iy >= a.ny || iz < 0 || iz >= a.nz) return;   // :586-588
                     const float4 f = a.field[((int64_t)ix + a.nx * ((int64_t)iy + (int64_t)a.ny * iz)) * a.nvec];
                     if (f.w == 0.0f) return;                                                          // :596
-                    const unsigned l0 = (unsigned)(kx + S * (ky + S * kz));
+                    const unsigned l0 = (unsigned)(kx + Sx * (ky + Sy * kz));
                     const unsigned long long k = micro_key(dot3(vx, vy, vz, f.x, f.y, f.z), sg ? lin_last - l0 : l0);   // :600-601
                     best = k > best ? k : best;
                 };
@@ -486,8 +487,8 @@ __global__ __launch_bounds__(1024) void stream_trace_micro_kernel(const TraceArg
                 }
                 if (best == 0ull) break;                          // (cannot happen: the centre is always a candidate)
                 const unsigned bl = ~(unsigned)best;              // argmax cell, column-major in the cube
-                const int bx = cx + (int)(bl % (unsigned)S) - d, by = cy + (int)((bl / (unsigned)S) % (unsigned)S) - d,
-                          bz = cz + (int)(bl / (unsigned)(S * S)) - d;
+                const int bx = cx + (int)(bl % (unsigned)Sx) - dx, by = cy + (int)((bl / (unsigned)Sx) % (unsigned)Sy) - dy,
+                          bz = cz + (int)(bl / (unsigned)(Sx * Sy)) - dz;
                 const float4 fb = a.field[((int64_t)bx + a.nx * ((int64_t)by + (int64_t)a.ny * bz)) * a.nvec];
                 const float bc = dot3(vx, vy, vz, fb.x, fb.y, fb.z);
                 if (!(fabsf(bc) < INFINITY)) break;               // !isfinite, :609
@@ -917,6 +918,7 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
     FIB_CHECK(prm->len_max >= 0 && prm->len_max < (1 << 24), FIB_ERR_INVALID, "invalid len_max");
     FIB_CHECK(prm->search_dist <= 60, FIB_ERR_UNSUPPORTED, "search_dist up to 60 voxels is supported (got %d)", prm->search_dist);
     FIB_CHECK(prm->interp == 0 || prm->interp == 1, FIB_ERR_INVALID, "interp must be 0 (nearest voxel, the reference) or 1 (trilinear)");
+    FIB_CHECK(prm->search_flat_axis >= 0 && prm->search_flat_axis <= 3, FIB_ERR_INVALID, "search_flat_axis must be 0 (none) or 1..3 (x, y, z)");
     FIB_CHECK(prm->interp == 0 || (prm->search_dist == 0 && !lin.lcms), FIB_ERR_UNSUPPORTED,
               "trilinear interpolation is an option of macro-scale angle-picked tracking only");
     FIB_CHECK((int64_t)prm->nx * prm->ny * prm->nz * prm->nvec < ((int64_t)1 << 28), FIB_ERR_UNSUPPORTED,
@@ -987,13 +989,16 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
     fib::DevBuf<float> d_lcm;
     if (prm->search_dist > 0) {
         // search_area (stream.jl:255-277), Float32 arithmetic like the reference's T; one entry per antipodal pair
-        const int d = prm->search_dist, S = 2 * d + 1;
+        const int d = prm->search_dist;
+        int d3[3] = {d, d, d};
+        if (prm->search_flat_axis >= 1 && prm->search_flat_axis <= 3) d3[prm->search_flat_axis - 1] = 0;   // micro_search_dist[thrudim] = 0, stream.jl:153-155
+        const int Sx = 2 * d3[0] + 1, Sy = 2 * d3[1] + 1, Sz = 2 * d3[2] + 1;
         std::vector<float4> tab;
-        const float den = (float)d + 0.5f;
-        const int64_t ncell = (int64_t)S * S * S;
+        const int64_t ncell = (int64_t)Sx * Sy * Sz;
         for (int64_t l = 0; l < ncell / 2; l++) {                 // the first half in column-major order; the centre is cell ncell/2
-            const int kx = (int)(l % S), ky = (int)((l / S) % S), kz = (int)(l / ((int64_t)S * S));
-            const float rx = (float)(kx - d) / den, ry = (float)(ky - d) / den, rz = (float)(kz - d) / den;
+            const int kx = (int)(l % Sx), ky = (int)((l / Sx) % Sy), kz = (int)(l / ((int64_t)Sx * Sy));
+            const float rx = (float)(kx - d3[0]) / ((float)d3[0] + 0.5f), ry = (float)(ky - d3[1]) / ((float)d3[1] + 0.5f),
+                        rz = (float)(kz - d3[2]) / ((float)d3[2] + 0.5f);
             float q = rx * rx; q = q + ry * ry; q = q + rz * rz;
             const float r = sqrtf(q);
             if (!(r < 1.0f)) continue;
@@ -1023,6 +1028,7 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
         if (ec == hipSuccess) ec = hipStreamSynchronize(st);     // (the tables are locals: they must outlive the copies)
         if (ec != hipSuccess) return bail(fib::fail(FIB_ERR_HIP, "search table upload failed: %s", hipGetErrorString(ec)));
         ta.search = d_search.p; ta.nsearch = (int)tab.size(); ta.search_dist = d; ta.search_cosang = prm->search_cosang;
+        ta.sdx = d3[0]; ta.sdy = d3[1]; ta.sdz = d3[2];
         ta.cell_start = d_cell.p; ta.G = G;
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);

@@ -1,6 +1,6 @@
 """stream host mirror (reference: stream.jl:7-8 `StreamWork, stream, stream_new_line, ...`): deterministic
-nearest-voxel / fixed-step Euler tractography: the angle-picking macro-scale path and the microscopy regime
-(cone search); LCM-guided tracking (stream.jl:380-495) is not covered."""
+nearest-voxel / fixed-step Euler tractography: the angle-picking macro-scale path, the microscopy regime
+(cone search) and LCM-guided tracking (stream.jl:380-495), on 3-D vector or 2-D angle inputs (stream.jl:147-172)."""
 import ctypes as C
 from typing import List, Optional, Sequence, Union
 
@@ -21,6 +21,41 @@ def cosd32(deg) -> np.float32:
     if d in table:
         return np.float32(table[d])
     return np.float32(np.cos(np.deg2rad(np.float64(d))))
+
+
+def sind_cosd32(x):
+    """sind.(x), cosd.(x) on Float32 angles in [-90, 90] (stream.jl:166-169): Base reduces by quadrants in degrees (exact at
+    multiples of 90) and evaluates on an extended-precision deg2rad -- here the Float64 function rounded once to Float32 with
+    the exact values forced (a Julia wrapper simply calls cosd / sind: julia/FibersHIP.jl)."""
+    xd = np.asarray(x, np.float32).astype(np.float64)
+    sn, cs = np.sin(np.deg2rad(xd)), np.cos(np.deg2rad(xd))
+    cs = np.where(np.abs(xd) == 90.0, 0.0, cs)
+    sn = np.where(xd == 90.0, 1.0, np.where(xd == -90.0, -1.0, sn))
+    return sn.astype(np.float32), cs.astype(np.float32)
+
+
+def angles_to_vectors(vol, volres):
+    """StreamWork's expansion of 2-D orientation angles (one frame) into 3-D vectors (stream.jl:147-172): the through-plane
+    dimension is the one with the largest voxel size (`argmax(volres)`: the first maximum), the other two carry
+    (cos, sin) -- radians when every value lies in [-pi/2 - eps(Float32), pi/2 + eps(Float32)] (tested first), degrees when in
+    [-90, 90], the reference's error otherwise.  Returns ([nx,ny,nz,3] float32 Fortran-ordered, thrudim 0-based).
+    (The `.* omask_array` of the reference is the field kernel's job: masked voxels get a zero vector either way.)"""
+    a = np.asarray(vol, np.float32)
+    if a.ndim == 4:
+        a = a[..., 0]
+    thru = int(np.argmax(np.asarray(volres, np.float32)))
+    sd = [c for c in range(3) if c != thru]
+    eps32 = float(np.finfo(np.float32).eps)
+    lo, hi = float(a.min()), float(a.max())
+    out = np.zeros(a.shape + (3,), np.float32, order="F")
+    if -np.pi / 2 - eps32 <= lo and hi <= np.pi / 2 + eps32:
+        out[..., sd[0]], out[..., sd[1]] = np.cos(a), np.sin(a)
+    elif -90 <= lo and hi <= 90:
+        sn, cs = sind_cosd32(a)
+        out[..., sd[0]], out[..., sd[1]] = cs, sn
+    else:
+        raise ValueError("Input orientations should be 3D vectors or angles in [-90, 90]")       # stream.jl:170
+    return out, thru
 
 
 def make_sublist(nsub: int, rng=None) -> np.ndarray:
@@ -77,15 +112,18 @@ def default_workspace(device: int) -> StreamWorkspace:
     return ws
 
 
-def _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff, search_dist=0, search_ang=10, ws=None, interp="nearest"):
+def _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff, search_dist=0, search_ang=10, ws=None, interp="nearest",
+            search_flat_axis=0):
     """search_dist > 0 selects the microscopy regime (stream.jl:83, 547-619); interp: "nearest" (the reference) or "trilinear"
-    (fib_stream_params.interp in include/fibers_hip.h)"""
+    (fib_stream_params.interp in include/fibers_hip.h); search_flat_axis 1..3: that axis is searched over one voxel only
+    (the through-plane axis of 2-D angle inputs, stream.jl:153-155)"""
     if interp not in ("nearest", "trilinear"):
         raise ValueError("interp must be 'nearest' or 'trilinear'")
     nx, ny, nz = shape
     return _lib.StreamParams(nx, ny, nz, nvec, int(len_min), int(len_max if len_max is not None else max(shape)),
                              float(cosd32(ang_thresh)), float(np.float32(step_size)), float(np.float32(smooth_coeff)),
-                             int(search_dist), float(cosd32(search_ang)), ws._h if ws is not None else None, 1 if interp == "trilinear" else 0)
+                             int(search_dist), float(cosd32(search_ang)), ws._h if ws is not None else None, 1 if interp == "trilinear" else 0,
+                             int(search_flat_axis))
 
 
 def stream(ovec: Union[MRI, Sequence[MRI]], *, f=None, f_thresh: float = 0.03, fa: Optional[MRI] = None,
@@ -107,12 +145,17 @@ def stream(ovec: Union[MRI, Sequence[MRI]], *, f=None, f_thresh: float = 0.03, f
     if mask is None:
         raise ValueError("mask is required (the reference builds the Tract header from it, stream.jl:784)")
     vols = []
+    flat_axis, angle_thru = 0, None
     for o in ovecs:
         v = o.vol if isinstance(o, MRI) else np.asarray(o)
-        if v.ndim != 4 or v.shape[3] != 3:
-            raise ValueError("Input orientations should be 3D vectors [nx,ny,nz,3] (2-D angle inputs, "
-                             "stream.jl:147-172, are outside the accelerated path)")
-        vols.append(np.asfortranarray(v, dtype=np.float32))
+        if v.ndim == 4 and v.shape[3] == 3:                     # orientation vectors (stream.jl:141)
+            vols.append(np.asfortranarray(v, dtype=np.float32))
+        elif v.ndim == 3 or (v.ndim == 4 and v.shape[3] == 1):  # 2-D orientation angles (stream.jl:147-172)
+            e, thru = angles_to_vectors(v, o.volres if isinstance(o, MRI) else (1.0, 1.0, 1.0))
+            vols.append(e)
+            flat_axis, angle_thru = thru + 1, thru
+        else:
+            raise ValueError("Input orientations should be 3D vectors or angles in [-90, 90]")
     shape = vols[0].shape[:3]
     # Is this in the microscopy regime (min voxel size under 50 um)?  (stream.jl:83)
     domicro = min(ovecs[0].volres if isinstance(ovecs[0], MRI) else (1, 1, 1)) <= 0.05
@@ -145,7 +188,8 @@ def stream(ovec: Union[MRI, Sequence[MRI]], *, f=None, f_thresh: float = 0.03, f
         sptr = sarr.ctypes.data
     sub = make_sublist(nsub, rng) if sublist is None else np.ascontiguousarray(sublist, np.float32).reshape(-1, 3)
     prm = _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff,
-                  int(search_dist) if domicro else 0, search_ang, interp=interp)
+                  int(search_dist) if domicro else 0, search_ang, interp=interp,
+                  search_flat_axis=flat_axis if domicro else 0)                 # micro_search_dist[thrudim] = 0 (stream.jl:153-155)
     ov = (C.c_void_p * nvec)(*[v.ctypes.data for v in vols])
     fv = None if fvols is None else (C.c_void_p * nvec)(*[v.ctypes.data for v in fvols])
     out = _lib.TractOut()
@@ -158,6 +202,12 @@ def stream(ovec: Union[MRI, Sequence[MRI]], *, f=None, f_thresh: float = 0.03, f
     else:
         if domicro:
             raise ValueError("LCM-guided tracking is a macro-scale mode (voxel size > 0.05 mm)")
+        if angle_thru is not None and angle_thru != 2:
+            # stream.jl:221 derives the LCM's in-plane dimensions from the FRAMES of the first input volume; with one-frame angle
+            # inputs that yields dimensions (1, 2) whatever the slice orientation, which only matches the expanded vectors when
+            # the through-plane dimension is the third
+            raise ValueError("LCM-guided tracking on 2-D angle inputs needs the through-plane dimension to be the third "
+                             "(largest voxel size along z): the reference pairs the LCM edges with dimensions (1, 2) there")
         lv = lcms.vol if isinstance(lcms, MRI) else np.asarray(lcms)
         if lv.shape != shape + (10,):
             raise ValueError("lcms must be [nx,ny,nz,10] (vectorised 4x4 symmetric local connection matrices)")
@@ -199,6 +249,29 @@ def _warn_thresh(name, thr, vol, maskbool):
 # ---------------------------------------------------------------------------------------------
 # device-resident form
 # ---------------------------------------------------------------------------------------------
+def angles_to_vectors_device(ang, volres=(1.0, 1.0, 1.0)):
+    """angles_to_vectors for a device-resident angle volume (float32 CUDA tensor of nvox angles): planar [3, nvox] vectors by
+    the same rules (stream.jl:147-172) -- radians if all values lie in [-pi/2, pi/2] (+- eps), degrees if in [-90, 90]."""
+    import torch
+    _chk_dev(ang, torch.float32, "angles")
+    a = ang.reshape(-1)
+    thru = int(np.argmax(np.asarray(volres, np.float32)))
+    sd = [c for c in range(3) if c != thru]
+    eps32 = float(np.finfo(np.float32).eps)
+    lo, hi = float(a.min()), float(a.max())
+    out = torch.zeros((3, a.numel()), dtype=torch.float32, device=a.device)
+    if -np.pi / 2 - eps32 <= lo and hi <= np.pi / 2 + eps32:
+        out[sd[0]], out[sd[1]] = torch.cos(a), torch.sin(a)
+    elif -90 <= lo and hi <= 90:
+        ad = a.double()
+        cs = torch.where(ad.abs() == 90.0, torch.zeros_like(ad), torch.cos(torch.deg2rad(ad)))
+        sn = torch.where(ad.abs() == 90.0, torch.sign(ad), torch.sin(torch.deg2rad(ad)))
+        out[sd[0]], out[sd[1]] = cs.float(), sn.float()
+    else:
+        raise ValueError("Input orientations should be 3D vectors or angles in [-90, 90]")
+    return out, thru
+
+
 def stream_field_device(ovec: List, f: Optional[List] = None, f_thresh: float = 0.03, fa=None, fa_thresh: float = 0.1,
                         mask=None, stream=None):
     """StreamWork mask + repack on the GPU (stream.jl:95-145).  ovec[k]: float32 CUDA [3, nvox]; f[k], fa: [nvox];

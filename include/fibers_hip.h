@@ -244,6 +244,11 @@ typedef struct {
      * current direction (corners without a vector dropped), s_c the sign of its cosine; a zero blend ends the line.  Bounds,
      * mask and the nearest voxel's pick still decide termination exactly as in the reference; macro scale, angle picking only. */
     int32_t interp;
+    /* microscopy regime with 2-D orientation-angle inputs (one frame per volume, stream.jl:147-172): StreamWork sets the search
+     * distance of the through-plane axis -- the one with the largest voxel size -- to 0 (stream.jl:153-155).  0: none (a cubic
+     * search area); 1, 2, 3: the x, y, z axis is searched over one voxel only.  (The angles themselves are expanded to 3-D
+     * vectors by the host-language wrapper, cos / sin or cosd / sind like the constructor does: ovec stays [nvox*3].) */
+    int32_t search_flat_axis;
 } fib_stream_params;
 
 typedef struct fib_stream_job fib_stream_job;

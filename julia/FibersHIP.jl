@@ -180,13 +180,14 @@ function rumba_rec(dwi::MRI, mask::MRI, odf_dirs::ODF=sphere_724, niter::Integer
   return RUMBASD(fodf, fgm, fcsf, peak, gfa, var, snr[], snrsd[])
 end
 
-# layout: fib_stream_params sizeof 64: nx@0 ny@4 nz@8 nvec@12 len_min@16 len_max@20 cosang_thresh@24 step_size@28 smooth_coeff@32 search_dist@36 search_cosang@40 ws@48 interp@56
+# layout: fib_stream_params sizeof 64: nx@0 ny@4 nz@8 nvec@12 len_min@16 len_max@20 cosang_thresh@24 step_size@28 smooth_coeff@32 search_dist@36 search_cosang@40 ws@48 interp@56 search_flat_axis@60
 struct FibStreamParams
   nx::Int32; ny::Int32; nz::Int32; nvec::Int32; len_min::Int32; len_max::Int32
   cosang_thresh::Float32; step_size::Float32; smooth_coeff::Float32
   search_dist::Int32; search_cosang::Float32          # microscopy regime (stream.jl:83, 547-619) when search_dist > 0
   ws::Ptr{Cvoid}                                      # optional tracer workspace (fibd_stream_ws_create); C_NULL for the host-buffer calls
   interp::Int32                                       # 0: nearest voxel (stream.jl:514); 1: trilinear blend (not in the reference)
+  search_flat_axis::Int32                             # microscopy regime + 2-D angle inputs: 1..3 = the through-plane axis (search distance 0, stream.jl:153-155); 0: none
 end
 
 # layout: fib_tract_out sizeof 48: nlines@0 npoints@8 npts@16 seed_index@24 xyz@32 flags@40
@@ -208,6 +209,28 @@ function stream(ovec::Union{MRI,Vector{MRI}}; f::Union{MRI,Vector{MRI},Nothing}=
   ovecs = isa(ovec, MRI) ? MRI[ovec] : ovec
   fs    = isa(f, MRI) ? MRI[f] : f
   nx, ny, nz = size(ovecs[1].vol)[1:3]
+  # 2-D orientation angles (one frame) become 3-D vectors here, with the reference's own arithmetic (stream.jl:147-172):
+  # through-plane = the dimension with the largest voxel size, cos / sin (radians) or cosd / sind (degrees) in the other two
+  flat_axis = Int32(0)
+  lcm_frames = size(ovecs[1].vol, 4)                                        # what stream.jl:221 looks at (BEFORE the expansion)
+  lcm_zero = [all(x -> x == 0, view(ovecs[1].vol, :, :, :, c)) for c in 1:lcm_frames]
+  ovecs = map(ovecs) do o
+    size(o.vol, 4) == 3 && return o
+    size(o.vol, 4) == 1 || error("Input orientations should be 3D vectors or angles ∊ [-90, 90]")
+    thrudim = argmax(o.volres); strdims = setdiff(1:3, thrudim)
+    flat_axis = Int32(thrudim)
+    a = view(o.vol, :, :, :, 1)
+    v = zeros(Float32, nx, ny, nz, 3)
+    if -π/2-eps(Float32) <= minimum(a) && maximum(a) <= π/2+eps(Float32)
+      v[:, :, :, strdims[1]] .= cos.(a);  v[:, :, :, strdims[2]] .= sin.(a)
+    elseif -90 <= minimum(a) && maximum(a) <= 90
+      v[:, :, :, strdims[1]] .= cosd.(a); v[:, :, :, strdims[2]] .= sind.(a)
+    else
+      error("Input orientations should be 3D vectors or angles ∊ [-90, 90]")
+    end
+    e = MRI(o, 3, Float32); e.vol .= v
+    e
+  end
   if !isnothing(seed) && size(seed.vol) != size(mask.vol)
     error("Dimension mismatch between seed mask " * string(size(seed.vol)) * " and brain mask " * string(size(mask.vol)))
   end
@@ -218,7 +241,8 @@ function stream(ovec::Union{MRI,Vector{MRI}}; f::Union{MRI,Vector{MRI},Nothing}=
   sublist = nsub > 0 ? hcat([Float32.(rand(Uniform(-.5+eps(), .5-eps()), 3)) for _ in 1:nsub]...) : zeros(Float32, 3, 1)
   prm = Ref(FibStreamParams(nx, ny, nz, length(ovecs), len_min, len_max,
                             cosd(Float32(ang_thresh)), Float32(step_size), Float32(smooth_coeff),
-                            domicro ? Int32(search_dist) : Int32(0), cosd(Float32(search_ang)), C_NULL, Int32(0)))
+                            domicro ? Int32(search_dist) : Int32(0), cosd(Float32(search_ang)), C_NULL, Int32(0),
+                            domicro ? flat_axis : Int32(0)))                   # micro_search_dist[thrudim] = 0, stream.jl:153-155
   pv = [pointer(o.vol) for o in ovecs]
   pf = isnothing(fs) ? C_NULL : [pointer(x.vol) for x in fs]
   out = FibTractOut()

@@ -608,11 +608,12 @@ typedef struct {
     /* microscopy regime (stream.jl:252-287): search_dist > 0 */
     int search_dist;
     float search_cosang;        /* cosd(search_ang) */
-    const float *search_area;   /* [3, S, S, S], S = 2*search_dist+1: unit vectors of the cells with rho < 1, else 0 */
+    const float *search_area;   /* [3, Sx, Sy, Sz], S = 2*sd+1 per axis: unit vectors of the cells with rho < 1, else 0 */
     /* LCM-guided tracking (stream.jl:200-236, 380-495): lcms != NULL */
     const float *lcms;          /* [10, nx, ny, nz] column-major, already thresholded (stream.jl:217) */
     int strdims[2];             /* in-plane dimensions, 0-based (stream.jl:221-223) */
     uint64_t rng_seed;          /* uniform draws: orc_uniform(rng_seed, line, k) stands in for Julia's global RNG */
+    int sd[3];                  /* micro_search_dist per axis: search_dist, or 0 along the through-plane axis of 2-D angle inputs (stream.jl:153-155) */
 } stream_work;
 
 /* The random-number contract of LCM-guided tracking.  The reference draws `rand(Categorical(lcm))` from Julia's global
@@ -779,18 +780,18 @@ static int new_point(const stream_work *W, const float pos_now[3], const float v
 }
 
 /* search_area of the microscopy regime (stream.jl:255-277), all arithmetic in Float32 like the reference's T */
-static float *micro_search_area(int d)
+static float *micro_search_area(const int d[3])
 {
-    const int S = 2 * d + 1;
-    float *sa = (float *)calloc((size_t)3 * S * S * S, sizeof(float));
-    const float den = (float)d + 0.5f;
-    for (int iz = 1; iz <= S; iz++)
-        for (int iy = 1; iy <= S; iy++)
-            for (int ix = 1; ix <= S; ix++) {
-                const float rx = (float)(ix - d - 1) / den, ry = (float)(iy - d - 1) / den, rz = (float)(iz - d - 1) / den;
+    const int Sx = 2 * d[0] + 1, Sy = 2 * d[1] + 1, Sz = 2 * d[2] + 1;
+    float *sa = (float *)calloc((size_t)3 * Sx * Sy * Sz, sizeof(float));
+    for (int iz = 1; iz <= Sz; iz++)
+        for (int iy = 1; iy <= Sy; iy++)
+            for (int ix = 1; ix <= Sx; ix++) {
+                const float rx = (float)(ix - d[0] - 1) / ((float)d[0] + 0.5f), ry = (float)(iy - d[1] - 1) / ((float)d[1] + 0.5f),
+                            rz = (float)(iz - d[2] - 1) / ((float)d[2] + 0.5f);                       /* :262-267 */
                 float q = rx * rx; q = q + ry * ry; q = q + rz * rz;
                 const float r = sqrtf(q);
-                float *v = sa + 3 * ((ix - 1) + (size_t)S * ((iy - 1) + (size_t)S * (iz - 1)));
+                float *v = sa + 3 * ((ix - 1) + (size_t)Sx * ((iy - 1) + (size_t)Sy * (iz - 1)));
                 if (r < 1.0f) { v[0] = rx / r; v[1] = ry / r; v[2] = rz / r; }      /* centre: 0/0 = NaN, kept (see below) */
             }
     return sa;
@@ -807,18 +808,19 @@ static int micro_new_point(const stream_work *W, const float pos_now[3], const f
     float rx = rintf(pos_next[0]), ry = rintf(pos_next[1]), rz = rintf(pos_next[2]);    /* :563 */
     if (!(rx >= 1.0f && rx <= (float)W->nx && ry >= 1.0f && ry <= (float)W->ny &&
           rz >= 1.0f && rz <= (float)W->nz)) return 0;                                    /* :566 */
-    const int cx = (int)rx, cy = (int)ry, cz = (int)rz, d = W->search_dist, S = 2 * d + 1;
+    const int cx = (int)rx, cy = (int)ry, cz = (int)rz;
+    const int dx = W->sd[0], dy = W->sd[1], dz = W->sd[2], Sx = 2 * dx + 1, Sy = 2 * dy + 1, Sz = 2 * dz + 1;
     if (!W->mask[(cx - 1) + (int64_t)W->nx * ((cy - 1) + (int64_t)W->ny * (cz - 1))]) return 0;   /* :569 */
     int have = 0, bx = 0, by = 0, bz = 0;
     float bestabs = -INFINITY, bestcos = -INFINITY;
-    /* argmax over the S^3 array in column-major order: first maximum, NaN wins (Base.argmax) */
-    for (int kz = 1; kz <= S; kz++)
-        for (int ky = 1; ky <= S; ky++)
-            for (int kx = 1; kx <= S; kx++) {
-                const int ix = cx - d + kx - 1, iy = cy - d + ky - 1, iz = cz - d + kz - 1;
+    /* argmax over the Sx x Sy x Sz array in column-major order: first maximum, NaN wins (Base.argmax) */
+    for (int kz = 1; kz <= Sz; kz++)
+        for (int ky = 1; ky <= Sy; ky++)
+            for (int kx = 1; kx <= Sx; kx++) {
+                const int ix = cx - dx + kx - 1, iy = cy - dy + ky - 1, iz = cz - dz + kz - 1;
                 float ca = -INFINITY, c = -INFINITY;
                 if (ix >= 1 && ix <= W->nx && iy >= 1 && iy <= W->ny && iz >= 1 && iz <= W->nz) {   /* :586-588 */
-                    const float *v = W->search_area + 3 * ((kx - 1) + (size_t)S * ((ky - 1) + (size_t)S * (kz - 1)));
+                    const float *v = W->search_area + 3 * ((kx - 1) + (size_t)Sx * ((ky - 1) + (size_t)Sy * (kz - 1)));
                     const int64_t lin = (ix - 1) + (int64_t)W->nx * ((iy - 1) + (int64_t)W->ny * (iz - 1));
                     const int zero = v[0] == 0.0f && v[1] == 0.0f && v[2] == 0.0f;
                     if (W->mask[lin] && !zero && !(dot3(vec_now, v) <= W->search_cosang)) {           /* :596-598 */
@@ -924,6 +926,14 @@ int64_t orc_stream_full(const float *ovecs, const uint8_t *mask, int nx, int ny,
                         int32_t **out_npts, int64_t **out_seed, float **out_xyz, uint8_t **out_flags, int64_t *out_total_pts,
                         int32_t *all_npts, int nthreads);
 
+int64_t orc_stream_flat(const float *ovecs, const uint8_t *mask, int nx, int ny, int nz, int nvec,
+                        const int32_t *seeds, int64_t nseed, const float *sublist, int nsub,
+                        int len_min, int len_max, float cosang_thresh, float step_size, float smooth_coeff,
+                        int search_dist, int search_flat, float search_cosang,
+                        const float *lcms, int strdim0, int strdim1, uint64_t rng_seed,
+                        int32_t **out_npts, int64_t **out_seed, float **out_xyz, uint8_t **out_flags, int64_t *out_total_pts,
+                        int32_t *all_npts, int nthreads);
+
 /* same driver; search_dist > 0 selects the microscopy regime (stream.jl:83, 252-287, 547-619) */
 int64_t orc_stream_micro(const float *ovecs, const uint8_t *mask, int nx, int ny, int nz, int nvec,
                          const int32_t *seeds, int64_t nseed, const float *sublist, int nsub,
@@ -948,9 +958,26 @@ int64_t orc_stream_full(const float *ovecs, const uint8_t *mask, int nx, int ny,
                         int32_t **out_npts, int64_t **out_seed, float **out_xyz, uint8_t **out_flags, int64_t *out_total_pts,
                         int32_t *all_npts, int nthreads)
 {
-    float *sarea = search_dist > 0 ? micro_search_area(search_dist) : NULL;
+    return orc_stream_flat(ovecs, mask, nx, ny, nz, nvec, seeds, nseed, sublist, nsub, len_min, len_max, cosang_thresh, step_size,
+                           smooth_coeff, search_dist, -1, search_cosang, lcms, strdim0, strdim1, rng_seed, out_npts, out_seed, out_xyz,
+                           out_flags, out_total_pts, all_npts, nthreads);
+}
+
+/* .. with the search distance of one axis set to 0 (search_flat = 0..2; -1: none): what StreamWork does to the through-plane
+ * axis of 2-D orientation-angle inputs in the microscopy regime (stream.jl:153-155) */
+int64_t orc_stream_flat(const float *ovecs, const uint8_t *mask, int nx, int ny, int nz, int nvec,
+                        const int32_t *seeds, int64_t nseed, const float *sublist, int nsub,
+                        int len_min, int len_max, float cosang_thresh, float step_size, float smooth_coeff,
+                        int search_dist, int search_flat, float search_cosang,
+                        const float *lcms, int strdim0, int strdim1, uint64_t rng_seed,
+                        int32_t **out_npts, int64_t **out_seed, float **out_xyz, uint8_t **out_flags, int64_t *out_total_pts,
+                        int32_t *all_npts, int nthreads)
+{
+    int sd3[3] = {search_dist, search_dist, search_dist};
+    if (search_flat >= 0 && search_flat < 3) sd3[search_flat] = 0;
+    float *sarea = search_dist > 0 ? micro_search_area(sd3) : NULL;
     stream_work W = {nx, ny, nz, nvec, ovecs, mask, len_min, len_max, cosang_thresh, step_size, smooth_coeff,
-                     search_dist, search_cosang, sarea, lcms, {strdim0, strdim1}, rng_seed};
+                     search_dist, search_cosang, sarea, lcms, {strdim0, strdim1}, rng_seed, {sd3[0], sd3[1], sd3[2]}};
     const int want_flags = lcms != NULL && out_flags != NULL;
     if (nthreads < 1) nthreads = 1;
     /* chunks of div(n, nthreads)+1 seeds (stream.jl:757-759) */

@@ -45,6 +45,7 @@ def lib():
         _LIB.orc_stream.restype = C.c_int64
         _LIB.orc_stream_micro.restype = C.c_int64
         _LIB.orc_stream_full.restype = C.c_int64
+        _LIB.orc_stream_flat.restype = C.c_int64
         _LIB.orc_uniform.restype = C.c_float
         _LIB.orc_find_peaks.restype = C.c_int
         _LIB.orc_max_threads.restype = C.c_int
@@ -333,9 +334,59 @@ def cosd32(deg):
     return f32(np.cos(np.deg2rad(np.float64(deg))))
 
 
-def stream_work(ovec, f=None, f_thresh=0.03, fa=None, fa_thresh=0.1, mask=None):
-    """StreamWork mask / vector repack (stream.jl:76-145). ovec: list of [nx,ny,nz,3]."""
+def sind_cosd32(x):
+    """sind.(x), cosd.(x) for Float32 angles in [-90, 90] (stream.jl:166-169).  Base's sind / cosd reduce the argument by
+    quadrants in degrees -- exact at multiples of 90 -- and evaluate the kernels on an extended-precision deg2rad: restated as
+    the Float64 function rounded once to Float32, with the exact values forced."""
+    xd = np.asarray(x, np.float32).astype(np.float64)
+    s_, c_ = np.sin(np.deg2rad(xd)), np.cos(np.deg2rad(xd))
+    c_ = np.where(np.abs(xd) == 90.0, 0.0, c_)
+    s_ = np.where(xd == 90.0, 1.0, np.where(xd == -90.0, -1.0, s_))
+    return s_.astype(np.float32), c_.astype(np.float32)
+
+
+def angles_to_vectors(vol, volres):
+    """2-D orientation angles -> 3-D vectors, as StreamWork expands them (stream.jl:147-172): the through-plane dimension is the
+    one with the largest voxel size (argmax: the first maximum), the angle lives in the other two; radians if every value is
+    within [-pi/2 - eps, pi/2 + eps] (tested first), degrees if within [-90, 90], an error otherwise.  Returns
+    (vectors [nx,ny,nz,3] float32, thrudim 0-based)."""
+    a = np.asarray(vol, np.float32)
+    if a.ndim == 4:
+        a = a[..., 0]
+    thru = int(np.argmax(np.asarray(volres, np.float32)))       # :149
+    sd = [c for c in range(3) if c != thru]                     # :151
+    eps32 = float(np.finfo(np.float32).eps)
+    lo, hi = float(a.min()), float(a.max())
+    out = np.zeros(a.shape + (3,), np.float32)
+    if -np.pi / 2 - eps32 <= lo and hi <= np.pi / 2 + eps32:    # :157-158 in radians
+        out[..., sd[0]] = np.cos(a)                             # Float32 cos / sin
+        out[..., sd[1]] = np.sin(a)
+    elif -90 <= lo and hi <= 90:                                # :163-164 in degrees
+        s_, c_ = sind_cosd32(a)
+        out[..., sd[0]] = c_
+        out[..., sd[1]] = s_
+    else:
+        raise ValueError("Input orientations should be 3D vectors or angles in [-90, 90]")   # :170
+    return out, thru
+
+
+def stream_work(ovec, f=None, f_thresh=0.03, fa=None, fa_thresh=0.1, mask=None, volres=(1.0, 1.0, 1.0)):
+    """StreamWork mask / vector repack (stream.jl:76-172). ovec: list of [nx,ny,nz,3] vectors or [nx,ny,nz(,1)] 2-D angles."""
     ovecs = [ovec] if isinstance(ovec, np.ndarray) else list(ovec)
+    raw = ovecs
+    ovecs = []
+    thrus = []
+    for v in raw:
+        v = np.asarray(v)
+        if v.ndim == 4 and v.shape[3] == 3:
+            ovecs.append(v)
+        else:
+            if mask is None:
+                raise ValueError("angle inputs need a mask here (stream.jl:96-100 would derive it from the angles)")
+            e, t = angles_to_vectors(v, volres)
+            ovecs.append(e)
+            thrus.append(t)
+    stream_work.last_thrudims = thrus
     fs = None if f is None else ([f] if isinstance(f, np.ndarray) else list(f))
     nvec = len(ovecs)
     nx, ny, nz = ovecs[0].shape[:3]
@@ -370,15 +421,19 @@ def seeds_from_mask(maskbool):
 
 def stream(ovec, sublist, f=None, f_thresh=0.03, fa=None, fa_thresh=0.1, mask=None, seed=None,
            len_min=3, len_max=None, ang_thresh=45, step_size=0.5, smooth_coeff=0.2, nthreads=1,
-           return_all_npts=False, search_dist=0, search_ang=10, lcms=None, lcm_thresh=0.099, rng_seed=0):
+           return_all_npts=False, search_dist=0, search_ang=10, lcms=None, lcm_thresh=0.099, rng_seed=0, volres=(1.0, 1.0, 1.0)):
     """stream (stream.jl:730) with an explicit `sublist` [nsub,3] instead of the global RNG
     (stream.jl:176-181).  Returns list of [npts,3] float32 arrays (1-based voxel coords) in
     reference order, plus seed_index (seed*nsub+sub) per kept line.
     search_dist > 0: the microscopy regime (stream.jl:83: minimum(volres) <= 0.05; 252-287, 547-619).
     lcms [nx,ny,nz,10]: LCM-guided tracking (stream.jl:200-236, 380-495); the uniforms behind `rand(Categorical(lcm))`
     come from the counter-based stream orc_uniform(rng_seed, line, k) (the random-number contract of this back end);
-    the result then carries `flags` (one per point: the LCM and the angle pick disagreed, stream.jl:538)."""
-    mk, arr = stream_work(ovec, f, f_thresh, fa, fa_thresh, mask)
+    the result then carries `flags` (one per point: the LCM and the angle pick disagreed, stream.jl:538).
+    ovec volumes with one frame are 2-D orientation angles (stream.jl:147-172, `volres` picks the through-plane dimension); in
+    the microscopy regime their through-plane search distance is 0 (stream.jl:153-155)."""
+    mk, arr = stream_work(ovec, f, f_thresh, fa, fa_thresh, mask, volres)
+    thrus = stream_work.last_thrudims
+    search_flat = thrus[-1] if (thrus and search_dist > 0) else -1          # (every angle volume sets it; the last one stands)
     nx, ny, nz = mk.shape
     if len_max is None:
         len_max = max(nx, ny, nz)                               # stream.jl:74 default
@@ -402,15 +457,19 @@ def stream(ovec, sublist, f=None, f_thresh=0.03, fa=None, fa_thresh=0.1, mask=No
         lv = np.asarray(lcms, np.float32)
         lcm_arr = np.asfortranarray(np.transpose(lv, (3, 0, 1, 2)))            # permutedims(lcms.vol, (4,1,2,3)), stream.jl:207
         lcm_arr = np.asfortranarray(np.where(lcm_arr >= f32(lcm_thresh), lcm_arr, f32(0)))   # .*= (. >= lcm_thresh), :217
-        ov1 = ovec if isinstance(ovec, np.ndarray) else ovec[0]
-        thru = [c for c in range(3) if np.all(np.asarray(ov1)[..., c] == 0)]    # stream.jl:221
+        ov1 = np.asarray(ovec if isinstance(ovec, np.ndarray) else ovec[0])
+        if ov1.ndim == 3:
+            ov1 = ov1[..., None]
+        # stream.jl:221 looks at the FRAMES of the first input volume: three for vectors, ONE for angle inputs (then the
+        # through-plane dimension is "1" if every angle is 0, none otherwise, and the first two of what is left are in-plane)
+        thru = [c for c in range(ov1.shape[3]) if np.all(ov1[..., c] == 0)]
         strd = [c for c in range(3) if c not in thru]                            # :223
         sd0, sd1 = strd[0], strd[1]
-    nl = L.orc_stream_full(_p(arr), _p(mk.astype(np.uint8, order="F")), nx, ny, nz, arr.shape[1],
+    nl = L.orc_stream_flat(_p(arr), _p(mk.astype(np.uint8, order="F")), nx, ny, nz, arr.shape[1],
                       _p(seeds), C.c_int64(seeds.shape[0]), _p(sub), sub.shape[0],
                       int(len_min), int(len_max), C.c_float(float(cosd32(ang_thresh))),
                       C.c_float(float(f32(step_size))), C.c_float(float(f32(smooth_coeff))),
-                      int(search_dist), C.c_float(float(cosd32(search_ang))),
+                      int(search_dist), int(search_flat), C.c_float(float(cosd32(search_ang))),
                       None if lcm_arr is None else _p(lcm_arr), int(sd0), int(sd1), C.c_uint64(int(rng_seed)),
                       C.byref(p_npts), C.byref(p_seed), C.byref(p_xyz), C.byref(p_flags), C.byref(total),
                       _p(all_npts), int(nthreads))

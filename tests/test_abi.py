@@ -86,7 +86,7 @@ def test_struct_layouts_of_the_header_match_the_bindings(tmp_path):
         "fib_dti_out": ["s0", "eigval1", "eigval2", "eigval3", "eigvec1", "eigvec2", "eigvec3", "rd", "md", "fa"],
         "fib_rumba_out": ["fodf", "fgm", "fcsf", "gfa", "var", "peak"],
         "fib_stream_params": ["nx", "ny", "nz", "nvec", "len_min", "len_max", "cosang_thresh", "step_size", "smooth_coeff", "search_dist",
-                              "search_cosang", "ws", "interp"],
+                              "search_cosang", "ws", "interp", "search_flat_axis"],
         "fib_tract_out": ["nlines", "npoints", "npts", "seed_index", "xyz", "flags"],
     }
     mirrors = {"fib_dti_out": _lib.DtiOut, "fib_rumba_out": _lib.RumbaOut, "fib_stream_params": _lib.StreamParams, "fib_tract_out": _lib.TractOut}

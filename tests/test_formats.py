@@ -165,6 +165,84 @@ def test_trk_scalars_and_properties_follow_the_reference_layout(fj, tmp_path):
     assert b1.scalars.shape == (8,) and np.array_equal(b1.scalars, sc[:, 0]) and b1.properties is None
 
 
+# ---- N2 against an INDEPENDENT implementation (tests/nifti_independent.py: written from the NIfTI-1 standard's offset table, shares
+# no code with fibers.jl_amd/nifti.py) and a committed hand-assembled byte fixture -----------------------------------------------------
+def test_mri_read_decodes_the_hand_assembled_fixture(fj):
+    """tests/golden/nifti/hand_be_int16.nii: big-endian int16, scl_slope 2 / scl_inter -3, qform only (rotated, qfac -1), mm + s;
+    b-table as rows.  What mri_read must return is computed here from the definitions, not from the module under test."""
+    import nifti_independent as ni
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nifti")
+    raw = open(os.path.join(d, "hand_be_int16.nii"), "rb").read()
+    assert len(raw) == 352 + int(np.prod(ni.FIX_SHAPE)) * 2 and raw[:4] == b"\x00\x00\x01\x5c"      # 348, big-endian
+    m = fj.mri_read(os.path.join(d, "hand_be_int16.nii"))
+    want = (ni.fixture_raw_values().astype(np.float64) * ni.FIX_SLOPE + ni.FIX_INTER).astype(np.int16)   # dtype.(vol*slope + inter), mri.jl:1664-1668
+    assert m.vol.dtype == np.int16 and m.vol.shape == ni.FIX_SHAPE and np.array_equal(m.vol, want)
+    assert m.niftihdr["do_bswap"] and m.nframes == 5
+    M = ni.quatern_to_affine(*ni.FIX_QUAT, *ni.FIX_QOFF, *ni.FIX_PIX[:3], -1.0)
+    assert np.allclose(m.vox2ras, M, atol=2e-6) and np.linalg.det(M[:3, :3]) < 0
+    assert np.allclose(m.volres, ni.FIX_PIX[:3], atol=1e-6)
+    assert abs(m.tr - 1750.0) < 1e-3                                       # seconds -> ms (mri.jl:1452-1461)
+    assert np.array_equal(m.bval, np.array([0, 1000, 1000, 2000, 3000], np.float32))
+    g = np.array([[0, 0, 0], [2, 0, 0], [0, 3, 0], [1, 1, 1], [-3, 0, 4]], np.float64)
+    gn = np.where(np.linalg.norm(g, axis=1, keepdims=True) > 0, g / np.maximum(np.linalg.norm(g, axis=1, keepdims=True), 1e-30), 0)
+    assert np.allclose(m.bvec, gn, atol=1e-7)                              # rows -> [n,3], normalised, 0/0 -> 0 (mri.jl:711-712)
+
+
+@pytest.mark.parametrize("layout", ["rows", "columns"])
+@pytest.mark.parametrize("endian", ["<", ">"])
+def test_mri_read_against_independently_assembled_files(fj, tmp_path, layout, endian):
+    """float32 / uint8 volumes, sform present (wins over the qform), millimetre / micron units, both byte orders, b-tables in both
+    layouts: files assembled by the independent packer"""
+    import nifti_independent as ni
+    rng = np.random.default_rng(3)
+    vol = np.asfortranarray(rng.normal(size=(3, 5, 4, 6)).astype(np.float32))
+    srow = np.array([[-1.5, 0.1, 0.0, 80.0], [0.1, 1.5, 0.2, -100.0], [0.0, -0.2, 2.0, -60.0]], np.float32)
+    raw = ni.assemble(vol, 16, endian=endian, pixdim=(1.5, 1.5, 2.0, 3.0, 0.0), quatern=(0.0, 0.0, 0.7), qoffset=(1.0, 2.0, 3.0),
+                      qform_code=1, sform_code=1, srow=srow, xyzt_units=2 | 16)
+    f = str(tmp_path / "a.nii")
+    open(f, "wb").write(raw)
+    bval = np.array([5, 1000, 2000, 1000, 3000, 5], np.float32)
+    bvec = rng.normal(size=(6, 3)).astype(np.float32)
+    if layout == "rows":
+        np.savetxt(str(tmp_path / "a.bvals"), bval[None], fmt="%g"); np.savetxt(str(tmp_path / "a.bvecs"), bvec.T, fmt="%.7f")
+    else:
+        np.savetxt(str(tmp_path / "a.bvals"), bval[:, None], fmt="%g"); np.savetxt(str(tmp_path / "a.bvecs"), bvec, fmt="%.7f")
+    m = fj.mri_read(f)
+    assert np.array_equal(m.vol, vol) and m.vol.dtype == np.float32
+    want = np.vstack([srow, [0, 0, 0, 1]])
+    assert np.allclose(m.vox2ras, want, atol=1e-6)                          # the sform wins (mri.jl:1530-1545)
+    assert np.allclose(m.volres, np.sqrt((srow[:, :3].astype(np.float64) ** 2).sum(axis=0)), atol=1e-6)
+    assert abs(m.tr - 3.0) < 1e-6                                          # already ms
+    assert np.array_equal(m.bval, bval) and np.allclose(m.bvec, bvec / np.linalg.norm(bvec, axis=1, keepdims=True), atol=2e-6)
+    # microns: sizes and offsets scaled to mm
+    rawu = ni.assemble(vol[..., 0].astype(np.float32), 16, endian=endian, pixdim=(10.0, 10.0, 40.0, 0.0, 0.0), qform_code=1, xyzt_units=3)
+    fu = str(tmp_path / "u.nii")
+    open(fu, "wb").write(rawu)
+    mu = fj.mri_read(fu)
+    assert np.allclose(mu.volres, (0.01, 0.01, 0.04), atol=1e-9) and min(mu.volres) <= 0.05      # the microscopy regime's test (stream.jl:85)
+
+
+def test_mri_write_output_parsed_by_the_independent_reader(fj, tmp_path):
+    import nifti_independent as ni
+    rng = np.random.default_rng(4)
+    for dt, code in ((np.float32, 16), (np.int16, 4), (np.uint8, 2)):
+        vol = np.asfortranarray((rng.normal(size=(6, 5, 4, 3)) * 50).astype(dt))
+        m = fj.MRI(vol, volres=(1.5, 1.5, 2.0), vox2ras=_affine())
+        m.tr = 8.5
+        f = str(tmp_path / ("w_%s.nii" % np.dtype(dt).name))
+        assert fj.mri_write(m, f) is False
+        raw = open(f, "rb").read()
+        h = ni.parse(raw)
+        assert h["endian"] == "<" and h["magic"] == b"n+1\0" and len(raw) == h["nbytes_expected"]
+        assert h["dim"][:5] == [4, 6, 5, 4, 3] and h["datatype"] == code and h["bitpix"] == np.dtype(dt).itemsize * 8
+        assert h["vox_offset"] == 352.0 and np.array_equal(h["data"], vol)
+        assert h["sform_code"] == 1 and h["qform_code"] == 1 and h["xyzt_units"] == (2 | 16)
+        assert np.allclose([h["srow_x"], h["srow_y"], h["srow_z"]], _affine()[:3], atol=1e-6)
+        assert np.allclose(h["pixdim"][1:5], (1.5, 1.5, 2.0, 8.5), atol=1e-6) and h["pixdim"][0] == -1.0
+        Mq = ni.quatern_to_affine(*h["quatern"], *h["qoffset"], *h["pixdim"][1:4], h["pixdim"][0])
+        assert np.allclose(Mq, _affine(), atol=1e-4)                        # the quaternion the writer derived reproduces the affine
+
+
 @pytest.mark.gpu
 def test_gpu_trk_serialiser_matches_host(fj, tmp_path):
     import torch
@@ -185,9 +263,10 @@ def test_gpu_trk_serialiser_matches_host(fj, tmp_path):
 
 
 @pytest.mark.gpu
-def test_fit_streams_a_memory_mapped_nifti_file(fj, tmp_path):
+def test_fit_streams_a_memory_mapped_nifti_file(fj, orc, tmp_path):
     """N2 on the device path: mri_read(..., mmap=True) returns the .nii file itself as `vol`; fib_dti_fit / fib_gqi_rec gather
-    their chunks from the mapping into the pinned ring (file -> pinned -> HBM).  Same results as from an in-memory array."""
+    their chunks from the mapping into the pinned ring (file -> pinned -> HBM).  The fits of the mapped file are compared with the
+    ORACLE run on the arrays the file was written from (and, bit for bit, with the fits of an in-memory copy)."""
     from fibers_jl_amd import phantom
     shape = (20, 18, 16)
     bval, bvec = phantom.scheme_dti(30, 3, 1000.0, seed=2)
@@ -207,7 +286,18 @@ def test_fit_streams_a_memory_mapped_nifti_file(fj, tmp_path):
         b = fj.dti_fit(fj.MRI(dwi, m.bval, m.bvec), mask)
         for k in fj.dti.DTI_FIELDS:
             assert np.array_equal(getattr(a, k).vol, getattr(b, k).vol, equal_nan=True), k
+        from util import assert_dti_close, peak_mismatches_are_ties
+        ones = np.ones(shape, np.uint8)
+        ref = orc.dti_fit(dwi, ones, bval, bvec, nthreads=4)                 # the oracle never sees the file
+        # (0.5 % non-positive samples: those voxels take the per-voxel pinv branch, dti.jl:297-303 -> its looser tolerances)
+        assert_dti_close({k: getattr(a, k).vol for k in fj.dti.DTI_FIELDS}, ref, ones, label="mmap dti",
+                         s0_rtol=2e-3, ev_rtol=5e-3, ev_atol=2e-6, fa_atol=5e-3, vec_tol=1e-3, gap=0.2)
         ga, gb = fj.gqi_rec(m, mask), fj.gqi_rec(fj.MRI(dwi, m.bval, m.bvec), mask)
+        rg = orc.gqi_rec(dwi, ones, bval, bvec, fj.sphere_642.vertices, fj.sphere_642.faces, 1.25, nthreads=4)
+        assert (np.abs(ga.odf.vol - rg["odf"]) / (np.abs(rg["odf"]).max(axis=3, keepdims=True) + 1e-30)).max() < 2e-5
+        nv = fj.sphere_642.nvert
+        peak_mismatches_are_ties(rg["odf"], rg["peak"], [p.vol for p in ga.peak], np.asarray(fj.sphere_642.vertices, np.float32)[:nv],
+                                 faces=np.asarray(fj.sphere_642.faces))
         assert np.array_equal(ga.odf.vol, gb.odf.vol) and all(np.array_equal(ga.qa[k].vol, gb.qa[k].vol, equal_nan=True) for k in range(3))
     finally:
         os.environ.pop("FIBERS_HOST_CHUNK", None)

@@ -316,3 +316,106 @@ def test_trilinear_option_follows_its_definition(fj, orc, nvec, smooth):
     want = np.concatenate(xyz, 0)
     assert np.array_equal(tr.xyz, want), float(np.abs(tr.xyz - want).max())
     assert tr.nstr > 200 and (tr.nstr != near.nstr or not np.array_equal(tr.xyz, near.xyz))   # (it is a different tracker)
+
+
+# ---- 2-D orientation-angle inputs (stream.jl:147-172): one frame per volume, expanded by the StreamWork constructor ----------------
+def _angle_case(shape, seed, unit, nvec=1):
+    rng = np.random.default_rng(seed)
+    span = 1.3 if unit == "rad" else 75.0
+    angs = [np.asfortranarray((rng.uniform(-span, span, shape) * 0.5 + (0.3 if unit == "rad" else 20.0) * np.sin(np.arange(shape[0]) / 5.0)[:, None, None])
+                              .clip(-span, span).astype(np.float32)) for _ in range(nvec)]
+    mask = (rng.random(shape) < 0.95).astype(np.uint8)
+    return angs, mask
+
+
+@pytest.mark.parametrize("unit", ["rad", "deg"])
+@pytest.mark.parametrize("shape,volres", [((28, 24, 1), (0.5, 0.5, 2.0)), ((10, 14, 12), (3.0, 1.0, 1.0)), ((12, 9, 11), (1.0, 2.5, 1.0))])
+def test_stream_angle_inputs_macro_exact(fj, orc, unit, shape, volres):
+    """angles in radians / degrees, every through-plane orientation (argmax of the voxel size): the wrapper's expansion + the
+    tracer against the oracle's own expansion, exactly; and equal to feeding the expanded vectors"""
+    angs, mask = _angle_case(shape, 31, unit)
+    sub = np.array([[0.1, -0.2, 0.0], [-0.3, 0.15, 0.0]], np.float32)
+    vol = fj.MRI(angs[0][..., None])
+    vol.volres = volres
+    tr = fj.stream(vol, mask=fj.MRI(mask), sublist=sub, len_max=30)
+    ref = orc.stream(angs[0], sub, mask=mask, volres=volres, len_max=30, nthreads=2)
+    assert len(ref["npts"]) > 50
+    _compare(tr, ref)
+    vec, thru = orc.angles_to_vectors(angs[0], volres)
+    assert thru == int(np.argmax(volres)) and (vec[..., thru] == 0).all()
+    assert np.allclose(np.linalg.norm(vec, axis=3), 1.0, atol=1e-6)
+    _compare(fj.stream(fj.MRI(np.asfortranarray(vec)), mask=fj.MRI(mask), sublist=sub, len_max=30), ref)
+
+
+def test_stream_angle_inputs_reject_what_the_reference_rejects(fj):
+    ang = np.full((6, 6, 1, 1), 120.0, np.float32)
+    with pytest.raises(ValueError, match="angles"):
+        fj.stream(fj.MRI(ang), mask=fj.MRI(np.ones((6, 6, 1), np.uint8)), sublist=np.zeros((1, 3), np.float32))
+
+
+@pytest.mark.parametrize("unit", ["rad", "deg"])
+def test_stream_angle_inputs_microscopy_regime_exact(fj, orc, unit):
+    """voxels of 10 um: the microscopy regime, whose search distance along the through-plane dimension of angle inputs is 0
+    (stream.jl:153-155): a (2d+1) x (2d+1) x 1 search area on a one-slice section"""
+    shape = (40, 36, 1)
+    rng = np.random.default_rng(5)
+    base = 0.4 * np.sin(np.arange(shape[0]) / 6.0)[:, None, None] + 0.2 * rng.normal(size=shape)
+    ang = np.asfortranarray((base if unit == "rad" else np.rad2deg(base)).astype(np.float32))
+    mask = (rng.random(shape) < 0.93).astype(np.uint8)
+    seed = np.zeros(shape, np.uint8); seed[2::4, 1::3, 0] = 1
+    sub = np.zeros((1, 3), np.float32)
+    volres = (0.01, 0.01, 0.04)
+    kw = dict(ang_thresh=30, step_size=1.0, smooth_coeff=0.0, search_dist=5, search_ang=25.0, len_max=40)
+    vol = fj.MRI(ang[..., None])
+    vol.volres = volres
+    tr = fj.stream(vol, mask=fj.MRI(mask), seed=fj.MRI(seed), sublist=sub, **kw)
+    ref = orc.stream(ang, sub, mask=mask, seed=seed, volres=volres, nthreads=2, **kw)
+    assert len(ref["npts"]) > 40 and ref["npts"].max() > 5
+    _compare(tr, ref)
+    assert (tr.xyz[:, 2] == 1.0).all()                              # the lines stay in the slice
+    # the flat search area matters: a cubic one gives the same lines HERE only because there is no other slice to visit
+    vec, _ = orc.angles_to_vectors(ang, volres)
+    cubic = orc.stream(vec, sub, mask=mask, seed=seed, nthreads=2, **kw)
+    assert np.array_equal(cubic["npts"], ref["npts"]) and np.array_equal(cubic["xyz"], ref["xyz"])
+
+
+def test_stream_angle_inputs_microscopy_flat_axis_in_a_volume(fj, orc):
+    """.. and in a VOLUME with anisotropic voxels the flat axis changes the result: angle inputs search one y-slice only"""
+    shape = (14, 9, 13)
+    rng = np.random.default_rng(9)
+    ang = np.asfortranarray((0.5 * np.sin(np.arange(shape[0]) / 4.0)[:, None, None] + 0.25 * rng.normal(size=shape)).astype(np.float32))
+    mask = np.ones(shape, np.uint8)
+    seed = np.zeros(shape, np.uint8); seed[1::3, 4, 2::4] = 1
+    sub = np.zeros((1, 3), np.float32)
+    volres = (0.01, 0.03, 0.01)                                       # through-plane = y
+    kw = dict(ang_thresh=35, step_size=1.0, smooth_coeff=0.0, search_dist=3, search_ang=30.0, len_max=25)
+    vol = fj.MRI(ang[..., None])
+    vol.volres = volres
+    tr = fj.stream(vol, mask=fj.MRI(mask), seed=fj.MRI(seed), sublist=sub, **kw)
+    ref = orc.stream(ang, sub, mask=mask, seed=seed, volres=volres, nthreads=2, **kw)
+    _compare(tr, ref)
+    assert (tr.xyz[:, 1] == 5.0).all()                              # y never changes: the search area is one voxel thick there
+    vec, thru = orc.angles_to_vectors(ang, volres)
+    assert thru == 1
+    cubic = orc.stream(vec, sub, mask=mask, seed=seed, nthreads=2, **kw)
+    assert not np.array_equal(cubic["xyz"], ref["xyz"])             # vector inputs search the cube
+
+
+def test_stream_angle_inputs_lcm_exact(fj, orc):
+    """LCM-guided tracking fed with 2-D angles (what the reference's microscopy data look like) on a one-slice section"""
+    n = 24
+    angs, mask = _angle_case((n, n, 1), 41, "rad", nvec=2)
+    angs[1] = np.asfortranarray(np.clip(angs[1] + 1.0, -1.5, 1.5).astype(np.float32))
+    rng = np.random.default_rng(42)
+    lcms = np.asfortranarray(rng.random((n, n, 1, 10)).astype(np.float32))
+    sub = np.array([[0.1, -0.2, 0.0], [0.3, 0.25, 0.0]], np.float32)
+    volres = (0.5, 0.5, 2.0)
+    vols = []
+    for a in angs:
+        v = fj.MRI(a[..., None]); v.volres = volres
+        vols.append(v)
+    tr = fj.stream(vols, mask=fj.MRI(mask), lcms=fj.MRI(lcms), lcm_thresh=0.2, sublist=sub, rng_seed=77, len_max=40)
+    ref = orc.stream(angs, sub, mask=mask, lcms=lcms, lcm_thresh=0.2, rng_seed=77, len_max=40, volres=volres, nthreads=2)
+    assert len(ref["npts"]) > 100
+    assert np.array_equal(tr.npts, ref["npts"]) and np.array_equal(tr.xyz, ref["xyz"])
+    assert np.array_equal(tr.scalars, ref["flags"].astype(np.float32))
