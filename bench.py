@@ -466,6 +466,19 @@ def main():
                                                            "integrator is a dependent chain of gathers from the Infinity-Cache-resident field, VALU-bound by its exact f64 norm"),
                                         note="one volume; wall = field all-gather + trace + scan + pack into a pre-allocated buffer (+ one host sync for "
                                              "the line count); seeds dealt round-robin over the ranks")
+        # the one-call form (fibd_stream_run: straight into buffers kept between calls) on the same field and seeds, for the record
+        if rank == 0 and world == 1:
+            try:
+                sbuf = fj.StreamBuffers(dev)
+                f_once = fd.allgather_slabs(field_loc, counts)
+                fj.stream_device_run(f_once, shape, seeds_all, sub, buffers=sbuf)
+                t_run = timed(lambda: fj.stream_device_run(f_once, shape, seeds_all, sub, buffers=sbuf), nst, 1) / nst
+                extra["stream_dti_ball"]["one_call_form"] = dict(ms_per_step=t_run * 1e3, mpoints_per_s=npoints / t_run / 1e6,
+                                                                 note="fibd_stream_run, one batch (more batches -- trace and pack overlapped on two streams -- "
+                                                                      "are slower: profiles/r04/stream_run_ab.txt)")
+                del sbuf, f_once
+            except Exception as e:                                                  # noqa: BLE001
+                extra["stream_dti_ball"]["one_call_form"] = dict(error=str(e))
         # the trilinear option (fib_stream_params.interp = 1; not in the reference) on the same field and seeds, rank 0's share
         if rank == 0:
             field_all = fd.allgather_slabs(field_loc, counts) if world == 1 else None

@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FIBERS_HIP_LIB") or os.path.join(_HERE, "libfibers_hip.so")   # override: A/B builds of the same ABI
 
 FIB_OK = 0
+FIB_ERR_CAPACITY = -9
 DTYPES = {"uint8": 0, "int8": 1, "int16": 2, "uint16": 3, "int32": 4, "uint32": 5,
           "float32": 6, "float64": 7, "int64": 8, "bool": 9}
 
@@ -77,6 +78,7 @@ _PROTOS = {
     "fibd_stream_field": (i32, [i32, i64, vp, vp, f32, vp, f32, vp, vp, vp, vp]),
     "fibd_stream_trace": (i32, [C.POINTER(StreamParams), vp, vp, i64, vp, i32, vp,
                                 C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]),
+    "fibd_stream_run": (i32, [C.POINTER(StreamParams), vp, vp, i64, vp, i32, vp, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64), vp]),
     "fibd_stream_ws_create": (i32, [i32, C.POINTER(vp)]),
     "fibd_stream_ws_destroy": (None, [vp]),
     "fibd_stream_pack": (i32, [vp, vp, vp, vp, vp]),

@@ -1515,18 +1515,66 @@ __global__ __launch_bounds__(1024) void mask_compact_kernel(const CompactArgs c)
                 if ((e >> lane) & 1ull) c.vidx[pv + __popcll(e & ((1ull << lane) - 1ull))] = (int32_t)vx;
                 if (lane == 0 && b) c.tiles[pt] = (int32_t)(vx >> 6);
             }
-        return;
+        if (!c.zero) return;
     }
-    // ---- outputs outside the mask: the job of the helper workgroups behind the compacting ones (so that the compacting
-    // workgroups' chain is not lengthened).  The (span of 8 sub-chunks, group of 16 rows) items are dealt out round-robin: a
+    // ---- outputs outside the mask: the job of the helper workgroups behind the compacting ones (the compacting workgroups'
+    // chain is not lengthened: they join in at the end).  The (span of 8 sub-chunks, group of 16 rows) items are dealt out round-robin: a
     // thread owns 4 consecutive voxels of each sub-chunk and walks the rows, one 16-byte store per row and sub-chunk when all
     // four are to be cleared (scalar stores for mixed groups).  With everything inside the mask an item is eight granule loads.
     const ZeroArgs &z = c.z;
     constexpr int ZS = 8, ZR = 16;                               // an item = 8 consecutive sub-chunks (128 KiB of every row) x 16 rows
-    __shared__ int s_nd[ZS], s_known;
+    __shared__ int s_nd[ZS], s_known, s_tot[2];
     const int nr = z.n0 + z.n1 + 12, ngrp = (nr + ZR - 1) / ZR;
     const int64_t nsub = (c.nvox + CB - 1) / CB, nspan = (nsub + ZS - 1) / ZS;
-    for (int64_t item = (int64_t)blockIdx.x - c.nchunks; item < nspan * ngrp; item += (int64_t)gridDim.x - c.nchunks) {
+    const int hb = (int)blockIdx.x, nh = (int)gridDim.x;        // (the compacting workgroups join in when their lists are written)
+    // First the whole picture, from the counts the compacting workgroups publish (bounded wait; they were dispatched first, but
+    // nothing depends on that: a helper that does not get every count in time falls through to the per-span path, which counts for
+    // itself): nothing outside the mask -> done; more than a quarter of the volume outside -> every output is cleared as a whole,
+    // each helper one contiguous slice of each array (pure streaming stores: the fill rate), and the contraction / peak kernels
+    // overwrite the voxels inside.
+    if (tid < 2) s_tot[tid] = 0;
+    __syncthreads();
+    {
+        long long nd = 0;
+        int unknown = 0;
+        for (int64_t sidx = tid; sidx < nsub; sidx += 1024) {
+            int got = -1;
+            for (int spin = 0; spin < 600; spin++) {
+                const unsigned long long w = __hip_atomic_load((fib_gu64 *)(c.sub_state + sidx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(w >> 32) == c.epoch) { got = (int)(unsigned)w; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (got < 0) unknown = 1; else nd += got;
+        }
+        int q = (int)nd;                                         // (<= 2^27 voxels in all)
+        for (int off = 32; off >= 1; off >>= 1) { q += __shfl_xor(q, off); unknown |= __shfl_xor(unknown, off); }
+        if (lane == 0) { atomicAdd(&s_tot[0], q); if (unknown) atomicOr(&s_tot[1], 1); }
+    }
+    __syncthreads();
+    const bool all_known = s_tot[1] == 0;
+    const int64_t total_dead = s_tot[0];
+    if (all_known && total_dead == 0) return;
+    if (all_known && total_dead * 4 > c.nvox && z.stride == c.nvox && (c.nvox & 3) == 0) {
+        auto clear = [&](float *p, int64_t nfl) {
+            if (!p || nfl <= 0) return;
+            if (reinterpret_cast<uintptr_t>(p) & 15) { for (int64_t i = (int64_t)hb * 1024 + tid; i < nfl; i += (int64_t)nh * 1024) p[i] = 0.0f; return; }
+            const int64_t nq = nfl >> 2;
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+            v4f *d = reinterpret_cast<v4f *>(p);
+            int64_t q = (int64_t)hb * 4096 + tid;
+            for (; q + 3072 < nq; q += (int64_t)nh * 4096) { d[q] = zero4; d[q + 1024] = zero4; d[q + 2048] = zero4; d[q + 3072] = zero4; }
+            for (int i = 0; i < 4; i++) if (q + 1024 * i < nq) d[q + 1024 * i] = zero4;
+        };
+        clear(z.out0, (int64_t)z.n0 * c.nvox);
+        clear(z.out1, (int64_t)z.n1 * c.nvox);
+        for (int k = 0; k < 3; k++) { clear(z.peak[k], 3 * c.nvox); clear(z.qa[k], c.nvox); }
+        return;
+    }
+    // otherwise span by span; a helper takes a contiguous run of items (the row groups of a span follow each other)
+    const int64_t nitem = nspan * ngrp, per = (nitem + nh - 1) / nh;
+    const int64_t item_hi = ((int64_t)hb + 1) * per < nitem ? ((int64_t)hb + 1) * per : nitem;
+    for (int64_t item = (int64_t)hb * per; item < item_hi; item++) {
         const int64_t span = item / ngrp;
         const int g = (int)(item % ngrp);
         __syncthreads();                                         // (s_nd of the previous item has been read)

@@ -560,9 +560,10 @@ __global__ __launch_bounds__(SCAN_T) void scan_block_kernel(const int32_t *npts,
 }
 
 // exclusive scan of the per-block totals in place (single workgroup, chunks of SCAN_T with a running carry)
-__global__ __launch_bounds__(SCAN_T) void scan_totals_kernel(Pair *block_tot, int nblocks, Pair *total) {
+// base (optional): the totals of everything before this batch of lines -- the offsets start there and *total continues from it
+__global__ __launch_bounds__(SCAN_T) void scan_totals_kernel(Pair *block_tot, int nblocks, Pair *total, const Pair *base = nullptr) {
     __shared__ Pair sh[SCAN_T];
-    Pair carry{0, 0};
+    Pair carry = base ? *base : Pair{0, 0};
     for (int base = 0; base < nblocks; base += SCAN_T) {
         const int i = base + (int)threadIdx.x;
         const Pair mine = i < nblocks ? block_tot[i] : Pair{0, 0};
@@ -592,6 +593,8 @@ struct PackArgs {
     float *out_xyz;
     int64_t nlines, line0, out_line0, out_pt0;
     int stride, nslots, len_min;
+    int64_t lines_cap, points_cap;   // capped: a line whose place lies beyond the caller's buffers is dropped (fibd_stream_run reports the need)
+    int capped;
     int trk;                    // 1: out_xyz is a .trk body: [Int32 npts, npts x 3 Float32 ((xyz+.5)*voxel_size)] per line
     float vs[3];
 };
@@ -621,7 +624,8 @@ __global__ __launch_bounds__(PK_WAVES * 64) void stream_pack_kernel(const PackAr
                 nf = nfr & 0x3fffffff; nb = n - nf; bs = nf + (nfr >> 30);
                 const Pair e = a.excl[li], bo = a.block_off[li / SCAN_B];
                 const int64_t pt = a.out_pt0 + e.pts + bo.pts, l0 = a.out_line0 + e.lines + bo.lines;
-                if (a.trk) {
+                if (a.capped && (l0 >= a.lines_cap || pt + n > a.points_cap)) { nf = 0; nb = 0; bs = 0; }   // no room: dropped
+                else if (a.trk) {
                     reinterpret_cast<int32_t *>(a.out_xyz)[l0 + 3 * pt] = n;          // write(io, Int32(npts)), trk.jl:472
                     p0 = pt * 3 + l0 + 1;
                 } else {
@@ -714,9 +718,12 @@ __global__ __launch_bounds__(256) void stream_pack_tile_kernel(const PackArgs a)
                 nf = nfr & 0x3fffffff; nb = n - nf; bs = nf + (nfr >> 30);
                 const Pair e = a.excl[li], bo = a.block_off[li / SCAN_B];
                 const int64_t pt = a.out_pt0 + e.pts + bo.pts, l0 = a.out_line0 + e.lines + bo.lines;
-                if (a.trk) { p0 = pt * 3 + l0 + 1; gs = p0 - 1; }   // the Int32 point count precedes the points (trk.jl:472)
-                else { a.out_npts[l0] = n; a.out_seed[l0] = a.line0 + li; p0 = pt * 3; gs = p0; }
-                ge = p0 + (int64_t)n * 3;
+                if (a.capped && (l0 >= a.lines_cap || pt + n > a.points_cap)) { n = 0; nf = 0; nb = 0; bs = 0; }   // no room: dropped
+                else {
+                    if (a.trk) { p0 = pt * 3 + l0 + 1; gs = p0 - 1; }   // the Int32 point count precedes the points (trk.jl:472)
+                    else { a.out_npts[l0] = n; a.out_seed[l0] = a.line0 + li; p0 = pt * 3; gs = p0; }
+                    ge = p0 + (int64_t)n * 3;
+                }
             } else n = 0;
         }
         int mf = nb > 0 ? bs + nb : nf;                        // slots of the tile that hold points of kept lines
@@ -755,8 +762,10 @@ __global__ __launch_bounds__(256) void stream_pack_tile_kernel(const PackArgs a)
                 if (t < nf) pos[i] = nf - 1 - t;
                 else if (t >= bs && t - bs < nb) pos[i] = nf + (t - bs);
             }
-            if (pos[i] >= 0) v[i] = tbase[(int64_t)c * (16 * PK_LINES)];
-            else v[i] = P3{0.f, 0.f, 0.f};
+            if (pos[i] >= 0) {                                  // read once: non-temporal (the orientation field should keep the Infinity Cache)
+                const float *src = reinterpret_cast<const float *>(tbase + (int64_t)c * (16 * PK_LINES));
+                v[i] = P3{__builtin_nontemporal_load(src), __builtin_nontemporal_load(src + 1), __builtin_nontemporal_load(src + 2)};
+            } else v[i] = P3{0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -804,6 +813,9 @@ struct fib_stream_ws {
     size_t bytes = 0;
     bool busy = false, pending = false;
     hipEvent_t done = nullptr;
+    // fibd_stream_run: the stream its pack kernels run on and the events that order the batches (created on first use)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_traced[2] = {nullptr, nullptr}, ev_packed[2] = {nullptr, nullptr};
 };
 
 extern "C" int fibd_stream_ws_create(int device, fib_stream_ws **ws) try {
@@ -826,6 +838,8 @@ extern "C" void fibd_stream_ws_destroy(fib_stream_ws *ws) try {
     if (ws->pending) (void)hipEventSynchronize(ws->done);
     if (ws->p) (void)hipFree(ws->p);
     if (ws->done) (void)hipEventDestroy(ws->done);
+    for (int i = 0; i < 2; i++) { if (ws->ev_traced[i]) (void)hipEventDestroy(ws->ev_traced[i]); if (ws->ev_packed[i]) (void)hipEventDestroy(ws->ev_packed[i]); }
+    if (ws->side) (void)hipStreamDestroy(ws->side);
     delete ws;
 } FIB_API_CATCH_VOID
 
@@ -1100,18 +1114,21 @@ __global__ __launch_bounds__(256) void stream_unpack_flags_kernel(float *xyz, ui
 static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, void *stream);
 
 // whole-tile kernel while 16 (len_max + 2) points (+ the .trk headers and the alignment slack) fit in LDS
-static int launch_pack(fib_stream_job *job, const PackArgs &pa, hipStream_t st) {
-    job->last_stream = st;
-    const size_t smem = ((size_t)PK_LINES * job->stride * 3 + PK_LINES + 8) * sizeof(float);
+static int launch_pack_n(const PackArgs &pa, int64_t nlines, int stride, hipStream_t st) {
+    const size_t smem = ((size_t)PK_LINES * stride * 3 + PK_LINES + 8) * sizeof(float);
     const char *e = getenv("FIBERS_PACK_KERNEL");
     if (smem <= 120 * 1024 && !(e && e[0] == 'w')) {
         if (smem > 48 * 1024)
             FIB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stream_pack_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(stream_pack_tile_kernel, dim3((unsigned)fib::cdiv(job->nlines, PK_LINES)), dim3(256), smem, st, pa);
+        hipLaunchKernelGGL(stream_pack_tile_kernel, dim3((unsigned)fib::cdiv(nlines, PK_LINES)), dim3(256), smem, st, pa);
     } else
-        hipLaunchKernelGGL(stream_pack_kernel, dim3((unsigned)fib::cdiv(job->nlines, PK_LINES * PK_WAVES)), dim3(PK_WAVES * 64), 0, st, pa);
+        hipLaunchKernelGGL(stream_pack_kernel, dim3((unsigned)fib::cdiv(nlines, PK_LINES * PK_WAVES)), dim3(PK_WAVES * 64), 0, st, pa);
     FIB_HIP(hipGetLastError());
     return FIB_OK;
+}
+static int launch_pack(fib_stream_job *job, const PackArgs &pa, hipStream_t st) {
+    job->last_stream = st;
+    return launch_pack_n(pa, job->nlines, job->stride, st);
 }
 
 // second pass of a two-pass job: the same trace, every kept line written straight to its place (packed arrays or .trk body)
@@ -1189,6 +1206,145 @@ extern "C" int fibd_stream_pack_trk(fib_stream_job *job, const float voxel_size[
     { const int rcl = launch_pack(job, pa, (hipStream_t)stream); if (rcl != FIB_OK) return rcl; }
     FIB_HIP(hipGetLastError());
     return FIB_OK;
+} FIB_API_CATCH
+
+// stream (stream.jl:730-790) in ONE call, straight into the caller's buffers (no second call, no allocation by the library).
+// The lines can be traced in batches (FIBERS_STREAM_BATCHES, default 1), a batch being packed on the workspace's second stream
+// while the next one is traced on the caller's; two scratch buffers alternate and the offsets of a batch continue from the
+// running totals of the batches before it (device-resident: no host round trip in between).  MEASURED (tools/stream_run_ab.py,
+// profiles/r04/stream_run_ab.txt): the overlap does not pay -- 1.30 ms for trace + pack one after the other, 1.33 / 1.37 / 1.44 /
+// 1.50 / 1.55 ms with 1 / 2 / 3 / 4 / 8 batches: since the flat trace loop both kernels are bound by the same HBM traffic
+// (2.4 GB + 3.2 GB per million lines at ~5 TB/s), and side by side each just gets half of it.  Hence the default of one batch.
+// Macro-scale angle picking only (nearest voxel or trilinear); the microscopy regime and LCM runs use fibd_stream_trace / _pack.
+extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4, const int64_t *seeds, int64_t nseed,
+                               const float *sublist, int32_t nsub, int32_t *npts, int64_t *seed_index, int64_t lines_cap,
+                               float *xyz, int64_t points_cap, int64_t *nlines_out, int64_t *npoints_out, void *stream) try {
+    FIB_CHECK(prm && field4 && nlines_out && npoints_out, FIB_ERR_INVALID, "NULL argument");
+    *nlines_out = 0; *npoints_out = 0;
+    FIB_CHECK(nseed >= 0 && (nseed == 0 || seeds), FIB_ERR_INVALID, "invalid seed list");
+    FIB_CHECK(nsub >= 1 && sublist, FIB_ERR_INVALID, "sublist must hold at least one offset (use [0,0,0] for nsub=0, stream.jl:180)");
+    FIB_CHECK(prm->nx > 0 && prm->ny > 0 && prm->nz > 0 && prm->nvec >= 1 && prm->nvec <= 8, FIB_ERR_INVALID, "invalid volume / nvec");
+    FIB_CHECK(prm->len_max >= 0 && prm->len_max < (1 << 24), FIB_ERR_INVALID, "invalid len_max");
+    FIB_CHECK(prm->search_dist == 0, FIB_ERR_UNSUPPORTED, "fibd_stream_run covers macro-scale tracking (search_dist 0); use fibd_stream_trace for the microscopy regime");
+    FIB_CHECK(prm->interp == 0 || prm->interp == 1, FIB_ERR_INVALID, "interp must be 0 (nearest voxel, the reference) or 1 (trilinear)");
+    FIB_CHECK((int64_t)prm->nx * prm->ny * prm->nz * prm->nvec < ((int64_t)1 << 28), FIB_ERR_UNSUPPORTED,
+              "orientation fields of 2^28 vectors or more are not supported (32-bit gather offsets)");
+    FIB_CHECK(lines_cap >= 0 && points_cap >= 0 && (lines_cap == 0 || (npts && seed_index)) && (points_cap == 0 || xyz), FIB_ERR_INVALID, "invalid output buffers");
+    const int64_t nl = nseed * nsub;
+    if (nl == 0) return FIB_OK;
+    int device = 0;
+    FIB_HIP(hipGetDevice(&device));
+    hipStream_t st = (hipStream_t)stream;
+    // batches: whole scan blocks; one by default (see above)
+    int64_t nbatch = 1;
+    if (const char *e = getenv("FIBERS_STREAM_BATCHES")) { const int v = atoi(e); if (v >= 1 && v <= 64) nbatch = v; }
+    const int64_t BL = fib::cdiv(fib::cdiv(nl, nbatch), SCAN_B) * SCAN_B;
+    nbatch = fib::cdiv(nl, BL);
+    const int stride = prm->len_max + 2, nslots = prm->len_max + 4;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t b_scr = up((size_t)fib::cdiv(BL, SCR_TILE) * SCR_TILE * nslots * 3 * sizeof(float));
+    const size_t b_i32 = up((size_t)BL * sizeof(int32_t)), b_excl = up((size_t)BL * sizeof(Pair)), b_bt = up((size_t)fib::cdiv(BL, SCAN_B) * sizeof(Pair));
+    const size_t PB = b_scr + 2 * b_i32 + b_excl + b_bt;
+    const size_t sbytes = 2 * PB + up((size_t)(nbatch + 1) * sizeof(Pair));
+    // the caller's workspace when it is free, else one of our own for the call
+    fib_stream_ws *ws = reinterpret_cast<fib_stream_ws *>(prm->ws), *own = nullptr;
+    bool have = false;
+    if (ws) {
+        std::lock_guard<std::mutex> lk(ws->mu);
+        if (!ws->busy && ws->device == device) { ws->busy = true; have = true; }
+    }
+    if (!have) {
+        int rcw = fibd_stream_ws_create(device, &own);
+        if (rcw != FIB_OK) return rcw;
+        ws = own; ws->busy = true;
+    }
+    auto release = [&](int code) {
+        if (own) { (void)hipStreamSynchronize(st); if (own->side) (void)hipStreamSynchronize(own->side); own->busy = false; fibd_stream_ws_destroy(own); }
+        else {
+            std::lock_guard<std::mutex> lk(ws->mu);
+            ws->pending = hipEventRecord(ws->done, st) == hipSuccess;
+            if (!ws->pending) (void)hipStreamSynchronize(st);
+            ws->busy = false;
+        }
+        return code;
+    };
+    if (ws->bytes < sbytes) {
+        if (ws->pending) { (void)hipEventSynchronize(ws->done); ws->pending = false; }
+        if (ws->p) (void)hipFree(ws->p);
+        ws->p = nullptr; ws->bytes = 0;
+        if (hipMalloc(&ws->p, sbytes) != hipSuccess) { ws->p = nullptr; return release(fib::fail(FIB_ERR_NOMEM, "cannot allocate %zu bytes of streamline scratch", sbytes)); }
+        ws->bytes = sbytes;
+    }
+    if (ws->pending) { (void)hipStreamWaitEvent(st, ws->done, 0); ws->pending = false; }
+    if (!ws->side) {
+        if (hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking) != hipSuccess) { ws->side = nullptr; return release(fib::fail(FIB_ERR_HIP, "hipStreamCreate failed")); }
+        for (int i = 0; i < 2; i++)
+            if (hipEventCreateWithFlags(&ws->ev_traced[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ws->ev_packed[i], hipEventDisableTiming) != hipSuccess)
+                return release(fib::fail(FIB_ERR_HIP, "hipEventCreate failed"));
+    }
+    char *base = reinterpret_cast<char *>(ws->p);
+    Pair *running = reinterpret_cast<Pair *>(base + 2 * PB);           // [nbatch + 1]: totals of the batches before b
+    if (hipMemsetAsync(running, 0, sizeof(Pair), st) != hipSuccess) return release(fib::fail(FIB_ERR_HIP, "hipMemsetAsync failed"));
+    for (int64_t b = 0; b < nbatch; b++) {
+        const int buf = (int)(b & 1);
+        char *pb = base + (size_t)buf * PB;
+        float *scr = reinterpret_cast<float *>(pb);
+        int32_t *bn = reinterpret_cast<int32_t *>(pb + b_scr), *bf = reinterpret_cast<int32_t *>(pb + b_scr + b_i32);
+        Pair *bex = reinterpret_cast<Pair *>(pb + b_scr + 2 * b_i32), *bbt = reinterpret_cast<Pair *>(pb + b_scr + 2 * b_i32 + b_excl);
+        const int64_t l0 = b * BL, nb = std::min<int64_t>(BL, nl - l0);
+        if (b >= 2) (void)hipStreamWaitEvent(st, ws->ev_packed[buf], 0);       // the pack of batch b - 2 has left this buffer
+        TraceArgs ta{};
+        ta.field = reinterpret_cast<const float4 *>(field4); ta.seeds = seeds; ta.sublist = sublist;
+        ta.scratch = scr; ta.npts = bn; ta.nfwd = bf; ta.line0 = l0; ta.nlines = nb;
+        ta.nx = prm->nx; ta.ny = prm->ny; ta.nz = prm->nz; ta.nvec = prm->nvec; ta.nsub = nsub;
+        ta.len_max = prm->len_max; ta.stride = stride; ta.nslots = nslots;
+        ta.cosang = prm->cosang_thresh; ta.step = prm->step_size; ta.smooth = prm->smooth_coeff;
+        const unsigned grid = (unsigned)fib::cdiv(nb, 256);
+        {
+            fib::ProfScope prof("stream_trace", st);
+            if (prm->interp) {
+                if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1, false, 0, true>), dim3(grid), dim3(256), 0, st, ta);
+                else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, false, 0, true>), dim3(grid), dim3(256), 0, st, ta);
+                else                     hipLaunchKernelGGL((stream_trace_kernel<0, false, 0, true>), dim3(grid), dim3(256), 0, st, ta);
+            } else {
+                if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1>), dim3(grid), dim3(256), 0, st, ta);
+                else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3>), dim3(grid), dim3(256), 0, st, ta);
+                else                     hipLaunchKernelGGL((stream_trace_kernel<0>), dim3(grid), dim3(256), 0, st, ta);
+            }
+        }
+        const int nblk = (int)fib::cdiv(nb, SCAN_B);
+        {
+            fib::ProfScope prof("stream_scan", st);
+            hipLaunchKernelGGL(scan_block_kernel, dim3(nblk), dim3(SCAN_T), 0, st, bn, nb, prm->len_min, bex, bbt);
+            hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(SCAN_T), 0, st, bbt, nblk, running + b + 1, (const Pair *)(running + b));
+        }
+        if (hipGetLastError() != hipSuccess || hipEventRecord(ws->ev_traced[buf], st) != hipSuccess ||
+            hipStreamWaitEvent(ws->side, ws->ev_traced[buf], 0) != hipSuccess)
+            return release(fib::fail(FIB_ERR_HIP, "streamline trace launch failed"));
+        PackArgs pa{};
+        pa.scratch = scr; pa.npts = bn; pa.nfwd = bf; pa.excl = bex; pa.block_off = bbt;
+        pa.out_npts = npts; pa.out_seed = seed_index; pa.out_xyz = xyz;
+        pa.nlines = nb; pa.line0 = l0; pa.out_line0 = 0; pa.out_pt0 = 0;
+        pa.stride = stride; pa.nslots = nslots; pa.len_min = prm->len_min;
+        pa.lines_cap = lines_cap; pa.points_cap = points_cap; pa.capped = 1;
+        {
+            fib::ProfScope prof("stream_pack", ws->side);
+            const int rcl = launch_pack_n(pa, nb, stride, ws->side);
+            if (rcl != FIB_OK) return release(rcl);
+        }
+        if (hipEventRecord(ws->ev_packed[buf], ws->side) != hipSuccess) return release(fib::fail(FIB_ERR_HIP, "hipEventRecord failed"));
+    }
+    (void)hipStreamWaitEvent(st, ws->ev_packed[(nbatch - 1) & 1], 0);          // the caller's stream continues behind the last packs
+    if (nbatch >= 2) (void)hipStreamWaitEvent(st, ws->ev_packed[(nbatch - 2) & 1], 0);
+    Pair tot{0, 0};
+    hipError_t e = hipMemcpyAsync(&tot, running + nbatch, sizeof(Pair), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return release(fib::fail(FIB_ERR_HIP, "streamline run failed: %s", hipGetErrorString(e)));
+    *nlines_out = tot.lines; *npoints_out = tot.pts;
+    if (tot.lines > lines_cap || tot.pts > points_cap)
+        return release(fib::fail(FIB_ERR_CAPACITY, "output buffers too small: %lld lines / %lld points needed, %lld / %lld given",
+                                 (long long)tot.lines, (long long)tot.pts, (long long)lines_cap, (long long)points_cap));
+    return release(FIB_OK);
 } FIB_API_CATCH
 
 extern "C" int fibd_stream_all_npts(fib_stream_job *job, int32_t *all_npts, void *stream) try {

@@ -345,3 +345,54 @@ def stream_device(field, shape, seeds, sublist, len_min=3, len_max=None, ang_thr
     finally:
         L.fib_stream_job_destroy(job)
     return out
+
+
+class StreamBuffers:
+    """Caller-owned output buffers of `stream_device_run` (npts int32 [lines], seed_index int64 [lines], xyz float32 [points, 3]):
+    kept between calls, grown when a call reports that it needs more (the steady state of a stream of volumes allocates nothing)."""
+
+    def __init__(self, device, lines: int = 0, points: int = 0):
+        self.device = device
+        self.npts = self.seed_index = self.xyz = None
+        self.reserve(lines, points)
+
+    def reserve(self, lines: int, points: int):
+        import torch
+        if self.npts is None or self.npts.numel() < lines:
+            self.npts = torch.empty(int(lines), dtype=torch.int32, device=self.device)
+            self.seed_index = torch.empty(int(lines), dtype=torch.int64, device=self.device)
+        if self.xyz is None or self.xyz.shape[0] < points:
+            self.xyz = torch.empty((int(points), 3), dtype=torch.float32, device=self.device)
+
+
+def stream_device_run(field, shape, seeds, sublist, buffers: StreamBuffers = None, len_min=3, len_max=None, ang_thresh=45, step_size=0.5,
+                      smooth_coeff=0.2, stream=None, workspace="default", interp="nearest"):
+    """stream_device in ONE library call (fibd_stream_run): the lines are traced in batches and each batch is packed, on a second
+    stream, while the next is traced; results go straight into `buffers` (grown and the call repeated when they are too small:
+    a first call sizes them).  Same lines, order and layout as stream_device; macro-scale angle picking only.
+    Returns dict(npts, seed_index, xyz) -- views of the buffers, valid until the next call with them."""
+    import torch
+    _chk_dev(field, torch.float32, "field")
+    _chk_dev(seeds, torch.int64, "seeds")
+    _chk_dev(sublist, torch.float32, "sublist")
+    nvec = field.shape[1]
+    ws = default_workspace(field.device.index or 0) if isinstance(workspace, str) else workspace
+    prm = _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff, 0, 10, ws, interp)
+    nl_max = int(seeds.numel()) * int(sublist.shape[0])
+    if buffers is None:
+        buffers = StreamBuffers(field.device)
+    if buffers.npts is None or buffers.npts.numel() == 0:
+        buffers.reserve(nl_max, 32 * nl_max)                    # a first guess; the call below says what is needed
+    L = _lib.lib()
+    sp = _stream_ptr(stream)
+    nl, npnt = C.c_int64(0), C.c_int64(0)
+    for attempt in range(2):
+        rc = L.fibd_stream_run(C.byref(prm), field.data_ptr(), seeds.data_ptr(), seeds.numel(), sublist.data_ptr(), sublist.shape[0],
+                               buffers.npts.data_ptr(), buffers.seed_index.data_ptr(), buffers.npts.numel(),
+                               buffers.xyz.data_ptr(), buffers.xyz.shape[0], C.byref(nl), C.byref(npnt), sp)
+        if rc == _lib.FIB_ERR_CAPACITY and attempt == 0:
+            buffers.reserve(int(nl.value * 1.02) + 16, int(npnt.value * 1.02) + 1024)
+            continue
+        _lib.check(rc)
+        break
+    return dict(npts=buffers.npts[: nl.value], seed_index=buffers.seed_index[: nl.value], xyz=buffers.xyz[: npnt.value], buffers=buffers)

@@ -41,7 +41,8 @@ typedef enum {
     FIB_ERR_MISSING_BVEC = -5,  /* "Missing gradient table from input DWI structure" (dti.jl:228 gqi.jl:116 dsi.jl:178) */
     FIB_ERR_DIM_MISMATCH = -6,  /* "Dimension mismatch between seed mask ... and brain mask ..." (stream.jl:746-749) */
     FIB_ERR_UNSUPPORTED = -7,   /* e.g. q-space grid other than 16^3, ODF vertex degree too large */
-    FIB_ERR_NOMEM = -8
+    FIB_ERR_NOMEM = -8,
+    FIB_ERR_CAPACITY = -9       /* caller-provided output buffers too small (fibd_stream_run): the counts say what is needed */
 } fib_status;
 
 /* element type of a mask / seed volume handed over by the host (any numeric array in Julia) */
@@ -281,6 +282,17 @@ int fibd_stream_trace(const fib_stream_params *prm, const float *field4, const i
  * npts [nlines] int32, seed_index [nlines] int64 (= seed*nsub+sub), xyz [3*npoints] (x,y,z per point,
  * line after line, each line ordered [fwd_N..fwd_1, bwd_1..bwd_M] as stream.jl:652 builds it). */
 int fibd_stream_pack(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, void *stream);
+
+/* trace + pack in ONE call into caller-provided device buffers (npts [lines_cap] int32, seed_index [lines_cap] int64, xyz
+ * [3*points_cap] float): the same lines, order and layout as fibd_stream_trace + fibd_stream_pack without the second call and
+ * without any allocation on the caller's side of the boundary between them.  (FIBERS_STREAM_BATCHES=n traces the lines in n
+ * batches and packs each on a second stream while the next is traced; measured slower than one batch: both kernels are bound by
+ * the same HBM traffic.)  *nlines / *npoints receive the totals; when they exceed the capacities the call
+ * returns FIB_ERR_CAPACITY (lines that did not fit are missing from the buffers; call again with larger ones).  Macro-scale angle
+ * picking only (prm->search_dist == 0, no LCMs); synchronises `stream`. */
+int fibd_stream_run(const fib_stream_params *prm, const float *field4, const int64_t *seeds, int64_t nseed,
+                    const float *sublist, int32_t nsub, int32_t *npts, int64_t *seed_index, int64_t lines_cap,
+                    float *xyz, int64_t points_cap, int64_t *nlines, int64_t *npoints, void *stream);
 
 /* LCM-guided tracking (stream(...; lcms, lcm_thresh), stream.jl:200-236, 380-495, 526-538): when a line enters a new
  * voxel the exit edge is drawn from the voxel's local connection matrix restricted to the entry edge, and the

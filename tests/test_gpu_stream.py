@@ -419,3 +419,52 @@ def test_stream_angle_inputs_lcm_exact(fj, orc):
     assert len(ref["npts"]) > 100
     assert np.array_equal(tr.npts, ref["npts"]) and np.array_equal(tr.xyz, ref["xyz"])
     assert np.array_equal(tr.scalars, ref["flags"].astype(np.float32))
+
+
+# ---- fibd_stream_run: trace and pack in one call, batches overlapped on two streams ---------------------------------------------------
+@pytest.mark.parametrize("nvec,batches", [(1, 1), (1, 3), (3, 4), (2, 2)])
+def test_stream_run_matches_trace_plus_pack(fj, monkeypatch, nvec, batches):
+    """the one-call form (batches of lines, each packed on a second stream while the next is traced) returns exactly what
+    fibd_stream_trace + fibd_stream_pack return: same lines, order, seed indices and points; buffers are sized by a first call,
+    reused by the second, and a call with too little room says how much it needs"""
+    import torch
+    n = 20
+    dev = torch.device("cuda", 0)
+    f = _fields(n, 4)
+    names = ["wavy", "circ", "noisy"][:nvec]
+    ov = [torch.from_numpy(np.ascontiguousarray(f[k].reshape(-1, 3, order="F").T)).to(dev) for k in names]
+    mask = torch.from_numpy((np.random.default_rng(3).random(n ** 3) < 0.9).astype(np.uint8)).to(dev)
+    field, mout = fj.stream_field_device(ov, mask=mask)
+    seeds = torch.nonzero(mout).flatten()
+    sub = torch.from_numpy(fj.make_sublist(2, np.random.default_rng(8))).to(dev)
+    kw = dict(len_min=2, len_max=30, smooth_coeff=0.3)
+    ref = fj.stream_device(field, (n, n, n), seeds, sub, **kw)
+    monkeypatch.setenv("FIBERS_STREAM_BATCHES", str(batches))
+    bufs = fj.StreamBuffers(dev)
+    got = fj.stream_device_run(field, (n, n, n), seeds, sub, buffers=bufs, **kw)          # first call: sizes the buffers (one retry)
+    for k in ("npts", "seed_index", "xyz"):
+        assert torch.equal(got[k], ref[k]), k
+    assert int(ref["npts"].numel()) > 1000
+    ptr = bufs.xyz.data_ptr()
+    bufs.xyz.fill_(-1.0); bufs.npts.fill_(-1)
+    got = fj.stream_device_run(field, (n, n, n), seeds, sub, buffers=bufs, **kw)          # steady state: no allocation
+    assert bufs.xyz.data_ptr() == ptr
+    for k in ("npts", "seed_index", "xyz"):
+        assert torch.equal(got[k], ref[k]), k
+    # too little room: the library reports the totals and writes nothing beyond the buffers
+    from fibers_jl_amd import _lib
+    import ctypes as C
+    small_n = torch.full((100,), -7, dtype=torch.int32, device=dev)
+    small_s = torch.zeros(100, dtype=torch.int64, device=dev)
+    small_x = torch.full((1000 + 8, 3), -7.0, device=dev)
+    import sys
+    smod = sys.modules[fj.stream_device_run.__module__]                                # (fj.stream is the function, not the module)
+    prm = smod._params((n, n, n), nvec, 2, 30, 45, 0.5, 0.3, 0, 10, smod.default_workspace(0))
+    nl, npnt = C.c_int64(0), C.c_int64(0)
+    rc = _lib.lib().fibd_stream_run(C.byref(prm), field.data_ptr(), seeds.data_ptr(), seeds.numel(), sub.data_ptr(), sub.shape[0],
+                                    small_n.data_ptr(), small_s.data_ptr(), 100, small_x.data_ptr(), 1000, C.byref(nl), C.byref(npnt), None)
+    torch.cuda.synchronize()
+    assert rc == _lib.FIB_ERR_CAPACITY and nl.value == ref["npts"].numel() and npnt.value == ref["xyz"].shape[0]
+    assert (small_x[1000:] == -7.0).all()                                              # nothing written past the capacity
+    kept = small_n != -7
+    assert torch.equal(small_n[kept], ref["npts"][:100][kept[:100]])                    # what was written is right
