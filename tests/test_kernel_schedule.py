@@ -17,3 +17,6 @@ def test_stage_loops_do_not_wait_on_the_loads_they_have_just_issued():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_loop_waits.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count(": ok") >= 20, r.stdout[-2000:]
+    # the kernel whose samples travel through LDS: its hand-counted vmcnt(2) waits follow exactly the two sample requests, and the
+    # DRAIN wait sits directly in front of the first row store (tools/check_loop_waits.py check_slds)
+    assert r.stdout.count("slds ok") >= 1, r.stdout[-2000:]

@@ -83,6 +83,59 @@ def check(body):
     return bad
 
 
+VMEM = re.compile(r"(buffer_|global_|flat_|scratch_)(load|store|atomic)")
+SAMPLE_REQ = re.compile(r"buffer_load_dwordx4 .* offen nt lds")
+
+
+def check_slds(body):
+    """Kernels whose samples travel through LDS (they issue `buffer_load_dwordx4 .. offen nt lds` requests): the stage loop's
+    synchronisation is hand-counted, and a reordering by the compiler or an extra load in the split would silently leave a stale
+    sample tile.  Asserted on the assembly:
+      * every `s_waitcnt vmcnt(2)` behind the first MFMA (= in the stage loop) has the two sample requests as the LAST two
+        vector-memory instructions before it -- vmcnt(2) then means "everything but the request just issued";
+      * the first non-temporal row store (`global_store_dwordx4 .. nt`) behind each item's last MFMA is directly preceded, with no
+        vector-memory instruction in between, by an `s_waitcnt vmcnt(0)` (the DRAIN wait: after the stores no wait can tell the
+        requests in flight from the stores)."""
+    if not any(SAMPLE_REQ.match(x) for x in body):
+        return []
+    bad = []
+    first_mfma = next((i for i, x in enumerate(body) if x.startswith("v_mfma")), None)
+    if first_mfma is None:
+        return ["no MFMA in a kernel with sample requests"]
+    nwait = 0
+    for i, ins in enumerate(body):
+        if i < first_mfma or not (ins.startswith("s_waitcnt") and "vmcnt(2)" in ins):
+            continue
+        nwait += 1
+        prev = [x for x in body[:i] if VMEM.match(x)][-2:]
+        if len(prev) < 2 or not all(SAMPLE_REQ.match(x) for x in prev):
+            bad.append("line %d: vmcnt(2) does not follow the two sample requests (last vector-memory instructions: %s)" % (i, prev))
+    if nwait == 0:
+        bad.append("no vmcnt(2) wait in the stage loop")
+    # the DRAIN wait: walk back from the first nt row store after an MFMA run
+    seen_mfma = False
+    ndrain = 0
+    for i, ins in enumerate(body):
+        if ins.startswith("v_mfma"):
+            seen_mfma = True
+            continue
+        if seen_mfma and re.match(r"global_store_dwordx4 .* nt", ins):
+            j = i - 1
+            ok = False
+            while j >= 0 and not VMEM.match(body[j]):
+                if body[j].startswith("s_waitcnt") and "vmcnt(0)" in body[j]:
+                    ok = True
+                    break
+                j -= 1
+            ndrain += 1
+            if not ok:
+                bad.append("line %d: the first row store after the MFMA block is not directly behind an s_waitcnt vmcnt(0)" % i)
+            seen_mfma = False
+    if ndrain == 0:
+        bad.append("no row store found behind the MFMA block")
+    return bad
+
+
 def demangled(name):
     try:
         return subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip()
@@ -105,6 +158,12 @@ def main():
         for i, ins, nl in bad:
             print("      line %d: %s  (after %d loads issued since the last barrier / branch)" % (i, ins, nl))
         nbad += len(bad)
+        sl = check_slds(body)
+        if any(SAMPLE_REQ.match(x) for x in body):
+            print("%-60s sample-tile synchronisation: %s" % ("", "slds ok" if not sl else "%d PROBLEMS" % len(sl)))
+        for msg in sl:
+            print("      " + msg)
+        nbad += len(sl)
     return 1 if nbad else 0
 
 

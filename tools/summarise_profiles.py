@@ -6,7 +6,7 @@ import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
@@ -60,6 +60,26 @@ for sub in ("gqi_sq", "gqi_sq2", "dsi_sq", "dsi_sq2"):
     for k, v in pmc(sub).items():
         if "gemm" in k or "peaks" in k or "dsi2" in k:
             lines.append("  PMC %-40s %s" % (k[:40], ", ".join("%s=%.4g" % kv for kv in sorted(v.items()))))
+# the tracer's issue / wait / occupancy counters (one pass per counter set; the last dispatch of each kernel)
+st = defaultdict(dict)
+for sub in sorted(os.path.basename(d) for d in glob.glob(os.path.join(src, "stream_SQ_*")) if os.path.isdir(d)):
+    for k, v in pmc(sub).items():
+        if k.startswith("stream_"):
+            st[k].update(v)
+if st:
+    lines.append("== tracer counters (rocprofv3 --pmc, tools/prof_step.py stream; per launch) ==")
+    for k, v in st.items():
+        lines.append("  PMC %-44s %s" % (k[:44], ", ".join("%s=%.4g" % kv for kv in sorted(v.items()))))
+        if "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v and v["GRBM_GUI_ACTIVE"]:
+            # SQ_ACTIVE_INST_VALU counts quad-cycles over all SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+            busy = v["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (v["GRBM_GUI_ACTIVE"] / 8.0)
+            lines.append("      -> vector-ALU issue busy %.0f %% of the kernel's cycles on the average SIMD; waiting on an instruction %.0f %% of the wave-cycles"
+                         % (100 * busy, 100 * v.get("SQ_WAIT_INST_ANY", 0) / max(v.get("SQ_WAVE_CYCLES", 1), 1)))
+for t in ("gqi_timeline.txt", "gqi_timeline_ball.txt"):
+    if os.path.exists(os.path.join(src, t)):
+        shutil.copy(os.path.join(src, t), os.path.join(dst, t))
+        lines.append("== %s ==" % t)
+        lines += ["  " + x.rstrip() for x in open(os.path.join(src, t))]
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 gem = [v for k, v in traffic.items() if k.startswith("odf_gemm3_kernel<10, 1, 8, false, true")] or [v for k, v in traffic.items() if k.startswith("odf_gemm")]
 if gem:   # what bench.py reports as roofline.traffic (per launch of the dominant kernel)
