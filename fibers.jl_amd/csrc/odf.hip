@@ -73,7 +73,7 @@ struct GemmArgs {
     int pair_role;                // 0: none; 1: publish my item number; 2: wait (bounded) until my partner has reached my item
     int h2;                       // the images hold two fp16 pieces per element, scaled by the power of two sa (gemm3_body H2) ..
     float h2_inv_sa;              // .. and 1 / sa
-    int phase_item;               // diagnostic build: the work item whose phases are stamped (FIB_PHASE)
+    int phase_item, phase_wg;     // diagnostic build: the work item and the workgroup whose phases are stamped (FIB_PHASE; FIBERS_PHASE_ITEM / _WG)
 };
 
 // Diagnostic build only (make stamp -> libfibers_hip_stamp.so, -DFIB_CLOCK_STAMP; in the product library no stamp executes):
@@ -97,7 +97,7 @@ __device__ unsigned long long fib_phase_stamps[2][256];
 #define FIB_PHASE_VARS() int fps_n_ = 0
 #define FIB_PHASE(item_, wave_, id_)                                                                                                \
     do {                                                                                                                            \
-        if (blockIdx.x == 8 && (item_) == a.phase_item && ((wave_) & 3) == 0 && fps_n_ < 256) {                                     \
+        if ((int)blockIdx.x == a.phase_wg && (item_) == a.phase_item && ((wave_) & 3) == 0 && fps_n_ < 256) {                                     \
             unsigned long long t_;                                                                                                  \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                                          \
             if ((threadIdx.x & 63) == 0) fib_phase_stamps[(wave_) >> 2][fps_n_] = (t_ << 8) | (unsigned)(id_);                      \
@@ -954,11 +954,13 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
         for (int i = 0; i < NA; i++) {
             int p = wave + i * NW;
             p = p < NPIECE ? p : NPIECE - 1;
-            if constexpr (H2 && FUSE && !FOLD) {
-                // (SLDS: as inline assembly, like the sample requests -- a builtin LDS-DMA in flight makes hipcc close every barrier with
-                // s_waitcnt vmcnt(0), and that would wait for the sample request that is meant to stay in flight across it)
+            if constexpr (H2) {
+                // (as inline assembly through ONE buffer resource over the image: per piece a scalar offset and the LDS address, nothing
+                // else.  SLDS needs it -- a builtin LDS-DMA in flight makes hipcc close every barrier with s_waitcnt vmcnt(0), and that
+                // would wait for the sample request that is meant to stay in flight across it; [r4] the other fp16-piece kernels take the
+                // same path for its instruction count: they close a stage with an explicit vmcnt(0) + barrier, which covers these requests)
                 const uint32_t d = lds_l + (uint32_t)(buf * TILEB + p * 1024);   // (integer arithmetic on the LDS address: a pointer cast per piece is a null check per piece)
-                const uint32_t so = (uint32_t)((tile_m * ntiles + t) * TILEB + p * 1024);
+                const uint32_t so = __builtin_amdgcn_readfirstlane((uint32_t)((tile_m * ntiles + t) * TILEB + p * 1024));   // (wave-uniform by construction)
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(d), "v"(a_off), "s"(rsrcA), "s"(so) : "memory");
             } else {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + p * 1024 + a_off),
@@ -3075,6 +3077,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
     ga.Aextra = plan->Aextra.p; ga.h2 = plan->h2 ? 1 : 0; ga.h2_inv_sa = 1.0f / plan->h2_sa;
 #ifdef FIB_CLOCK_STAMP
     { const char *pi = getenv("FIBERS_PHASE_ITEM"); ga.phase_item = pi ? atoi(pi) : 2; }
+    { const char *pw = getenv("FIBERS_PHASE_WG"); ga.phase_wg = pw ? atoi(pw) : 8; }        // (odf_dsi2_kernel: 8 = an ODF-tile workgroup, 136 = a pdf-tile one)
 #endif
     ga.vec_ok = (nvox % 4 == 0 && ((uintptr_t)odf & 15) == 0 && (pdf == nullptr || ((uintptr_t)pdf & 15) == 0)) ? 1 : 0; ga.vidx = plan->live_vox.p; ga.nlive = plan->live_counts.p; ga.mask = mask; ga.effbits = plan->effbits.p;
     ga.out0 = pdf; ga.out1 = odf; ga.nvox = nvox;
