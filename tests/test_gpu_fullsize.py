@@ -269,3 +269,45 @@ def test_c5_stream_three_peaks_10m(fj, dev, dsi_result):
         i = pos[int(pick[sd]) * 10 + so]
         assert np.array_equal(xyz[off[i]:off[i + 1]].cpu().numpy(), ref["xyz"][roff[j]:roff[j + 1]]), (j, rs)
     assert len(ref["npts"]) == sum(1 for sd in pick for so in range(10) if int(sd) * 10 + so in pos)   # and no line more or less
+
+
+# ---- the one-launch mask compaction at sizes where a chunk holds several sub-chunks and the helper workgroups take every path --------
+@pytest.mark.parametrize("shape,dead", [((161, 163, 150), 0.10), ((161, 163, 150), 0.0), ((97, 101, 100), 0.55), ((203, 199, 204), 0.02)])
+def test_mask_compaction_and_clearing_at_scale(fj, dev, shape, dead):
+    """3.9 M / 1.0 M / 8.2 M voxels (not multiples of the 4 096-voxel sub-chunk; 4 to 9 sub-chunks per chunk): a random mask with 10 % /
+    0 % / 55 % / 2 % of the voxels outside -- the helpers' span-by-span path, the nothing-to-do path, the clear-everything path and the
+    voxel-by-voxel path.  A voxel's result depends on its own samples only, so the masked run must equal the all-ones run at the
+    voxels inside, bit for bit, and be exactly zero outside -- in output buffers that start as NaN garbage."""
+    import torch
+    from fibers_jl_amd import phantom
+    nvox = int(np.prod(shape))
+    if nvox % 4:
+        shape = (shape[0] + (4 - shape[0] % 4) % 4,) + shape[1:]          # (the fused scan wants whole quads; ragged volumes: test_gpu_odf)
+        nvox = int(np.prod(shape))
+    bval, bvec = phantom.scheme_gqi(2, 14, (1000.0, 2500.0), 7)            # 30 frames: a small contraction, the compaction dominates
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    dwi = torch.rand((len(bval), nvox), device=dev, generator=g) * 1000.0 + 1.0
+    plan = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642)
+    ones = torch.ones(nvox, dtype=torch.uint8, device=dev)
+    full = fj.odf_rec_device(plan, dwi, ones, normalize=False)
+    torch.cuda.synchronize()
+    mask = (torch.rand(nvox, device=dev, generator=g) >= dead).to(torch.uint8) if dead > 0 else ones.clone()
+    if dead > 0:                                                           # runs of voxels outside as well as scattered ones
+        mask[nvox // 3: nvox // 3 + 70000] = 0
+        mask[-5000:] = 0
+    nan = float("nan")
+    out = dict(odf=torch.full((plan.nvert, nvox), nan, device=dev), peak=[torch.full((3, nvox), nan, device=dev) for _ in range(3)],
+               qa=[torch.full((nvox,), nan, device=dev) for _ in range(3)], odfmax=torch.empty(2, device=dev))
+    got = fj.odf_rec_device(plan, dwi, mask, out=out, normalize=False)
+    torch.cuda.synchronize()
+    live = mask.bool()
+    assert torch.equal(got["odf"][:, live], full["odf"][:, live])
+    assert (got["odf"][:, ~live] == 0).all()
+    for k in range(3):
+        assert torch.equal(got["peak"][k][:, live], full["peak"][k][:, live]) and (got["peak"][k][:, ~live] == 0).all()
+        assert torch.equal(got["qa"][k][live], full["qa"][k][live]) and (got["qa"][k][~live] == 0).all()
+    assert not torch.isnan(got["odf"]).any()
+    # the same buffers again, declared clean outside the mask: identical
+    got2 = fj.odf_rec_device(plan, dwi, mask, out=out, normalize=False, out_prezeroed=True)
+    torch.cuda.synchronize()
+    assert (got2["odf"][:, ~live] == 0).all() and torch.equal(got2["odf"][:, live], full["odf"][:, live])
