@@ -251,19 +251,20 @@ def main():
     qn_ms, qn_n = prof_get(L, "qa_normalize")
     value = nvox * args.steps / dt / 1e6
 
-    fused = os.environ.get("FIBERS_ODF_UNFUSED") is None and os.environ.get("FIBERS_ODF_GEMM", "bf16x3").lower() != "f32"
+    fmt = plan.format                                         # what the plan's kernels run, read back from the library (not from the environment)
+    fused = os.environ.get("FIBERS_ODF_UNFUSED") is None and fmt != "f32"
     flops = 2.0 * nvert * nvol * nloc                      # algorithmic: 173 340 flop/voxel, this rank's voxels per launch
     gemm_avg_ms = gemm_ms / max(gemm_n, 1)
     achieved = flops / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0
     gemm_bytes = (4.0 * nvol + 1 + 4.0 * nvert + (48 if fused else 0)) * nloc   # read DWI + mask, write ODF (+ peaks and qa when fused)
-    split = os.environ.get("FIBERS_ODF_GEMM", "bf16x3").lower() != "f32"
+    split = fmt != "f32"
     hbm2 = dict(achieved=gemm_bytes / (gemm_avg_ms * 1e-3) / 1e9 if gemm_n else 0.0, peak=PEAK_HBM_GBS, unit="GB/s",
                 algorithmic_bytes=gemm_bytes, frac=gemm_bytes / (gemm_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if gemm_n else 0.0)
     pk = dict(avg_kernel_ms=peaks_ms / max(peaks_n, 1), post_ms=post_ms / max(post_n, 1), mask_compact_ms=mc_ms / max(mc_n, 1),
               qa_normalize_ms=qn_ms / max(qn_n, 1), launches_per_step=4 if fused else 6,
               note=("fused: a step is 4 launches -- mask_compact (voxel list by decoupled look-back + outputs outside the mask), the contraction "
                     "kernel, odf_post (redo list + exact odfmax), qa_normalize") if fused else "separate peak kernel (ODF re-read)")
-    exact = os.environ.get("FIBERS_ODF_EXACT", "0") not in ("", "0")
+    exact = fmt == "bf16x3"
     nprod = 6 if exact else 3
     if split:
         # every f32 product = 3 piece products of two fp16 pieces per operand (default; FIBERS_ODF_EXACT=1: 6 products of three
@@ -368,16 +369,8 @@ def main():
         # ---- the headline step with the other operand format (a plan built under FIBERS_ODF_EXACT picks it up): the exact 3 x bf16 split
         # when the line runs the default, the two-piece fp16 form when the line itself was run with FIBERS_ODF_EXACT=1 ------------------
         try:
-            prev = os.environ.get("FIBERS_ODF_EXACT")
-            if exact:
-                os.environ.pop("FIBERS_ODF_EXACT", None)
-            else:
-                os.environ["FIBERS_ODF_EXACT"] = "1"
-            plan_x = fj.OdfPlan("gqi", bval, bvec, sph, sigma=1.25, device=dev.index)
-            if prev is None:
-                os.environ.pop("FIBERS_ODF_EXACT", None)
-            else:
-                os.environ["FIBERS_ODF_EXACT"] = prev
+            plan_x = fj.OdfPlan("gqi", bval, bvec, sph, sigma=1.25, device=dev.index, format="fp16x2" if exact else "bf16x3")
+            assert plan_x.format == ("fp16x2" if exact else "bf16x3")
             out_x = fj.odf_rec_device(plan_x, dwi, mask, normalize=True)
             t_x = timed(lambda: fj.odf_rec_device(plan_x, dwi, mask, out=out_x, normalize=True), args.steps, 1) / args.steps
             gx_ms, gx_n = prof_get(L, "odf_gemm")
@@ -630,7 +623,7 @@ def main():
         n5 = len(b5)
         dsi_bytes = (4.0 * n5 + 1 + 4.0 * n5 + 4.0 * nvert + 48) * nloc          # 5 456 B / voxel (DWI + mask in; pdf, odf, peaks, qa out)
         dsi_k_ms = g_ms / max(g_n, 1)
-        nprod5 = 6 if os.environ.get("FIBERS_ODF_EXACT", "0") not in ("", "0") else 3
+        nprod5 = 6 if p5.format == "bf16x3" else 3
         dsi_exec = nprod5 * 2.0 * (320 + 288) * 272 * nloc                       # executed MFMA flops: piece products x (10 + 9 blocks) x 32 rows x 17 stages x 16
         extra["dsi_rec_140x515"] = dict(mvoxels_per_s=nvox / t_dsi / 1e6, ms_per_step=t_dsi * 1e3,
                                         gemm_kernel_ms=dsi_k_ms, fold_kernel_ms=f_ms / max(f_n, 1), peaks_kernel_ms=q_ms / max(q_n, 1),
