@@ -468,7 +468,7 @@ def main():
                 t_run = timed(lambda: fj.stream_device_run(f_once, shape, seeds_all, sub, buffers=sbuf), nst, 1) / nst
                 extra["stream_dti_ball"]["one_call_form"] = dict(ms_per_step=t_run * 1e3, mpoints_per_s=npoints / t_run / 1e6,
                                                                  note="fibd_stream_run, one batch (more batches -- trace and pack overlapped on two streams -- "
-                                                                      "are slower: profiles/r04/stream_run_ab.txt)")
+                                                                      "are slower: profiles/r04/negative_results.txt)")
                 del sbuf, f_once
             except Exception as e:                                                  # noqa: BLE001
                 extra["stream_dti_ball"]["one_call_form"] = dict(error=str(e))

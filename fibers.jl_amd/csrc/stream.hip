@@ -1212,7 +1212,7 @@ extern "C" int fibd_stream_pack_trk(fib_stream_job *job, const float voxel_size[
 // The lines can be traced in batches (FIBERS_STREAM_BATCHES, default 1), a batch being packed on the workspace's second stream
 // while the next one is traced on the caller's; two scratch buffers alternate and the offsets of a batch continue from the
 // running totals of the batches before it (device-resident: no host round trip in between).  MEASURED (tools/stream_run_ab.py,
-// profiles/r04/stream_run_ab.txt): the overlap does not pay -- 1.30 ms for trace + pack one after the other, 1.33 / 1.37 / 1.44 /
+// profiles/r04/negative_results.txt): the overlap does not pay -- 1.30 ms for trace + pack one after the other, 1.33 / 1.37 / 1.44 /
 // 1.50 / 1.55 ms with 1 / 2 / 3 / 4 / 8 batches: since the flat trace loop both kernels are bound by the same HBM traffic
 // (2.4 GB + 3.2 GB per million lines at ~5 TB/s), and side by side each just gets half of it.  Hence the default of one batch.
 // Macro-scale angle picking only (nearest voxel or trilinear); the microscopy regime and LCM runs use fibd_stream_trace / _pack.
