@@ -594,6 +594,8 @@ __device__ const short fib_f642_slot_vertex_dev[2 * 161] = {
 };
 constexpr int FQ_CAP = 10;                       // candidates per lane half that the list holds (a longer list: odf_redo_kernel)
 constexpr int FQ_LIST = FQ_CAP * 512;            // bytes per wave: [FQ_CAP][2][64] dwords
+constexpr int FQ_CAPB = 9;                       // .. the DSI pair kernel's ODF tile: slots as bytes, [FQ_CAPB][64] dwords + [FQ_CAPB][64] bytes
+constexpr int FQ_LISTB = FQ_CAPB * 320;
 constexpr int FQ_NPOS = 320, FQ_NSLOT = 2 * 161, FQ_NV = 321;
 constexpr int FQ_TABB = (2 * FQ_NPOS + FQ_NSLOT + 3 * FQ_NV) * 4 + 12;   // byte offset of each position's output row, vertex-of-slot, vertex coordinates (16-byte multiple)
 static_assert(FQ_TABB % 16 == 0, "table block keeps the LDS carve-up 16-byte aligned");
@@ -618,7 +620,10 @@ __device__ __forceinline__ float fq_max2(float a, float b) { return __builtin_fm
 // scaling and the zeroing of voxels that are skipped or outside the mask
 // DRAIN: wait for the caller's requests in flight (the next item's first pieces and samples, issued a scan ago) right before the first
 // row store goes out -- after the stores no wait can tell those requests from the stores (gemm3_body SLDS)
-template <int NW, bool PRE = false, bool SCALE = false, bool POW2 = false, bool DRAIN = false>
+// TRN: 2-KiB transposition tiles of the wave (2: half block h + 1 is put down while h is read back; 1: one after the other);
+// LB: the candidate lists keep the slot in a byte ([FQ_CAP][64] amplitudes, then [FQ_CAP][64] slot bytes: FQ_LISTB per wave)
+// CAP: entries per list -- where LDS is short (the DSI pair kernel's ODF tile, whose samples travel through LDS as well)
+template <int NW, bool PRE = false, bool SCALE = false, bool POW2 = false, bool DRAIN = false, int TRN = 2, bool LB = false, int CAP = FQ_CAP>
 __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (&acc)[10], float xrow, float vmax, float vnf, bool inb, bool lv,
                                                      int64_t vox, int lane, char *tr, char *lst, const uint64_t *posoff, const int *slotv, const float *vl,
                                                      unsigned &en_run, float scale = 1.0f, float xscale = 1.0f) {
@@ -684,6 +689,11 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
     // in the tile, a lane that flagged one of its 8 slots reads the amplitude back by its dynamic index (registers cannot
     // be indexed per lane) and appends (amplitude, slot) to its candidate list. ----------------------------------------------
     uint32_t *lw = reinterpret_cast<uint32_t *>(lst) + lane;      // entry k of this lane: amplitude at lw[k*128], slot at lw[k*128 + 64]
+    uint8_t *lb = reinterpret_cast<uint8_t *>(lst) + CAP * 256 + lane;   // (LB: amplitude at lw[k*64], slot at lb[k*64])
+    auto list_put = [&](int k, float x, uint32_t slot) {
+        if constexpr (LB) { lw[k * 64] = __float_as_uint(x); lb[k * 64] = (uint8_t)slot; }
+        else { lw[k * 128] = __float_as_uint(x); lw[k * 128 + 64] = slot; }
+    };
     int cnt = 0;
     {
         const int qsrc = 4 * (lane & 7);
@@ -696,17 +706,18 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
             // software pipeline over the 20 half blocks: half block h + 1 goes into the other tile before tile h is read back
             auto put = [&](int h) {
                 const int m = h >> 1, hb = h & 1;
-                float *tw = reinterpret_cast<float *>(tr + hb * 2048) + kh * 32 + col;
+                float *tw = reinterpret_cast<float *>(tr + (TRN == 2 ? hb * 2048 : 0)) + kh * 32 + col;
 #pragma unroll
                 for (int r = 8 * hb; r < 8 * hb + 8; r++) tw[(8 * ((r >> 2) & 1) + 2 * (r & 3)) * 32] = acc[m][r];
             };
-            put(0);
+            if (TRN == 2) put(0);
 #pragma unroll
             for (int h = 0; h < 20; h++) {
                 const int m = h >> 1, hb = h & 1;
-                if (h + 1 < 20) put(h + 1);
-                const float *tw = reinterpret_cast<const float *>(tr + hb * 2048) + kh * 32 + col;
-                const float4 *trd = reinterpret_cast<const float4 *>(tr + hb * 2048) + lane;
+                if (TRN == 2) { if (h + 1 < 20) put(h + 1); }
+                else put(h);                            // (one tile: behind the reads of half block h - 1 -- a wave's LDS operations execute in order)
+                const float *tw = reinterpret_cast<const float *>(tr + (TRN == 2 ? hb * 2048 : 0)) + kh * 32 + col;
+                const float4 *trd = reinterpret_cast<const float4 *>(tr + (TRN == 2 ? hb * 2048 : 0)) + lane;
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     const float4 v4 = trd[j * 64];
@@ -723,7 +734,7 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
                         byte &= ~(1u << b);
                         const int j = 7 - b;
                         const float x = tw[(8 * (j >> 2) + 2 * (j & 3)) * 32];
-                        if (cnt < FQ_CAP) { lw[cnt * 128] = __float_as_uint(x); lw[cnt * 128 + 64] = (uint32_t)(16 * m + 8 * hb + j); }
+                        if (cnt < CAP) list_put(cnt, x, (uint32_t)(16 * m + 8 * hb + j));
                         cnt++;
                     }
                 }
@@ -732,7 +743,7 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
         if constexpr (DRAIN) __builtin_amdgcn_s_waitcnt(0x0F70);
         if (__all(qinb)) rows_out(std::false_type{}); else rows_out(std::true_type{});   // (the guarded copy: ragged end of the voxel list)
         if (inb && kh == 0) a.out1[(int64_t)FIB_F642_POLE * a.stride + vox] = xrow;
-        if (cpole) { if (cnt < FQ_CAP) { lw[cnt * 128] = __float_as_uint(xrow); lw[cnt * 128 + 64] = 160u; } cnt++; }
+        if (cpole) { if (cnt < CAP) list_put(cnt, xrow, 160u); cnt++; }
     }
     // ---- minimum (gqi.jl:147), bounds of the mean (gqi.jl:164) over this half's 160 rows ---------------------------------
     float vmin = INFINITY;
@@ -749,9 +760,12 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
     // ---- top three of this half's candidates in the order of sortperm!(odf_peak, rev=true) (gqi.jl:198) -------------------
     Top3 t;
     top3_clear(t);
-    const int nl = cnt < FQ_CAP ? cnt : FQ_CAP;
+    const int nl = cnt < CAP ? cnt : CAP;
     for (int i = 0; __any(i < nl); i++)
-        if (i < nl) top3_insert(t, __uint_as_float(lw[i * 128]), slotv[kh * 161 + (int)lw[i * 128 + 64]]);
+        if (i < nl) {
+            if constexpr (LB) top3_insert(t, __uint_as_float(lw[i * 64]), slotv[kh * 161 + (int)lb[i * 64]]);
+            else top3_insert(t, __uint_as_float(lw[i * 128]), slotv[kh * 161 + (int)lw[i * 128 + 64]]);
+        }
     // ---- merge the two lane halves of a voxel ---------------------------------------------------------------------------
     unsigned long long ok[3];
 #pragma unroll
@@ -766,7 +780,7 @@ __device__ __forceinline__ void gemm3_epilogue_fused(const GemmArgs &a, f32x16 (
     const float vmin_t = fq_min3(vmin, __shfl_xor(vmin, 32), xrow);
     const float vsum_t = (vsum + __shfl_xor(vsum, 32)) + xrow;
     const bool finite = fabsf(vsum_t) < INFINITY;       // false for NaN / Inf columns
-    const bool redo = inb && (!finite || nonfinite || cnt > FQ_CAP || cnt_o > FQ_CAP);   // (nonfinite: the column is recomputed after this kernel)
+    const bool redo = inb && (!finite || nonfinite || cnt > CAP || cnt_o > CAP);   // (nonfinite: the column is recomputed after this kernel)
     const float mean = vsum_t / (float)FQ_NV;
     const float eps = (2.1f * 5.9604645e-8f) * (float)FQ_NV * (fabsf(mean) + 2.0f * fabsf(fminf(vmin_t, 0.0f)));   // see odfmax_contribute
     if (kh == 0 && inb) {
@@ -833,11 +847,15 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {      // ro
 // lowest frame that the stage touches on that side: one buffer resource per stage and side).
 constexpr int FKMAX = 512, FSMAX = FKMAX / KT;
 // LDS of one instantiation: stage ring + per-wave transposition tiles + extra-row table + fold tables + fused-scan lists / tables
-template <int MB, int NX, int NW, bool FOLD, bool FUSE, bool H2>
+// (ONE && FOLD && H2 = the DSI pair kernel's tiles: the samples of both fold sides travel through LDS too -- 8 KiB per wave -- and the ODF
+// tile pays for them with one transposition tile instead of two and byte-sized slots in the candidate lists)
+template <int MB, int NX, int NW, bool FOLD, bool FUSE, bool H2, bool ONE = false>
 constexpr int gemm3_lds_bytes() {
-    return 2 * (H2 ? 2 : 3) * MB * 1024 + NW * (FUSE ? 4096 : 2048) + (NX > 0 ? (FUSE ? 2048 : 8192) : 0) +
-           (FOLD ? 2 * FKMAX * 4 + 4 * FSMAX * 4 + (FUSE ? 0 : 2 * FKMAX * 4) : 0) + (FUSE ? NW * FQ_LIST + FQ_TABB : 0) +
-           (H2 && FUSE && !FOLD ? NW * (4096 + 512) : 0);   // (SLDS: two sample tiles + the next items' mask bytes and list entries, per wave)
+    constexpr bool SF = H2 && FOLD && ONE;
+    return 2 * (H2 ? 2 : 3) * MB * 1024 + NW * (FUSE && !SF ? 4096 : 2048) + (NX > 0 ? (FUSE ? 2048 : 8192) : 0) +
+           (FOLD ? 2 * FKMAX * 4 + 4 * FSMAX * 4 + (FUSE ? 0 : 2 * FKMAX * 4) : 0) + (FUSE ? NW * (SF ? FQ_LISTB : FQ_LIST) + FQ_TABB : 0) +
+           (H2 && FUSE && !FOLD ? NW * (4096 + 512) : 0) +   // (SLDS: two sample tiles + the next items' mask bytes and list entries, per wave)
+           (SF ? NW * (8192 + 256) : 0);                     // (.. two sample tiles of two sides + the list entries)
 }
 // ONE: the workgroup works on a single-tile image of its own (odf_dsi2_kernel: the DSI rows are cut into an ODF tile and a pdf tile
 // with images of different shapes); the work list still deals the items of both tiles (a.ntile_m = 2), and with an even number
@@ -854,23 +872,32 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     constexpr int NXA = NX > 0 ? NX : 1;
     constexpr int XTAB = NX > 0 ? (FUSE ? 2048 : 8192) : 0;   // coefficients of the extra rows, all stages of all M tiles: [ntile_m][NX][Kpad] f32
     constexpr int FTAB = FOLD ? 2 * FKMAX * 4 + 4 * FSMAX * 4 + (FUSE ? 0 : 2 * FKMAX * 4) : 0;   // (a tile with pdf rows: + the row -> frame tables)
-    constexpr int QTAB = FUSE ? NW * FQ_LIST + FQ_TABB : 0;   // fused peak scan: candidate lists + lookup tables
-    constexpr int TRB = FUSE ? 4096 : 2048;                   // per-wave transposition tile(s) of the epilogue
+    // SLDS (fused GQI on fp16 pieces; [r4] both tiles of the DSI pair kernel, SLDSF): the samples travel through LDS, see below
+    constexpr bool SLDSF = H2 && FOLD && ONE;
+    constexpr bool SLDS = (H2 && FUSE && !FOLD) || SLDSF;
+    constexpr bool BOOK = SLDS && !FOLD;                      // the next item's mask bytes and list entries by LDS-DMA as well
+    constexpr int BOOKB = BOOK ? 512 : (SLDSF ? 256 : 0);     // (SLDSF: the list entries only -- the mask byte is not looked at before the epilogue)
+    constexpr int BOOKV = BOOK ? 64 : 0;                      // dword index of the list entries in the book
+    constexpr int QLIST = SLDSF ? FQ_LISTB : FQ_LIST;
+    constexpr int QTAB = FUSE ? NW * QLIST + FQ_TABB : 0;     // fused peak scan: candidate lists + lookup tables
+    constexpr int TRB = FUSE && !SLDSF ? 4096 : 2048;         // per-wave transposition tile(s) of the epilogue
     // SLDS (fused GQI on fp16 pieces): the samples travel through LDS -- two tiles [16 frames][32 voxels] per wave, filled by
     // range-checked `buffer_load_dwordx4 .. lds` (a lane = 4 consecutive voxels of one frame: the voxel list is made of aligned quads),
     // two stages ahead of the split that reads them.  With the samples in registers a wave can have ONE stage in flight, a request
     // can precede its use by at most a stage, and a stage had settled at the ~1.5 us a sample load takes under load (twice what its
     // MFMAs need); requests in LDS cost no registers, so they also cross an item's epilogue.
-    constexpr bool SLDS = H2 && FUSE && !FOLD;
-    constexpr int STILE = SLDS ? NW * (4096 + 512) : 0;
-    static_assert(2 * TILEB + NW * TRB + XTAB + FTAB + QTAB + STILE == gemm3_lds_bytes<MB, NX, NW, FOLD, FUSE, H2>(), "LDS carve-up");
-    uint64_t *q_posoff = reinterpret_cast<uint64_t *>(lds + 2 * TILEB + NW * TRB + XTAB + FTAB + (FUSE ? NW * FQ_LIST : 0));   // [320] matrix row -> byte offset of its output row
+    // SLDSF: a tile per fold side, [2 sides][16 folded frames][32 voxels]: a lane's DMA row = the frame the fold table names for it
+    constexpr int SSLOT = FOLD ? 4096 : 2048;                 // bytes per wave and sample slot
+    constexpr int NSREQ = FOLD ? 4 : 2;                       // DMA instructions of a stage's sample request
+    constexpr int STILE = SLDS ? NW * (2 * SSLOT + BOOKB) : 0;
+    static_assert(2 * TILEB + NW * TRB + XTAB + FTAB + QTAB + STILE == gemm3_lds_bytes<MB, NX, NW, FOLD, FUSE, H2, ONE>(), "LDS carve-up");
+    static_assert(gemm3_lds_bytes<MB, NX, NW, FOLD, FUSE, H2, ONE>() <= 160 * 1024, "LDS of a CU");
+    uint64_t *q_posoff = reinterpret_cast<uint64_t *>(lds + 2 * TILEB + NW * TRB + XTAB + FTAB + (FUSE ? NW * QLIST : 0));   // [320] matrix row -> byte offset of its output row
     int *q_slotv = reinterpret_cast<int *>(q_posoff + FQ_NPOS);                                                                               // [2][161] (half, slot) -> vertex
     float *q_vl = reinterpret_cast<float *>(q_slotv + FQ_NSLOT);                                                   // [321][3]
     uint32_t *f_off = reinterpret_cast<uint32_t *>(lds + 2 * TILEB + NW * TRB + XTAB);   // [2][FKMAX] byte offset of sample J's frame, side a / b
-    int32_t *f_base = reinterpret_cast<int32_t *>(f_off + 2 * FKMAX);                      // [2][FSMAX] lowest frame of the stage
-    int32_t *f_span = f_base + 2 * FSMAX;                                                  // [2][FSMAX] frames spanned (0: none)
-    int32_t *f_row = f_span + 2 * FSMAX;                                                   // [2][FKMAX] (FOLD, not FUSE) folded pdf row -> its two frames
+    int32_t *f_bs = reinterpret_cast<int32_t *>(f_off + 2 * FKMAX);                        // [FSMAX][4] per stage: lowest frame the stage touches, frames spanned (0: none), side a | side b
+    int32_t *f_row = f_bs + 4 * FSMAX;                                                   // [2][FKMAX] (FOLD, not FUSE) folded pdf row -> its two frames
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, kh = lane >> 5;
@@ -897,15 +924,15 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
                 const int f = J < a.K ? fr[J] : -1;
                 if (f >= 0) { lo = f < lo ? f : lo; hi = f > hi ? f : hi; }
             }
-            f_base[side * FSMAX + t] = hi >= 0 ? lo : 0;
-            f_span[side * FSMAX + t] = hi >= 0 ? hi - lo + 1 : 0;
+            f_bs[4 * t + 2 * side] = hi >= 0 ? lo : 0;
+            f_bs[4 * t + 2 * side + 1] = hi >= 0 ? hi - lo + 1 : 0;
         }
         __syncthreads();
         for (int i = tid; i < 2 * a.Kpad; i += NW * 64) {
             const int side = i / a.Kpad, J = i - side * a.Kpad;
             const int f = J < a.K ? (side ? a.rowB : a.rowA)[J] : -1;
             // (the host checked that a stage's span times the frame size stays below 0xE0000000; 0xF0000000 + 4 vox is past every span)
-            f_off[side * FKMAX + J] = f >= 0 ? (uint32_t)(f - f_base[side * FSMAX + J / KT]) * row_bytes : 0xF0000000u;
+            f_off[side * FKMAX + J] = f >= 0 ? (uint32_t)(f - f_bs[4 * (J / KT) + 2 * side]) * row_bytes : 0xF0000000u;
             if (!FUSE) f_row[side * FKMAX + J] = f;     // (the folded pdf rows are the folded samples: same tables, dsi_fold_kernel)
         }
         __syncthreads();
@@ -974,8 +1001,8 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     // offsets j*row_bytes go in as scalar offsets, the lane's (voxel + 8h rows) as the 32-bit vector offset.
     auto load_B = [&](int t, uint32_t s_off, bool live) {
         if constexpr (FOLD) {
-            const int ba = __builtin_amdgcn_readfirstlane(f_base[t]), bb = __builtin_amdgcn_readfirstlane(f_base[FSMAX + t]);
-            const int sa = live ? __builtin_amdgcn_readfirstlane(f_span[t]) : 0, sb = live ? __builtin_amdgcn_readfirstlane(f_span[FSMAX + t]) : 0;
+            const int ba = __builtin_amdgcn_readfirstlane(f_bs[4 * t]), bb = __builtin_amdgcn_readfirstlane(f_bs[4 * t + 2]);
+            const int sa = live ? __builtin_amdgcn_readfirstlane(f_bs[4 * t + 1]) : 0, sb = live ? __builtin_amdgcn_readfirstlane(f_bs[4 * t + 3]) : 0;
             const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(Sbase + (int64_t)ba * row_bytes), 0, (int)((uint32_t)sa * row_bytes), 0x00020000);
             const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(Sbase + (int64_t)bb * row_bytes), 0, (int)((uint32_t)sb * row_bytes), 0x00020000);
             const u32x4_t *pa = reinterpret_cast<const u32x4_t *>(f_off + t * KT + 8 * kh), *pb = reinterpret_cast<const u32x4_t *>(f_off + FKMAX + t * KT + 8 * kh);
@@ -997,10 +1024,44 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     };
     // SLDS: samples of stage t (frames 16 t ..) of the voxel quads at byte offsets qoff into this wave's sample tile `slot`.  Inline
     // assembly: hipcc treats its own LDS-DMA builtins as stores that a later LDS read may depend on
-    char *stile = lds + 2 * TILEB + NW * TRB + XTAB + FTAB + QTAB + wave * 4096;
+    char *stile = lds + 2 * TILEB + NW * TRB + XTAB + FTAB + QTAB + wave * (2 * SSLOT);
     const uint32_t stile_l = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char *)stile);
     const uint32_t lane_rows = (uint32_t)(lane >> 3) * row_bytes;
-    auto load_S = [&](int t, uint32_t qoff, bool live, int slot) {
+    // (SLDSF) what a stage's request needs from the fold tables: read at the top of the split, next to the sample reads -- one LDS round
+    // trip instead of six in a row behind the split
+    struct FoldReq { u32x4_t bs; uint32_t o[4]; };
+    auto fold_tab = [&](int t) {
+        FoldReq q;
+        if constexpr (FOLD) {
+            q.bs = *reinterpret_cast<const u32x4_t *>(f_bs + 4 * t);
+            const uint32_t *fo = f_off + t * KT + (lane >> 3);
+            q.o[0] = fo[0]; q.o[1] = fo[8]; q.o[2] = fo[FKMAX]; q.o[3] = fo[FKMAX + 8];
+        }
+        return q;
+    };
+    auto load_S = [&](int t, uint32_t qoff, bool live, int slot, const FoldReq &fq) {
+        if constexpr (FOLD) {
+            // per side one buffer resource over the frames the stage touches (f_bs), the lane's frame by the fold table: a partner that
+            // does not exist has an offset past every span and reads 0.0
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                const uint32_t fb = (uint32_t)__builtin_amdgcn_readfirstlane((int)fq.bs[2 * side]);
+                const uint32_t fsr = (uint32_t)__builtin_amdgcn_readfirstlane((int)fq.bs[2 * side + 1]);
+                const uint32_t fs = live ? fsr : 0u;
+                const uint64_t b = reinterpret_cast<uint64_t>(Sbase) + (uint64_t)fb * row_bytes;
+                i32x4_t r;
+                r[0] = (int)(uint32_t)b;
+                r[1] = (int)(uint32_t)((b >> 32) & 0xffffu);
+                r[2] = (int)(fs * row_bytes);
+                r[3] = 0x00020000;
+                const uint32_t v0 = qoff + fq.o[2 * side], v1 = qoff + fq.o[2 * side + 1];
+                const uint32_t d0 = stile_l + (uint32_t)(slot * SSLOT + side * 2048);
+                // (default cache policy: the partner tile's workgroup reads the same samples from the XCD's L2)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(d0), "v"(v0), "s"(r) : "memory");
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(d0 + 1024u), "v"(v1), "s"(r) : "memory");
+            }
+            return;
+        }
         const int rem = live ? a.K - t * KT : 0;
         const uint64_t span = (uint64_t)(rem > 0 ? rem : 0) * row_bytes;
         const uint64_t b = reinterpret_cast<uint64_t>(Sbase) + (rem > 0 ? (uint64_t)(uint32_t)(t * KT) * row_bytes : 0ull);
@@ -1016,7 +1077,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     };
     // SLDS: the NEXT item's mask byte (book[lane]) and the list entry of the item after it (book[64 + lane]) also come by LDS-DMA, one
     // item ahead: a plain load at the top of an item would wait (vmcnt, in issue order) until the epilogue's row stores have drained
-    uint32_t *book = reinterpret_cast<uint32_t *>(lds + 2 * TILEB + NW * TRB + XTAB + FTAB + QTAB + NW * 4096 + wave * 512);
+    uint32_t *book = reinterpret_cast<uint32_t *>(lds + 2 * TILEB + NW * TRB + XTAB + FTAB + QTAB + NW * 2 * SSLOT + wave * BOOKB);
     const uint32_t book_l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char *)book));
     auto book_mask = [&](int64_t voxn) {
         const uint8_t *mp = a.mask + voxn;
@@ -1025,7 +1086,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     auto book_vidx = [&](const Work &w) {
         const int64_t sl = (int64_t)w.tile_n * WGV + wave * 32 + col;
         const int32_t *vp = a.vidx + (sl < a.nvox ? sl : a.nvox - 1);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(book_l + 256u), "v"(vp) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(book_l + 4u * BOOKV), "v"(vp) : "memory");
     };
     auto lane_state = [&](const Work &w, int32_t vr, bool &inb, int64_t &vox, uint32_t &s_off) {
         inb = (int64_t)w.tile_n * WGV + wave * 32 + col < nlive;
@@ -1077,10 +1138,16 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     // (SLDS: reads the stage's samples from sample tile `slot` and, when done, requests stage tn of the quads at qo into that tile)
     auto split = [&](int tile_m, int t, int slot = 0, int tn = 0, uint32_t qo = 0, bool live = false) {
         float cs[H2 ? 8 : 1];
+        FoldReq fq;
         if constexpr (SLDS) {
-            const float *sp = reinterpret_cast<const float *>(stile + slot * 2048) + (8 * kh) * 32 + col;
+            fq = fold_tab(tn);
+            const float *sp = reinterpret_cast<const float *>(stile + slot * SSLOT) + (8 * kh) * 32 + col;
 #pragma unroll
             for (int j = 0; j < 8; j++) braw[j] = sp[j * 32];
+            if constexpr (FOLD) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) brawb[j] = sp[512 + j * 32];
+            }
             // (all eight reads before the first use: left alone hipcc reads a pair, waits, clamps it, reads the next pair into the same
             // registers -- four LDS round trips in a row at the top of every split, and a wave issues one instruction per ~4 cycles)
             __builtin_amdgcn_sched_barrier(0);
@@ -1157,7 +1224,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
                     bp[0][jj] = h; bp[1][jj] = l;
                 }
             }
-            if constexpr (SLDS) load_S(tn, qo, live, slot);
+            if constexpr (SLDS) load_S(tn, qo, live, slot, fq);
         }
     };
 
@@ -1166,7 +1233,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     uint32_t qoff = SLDS ? (uint32_t)__shfl((int)vox, 4 * (lane & 7)) * 4u : 0u, qoff_n = 0u;   // SLDS: byte offset of the voxel quad this lane requests
     // ---- ring prologue: stage 0's pieces into LDS, its samples into registers (SLDS: stages 0 and 1 into the sample tiles) ----------
     stage_A(cur.tile_m, 0, 0);
-    if constexpr (SLDS) { stage_A(cur.tile_m, 1, 1); load_S(0, qoff, true, 0); load_S(1, qoff, true, 1); book_mask(vox); }
+    if constexpr (SLDS) { stage_A(cur.tile_m, 1, 1); load_S(0, qoff, true, 0, fold_tab(0)); load_S(1, qoff, true, 1, fold_tab(1)); if constexpr (BOOK) book_mask(vox); }
     else load_B(0, s_off, true);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();                                     // (also: the extra rows' table is complete)
@@ -1198,18 +1265,19 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
         float sraw = 0.0f;                               // DSI: the sample that sum(p) is a multiple of (dsi.jl:224-225)
         if (a.scale_frame >= 0) sraw = *reinterpret_cast<const float *>(Sbase + (int64_t)a.scale_frame * a.stride * 4 + (uint32_t)(vox * 4));
         bool lv;                                         // voxels of a listed quad that are outside the mask: zeros
-        if constexpr (SLDS) lv = inb && (book[lane] & 0xffu) != 0u;
+        if constexpr (BOOK) lv = inb && (book[lane] & 0xffu) != 0u;
         else lv = inb && a.mask[vox] != 0;
         // (unconditionally: vraw_nxt is a load, and a load whose only use sits behind a branch stays "in flight" for hipcc's waitcnt
         // insertion on the other path -- it then guards the first overwrite of a register near it with an s_waitcnt vmcnt(0) in
         // the middle of the stage loop, behind the next stage's loads: 11 % of the fused kernel, tools/check_loop_waits.py)
         bool inb_n = false; int64_t vox_n = 0; uint32_t s_off_n = 0;
         lane_state(nxt, vraw_nxt, inb_n, vox_n, s_off_n);
-        if constexpr (SLDS) {
-            qoff_n = (uint32_t)__shfl((int)vox_n, 4 * (lane & 7)) * 4u;
+        if constexpr (SLDS) qoff_n = (uint32_t)__shfl((int)vox_n, 4 * (lane & 7)) * 4u;
+        if constexpr (BOOK) {
             book_mask(vox_n);                            // (behind the read of book[lane] above)
             book_vidx(work_at(g / ntiles + 2));
         }
+        if constexpr (SLDSF) book_vidx(work_at(g / ntiles + 2));
         for (int t = 0; t < ntiles; t++, g++) {
             const int cb = g & 1;
             const char *L = lds + cb * TILEB;
@@ -1305,7 +1373,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
             // wait -- all it and stage 1 need was requested before the previous item's stores and the epilogue has waited for it --
             // EXCEPT in a workgroup's first item: there an early wave's request for stage 2 went out behind the prologue's wait
             // (a stale sample tile in stage 1 otherwise: seen as a rare wrong ODF under concurrent launches, tests/test_gpu_hosttier.py)
-            if constexpr (SLDS) { if (t > 0 || g == 0) __builtin_amdgcn_s_waitcnt(0x0F72); }
+            if constexpr (SLDS) { if (t > 0 || g == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | NSREQ); }   // (SLDSF: four instructions)
             else
             __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): the next stage's pieces and samples have landed
             FIB_PHASE(g / ntiles, wave, 6);             // loads landed
@@ -1329,8 +1397,8 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
             if constexpr (FUSE) {
                 float fscale = 1.0f;                      // DSI (the FOLD form): 1 / sum(p), NaN where a sample is not finite (see gemm3_epilogue)
                 if (FOLD) { const float s0 = sraw < 0.0f ? 0.0f : sraw; fscale = vn != vn ? __builtin_nanf("") : 1.0f / (a.scale_coef * s0); }
-                gemm3_epilogue_fused<NW, false, FOLD || H2, H2 && !FOLD, SLDS>(a, acc, early ? xfin[0] : xacc[0], vm, vn, inb, lv, vox, lane, lds + 2 * TILEB + wave * TRB,
-                                                            lds + 2 * TILEB + NW * TRB + XTAB + FTAB + wave * FQ_LIST, q_posoff, q_slotv, q_vl, en_run,
+                gemm3_epilogue_fused<NW, false, FOLD || H2, H2 && !FOLD, SLDS, SLDSF ? 1 : 2, SLDSF, SLDSF ? FQ_CAPB : FQ_CAP>(a, acc, early ? xfin[0] : xacc[0], vm, vn, inb, lv, vox, lane, lds + 2 * TILEB + wave * TRB,
+                                                            lds + 2 * TILEB + NW * TRB + XTAB + FTAB + wave * QLIST, q_posoff, q_slotv, q_vl, en_run,
                                                             fscale * asc, fscale);
             }
             else {
@@ -1338,6 +1406,9 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
                 // address of the epilogue is hoisted out of the persistent loop and parked in registers / scratch)
                 int le = lane;
                 asm volatile("" : "+v"(le));
+                // (SLDS: everything in flight -- the next item's first pieces and samples -- lands before the first row store goes out: behind
+                // the stores no wait can tell those requests from the stores)
+                if constexpr (SLDS) __builtin_amdgcn_s_waitcnt(0x0F70);
                 if constexpr (FOLD)
                     gemm3_epilogue<MB, NX, false, 0, true, H2>(a, acc, xacc, vm, vn, inb, lv, vox, le, cur.tile_m, sraw, lds + 2 * TILEB + wave * TRB, f_row, f_row + FKMAX, asc);
                 else
@@ -1348,7 +1419,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
         if (!nxt.valid) break;
         cur = nxt; inb = inb_n; vox = vox_n; s_off = s_off_n; qoff = qoff_n;
         nxt = work_at(g / ntiles + 1);
-        if constexpr (SLDS) vraw_nxt = (int32_t)book[64 + lane];   // (requested at the top of the item that has just ended)
+        if constexpr (SLDS) vraw_nxt = (int32_t)book[BOOKV + lane];   // (requested at the top of the item that has just ended)
         else vraw_nxt = vidx_at(nxt);     // (clamped: always a valid address)
         clear(early);
     }
@@ -1377,7 +1448,7 @@ __global__ __launch_bounds__(NW * 64, 2) void odf_gemm3_kernel(const GemmArgs a)
 // others pdf tiles, each kind walking the XCD's voxel groups with its own stride: the split follows the two tiles' costs.
 template <int MBB, bool H2>
 __global__ __launch_bounds__(512, 2) void odf_dsi2_kernel(const GemmArgs a) {
-    constexpr int LA_ = gemm3_lds_bytes<10, 1, 8, true, true, H2>(), LB_ = gemm3_lds_bytes<MBB, 0, 8, true, false, H2>();
+    constexpr int LA_ = gemm3_lds_bytes<10, 1, 8, true, true, H2, true>(), LB_ = gemm3_lds_bytes<MBB, 0, 8, true, false, H2, true>();
     __shared__ __attribute__((aligned(16))) char lds[LA_ > LB_ ? LA_ : LB_];
     const int wslot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
     GemmArgs b = a;

@@ -84,52 +84,58 @@ def check(body):
 
 
 VMEM = re.compile(r"(buffer_|global_|flat_|scratch_)(load|store|atomic)")
-SAMPLE_REQ = re.compile(r"buffer_load_dwordx4 .* offen nt lds")
+LDS_DMA = re.compile(r"(buffer_load_\w+ .* lds|global_load_lds_)")
+SAMPLE_REQ = re.compile(r"buffer_load_dwordx4 v\d+, s\[\d+:\d+\], 0 offen( nt)? lds")   # (a piece request carries a scalar offset instead of the 0)
 
 
 def check_slds(body):
-    """Kernels whose samples travel through LDS (they issue `buffer_load_dwordx4 .. offen nt lds` requests): the stage loop's
-    synchronisation is hand-counted, and a reordering by the compiler or an extra load in the split would silently leave a stale
-    sample tile.  Asserted on the assembly:
-      * every `s_waitcnt vmcnt(2)` behind the first MFMA (= in the stage loop) has the two sample requests as the LAST two
-        vector-memory instructions before it -- vmcnt(2) then means "everything but the request just issued";
-      * the first non-temporal row store (`global_store_dwordx4 .. nt`) behind each item's last MFMA is directly preceded, with no
-        vector-memory instruction in between, by an `s_waitcnt vmcnt(0)` (the DRAIN wait: after the stores no wait can tell the
-        requests in flight from the stores)."""
-    if not any(SAMPLE_REQ.match(x) for x in body):
+    """Kernels whose samples travel through LDS (they issue `buffer_load_dwordx4 v, s[rsrc], 0 offen [nt] lds` requests): the stage
+    loop's synchronisation is hand-counted, and a reordering by the compiler or an extra load in the split would silently leave a
+    stale sample tile.  A stage's request is N instructions: 2 in the fused GQI kernel (non-temporal), 4 in the DSI pair kernel (two
+    fold sides, default cache policy: the partner tile reads the same samples).  Asserted on the assembly:
+      * every `s_waitcnt vmcnt(N)` behind the first MFMA (= in the stage loop) has N sample requests as the LAST N vector-memory
+        instructions before it -- vmcnt(N) then means "everything but the request just issued";
+      * between the first row store (`global_store_dwordx4`) behind each MFMA run and the last request to LDS before it there is
+        an `s_waitcnt vmcnt(0)` (the DRAIN wait: after the stores no wait can tell the requests in flight from the stores)."""
+    reqs = [x for x in body if SAMPLE_REQ.match(x)]
+    if not reqs:
         return []
+    n = 2 if all(" nt " in x for x in reqs) else 4
     bad = []
     first_mfma = next((i for i, x in enumerate(body) if x.startswith("v_mfma")), None)
     if first_mfma is None:
         return ["no MFMA in a kernel with sample requests"]
     nwait = 0
     for i, ins in enumerate(body):
-        if i < first_mfma or not (ins.startswith("s_waitcnt") and "vmcnt(2)" in ins):
+        if i < first_mfma or not (ins.startswith("s_waitcnt") and "vmcnt(%d)" % n in ins):
+            continue
+        nxt = next((x for x in body[i + 1:i + 4] if not x.startswith(".LBB")), "")
+        if not nxt.startswith("s_barrier"):      # (a wait of the compiler's own for its own loads, e.g. a table prologue: not a stage's closing wait)
             continue
         nwait += 1
-        prev = [x for x in body[:i] if VMEM.match(x)][-2:]
-        if len(prev) < 2 or not all(SAMPLE_REQ.match(x) for x in prev):
-            bad.append("line %d: vmcnt(2) does not follow the two sample requests (last vector-memory instructions: %s)" % (i, prev))
+        prev = [x for x in body[:i] if VMEM.match(x)][-n:]
+        if len(prev) < n or not all(SAMPLE_REQ.match(x) for x in prev):
+            bad.append("line %d: vmcnt(%d) does not follow the %d sample requests (last vector-memory instructions: %s)" % (i, n, n, prev))
     if nwait == 0:
-        bad.append("no vmcnt(2) wait in the stage loop")
-    # the DRAIN wait: walk back from the first nt row store after an MFMA run
+        bad.append("no vmcnt(%d) wait in front of a barrier in the stage loop" % n)
+    # the DRAIN wait: walk back from the first row store after an MFMA run -- an s_waitcnt vmcnt(0) must come before any LDS-DMA request
     seen_mfma = False
     ndrain = 0
     for i, ins in enumerate(body):
         if ins.startswith("v_mfma"):
             seen_mfma = True
             continue
-        if seen_mfma and re.match(r"global_store_dwordx4 .* nt", ins):
+        if seen_mfma and re.match(r"global_store_dwordx4 ", ins):
             j = i - 1
             ok = False
-            while j >= 0 and not VMEM.match(body[j]):
+            while j >= 0 and not LDS_DMA.match(body[j]):
                 if body[j].startswith("s_waitcnt") and "vmcnt(0)" in body[j]:
                     ok = True
                     break
                 j -= 1
             ndrain += 1
             if not ok:
-                bad.append("line %d: the first row store after the MFMA block is not directly behind an s_waitcnt vmcnt(0)" % i)
+                bad.append("line %d: a request to LDS is still in flight at the first row store after the MFMA block (no s_waitcnt vmcnt(0) in between)" % i)
             seen_mfma = False
     if ndrain == 0:
         bad.append("no row store found behind the MFMA block")
