@@ -1102,7 +1102,8 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
     // of stage t+1 afterwards, waves 4-7 split stage t first and run its MFMA block afterwards, so that on every SIMD one wave's
     // VALU work falls into the other wave's MFMA block instead of both splitting with the matrix cores idle (s_setprio keeps the
     // MFMA block ahead of the splitting wave: without it the two instruction streams just alternate).
-    constexpr bool ANTI = FUSE && NW == 8;
+    constexpr bool ANTI = (FUSE || SLDSF) && NW == 8;   // ([r4] the DSI pair kernel's pdf tile too: it has no extra rows, whose sums only the fused epilogue takes from xfin)
+    static_assert(!ANTI || FUSE || NX == 0, "anti-phase halves without the fused epilogue: no extra rows");
     const bool early = ANTI && (a.anti & 1) != 0 && wave < NW / 2;
     const bool prio = ANTI && (a.anti & 2) != 0;
     float xfin[NXA], vmax_fin = 0.0f;                   // early waves: the sums of the item being accumulated (its last split is one stage ahead)
@@ -1248,10 +1249,14 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs &a, char *lds) {
             // it, so that the second reader finds the samples in the XCD's L2.  A hint, not a protocol: the wait is bounded, and
             // nothing but speed depends on it (relaxed agent-scope accesses of a counter, no data is handed over).
             if (a.pair_role != 0) {
-                unsigned *flag = a.pair_flags + (blockIdx.x & 7) * 32 + a.one_slot;
-                const unsigned item = (unsigned)(g / ntiles) + 1u;
-                if (a.pair_role == 1) { if (tid == 0) __hip_atomic_store(flag, item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                else {
+                const int it = g / ntiles;
+                if (a.pair_role == 1) {
+                    if (tid == 0) __hip_atomic_store(a.pair_flags + (blockIdx.x & 7) * 32 + a.one_slot, (unsigned)it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    // [r4] any split of the XCD's workgroups between the two tiles: voxel group k of the XCD is item k / dsi_na of ODF-tile workgroup k % dsi_na
+                    const int k = a.one_slot + it * a.one_stride;
+                    const unsigned *flag = a.pair_flags + (blockIdx.x & 7) * 32 + k % a.dsi_na;
+                    const unsigned item = (unsigned)(k / a.dsi_na) + 1u;
                     if (tid == 0) {
                         for (int spin = 0; spin < 4000; spin++) {
                             if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= item) break;
@@ -1452,7 +1457,7 @@ __global__ __launch_bounds__(512, 2) void odf_dsi2_kernel(const GemmArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[LA_ > LB_ ? LA_ : LB_];
     const int wslot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
     GemmArgs b = a;
-    const bool paired = a.pair_flags != nullptr && 2 * a.dsi_na == nslot && nslot <= 64;
+    const bool paired = a.pair_flags != nullptr && a.dsi_na <= 32;
     if (wslot < a.dsi_na) {
         b.one_slot = wslot; b.one_stride = a.dsi_na;
         b.pair_role = paired ? 1 : 0;
@@ -3223,17 +3228,15 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
             // blocks; ~4.5 us per block): 17 of 32 workgroups per XCD for the 515-point lattice
             const double ca = 68.0, cb = 19.0 + 4.5 * plan->MBB;
             int na = (int)(nslot * ca / (ca + cb) + 0.5);
-            // Default: as many ODF-tile as pdf-tile workgroups, paired (see gemm3_body): the pdf tile waits ~12 % of its time for its
-            // partner, but the samples are fetched once -- measured at 140^3 x 515: kernel 5.54 ms, FETCH_SIZE 6.5 GB against 5.40 ms
-            // and 10.1 GB for the cost-balanced split without pairing (FIBERS_DSI_NA=<n> selects that, tools/dsi_na_sweep.py).
+            // The pdf-tile workgroups follow the ODF-tile ones through the XCD's voxel groups (see gemm3_body: a bounded wait on the
+            // partner's item counter), so the samples are fetched from HBM once and the second reader finds them in the XCD's L2 --
+            // [r4] for any split, not only 16 | 16 (FIBERS_DSI_NA=<n> sets the split, FIBERS_DSI_PAIR=0 switches the waiting off:
+            // tools/dsi_na_sweep.py).
             const char *ena = getenv("FIBERS_DSI_NA");
             if (ena) na = atoi(ena);
             g.dsi_na = std::max(1, std::min(nslot - 1, na));
-            if (!ena && plan->pair_flags.p && nslot <= 64 && nslot % 2 == 0) {
-                g.dsi_na = nslot / 2;
-                g.pair_flags = plan->pair_flags.p;
-                // (the counters were cleared by mask_compact_kernel: one memset launch less)
-            }
+            const char *epair = getenv("FIBERS_DSI_PAIR");
+            if (plan->pair_flags.p && nslot <= 32 && !(epair && epair[0] == '0')) g.pair_flags = plan->pair_flags.p;   // (the counters were cleared by mask_compact_kernel)
             switch (plan->MBB) {
                 case 5: if (g.h2) hipLaunchKernelGGL((odf_dsi2_kernel<5, true>), dim3(pg), dim3(512), 0, s, g); else hipLaunchKernelGGL((odf_dsi2_kernel<5, false>), dim3(pg), dim3(512), 0, s, g); break;
                 case 7: if (g.h2) hipLaunchKernelGGL((odf_dsi2_kernel<7, true>), dim3(pg), dim3(512), 0, s, g); else hipLaunchKernelGGL((odf_dsi2_kernel<7, false>), dim3(pg), dim3(512), 0, s, g); break;
