@@ -167,6 +167,40 @@ def test_many_concurrent_calls_of_different_sizes_on_one_worker(fj, monkeypatch)
     assert not errs, errs
 
 
+def test_many_concurrent_dsi_calls_on_one_worker(fj):
+    """The DSI pair kernel keeps sample requests in flight across stages, items and its epilogue with hand-counted waits (the fused
+    GQI kernel's scheme: a hole in it once showed only under concurrent launches).  Three threads hammer one worker with
+    volumes of different sizes (several work items per workgroup, ragged ends, a masked volume): every result equals the
+    single-threaded one, bit for bit."""
+    from fibers_jl_amd import phantom
+    b5, g5 = phantom.scheme_dsi()
+    shapes = [(40, 36, 10), (9, 7, 5), (33, 30, 9)]
+    cases = []
+    for i, sh in enumerate(shapes):
+        d5, _, _ = phantom.make_volume(sh, b5, g5, seed=40 + i, crossing=True)
+        m = np.ones(sh, np.uint8) if i != 2 else (np.random.default_rng(7).random(sh) < 0.7).astype(np.uint8)
+        cases.append((fj.MRI(d5, b5, g5), fj.MRI(np.asfortranarray(m))))
+    want = [fj.dsi_rec(d, m) for d, m in cases]
+
+    def same(a, b):
+        assert np.array_equal(a.pdf.vol, b.pdf.vol) and np.array_equal(a.odf.vol, b.odf.vol)
+        for k in range(3):
+            assert np.array_equal(a.peak[k].vol, b.peak[k].vol) and np.array_equal(a.qa[k].vol, b.qa[k].vol, equal_nan=True)
+    errs = []
+
+    def run(i):
+        try:
+            d, m = cases[i]
+            for _ in range(6):
+                same(fj.dsi_rec(d, m), want[i])
+        except BaseException as e:                               # noqa: BLE001
+            errs.append((i, e))
+    th = [threading.Thread(target=run, args=(i,)) for i in range(len(cases))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+
+
 def test_gqi_unaligned_volume_does_not_depend_on_chunks_or_device_set(fj, orc, monkeypatch):
     """nvox % 4 != 0 (13 x 11 x 9 = 1287): the same kernel choice for every chunk, so chunk size and device set do not change
     a bit (the fused peak kernel needs 16-byte aligned rows; the choice is made from the whole volume, not per chunk)"""
