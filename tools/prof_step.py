@@ -48,7 +48,22 @@ elif what == "stream":
     field, mout = fj.stream_field_device([o["eigvec1"]], fa=o["fa"], fa_thresh=0.1, mask=bm)
     seeds = torch.nonzero(mout).flatten()
     sub = torch.tensor([[0.1, -0.2, 0.3]], dtype=torch.float32, device=dev)
-    for _ in range(steps):
-        fj.stream_device(field, SHAPE, seeds, sub)
+    import os
+    if os.environ.get("PROF_STREAM_RUN"):                  # the one-call form into kept buffers (what bench.py's extra times)
+        bufs = fj.StreamBuffers(dev)
+        for _ in range(steps):
+            fj.stream_device_run(field, SHAPE, seeds, sub, buffers=bufs)
+    elif os.environ.get("PROF_STREAM_PREALLOC"):           # the two-call form into a kept output buffer (bench.py's tracking step)
+        keep = {}
+
+        def xyz_out(n):
+            if keep.get("t") is None or keep["t"].numel() < 3 * n:
+                keep["t"] = torch.empty(int(3 * n * 1.05) + 16, dtype=torch.float32, device=dev)
+            return keep["t"]
+        for _ in range(steps):
+            fj.stream_device(field, SHAPE, seeds, sub, xyz_out=xyz_out)
+    else:
+        for _ in range(steps):
+            fj.stream_device(field, SHAPE, seeds, sub)
 torch.cuda.synchronize()
 print("done", what, steps)
