@@ -62,6 +62,7 @@ _PROTOS = {
     "fib_gqi_plan_create_fmt": (i32, [i32, vp, vp, i32, vp, i32, vp, i32, f32, i32, C.POINTER(vp)]),
     "fib_dsi_plan_create_fmt": (i32, [i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, C.POINTER(vp)]),
     "fib_odf_plan_format": (i32, [vp]),
+    "fib_odf_plan_list_unit": (i32, [vp, vp]),
     "fib_odf_default_format": (i32, []),
     "fib_odf_plan_destroy": (None, [vp]),
     "fib_odf_plan_matrix": (i32, [vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),

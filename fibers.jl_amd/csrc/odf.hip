@@ -88,6 +88,8 @@ struct fib_odf_plan {
     mutable fib::DevBuf<int32_t> live_vox, live_tiles, live_counts;   // mask compaction scratch (grow-only), counts = {voxels, tiles, +Inf voxels}
     mutable fib::DevBuf<unsigned long long> compact_state;   // the chunk granules of mask_compact_kernel [1024]
     mutable fib::DevBuf<unsigned long long> compact_sub;     // .. and its per-sub-chunk hints for the workgroups that clear outputs
+    mutable fib::DevBuf<unsigned long long> compact_state2;  // .. the chunks' counts under both list units [1024]
+    mutable fib::DevBuf<unsigned> compact_mode;              // .. and the unit of the next calls [2] (mask_compact_kernel)
     mutable unsigned compact_epoch = 0;              // .. and the call counter they are tagged with
     fib::DevBuf<unsigned> tickets;                   // [4]: chunk dispenser of mask_compact_kernel, arrival counter of odf_post_kernel (both 0 between calls)
     mutable fib::DevBuf<float> odfmax;
@@ -329,6 +331,20 @@ extern "C" int fib_odf_plan_format(const fib_odf_plan *plan) try {
     return !plan->split_bf16 ? FIB_ODF_FORMAT_F32 : (plan->h2 ? FIB_ODF_FORMAT_FP16X2 : FIB_ODF_FORMAT_BF16X3);
 } FIB_API_CATCH
 
+// the unit of the voxel list the plan's NEXT reconstruction call will use (mask_compact_kernel chooses it from the previous call's mask):
+// 1 = aligned groups of 32 voxels ("octets" of quads: a wave's 128-byte row segments are whole cache lines), 0 = aligned groups of 4
+extern "C" int fib_odf_plan_list_unit(const fib_odf_plan *plan, void *stream) try {
+    FIB_CHECK(plan != nullptr, FIB_ERR_INVALID, "plan is NULL");
+    { const char *e = getenv("FIBERS_ODF_LIST"); if (e && (e[0] == 'q' || e[0] == 'o')) return e[0] == 'o' ? 1 : 0; }
+    if (!plan->compact_mode.p) return 1;                       // (no call yet)
+    fib::DeviceGuard guard;
+    { const int rcd = fib::use_device(plan->device); if (rcd != FIB_OK) return rcd; }
+    unsigned w[2] = {1u, 1u};
+    FIB_HIP(hipMemcpyAsync(w, plan->compact_mode.p, sizeof w, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    FIB_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return (int)(w[(plan->compact_epoch + 1u) & 1u] != 0u);
+} FIB_API_CATCH
+
 extern "C" int fib_gqi_plan_create_fmt(int device, const float *bval, const float *bvec, int nvol,
                                        const float *verts, int nverts, const int32_t *faces, int nfaces,
                                        float sigma, int format, fib_odf_plan **plan) try {
@@ -555,6 +571,12 @@ int launch_mask_compact(const fib_odf_plan *plan, const uint8_t *mask, int64_t n
         if ((rc = plan->compact_state.alloc(1024)) != FIB_OK) return rc;
         FIB_HIP(hipMemsetAsync(plan->compact_state.p, 0, 1024 * sizeof(unsigned long long), st));
     }
+    if (!plan->compact_state2.p) {
+        if ((rc = plan->compact_state2.alloc(1024)) != FIB_OK) return rc;
+        FIB_HIP(hipMemsetAsync(plan->compact_state2.p, 0, 1024 * sizeof(unsigned long long), st));
+        if ((rc = plan->compact_mode.alloc(2)) != FIB_OK) return rc;
+        FIB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(plan->compact_mode.p), 1, 2, st));   // octets until a call's counts say otherwise
+    }
     const size_t nsub = (size_t)fib::cdiv(nvox, CB);
     if (z && plan->compact_sub.n < nsub) {
         if ((rc = plan->compact_sub.alloc(nsub)) != FIB_OK) return rc;
@@ -568,6 +590,8 @@ int launch_mask_compact(const fib_odf_plan *plan, const uint8_t *mask, int64_t n
     if (z) c.z = *z;
     c.clear = plan->pair_flags.p; c.nclear = plan->pair_flags.p ? 8 * 32 : 0;
     c.sub_state = plan->compact_sub.p;
+    c.state2 = plan->compact_state2.p; c.mode = plan->compact_mode.p;
+    { const char *e = getenv("FIBERS_ODF_LIST"); c.force = !e ? -1 : (e[0] == 'q' ? 0 : (e[0] == 'o' ? 1 : -1)); }   // quads | octets | auto
     fib::ProfScope prof("mask_compact", st);
     // with outputs to clear: helpers behind the compacting workgroups, so that a volume that is mostly outside the mask is cleared by the whole chip
     const int grid = nchunks + (z ? 256 : 0);

@@ -155,6 +155,14 @@ class OdfPlan:
             _lib.check(code if code < 0 else -1)
         return {v: k for k, v in ODF_FORMATS.items()}[code]
 
+    def list_unit(self, stream=None) -> str:
+        """diagnostic: the unit of the voxel list the next reconstruction call on this plan will use ("octets": aligned groups of 32
+        voxels, the default; "quads": aligned groups of 4, chosen by the previous call for sparse masks).  Results do not depend on it."""
+        code = _lib.lib().fib_odf_plan_list_unit(self._h, _stream_ptr(stream))
+        if code < 0:
+            _lib.check(code)
+        return "octets" if code else "quads"
+
     def matrix(self):
         nr, nv, nt = C.c_int(0), C.c_int(0), C.c_int(0)
         L = _lib.lib()

@@ -112,6 +112,11 @@ int fib_dsi_plan_create_fmt(int device, const float *bval, const float *bvec, in
                             const float *verts, int nverts, const int32_t *faces, int nfaces,
                             int hann_width, int format, fib_odf_plan **plan);
 int fib_odf_plan_format(const fib_odf_plan *plan);   /* FIB_ODF_FORMAT_* (> 0) or a negative error code */
+/* Diagnostic: the unit of the voxel list the plan's next fibd_odf_rec call will use -- 1: aligned groups of 32 voxels (a wave's
+ * 128-byte row segments are whole cache lines whatever the mask's runs look like; the default), 0: aligned groups of 4 (chosen by
+ * the previous call when groups of 32 would list more than 1.5 x the voxels: sparse masks).  Results do not depend on it.
+ * Waits for `stream`.  FIBERS_ODF_LIST=quads|octets pins it. */
+int fib_odf_plan_list_unit(const fib_odf_plan *plan, void *stream);
 int fib_odf_default_format(void);
 void fib_odf_plan_destroy(fib_odf_plan *plan);
 /* host copy of the reconstruction matrix [nrows x nvol] column-major (GQI: nrows = nvert;

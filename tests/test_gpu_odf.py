@@ -699,3 +699,57 @@ def test_late_large_samples_lower_the_sample_scale(fj, orc):
         err = np.abs(got.odf.vol[m] - ref["odf"][m]) / top
         assert err.max() <= (2e-5 if label != "all samples denormal" else 2e-2), "%s: odf rel err %g" % (label, err.max())   # (a denormal sum carries a few bits)
         _check_odf_rec(got.odf.vol, [p.vol for p in got.peak], [q.vol[..., 0] for q in got.qa], ref, mask, label=label)
+
+
+def _rec_dict(out):
+    import torch
+    torch.cuda.synchronize()
+    return {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in out.items()}
+
+
+@pytest.mark.parametrize("kind", ["gqi", "dsi"])
+def test_list_unit_does_not_change_results_and_follows_the_mask(fj, kind, monkeypatch):
+    """The voxel list of the contraction kernels is made of aligned groups of 32 voxels by default (a wave's 128-byte row segments
+    are whole cache lines whatever the mask's runs look like) and of aligned groups of 4 when the previous call's mask was sparse.
+    Outputs are bit-identical either way (ragged ball mask, runs that start anywhere, isolated voxels, a volume that does not end on
+    a group of 32); after a call with a sparse mask the plan switches to groups of 4, after a blob it switches back."""
+    import torch
+    from fibers_jl_amd import phantom
+    dev = torch.device("cuda", 0)
+    shape = (27, 22, 14)                                   # 8 316 voxels = 259 groups of 32 + 28
+    bval, bvec = (phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3) if kind == "gqi" else phantom.scheme_dsi())
+    dwi, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=31, device=dev)
+    nvox = dwi.shape[1]
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    ball = phantom.ball_mask_torch(shape, dev).reshape(-1)
+    sparse = (torch.rand(nvox, device=dev, generator=g) < 0.02).to(torch.uint8)
+    runs = torch.zeros(nvox, dtype=torch.uint8, device=dev)
+    for a, b in ((3, 41), (77, 78), (130, 389), (1001, 1033), (nvox - 9, nvox)):
+        runs[a:b] = 1
+    plan = fj.OdfPlan(kind, bval, bvec, fj.sphere_642, device=0)
+    for name, mask in (("ball", ball), ("sparse", sparse), ("runs", runs)):
+        res = {}
+        for unit in ("quads", "octets"):
+            monkeypatch.setenv("FIBERS_ODF_LIST", unit)
+            res[unit] = _rec_dict(fj.odf_rec_device(plan, dwi, mask))
+        monkeypatch.delenv("FIBERS_ODF_LIST")
+        a, b = res["quads"], res["octets"]
+        for k in a:
+            if isinstance(a[k], list):
+                assert all(torch.equal(x, y) or torch.equal(torch.nan_to_num(x, nan=-7.0), torch.nan_to_num(y, nan=-7.0)) for x, y in zip(a[k], b[k])), (name, k)
+            else:
+                assert torch.equal(torch.nan_to_num(a[k], nan=-7.0), torch.nan_to_num(b[k], nan=-7.0)), (name, k)
+        dead = mask == 0
+        assert float(a["odf"][:, dead].abs().max()) == 0.0, name
+    # the plan follows the mask (one call behind): long runs -> groups of 32, isolated voxels -> groups of 4
+    slab = torch.zeros(nvox, dtype=torch.uint8, device=dev)
+    slab[37:5000] = 1
+    fj.odf_rec_device(plan, dwi, slab)
+    assert plan.list_unit() == "octets"
+    fj.odf_rec_device(plan, dwi, sparse)
+    assert plan.list_unit() == "quads"
+    got = _rec_dict(fj.odf_rec_device(plan, dwi, slab))     # this call runs on groups of 4 ..
+    assert plan.list_unit() == "octets"                     # .. and puts the next one back on groups of 32
+    monkeypatch.setenv("FIBERS_ODF_LIST", "octets")
+    want = _rec_dict(fj.odf_rec_device(plan, dwi, slab))
+    assert torch.equal(got["odf"], want["odf"]) and all(torch.equal(x, y) for x, y in zip(got["peak"], want["peak"]))
