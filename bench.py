@@ -166,10 +166,10 @@ def main():
     nxy = nx * ny
     nvox = nxy * nz
     sph = fj.sphere_642
-    z0, z1 = fd.slab_bounds(nz, world, rank)
+    z0, z1 = fd.slab_bounds(nz, world, rank, nxy)
     v0, v1 = z0 * nxy, z1 * nxy
     nloc = v1 - v0
-    counts = [(b - a) * nxy for a, b in (fd.slab_bounds(nz, world, r) for r in range(world))]
+    counts = [(b - a) * nxy for a, b in (fd.slab_bounds(nz, world, r, nxy) for r in range(world))]
 
     def sync():
         torch.cuda.synchronize()
@@ -350,9 +350,9 @@ def main():
         # qa_normalize from the pair).  No 8-GPU node has run this bench: this bounds the strong-scaling efficiency from the fixed
         # per-step cost alone (ideal = the N = 1 step / 8) ------------------------------------------------------------------------
         try:
-            zs0, zs1 = fd.slab_bounds(nz, 8, 0)
+            zs0, zs1 = fd.slab_bounds(nz, 8, 0, nxy)
             ns = (zs1 - zs0) * nxy
-            counts8 = [(b - a) * nxy for a, b in (fd.slab_bounds(nz, 8, r) for r in range(8))]
+            counts8 = [(b - a) * nxy for a, b in (fd.slab_bounds(nz, 8, r, nxy) for r in range(8))]
             dwi_s = dwi[:, :ns].contiguous()
             mask_s = torch.ones(ns, dtype=torch.uint8, device=dev)
             out_s = fj.odf_rec_device(plan, dwi_s, mask_s, normalize=False)

@@ -124,6 +124,19 @@ def test_slab_bounds_and_seed_shards():
             assert b[0][0] == 0 and b[-1][1] == nz
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             assert max(z1 - z0 for z0, z1 in b) - min(z1 - z0 for z0, z1 in b) <= 1
+    # with the slice size given the cut keeps every slab's voxel count a multiple of 32 where the slice count allows it (the slabs' rows
+    # then start on cache lines: tools/slab_alignment.py), still contiguous, complete and near-equal
+    for nz, nxy in ((140, 140 * 140), (141, 140 * 140), (7, 140 * 140), (64, 33 * 31), (50, 128 * 128)):
+        for w in (1, 2, 3, 4, 8):
+            b = [fd.slab_bounds(nz, w, r, nxy) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == nz and all(b[i][1] == b[i + 1][0] for i in range(w - 1)), (nz, nxy, w, b)
+            unit = 32 // np.gcd(nxy, 32)
+            if nz // unit >= w:
+                assert all(((z1 - z0) * nxy) % 32 == 0 for z0, z1 in b[:-1]), (nz, nxy, w, b)
+                assert max(z1 - z0 for z0, z1 in b) - min(z1 - z0 for z0, z1 in b) <= 2 * unit
+            else:
+                assert b == [fd.slab_bounds(nz, w, r) for r in range(w)]
+    assert [z1 - z0 for z0, z1 in (fd.slab_bounds(140, 8, r, 19600) for r in range(8))] == [18, 18, 18, 18, 18, 18, 16, 16]
     seeds = np.arange(11) * 3
     got = np.sort(np.concatenate([fd.shard_seeds(seeds, 4, r)[0] for r in range(4)]))
     assert np.array_equal(got, seeds)
