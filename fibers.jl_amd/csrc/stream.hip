@@ -188,6 +188,12 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
     const float omc = 1.0f - a.smooth;
     int ivec = 0, npts = 0, nf = 0, pass = 0, gap = 0;
     unsigned ndraw = 0;                                           // uniforms consumed by this line (LCM)
+    // [r4] The voxel's vectors stay in registers while the line stays in the voxel (a step is half a voxel: 35-50 % of the steps do): a
+    // lane that does not need the gather is switched off for it.  Same data, same arithmetic.  Three vectors per voxel (C5): trace
+    // 6.4 -> 6.0 ms; one vector (C4): nothing (tools/stream_c5_times.py, stream_kernel_times.py).
+    constexpr int NCV = NVEC > 0 ? NVEC : 1;
+    float4 cvec[NCV];
+    uint32_t cvox = 0xffffffffu;
     float px = p0x, py = p0y, pz = p0z;
     float vx, vy, vz;
     {
@@ -206,9 +212,16 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
             const float4 *cand = reinterpret_cast<const float4 *>(fbase + (size_t)(vox * (uint32_t)(nvec * 16)));
             float bx = 0.0f, by = 0.0f, bz = 0.0f, bestc = 0.0f, besta = 0.0f;
             int best = 0;
+            if constexpr (NVEC > 0) {
+                if (vox != cvox) {
+#pragma unroll
+                    for (int k = 0; k < NVEC; k++) cvec[k] = cand[k];
+                    cvox = vox;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < nvec; k++) {                      // stream_pick_by_angle!, stream.jl:350-361
-                const float4 w = cand[k];
+                const float4 w = NVEC > 0 ? cvec[k < NCV ? k : 0] : cand[k];
                 float c, ca;
                 if (w.x == 0.0f && w.y == 0.0f && w.z == 0.0f) { c = -INFINITY; ca = -INFINITY; }
                 else { c = dot3(vx, vy, vz, w.x, w.y, w.z); ca = fabsf(c); }
