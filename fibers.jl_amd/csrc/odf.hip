@@ -90,6 +90,7 @@ struct fib_odf_plan {
     mutable fib::DevBuf<unsigned long long> compact_sub;     // .. and its per-sub-chunk hints for the workgroups that clear outputs
     mutable fib::DevBuf<unsigned long long> compact_state2;  // .. the chunks' counts under both list units [1024]
     mutable fib::DevBuf<unsigned> compact_mode;              // .. and the unit of the next calls [2] (mask_compact_kernel)
+    mutable fib::DevBuf<unsigned long long> compact_oct;     // .. which octets hold a voxel inside the mask (granules of 32 octets), for the clearing workgroups
     mutable unsigned compact_epoch = 0;              // .. and the call counter they are tagged with
     fib::DevBuf<unsigned> tickets;                   // [4]: chunk dispenser of mask_compact_kernel, arrival counter of odf_post_kernel (both 0 between calls)
     mutable fib::DevBuf<float> odfmax;
@@ -591,11 +592,19 @@ int launch_mask_compact(const fib_odf_plan *plan, const uint8_t *mask, int64_t n
     c.clear = plan->pair_flags.p; c.nclear = plan->pair_flags.p ? 8 * 32 : 0;
     c.sub_state = plan->compact_sub.p;
     c.state2 = plan->compact_state2.p; c.mode = plan->compact_mode.p;
+    const size_t noct = (size_t)fib::cdiv(nvox, 1024);
+    if (z && noct * sizeof(unsigned) <= 48 * 1024) {           // (the clearing workgroups keep the bits in LDS: volumes up to 12.5 M voxels)
+        if (plan->compact_oct.n < noct) {
+            if ((rc = plan->compact_oct.alloc(noct)) != FIB_OK) return rc;
+            FIB_HIP(hipMemsetAsync(plan->compact_oct.p, 0, noct * sizeof(unsigned long long), st));
+        }
+        c.oct_bits = plan->compact_oct.p; c.oct_words = (int)noct;
+    }
     { const char *e = getenv("FIBERS_ODF_LIST"); c.force = !e ? -1 : (e[0] == 'q' ? 0 : (e[0] == 'o' ? 1 : -1)); }   // quads | octets | auto
     fib::ProfScope prof("mask_compact", st);
     // with outputs to clear: helpers behind the compacting workgroups, so that a volume that is mostly outside the mask is cleared by the whole chip
     const int grid = nchunks + (z ? 256 : 0);
-    hipLaunchKernelGGL(mask_compact_kernel, dim3(grid), dim3(1024), 0, st, c);
+    hipLaunchKernelGGL(mask_compact_kernel, dim3(grid), dim3(1024), c.oct_words * sizeof(unsigned), st, c);
     FIB_HIP(hipGetLastError());
     return FIB_OK;
 }
