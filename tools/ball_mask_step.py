@@ -8,7 +8,9 @@ bval, bvec = phantom.scheme_gqi()
 dwi, _ = phantom.make_dwi_torch((140,140,140), bval, bvec, seed=3, device=dev)
 mask = phantom.ball_mask_torch((140,140,140), dev)
 kind = os.environ.get("MASK", "ball")
-if kind == "slab":                                   # as many voxels as the ball holds, as one contiguous run
+if kind == "ones":
+    mask = torch.ones(140**3, dtype=torch.uint8, device=dev)
+elif kind == "slab":                                   # as many voxels as the ball holds, as one contiguous run
     n = int(mask.sum().item()); mask = torch.zeros(140**3, dtype=torch.uint8, device=dev); mask[:n] = 1
 elif kind == "rows":                                 # the ball's voxel count as full x-rows (no ragged row ends), every other row
     n = int(mask.sum().item()); m = torch.zeros(140*140, 140, dtype=torch.uint8, device=dev); m[: 2 * (n // 140) : 2] = 1; mask = m.reshape(-1)
