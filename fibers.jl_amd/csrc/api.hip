@@ -259,8 +259,11 @@ using ChunkFn = std::function<int(int chunk, int64_t v0, int64_t n, const float 
 
 int64_t pick_chunk(int64_t nrange, int rows_in, int rows_out) {
     const int rows = rows_in > rows_out ? rows_in : rows_out;
-    int64_t c = 131072;                                  // two 256-voxel work items per CU for the contraction kernel
-    while (c > 8192 && c * rows * 4 > (int64_t)192 << 20) c >>= 1;
+    // [r4] 262 144 voxels (four 256-voxel work items per CU for the contraction kernel) as long as a ring slot stays below 384 MB: fib_gqi_rec
+    // 140^3 x 270 takes 103 ms with chunks of 131 072 voxels, 90-93 ms with 262 144 (95 with 524 288: fewer chunks to overlap;
+    // tools/host_tier_sweep.py); the pinned ring is 3 x (rows_in + rows_out) x chunk x 4 bytes per device
+    int64_t c = 262144;
+    while (c > 8192 && c * rows * 4 > (int64_t)384 << 20) c >>= 1;
     if (const char *e = getenv("FIBERS_HOST_CHUNK")) { const long long v = atoll(e); if (v >= 1024) c = v / 4 * 4; }
     return c < nrange ? c : (nrange + 3) / 4 * 4;
 }
