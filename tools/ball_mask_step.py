@@ -4,7 +4,8 @@ import torch
 import fibers_jl_amd as fj
 from fibers_jl_amd import phantom
 dev = torch.device("cuda", 0); L = fj.lib()
-bval, bvec = phantom.scheme_gqi()
+rec = os.environ.get("KIND", "gqi")
+bval, bvec = phantom.scheme_gqi() if rec == "gqi" else phantom.scheme_dsi()
 dwi, _ = phantom.make_dwi_torch((140,140,140), bval, bvec, seed=3, device=dev)
 mask = phantom.ball_mask_torch((140,140,140), dev)
 kind = os.environ.get("MASK", "ball")
@@ -19,7 +20,7 @@ elif kind.startswith("blocks"):                      # every other block of B vo
     n = int(mask.sum().item()); idx = torch.arange(140**3, device=dev)
     mask = ((((idx - O) // B) % 2 == 0) & (idx >= O) & (idx < O + 2 * n)).to(torch.uint8)
 mask = mask.reshape(-1).contiguous()
-plan = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642, sigma=1.25, device=0)
+plan = fj.OdfPlan(rec, bval, bvec, fj.sphere_642, sigma=1.25, hann_width=32, device=0)
 out = fj.odf_rec_device(plan, dwi, mask, normalize=True)
 for _ in range(40): fj.odf_rec_device(plan, dwi, mask, out=out, normalize=True)
 torch.cuda.synchronize(); L.fib_profile_enable(1); L.fib_profile_reset()
