@@ -255,7 +255,53 @@ struct Rows { const float *in; float *out; int nrows; };   // a planar host arra
 
 // what a fit does with one chunk, all pointers on the device: din = the input rows back to back (row stride n), dmask = n
 // bytes, dout = the output rows back to back (row stride n)
-using ChunkFn = std::function<int(int chunk, int64_t v0, int64_t n, const float *din, const uint8_t *dmask, float *dout, hipStream_t st)>;
+using ChunkFn = std::function<int(int chunk, int64_t rel, int64_t n, const float *din, const uint8_t *dmask, float *dout, hipStream_t st)>;
+
+// [r4] The voxels of [vbeg, vend) inside the mask as runs.  With a mask that leaves a good part of the volume out, the host tier moves the
+// voxels inside only: the gather stage packs their runs densely into the pinned ring, the device works on a dense all-inside chunk (whose
+// rows are aligned whatever the mask looks like), the scatter stage puts the runs back and zero-fills the gaps.  A ball mask (36 % inside)
+// moves 36 % of the bytes over PCIe.  Voxels are independent (dti.jl:258, gqi.jl:132, dsi.jl:197): results do not depend on it.
+struct LiveMap {
+    std::vector<int64_t> start, len, off;                // run i: voxels [start, start + len), `off` voxels inside the mask before it
+    int64_t nlive = 0, vbeg = 0, vend = 0;
+    size_t run_at(int64_t l) const { return (size_t)(std::upper_bound(off.begin(), off.end(), l) - off.begin()) - 1; }   // the run that holds inside-voxel l
+};
+int build_live_map(CopyPool &pool, const void *mask, int mask_dtype, int64_t vbeg, int64_t vend, LiveMap &m) {
+    m = LiveMap{};
+    m.vbeg = vbeg; m.vend = vend;
+    const int64_t n = vend - vbeg;
+    if (n <= 0) return FIB_OK;
+    std::vector<uint8_t> m8((size_t)n);
+    const int64_t piece = 1 << 18;
+    std::atomic<int> merr{FIB_OK};
+    pool.run((int)fib::cdiv(n, piece), [&](int i) {
+        const int64_t a = (int64_t)i * piece, c = std::min<int64_t>(piece, n - a);
+        if (mask_convert_range(mask, mask_dtype, vbeg + a, c, false, m8.data() + a) != FIB_OK) merr = FIB_ERR_INVALID;
+    });
+    if (merr != FIB_OK) return fib::fail(FIB_ERR_INVALID, "unknown mask dtype %d", mask_dtype);
+    for (int64_t i = 0; i < n;) {
+        const uint8_t *p = (const uint8_t *)memchr(m8.data() + i, 1, (size_t)(n - i));      // (mask_convert_range writes 0 / 1)
+        if (!p) break;
+        const int64_t a = p - m8.data();
+        const uint8_t *q = (const uint8_t *)memchr(p, 0, (size_t)(n - a));
+        const int64_t b = q ? q - m8.data() : n;
+        m.start.push_back(vbeg + a); m.len.push_back(b - a); m.off.push_back(m.nlive);
+        m.nlive += b - a;
+        i = b;
+    }
+    return FIB_OK;
+}
+// a mask that keeps less than this share of a slab is worth the packing
+constexpr double LIVE_PACK_BELOW = 0.9;
+// the slab's LiveMap where packing pays (*use = &lm), NULL where the mask keeps (nearly) everything.  FIBERS_HOST_PACK=0: never.
+int live_map_for(DevState &d, const void *mask, int mask_dtype, int64_t v0, int64_t v1, LiveMap &lm, const LiveMap **use) {
+    *use = nullptr;
+    const char *e = getenv("FIBERS_HOST_PACK");
+    if ((e && e[0] == '0') || v1 <= v0) return FIB_OK;
+    RC(build_live_map(*d.pool, mask, mask_dtype, v0, v1, lm));
+    if ((double)lm.nlive < LIVE_PACK_BELOW * (double)(v1 - v0)) *use = &lm;
+    return FIB_OK;
+}
 
 int64_t pick_chunk(int64_t nrange, int rows_in, int rows_out) {
     const int rows = rows_in > rows_out ? rows_in : rows_out;
@@ -264,18 +310,29 @@ int64_t pick_chunk(int64_t nrange, int rows_in, int rows_out) {
     // tools/host_tier_sweep.py); the pinned ring is 3 x (rows_in + rows_out) x chunk x 4 bytes per device
     int64_t c = 262144;
     while (c > 8192 && c * rows * 4 > (int64_t)384 << 20) c >>= 1;
-    if (const char *e = getenv("FIBERS_HOST_CHUNK")) { const long long v = atoll(e); if (v >= 1024) c = v / 4 * 4; }
-    return c < nrange ? c : (nrange + 3) / 4 * 4;
+    if (const char *e = getenv("FIBERS_HOST_CHUNK")) { const long long v = atoll(e); if (v >= 1024) c = v / 32 * 32; }
+    return c < nrange ? c : std::max<int64_t>((nrange + 3) / 4 * 4, 4);
 }
 
 // voxels [vbeg, vend) of a volume of nvox voxels through device d.  Blocking.  The caller holds d.mu.
+// lm != NULL: only the voxels inside the mask travel (LiveMap); fn then sees dense chunks whose mask is all ones (padded with voxels
+// outside to a multiple of 32) and `rel` counts voxels inside the mask.  rel = the chunk's offset in that numbering (lm) or from vbeg.
 int run_chunks(DevState &d, int64_t vbeg, int64_t vend, int64_t nvox, const std::vector<Rows> &ins, const void *mask, int mask_dtype,
-               const std::vector<Rows> &outs, int64_t chunk, const ChunkFn &fn) {
+               const std::vector<Rows> &outs, int64_t chunk, const ChunkFn &fn, const LiveMap *lm = nullptr) {
     if (vend <= vbeg) return FIB_OK;
     FIB_HIP(hipSetDevice(d.device));
     int rin = 0, rout = 0;
     for (auto &r : ins) rin += r.nrows;
     for (auto &r : outs) rout += r.nrows;
+    const int64_t total = lm ? lm->nlive : vend - vbeg;
+    auto zero_rows = [&](int64_t a, int64_t b2) {         // every output row, voxels [a, b2)
+        if (b2 <= a) return;
+        std::vector<float *> rows;
+        for (auto &r : outs) for (int i = 0; i < r.nrows; i++) rows.push_back(r.out + (int64_t)i * nvox);
+        d.pool->run((int)rows.size(), [&](int i) { memset(rows[i] + a, 0, (size_t)(b2 - a) * 4); });
+    };
+    if (lm && total == 0) { zero_rows(vbeg, vend); return FIB_OK; }
+    if (lm) chunk = (chunk + 31) / 32 * 32;
     const size_t in_bytes = (size_t)rin * chunk * 4 + (size_t)chunk, out_bytes = (size_t)rout * chunk * 4;
     for (int b = 0; b < NBUF; b++) {
         RC(d.pin_in[b].ensure(in_bytes));
@@ -283,45 +340,98 @@ int run_chunks(DevState &d, int64_t vbeg, int64_t vend, int64_t nvox, const std:
         RC(d.dev_in[b].ensure(in_bytes));
         RC(d.dev_out[b].ensure(out_bytes));
     }
-    const int nchunks = (int)fib::cdiv(vend - vbeg, chunk);
+    const int nchunks = (int)fib::cdiv(total, chunk);
     std::atomic<int> err{FIB_OK};
+    // chunk k: `n` voxels that travel, `nd` voxels the device sees (lm: padded to a multiple of 32 so that its rows stay on cache lines)
+    auto span = [&](int k, int64_t &o0, int64_t &n, int64_t &nd) {
+        o0 = (int64_t)k * chunk; n = std::min<int64_t>(chunk, total - o0);
+        nd = lm ? (n + 31) / 32 * 32 : n;
+    };
+    // lm: the pieces of the caller's rows that make up inside-voxels [l0, l0 + n): f(voxel, position in the chunk, count, run index, piece starts its run)
+    auto for_pieces = [&](int64_t l0, int64_t n, const std::function<void(int64_t, int64_t, int64_t, size_t, bool)> &f) {
+        size_t ri = lm->run_at(l0);
+        int64_t done = 0;
+        while (done < n) {
+            const int64_t inrun = l0 + done - lm->off[ri];
+            const int64_t c = std::min<int64_t>(lm->len[ri] - inrun, n - done);
+            f(lm->start[ri] + inrun, done, c, ri, inrun == 0);
+            done += c; ri++;
+        }
+    };
     auto scatter = [&](int k) {                          // chunk k: pinned ring -> the caller's arrays
         const int b = k % NBUF;
-        const int64_t v0 = vbeg + (int64_t)k * chunk, n = std::min<int64_t>(chunk, vend - v0);
+        int64_t o0, n, nd;
+        span(k, o0, n, nd);
         if (hipEventSynchronize(d.e_out[b]) != hipSuccess) { err = fib::fail(FIB_ERR_HIP, "device-to-host copy of chunk %d failed", k); return; }
         std::vector<std::pair<float *, const float *>> rows;
         const float *src = reinterpret_cast<const float *>(d.pin_out[b].p);
-        for (auto &r : outs) for (int i = 0; i < r.nrows; i++) { rows.emplace_back(r.out + (int64_t)i * nvox + v0, src); src += n; }
-        d.pool->run((int)rows.size(), [&](int i) { memcpy(rows[i].first, rows[i].second, (size_t)n * 4); });
+        if (!lm) {
+            const int64_t v0 = vbeg + o0;
+            for (auto &r : outs) for (int i = 0; i < r.nrows; i++) { rows.emplace_back(r.out + (int64_t)i * nvox + v0, src); src += n; }
+            d.pool->run((int)rows.size(), [&](int i) { memcpy(rows[i].first, rows[i].second, (size_t)n * 4); });
+            return;
+        }
+        for (auto &r : outs) for (int i = 0; i < r.nrows; i++) { rows.emplace_back(r.out + (int64_t)i * nvox, src); src += nd; }
+        const bool last = k == nchunks - 1;
+        d.pool->run((int)rows.size(), [&](int i) {
+            float *row = rows[i].first;
+            const float *s = rows[i].second;
+            size_t rl = 0;
+            for_pieces(o0, n, [&](int64_t vox, int64_t pos, int64_t c, size_t ri, bool first) {
+                if (first) {                             // the gap in front of the run: voxels outside the mask read 0
+                    const int64_t g0 = ri == 0 ? lm->vbeg : lm->start[ri - 1] + lm->len[ri - 1];
+                    if (vox > g0) memset(row + g0, 0, (size_t)(vox - g0) * 4);
+                }
+                memcpy(row + vox, s + pos, (size_t)c * 4);
+                rl = ri;
+            });
+            if (last) {
+                const int64_t g0 = lm->start[rl] + lm->len[rl];
+                if (lm->vend > g0) memset(row + g0, 0, (size_t)(lm->vend - g0) * 4);
+            }
+        });
     };
     auto enqueue = [&](int k) -> int {                   // chunk k: gather, upload, compute, download (asynchronous from the upload on)
         const int b = k % NBUF;
-        const int64_t v0 = vbeg + (int64_t)k * chunk, n = std::min<int64_t>(chunk, vend - v0);
+        int64_t o0, n, nd;
+        span(k, o0, n, nd);
         // the pinned input buffer is free once the upload of chunk k - NBUF has completed
         if (k >= NBUF) FIB_HIP(hipEventSynchronize(d.e_in[b]));
         {
             std::vector<std::pair<float *, const float *>> rows;
             float *dst = reinterpret_cast<float *>(d.pin_in[b].p);
-            for (auto &r : ins) for (int i = 0; i < r.nrows; i++) { rows.emplace_back(dst, r.in + (int64_t)i * nvox + v0); dst += n; }
-            uint8_t *m8 = reinterpret_cast<uint8_t *>(d.pin_in[b].p) + (size_t)rin * n * 4;
+            uint8_t *m8 = reinterpret_cast<uint8_t *>(d.pin_in[b].p) + (size_t)rin * nd * 4;
             std::atomic<int> merr{FIB_OK};
-            d.pool->run((int)rows.size() + 1, [&](int i) {
-                if (i < (int)rows.size()) memcpy(rows[i].first, rows[i].second, (size_t)n * 4);
-                else if (mask_convert_range(mask, mask_dtype, v0, n, false, m8) != FIB_OK) merr = FIB_ERR_INVALID;
-            });
+            if (!lm) {
+                const int64_t v0 = vbeg + o0;
+                for (auto &r : ins) for (int i = 0; i < r.nrows; i++) { rows.emplace_back(dst, r.in + (int64_t)i * nvox + v0); dst += n; }
+                d.pool->run((int)rows.size() + 1, [&](int i) {
+                    if (i < (int)rows.size()) memcpy(rows[i].first, rows[i].second, (size_t)n * 4);
+                    else if (mask_convert_range(mask, mask_dtype, v0, n, false, m8) != FIB_OK) merr = FIB_ERR_INVALID;
+                });
+            } else {
+                for (auto &r : ins) for (int i = 0; i < r.nrows; i++) { rows.emplace_back(dst, r.in + (int64_t)i * nvox); dst += nd; }
+                d.pool->run((int)rows.size() + 1, [&](int i) {
+                    if (i == (int)rows.size()) { memset(m8, 1, (size_t)n); memset(m8 + n, 0, (size_t)(nd - n)); return; }
+                    float *o = rows[i].first;
+                    const float *row = rows[i].second;
+                    for_pieces(o0, n, [&](int64_t vox, int64_t pos, int64_t c, size_t, bool) { memcpy(o + pos, row + vox, (size_t)c * 4); });
+                    if (nd > n) memset(o + n, 0, (size_t)(nd - n) * 4);
+                });
+            }
             if (merr != FIB_OK) return fib::fail(FIB_ERR_INVALID, "unknown mask dtype %d", mask_dtype);
         }
-        const size_t ib = (size_t)rin * n * 4 + (size_t)n;
+        const size_t ib = (size_t)rin * nd * 4 + (size_t)nd;
         // device buffers of this ring slot: the kernels of chunk k - NBUF have read dev_in, its download has read dev_out
         if (k >= NBUF) { FIB_HIP(hipStreamWaitEvent(d.s_in, d.e_cmp[b], 0)); FIB_HIP(hipStreamWaitEvent(d.s_cmp, d.e_out[b], 0)); }
         FIB_HIP(hipMemcpyAsync(d.dev_in[b].p, d.pin_in[b].p, ib, hipMemcpyHostToDevice, d.s_in));
         FIB_HIP(hipEventRecord(d.e_in[b], d.s_in));
         FIB_HIP(hipStreamWaitEvent(d.s_cmp, d.e_in[b], 0));
-        RC(fn(k, v0, n, reinterpret_cast<const float *>(d.dev_in[b].p), reinterpret_cast<const uint8_t *>(d.dev_in[b].p) + (size_t)rin * n * 4,
+        RC(fn(k, o0, nd, reinterpret_cast<const float *>(d.dev_in[b].p), reinterpret_cast<const uint8_t *>(d.dev_in[b].p) + (size_t)rin * nd * 4,
               reinterpret_cast<float *>(d.dev_out[b].p), d.s_cmp));
         FIB_HIP(hipEventRecord(d.e_cmp[b], d.s_cmp));
         FIB_HIP(hipStreamWaitEvent(d.s_out, d.e_cmp[b], 0));
-        FIB_HIP(hipMemcpyAsync(d.pin_out[b].p, d.dev_out[b].p, (size_t)rout * n * 4, hipMemcpyDeviceToHost, d.s_out));
+        FIB_HIP(hipMemcpyAsync(d.pin_out[b].p, d.dev_out[b].p, (size_t)rout * nd * 4, hipMemcpyDeviceToHost, d.s_out));
         FIB_HIP(hipEventRecord(d.e_out[b], d.s_out));
         return FIB_OK;
     };
@@ -434,11 +544,14 @@ extern "C" int fib_dti_fit(int device, const float *dwi, int nx, int ny, int nz,
         slab(nvox, (int)ws.size(), i, v0, v1);
         fib_dti_plan *plan = nullptr;
         RC(dti_plan_for(d, bval, bvec, nvol, &plan));
-        return run_chunks(d, v0, v1, nvox, ins, mask, mask_dtype, outs, pick_chunk(v1 - v0, nvol, 16),
+        LiveMap lm;
+        const LiveMap *use = nullptr;
+        RC(live_map_for(d, mask, mask_dtype, v0, v1, lm, &use));
+        return run_chunks(d, v0, v1, nvox, ins, mask, mask_dtype, outs, pick_chunk(use ? use->nlive : v1 - v0, nvol, 16),
                           [&](int, int64_t, int64_t n, const float *din, const uint8_t *dm, float *b, hipStream_t st) -> int {
                               fib_dti_out dev{b, b + n, b + 2 * n, b + 3 * n, b + 4 * n, b + 7 * n, b + 10 * n, b + 13 * n, b + 14 * n, b + 15 * n};
                               return fibd_dti_fit(plan, din, dm, n, &dev, st);
-                          });
+                          }, use);
     });
 } FIB_API_CATCH
 
@@ -458,10 +571,13 @@ extern "C" int fib_adc_fit(int device, const float *dwi, int nx, int ny, int nz,
         slab(nvox, (int)ws.size(), i, v0, v1);
         fib_dti_plan *plan = nullptr;
         RC(dti_plan_for(d, bval, nullptr, nvol, &plan));
-        return run_chunks(d, v0, v1, nvox, ins, mask, mask_dtype, outs, pick_chunk(v1 - v0, nvol, 2),
+        LiveMap lm;
+        const LiveMap *use = nullptr;
+        RC(live_map_for(d, mask, mask_dtype, v0, v1, lm, &use));
+        return run_chunks(d, v0, v1, nvox, ins, mask, mask_dtype, outs, pick_chunk(use ? use->nlive : v1 - v0, nvol, 2),
                           [&](int, int64_t, int64_t n, const float *din, const uint8_t *dm, float *b, hipStream_t st) -> int {
                               return fibd_adc_fit(plan, din, dm, n, b, b + n, st);
-                          });
+                          }, use);
     });
 } FIB_API_CATCH
 
@@ -536,7 +652,7 @@ int odf_rec_host(int device, const OdfSpec &spec, const float *dwi, int nx, int 
     // per worker: qa of its slab stays on the device until the global odfmax is known; one {max, NaN flag} pair per chunk
     // (the buffer belongs to the CALL, not to the worker: the worker's lock is released between the two passes below, and another
     // thread's call on the same worker must not find -- or reallocate -- this call's qa)
-    struct Slab { int64_t v0 = 0, v1 = 0; float *qa = nullptr; std::vector<float> maxes; fib::DevBuf<float> keep; };
+    struct Slab { int64_t v0 = 0, v1 = 0, nq = 0; float *qa = nullptr; std::vector<float> maxes; fib::DevBuf<float> keep; LiveMap lm; const LiveMap *use = nullptr; };
     std::vector<Slab> slabs((size_t)nw);
     RC(for_each_worker(ws, [&](int i, DevState &d) -> int {
         Slab &sl = slabs[i];
@@ -545,22 +661,26 @@ int odf_rec_host(int device, const OdfSpec &spec, const float *dwi, int nx, int 
         if (nr <= 0) return FIB_OK;
         fib_odf_plan *plan = nullptr;
         RC(odf_plan_for(d, spec, &plan));
-        const int64_t chunk = pick_chunk(nr, nvol, rows_out);
-        const int nchunks = (int)fib::cdiv(nr, chunk);
+        RC(live_map_for(d, mask, mask_dtype, sl.v0, sl.v1, sl.lm, &sl.use));
+        const int64_t ntr = sl.use ? sl.use->nlive : nr;        // voxels that travel
+        const int64_t chunk = pick_chunk(ntr, nvol, rows_out);
+        const int nchunks = (int)fib::cdiv(ntr, chunk);
+        sl.nq = (ntr + 31) / 32 * 32 + 32;                      // a plane of the qa kept on the device (a packed chunk is padded to 32 voxels)
         FIB_HIP(hipSetDevice(d.device));
-        RC(sl.keep.alloc((size_t)3 * nr + (size_t)2 * nchunks));
+        RC(sl.keep.alloc((size_t)3 * sl.nq + (size_t)2 * std::max(nchunks, 1)));
         sl.qa = sl.keep.p;
-        float *dmax = sl.qa + 3 * nr;
+        float *dmax = sl.qa + 3 * sl.nq;
+        const int64_t nq = sl.nq;
         RC(run_chunks(d, sl.v0, sl.v1, nvox, ins, mask, mask_dtype, outs, chunk,
-                      [&](int k, int64_t v0, int64_t n, const float *din, const uint8_t *dm, float *b, hipStream_t st) -> int {
+                      [&](int k, int64_t rel, int64_t n, const float *din, const uint8_t *dm, float *b, hipStream_t st) -> int {
                           float *dpdf = pdf ? b : nullptr, *dodf = b + (size_t)(pdf ? nvol : 0) * n, *dpk = dodf + (size_t)nvert * n;
                           float *pk[3] = {dpk, dpk + 3 * n, dpk + 6 * n};
-                          float *q[3] = {sl.qa + (v0 - sl.v0), sl.qa + nr + (v0 - sl.v0), sl.qa + 2 * nr + (v0 - sl.v0)};
+                          float *q[3] = {sl.qa + rel, sl.qa + nq + rel, sl.qa + 2 * nq + rel};
                           // (one volume in pieces: the same peak-finder form for every piece, whatever the cut -- see FIB_ODF_SEPARATE_PEAKS)
                           return fibd_odf_rec(plan, din, dm, n, dpdf, dodf, pk, q, dmax + 2 * k, nvox % 4 != 0 ? FIB_ODF_SEPARATE_PEAKS : 0, st);
-                      }));
+                      }, sl.use));
         sl.maxes.resize((size_t)2 * nchunks);
-        FIB_HIP(hipMemcpy(sl.maxes.data(), dmax, sl.maxes.size() * sizeof(float), hipMemcpyDeviceToHost));
+        if (nchunks > 0) FIB_HIP(hipMemcpy(sl.maxes.data(), dmax, sl.maxes.size() * sizeof(float), hipMemcpyDeviceToHost));
         return FIB_OK;
     }));
     // odfmax = maximum(mean(odf, dims=4)) over the whole volume (gqi.jl:164, dsi.jl:263); maximum() propagates NaN
@@ -571,17 +691,40 @@ int odf_rec_host(int device, const OdfSpec &spec, const float *dwi, int nx, int 
             if (sl.maxes[c + 1] != 0.0f || sl.maxes[c] != sl.maxes[c]) anynan = true;
             else if (sl.maxes[c] > odfmax) odfmax = sl.maxes[c];
         }
+    // (a packed slab leaves voxels out: their ODF is 0 and so is their mean -- the unpacked pipeline's kernels count it the same way)
+    for (auto &sl : slabs) if (sl.use && sl.use->nlive < sl.v1 - sl.v0 && 0.0f > odfmax) odfmax = 0.0f;
     if (anynan) odfmax = __builtin_nanf("");
+    const float qa_outside = 0.0f / odfmax;              // qa of a voxel outside the mask after `qa ./= odfmax`: 0, or NaN when odfmax is 0 / NaN
     // qa[k] ./= odfmax (gqi.jl:166-168) on every device, then out
     return for_each_worker(ws, [&](int i, DevState &d) -> int {
         Slab &sl = slabs[i];
         const int64_t nr = sl.v1 - sl.v0;
         if (nr <= 0) return FIB_OK;
         FIB_HIP(hipSetDevice(d.device));
-        float *q[3] = {sl.qa, sl.qa + nr, sl.qa + 2 * nr};
-        RC(fibd_qa_normalize(q, nr, odfmax, d.s_cmp));
-        for (int k = 0; k < 3; k++) FIB_HIP(hipMemcpyAsync(qa[k] + sl.v0, q[k], (size_t)nr * sizeof(float), hipMemcpyDeviceToHost, d.s_cmp));
+        float *q[3] = {sl.qa, sl.qa + sl.nq, sl.qa + 2 * sl.nq};
+        const int64_t ntr = sl.use ? sl.use->nlive : nr;
+        if (ntr > 0) RC(fibd_qa_normalize(q, ntr, odfmax, d.s_cmp));
+        if (!sl.use) {
+            for (int k = 0; k < 3; k++) FIB_HIP(hipMemcpyAsync(qa[k] + sl.v0, q[k], (size_t)nr * sizeof(float), hipMemcpyDeviceToHost, d.s_cmp));
+            FIB_HIP(hipStreamSynchronize(d.s_cmp));
+            return FIB_OK;
+        }
+        // packed: the three planes come back dense and go to their runs; the gaps read 0
+        std::vector<float> hq((size_t)3 * std::max<int64_t>(ntr, 1));
+        for (int k = 0; k < 3 && ntr > 0; k++) FIB_HIP(hipMemcpyAsync(hq.data() + (size_t)k * ntr, q[k], (size_t)ntr * sizeof(float), hipMemcpyDeviceToHost, d.s_cmp));
         FIB_HIP(hipStreamSynchronize(d.s_cmp));
+        const LiveMap &lm = *sl.use;
+        d.pool->run(3, [&](int k) {
+            float *row = qa[k];
+            const float *src = hq.data() + (size_t)k * ntr;
+            int64_t g0 = lm.vbeg;
+            for (size_t r = 0; r < lm.start.size(); r++) {
+                std::fill(row + g0, row + lm.start[r], qa_outside);
+                memcpy(row + lm.start[r], src + lm.off[r], (size_t)lm.len[r] * 4);
+                g0 = lm.start[r] + lm.len[r];
+            }
+            std::fill(row + g0, row + lm.vend, qa_outside);
+        });
         return FIB_OK;
     });
 }

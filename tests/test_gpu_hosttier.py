@@ -201,6 +201,55 @@ def test_many_concurrent_dsi_calls_on_one_worker(fj):
     assert not errs, errs
 
 
+def test_packing_the_voxels_inside_the_mask_does_not_change_results(fj, monkeypatch):
+    """With a mask that leaves a good part of the volume out the host tier moves the voxels inside only (runs packed densely
+    into the pinned ring, put back and the gaps zero-filled behind the device).  Same results bit for bit as the unpacked
+    pipeline (FIBERS_HOST_PACK=0), for every fit, with several chunks per call: a ball, isolated voxels, a mask that keeps nothing,
+    one that keeps the first and the last voxel only, runs across chunk boundaries."""
+    from fibers_jl_amd import phantom
+    shape = (23, 19, 11)
+    nvox = int(np.prod(shape))
+    rng = np.random.default_rng(77)
+    ball = np.zeros(shape, np.uint8)
+    x, y, z = np.meshgrid(*[np.arange(n) - (n - 1) / 2 for n in shape], indexing="ij")
+    ball[(x / 10.0) ** 2 + (y / 8.0) ** 2 + (z / 4.5) ** 2 <= 1.0] = 1
+    ends = np.zeros(nvox, np.uint8); ends[0] = 1; ends[-1] = 1
+    masks = {"ball": ball, "sparse": (rng.random(shape) < 0.03).astype(np.uint8), "none": np.zeros(shape, np.uint8),
+             "ends": ends.reshape(shape, order="F"), "half": (np.arange(nvox) % 700 < 300).astype(np.uint8).reshape(shape, order="F")}
+    bg, gg = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3)
+    dg, _, _ = phantom.make_volume(shape, bg, gg, seed=5, crossing=True)
+    b2, g2 = phantom.scheme_dti(30, 3, 1000.0, seed=2)
+    d2, _, _ = phantom.make_volume(shape, b2, g2, seed=6, nonpositive_frac=0.01)
+    b5, g5 = phantom.scheme_dsi()
+    d5, _, _ = phantom.make_volume((9, 8, 7), b5, g5, seed=7)
+    monkeypatch.setenv("FIBERS_HOST_CHUNK", "1024")
+    for name, m in masks.items():
+        mk = fj.MRI(np.asfortranarray(m))
+        res = {}
+        for pack in ("0", "1"):
+            monkeypatch.setenv("FIBERS_HOST_PACK", pack)
+            gq = fj.gqi_rec(fj.MRI(dg, bg, gg), mk)
+            dt = fj.dti_fit(fj.MRI(d2, b2, g2), mk)
+            ad = fj.adc_fit(fj.MRI(d2, b2, g2), mk)
+            res[pack] = (gq, dt, ad)
+        (g0, t0, a0), (g1, t1, a1) = res["0"], res["1"]
+        _same_gqi(g0, g1)
+        for k in fj.dti.DTI_FIELDS:
+            assert np.array_equal(getattr(t0, k).vol, getattr(t1, k).vol, equal_nan=True), (name, k)
+        assert np.array_equal(a0[0].vol, a1[0].vol, equal_nan=True) and np.array_equal(a0[1].vol, a1[1].vol, equal_nan=True), name
+        dead = m.reshape(-1, order="F") == 0
+        assert not g1.odf.vol.reshape(nvox, -1, order="F")[dead].any(), name
+    m5 = (rng.random((9, 8, 7)) < 0.4).astype(np.uint8)
+    monkeypatch.setenv("FIBERS_HOST_CHUNK", "1024")
+    out = {}
+    for pack in ("0", "1"):
+        monkeypatch.setenv("FIBERS_HOST_PACK", pack)
+        out[pack] = fj.dsi_rec(fj.MRI(d5, b5, g5), fj.MRI(np.asfortranarray(m5)))
+    assert np.array_equal(out["0"].pdf.vol, out["1"].pdf.vol) and np.array_equal(out["0"].odf.vol, out["1"].odf.vol)
+    for k in range(3):
+        assert np.array_equal(out["0"].peak[k].vol, out["1"].peak[k].vol) and np.array_equal(out["0"].qa[k].vol, out["1"].qa[k].vol, equal_nan=True)
+
+
 def test_gqi_unaligned_volume_does_not_depend_on_chunks_or_device_set(fj, orc, monkeypatch):
     """nvox % 4 != 0 (13 x 11 x 9 = 1287): the same kernel choice for every chunk, so chunk size and device set do not change
     a bit (the fused peak kernel needs 16-byte aligned rows; the choice is made from the whole volume, not per chunk)"""

@@ -11,7 +11,11 @@ bval, bvec = phantom.scheme_gqi()
 d, _ = phantom.make_dwi_torch(SHAPE, bval, bvec, 2, dev, nfib=1)
 host = np.asfortranarray(d.cpu().numpy().T.reshape(SHAPE + (len(bval),), order="F")); del d
 torch.cuda.empty_cache()
-dwi = fj.MRI(host, bval, bvec); mask = fj.MRI(np.ones(SHAPE, np.uint8))
+mk = np.ones(SHAPE, np.uint8)
+if os.environ.get("MASK") == "ball":
+    mk = np.asfortranarray(phantom.ball_mask_torch(SHAPE, dev).reshape(SHAPE[::-1]).permute(2, 1, 0).cpu().numpy().astype(np.uint8))
+dwi = fj.MRI(host, bval, bvec); mask = fj.MRI(mk)
+print("mask keeps %.1f %% of the volume" % (100.0 * mk.mean()))
 L = _lib.lib(); bv, bg = _check_tables(dwi); m, mdt = _mask_checked(mask, SHAPE)
 sph = fj.sphere_642
 v = np.asfortranarray(sph.vertices, np.float32); f = np.asfortranarray(sph.faces, np.int32)
