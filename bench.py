@@ -723,6 +723,23 @@ def main():
                                           note="fib_gqi_rec on pageable host arrays (the call a Julia wrapper makes): gather -> pinned ring -> H2D || kernels "
                                                "|| D2H -> scatter; PCIe Gen5 x16, both directions busy.  e2e_pcie_ms: outputs touched before the call; "
                                                "e2e_pcie_first_touch_ms: outputs freshly zero-allocated (np.zeros = calloc), first touch inside the call")
+            # the same call with the ball mask (36 % of the volume inside): only the voxels inside cross PCIe (api.hip LiveMap)
+            try:
+                mb = np.ascontiguousarray(phantom.ball_mask_torch(shape, dev).reshape(-1).cpu().numpy().astype(np.uint8))
+                m8_keep = m8
+                m8 = mb
+                tb = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    _lib.check(call())
+                    tb.append(time.perf_counter() - t0)
+                m8 = m8_keep
+                extra["gqi_host_tier"]["ball_mask"] = dict(e2e_pcie_ms=min(tb[1:]) * 1e3, voxels_in_mask=int(mb.sum()),
+                                                           mvoxels_in_mask_per_s=float(mb.sum()) / min(tb[1:]) / 1e6,
+                                                           note="fib_gqi_rec, outputs touched before the call, ball mask: the host tier packs the runs of "
+                                                                "the voxels inside the mask into the pinned ring and zero-fills the gaps on the way back")
+            except Exception as e:                                                          # noqa: BLE001
+                extra["gqi_host_tier"]["ball_mask"] = dict(error=str(e))
             del host, odf_h, pk_h, qa_h
         except Exception as e:                                                              # noqa: BLE001
             extra["gqi_host_tier"] = dict(error=str(e))
