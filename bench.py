@@ -39,64 +39,113 @@ def prof_get(L, name):
 
 
 # ---- CPU baselines: the oracle (C/OpenMP restatement of the reference's CPU path with its z-slice / seed-chunk threading) on
-# the box's host cores, bounded samples of the same workloads -----------------------------------------------------------------------
-def _slab_baseline(run, label, cores, target_s, unit_per_slice):
-    t_probe = run(cores)
-    nz = int(max(cores, min(SHAPE[2], round(target_s / max(t_probe, 1e-3)) * cores)))
-    nz = min(SHAPE[2], nz)
-    t = run(nz) if nz != cores else t_probe
-    return dict(value=unit_per_slice * nz / t / 1e6, unit="Mvoxels/s", cores=cores, kind="port",
-                sample="%s on a %dx%dx%d slab, %.1f s" % (label, SHAPE[0], SHAPE[1], nz, t))
+# the box's host cores, bounded samples of the same workloads.  Every figure is the MEDIAN of NRUNS timed runs of >= RUN_S seconds
+# each (a run = one or more calls on the same resident sample) after an untimed warm-up call on that sample (thread pool, input
+# pages); the sample is sized from short probe calls: the whole 140^3 volume when a call on it stays within a few seconds, else
+# whole slices in multiples of the thread count (one z-slice per thread and trip: the reference's static z-slice threading,
+# dti.jl:258 / gqi.jl:132 / dsi.jl:197, stays balanced), else `cores` slices of fewer rows.  Outputs are allocated zero-filled
+# inside every call, as the reference's entry points do (`MRI(mask, n, Float32)` -> zeros, mri.jl:251-255). -------------------------
+RUN_S = 2.5
+NRUNS = 3
 
 
-def cpu_baseline_gqi(bval, bvec, sph, seed, target_s=15.0):
-    from oracle import oracle as orc
+def _host_volume(shape3, bval, bvec, seed, **kw):
+    """[nx, ny, nz, nvol] float32, Fortran order (== MRI.vol memory), generated on the GPU when there is one (NumPy takes
+    minutes for 3 GB) and copied to pageable host memory"""
+    import torch
     from fibers_jl_amd import phantom
-    cores = orc.max_threads()
-    nx, ny = SHAPE[0], SHAPE[1]
+    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    d, _ = phantom.make_dwi_torch(shape3, bval, bvec, seed=seed, device=dev, **kw)
+    h = d.cpu().numpy()
+    del d
+    return h.T.reshape(tuple(shape3) + (len(bval),), order="F")
 
-    def run(nz):
-        dwi, _, _ = phantom.make_volume((nx, ny, nz), bval, bvec, seed, noise_frac=0.02, crossing=True)
-        mask = np.ones((nx, ny, nz), np.uint8)
+
+def _sample_shape(target_vox, cores):
+    nx, ny, nz = SHAPE
+    if target_vox >= nx * ny * nz:
+        return (nx, ny, nz)
+    nzc = min(nz, cores)
+    if target_vox >= nx * ny * nzc:
+        return (nx, ny, int(min(nz, target_vox // (nx * ny)) // nzc) * nzc)
+    return (nx, int(max(1, target_vox // (nx * nzc))), nzc)
+
+
+def _median_runs(call, t_call):
+    """NRUNS runs, each = calls on the same sample until RUN_S seconds have passed -> (median seconds per call, the runs' seconds
+    per call, calls in the median run)"""
+    per, reps = [], []
+    for _ in range(NRUNS):
+        n, t0 = 0, time.perf_counter()
+        while True:
+            call()
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= RUN_S:
+                break
+        per.append(el / n)
+        reps.append(n)
+    k = int(np.argsort(per)[len(per) // 2])
+    return float(per[k]), per, reps[k]
+
+
+def _fit_baseline(fit, label, bval, bvec, seed, cores, **gen_kw):
+    nx, ny, nz = SHAPE
+    full = nx * ny * nz
+    shp = _sample_shape(nx * 2 * min(nz, cores), cores)
+    while True:                                                   # probe calls: grow the sample until a call takes >= 0.25 s (or it is the whole volume)
+        dwi = _host_volume(shp, bval, bvec, seed, **gen_kw)
+        mask = np.ones(shp, np.uint8)
+        fit(dwi, mask)                                            # (untimed: thread pool, first touch of the input)
         t0 = time.perf_counter()
-        orc.gqi_rec(dwi, mask, bval, bvec, sph.vertices, sph.faces, 1.25, nthreads=cores)
-        return time.perf_counter() - t0
-    return _slab_baseline(run, "gqi_rec oracle (C/OpenMP restatement of gqi.jl:109-171, z-slice threads), %d frames" % len(bval),
-                          cores, target_s, nx * ny)
+        fit(dwi, mask)
+        t = time.perf_counter() - t0
+        nv = shp[0] * shp[1] * shp[2]
+        if t >= 0.25 or nv >= full:
+            break
+        shp = _sample_shape(nv * min(16.0, 0.6 / max(t, 1e-4)), cores)
+        del dwi
+    want = _sample_shape(nv / t * RUN_S, cores)
+    if want != shp:
+        del dwi
+        shp = want
+        dwi = _host_volume(shp, bval, bvec, seed, **gen_kw)
+        mask = np.ones(shp, np.uint8)
+        t0 = time.perf_counter()
+        fit(dwi, mask)                                            # warm-up on the final sample
+        t = time.perf_counter() - t0
+    nv = shp[0] * shp[1] * shp[2]
+    med, per, reps = _median_runs(lambda: fit(dwi, mask), t)
+    return dict(value=nv / med / 1e6, unit="Mvoxels/s", cores=cores, kind="port",
+                runs_mvoxels_per_s=[nv / p / 1e6 for p in per], spread=(max(per) - min(per)) / med,
+                sample="%s on a %dx%dx%d sample of the volume, all-ones mask: median of %d runs of %d call(s), %.1f s per run, after a warm-up call"
+                       % (label, shp[0], shp[1], shp[2], NRUNS, reps, med * reps))
 
 
-def cpu_baseline_dti(bval, bvec, target_s=5.0):
+def cpu_baseline_gqi(bval, bvec, sph, seed):
     from oracle import oracle as orc
-    from fibers_jl_amd import phantom
     cores = orc.max_threads()
-    nx, ny = SHAPE[0], SHAPE[1]
-
-    def run(nz):
-        dwi, _, _ = phantom.make_volume((nx, ny, nz), bval, bvec, 2)
-        mask = np.ones((nx, ny, nz), np.uint8)
-        t0 = time.perf_counter()
-        orc.dti_fit(dwi, mask, bval, bvec, nthreads=cores)
-        return time.perf_counter() - t0
-    return _slab_baseline(run, "dti_fit oracle (dti.jl:221-335), %d frames" % len(bval), cores, target_s, nx * ny)
+    return _fit_baseline(lambda d, m: orc.gqi_rec(d, m, bval, bvec, sph.vertices, sph.faces, 1.25, nthreads=cores),
+                         "gqi_rec oracle (C/OpenMP restatement of gqi.jl:109-171, z-slice threads), %d frames" % len(bval),
+                         bval, bvec, seed, cores)
 
 
-def cpu_baseline_dsi(bval, bvec, sph, target_s=8.0):
+def cpu_baseline_dti(bval, bvec):
     from oracle import oracle as orc
-    from fibers_jl_amd import phantom
     cores = orc.max_threads()
-    nx, ny = SHAPE[0], SHAPE[1]
-
-    def run(nz):
-        dwi, _, _ = phantom.make_volume((nx, ny, nz), bval, bvec, 5)
-        mask = np.ones((nx, ny, nz), np.uint8)
-        t0 = time.perf_counter()
-        orc.dsi_rec(dwi, mask, bval, bvec, sph.vertices, sph.faces, 32, nthreads=cores)
-        return time.perf_counter() - t0
-    return _slab_baseline(run, "dsi_rec oracle (dsi.jl:171-270: 16^3 FFT + trilinear radial integration per voxel), %d frames" % len(bval),
-                          cores, target_s, nx * ny)
+    return _fit_baseline(lambda d, m: orc.dti_fit(d, m, bval, bvec, nthreads=cores),
+                         "dti_fit oracle (dti.jl:221-335), %d frames" % len(bval), bval, bvec, 2, cores, nfib=1)
 
 
-def cpu_baseline_stream(target_s=5.0):
+def cpu_baseline_dsi(bval, bvec, sph):
+    from oracle import oracle as orc
+    cores = orc.max_threads()
+    return _fit_baseline(lambda d, m: orc.dsi_rec(d, m, bval, bvec, sph.vertices, sph.faces, 32, nthreads=cores),
+                         "dsi_rec oracle (dsi.jl:171-270: 16^3 FFT + trilinear radial integration per voxel), %d frames" % len(bval),
+                         bval, bvec, 5, cores)
+
+
+def cpu_baseline_stream():
     """tracking on the analytic fibre field, ball mask, one sub-voxel offset: a z-range of seeds of the full 140^3 field"""
     from oracle import oracle as orc
     from fibers_jl_amd import phantom
@@ -104,21 +153,78 @@ def cpu_baseline_stream(target_s=5.0):
     ov = np.asfortranarray(phantom.fibre_field(*SHAPE).astype(np.float32))
     mask = phantom.ball_mask(*SHAPE)
     sub = np.array([[0.1, -0.2, 0.3]], np.float32)
+    res = {}
 
-    def run(nzs):
+    def seeds(nzs):
         seed = np.zeros(SHAPE, np.uint8, order="F")
         z0 = SHAPE[2] // 2 - nzs // 2
         seed[:, :, z0:z0 + nzs] = mask[:, :, z0:z0 + nzs]
+        return seed
+
+    def run(seed):
         t0 = time.perf_counter()
         r = orc.stream(ov, sub, mask=mask, seed=seed, nthreads=cores)
-        return time.perf_counter() - t0, int(r["xyz"].shape[0]), int(seed.sum())
-    t, npnt, ns = run(2)
-    nzs = int(max(2, min(SHAPE[2], round(2 * target_s / max(t, 1e-3)))))
-    if nzs > 2:
-        t, npnt, ns = run(nzs)
-    return dict(value=npnt / t / 1e6, unit="Mpoints/s", cores=cores, kind="port",
+        res["points"], res["seeds"] = int(r["xyz"].shape[0]), int(seed.sum())
+        return time.perf_counter() - t0
+    nzs = 4
+    while True:
+        sd = seeds(nzs)
+        run(sd)
+        t = run(sd)
+        if t >= 0.25 or nzs >= SHAPE[2]:
+            break
+        nzs = int(min(SHAPE[2], max(nzs + 1, nzs * min(16.0, 0.6 / max(t, 1e-4)))))
+    want = int(min(SHAPE[2], max(2, round(nzs * RUN_S / t))))
+    if want != nzs:
+        nzs = want
+        sd = seeds(nzs)
+        t = run(sd)
+    med, per, reps = _median_runs(lambda: run(sd), t)
+    return dict(value=res["points"] / med / 1e6, unit="Mpoints/s", cores=cores, kind="port",
+                runs_mpoints_per_s=[res["points"] / p / 1e6 for p in per], spread=(max(per) - min(per)) / med,
                 sample="stream oracle (stream.jl:625-790, contiguous seed chunks per thread) from %d seeds (%d z-slices of the ball mask) "
-                       "of the 140^3 field, %d points, %.1f s" % (ns, nzs, npnt, t))
+                       "of the 140^3 field, %d points per call: median of %d runs of %d call(s), %.1f s per run, after a warm-up call"
+                       % (res["seeds"], nzs, res["points"], NRUNS, reps, med * reps))
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) the way the driver does --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same flags>` --
+    as a child process, pass rank 0's JSON line through and return the launcher's exit code (non-zero if any rank failed or no line
+    came back).  Runs before torch is imported: the parent never initialises the GPU."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout:
+        if ln.startswith("{"):
+            line = ln.rstrip("\n")
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if rc != 0:
+        sys.stderr.write("bench.py: the %d-rank launch failed (exit code %d)\n" % (n, rc))
+        return rc
+    if line is None:
+        sys.stderr.write("bench.py: the %d-rank launch produced no result line\n" % n)
+        return 1
+    try:
+        got = json.loads(line).get("n_gpus")
+    except ValueError:
+        got = None
+    if got != n:
+        sys.stderr.write("bench.py: asked for %d ranks, the result line says n_gpus = %r\n" % (n, got))
+        return 1
+    print(line, flush=True)
+    return 0
 
 
 def main():
@@ -130,9 +236,22 @@ def main():
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
 
+    # ---- `--gpus N` means N ranks.  Under a launcher (WORLD_SIZE set: the driver's torch.distributed.run) this process is one of
+    # them.  Without one and N > 1 the N ranks are started here as CHILD processes of torch.distributed.run, before this process has
+    # imported torch or made any HIP call (a process that has touched the GPU must never exec another program on this pool), rank 0's
+    # JSON line is forwarded and a failing rank makes this process fail.  In every case world == --gpus or the run stops: a
+    # `--gpus 8` run can never print an `n_gpus: 1` line.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's rank count and --gpus must agree "
+                         "(run `python bench.py --gpus N` without a launcher, or torch.distributed.run --nproc-per-node N ... --gpus N)\n"
+                         % (args.gpus, world))
+        sys.exit(2)
+
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # test hook (1-GPU box): FIBERS_BENCH_BACKEND=gloo FIBERS_BENCH_ONE_DEVICE=1 runs N ranks on cuda:0 over gloo, to
@@ -746,7 +865,7 @@ def main():
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline_gqi(bval, bvec, sph, seed=3, target_s=15.0 if world == 1 else 6.0)    # (N > 1: a shorter sample; the other ranks wait)
+        cpu = cpu_baseline_gqi(bval, bvec, sph, seed=3)    # (rank 0 only; at N > 1 the other ranks wait at the barrier below)
         if not args.no_extra and world == 1:
             b2, g2 = phantom.scheme_dti(60, 4, 1000.0, seed=2)
             b5, g5 = phantom.scheme_dsi()
