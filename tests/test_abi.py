@@ -115,3 +115,154 @@ def test_struct_layouts_of_the_header_match_the_bindings(tmp_path):
     for st, fl in fields.items():
         want = "# layout: %s sizeof %d: %s" % (st, got[(st, "sizeof")], " ".join("%s@%d" % (f, got[(st, f)]) for f in fl))
         assert want in jl, "julia/FibersHIP.jl lacks or misstates: " + want
+
+
+# ---- the three statements of every prototype -- include/fibers_hip.h, the ctypes table, the Julia ccalls -- must agree ---------------
+def _c_class(t):
+    """C parameter / return type -> class: ptr, i32, i64, u64, f32, f64, void"""
+    t = re.sub(r"\b(const|struct|volatile|restrict)\b", " ", t).strip()
+    if "*" in t or "[" in t:
+        return "ptr"
+    t = " ".join(t.split())
+    base = t.split(" ")[0] if t.split(" ")[0] not in ("unsigned",) else t
+    table = {"void": "void", "int": "i32", "int32_t": "i32", "int64_t": "i64", "uint64_t": "u64", "float": "f32", "double": "f64",
+             "uint32_t": "u32", "size_t": "u64"}
+    assert base in table, "unclassified C type %r" % t
+    return table[base]
+
+
+def _header_prototypes():
+    src = open(os.path.join(ROOT, "include", "fibers_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    protos = {}
+    for m in re.finditer(r"(?:^|[;}\n])\s*((?:const\s+)?[A-Za-z_][A-Za-z0-9_]*\s*\**)\s*\b(fibd?_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", src):
+        ret, name, params = m.group(1), m.group(2), m.group(3).strip()
+        args = []
+        if params and params != "void":
+            for p in params.split(","):
+                p = p.strip()
+                if "*" in p or "[" in p:
+                    args.append("ptr")
+                else:
+                    args.append(_c_class(" ".join(p.split()[:-1])))          # drop the parameter name
+        protos[name] = (_c_class(ret), args)
+    return protos
+
+
+def _ctypes_class(t):
+    if t is None:
+        return "void"
+    if t in (C.c_void_p, C.c_char_p) or isinstance(t, type) and (issubclass(t, C._Pointer) or issubclass(t, C.Array)):
+        return "ptr"
+    return {C.c_int: "i32", C.c_int32: "i32", C.c_int64: "i64", C.c_uint64: "u64", C.c_float: "f32", C.c_double: "f64"}[t]
+
+
+def _julia_class(t):
+    t = t.strip()
+    if t.startswith(("Ptr{", "Ref{")) or t in ("Cstring",):
+        return "ptr"
+    return {"Cint": "i32", "Int32": "i32", "Int64": "i64", "UInt64": "u64", "Cfloat": "f32", "Float32": "f32", "Cdouble": "f64", "Cvoid": "void"}[t]
+
+
+def _split_top(s):
+    """split on commas that are not inside braces / parentheses"""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "{(":
+            depth += 1
+        elif ch in "})":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return [x.strip() for x in out if x.strip()]
+
+
+def _julia_ccalls(path):
+    """every `ccall((:name, libfibers), Ret, (T...), args...)` of a Julia file -> [(name, ret class, [arg classes], number of values passed)]"""
+    src = open(path).read()
+    calls = []
+    for m in re.finditer(r"ccall\(\(:(\w+),\s*libfibers\),\s*(\w+),\s*\(", src):
+        i, depth = m.end(), 1
+        while depth:                                                   # the argument-type tuple
+            depth += {"(": 1, ")": -1}.get(src[i], 0)
+            i += 1
+        types = _split_top(src[m.end():i - 1])
+        j, depth = i, 1                                                # the rest of the ccall: the values
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[j], 0)
+            j += 1
+        vals = _split_top(src[i:j - 1].lstrip(", \n"))
+        calls.append((m.group(1), _julia_class(m.group(2)), [_julia_class(t) for t in types], len(vals)))
+    return calls
+
+
+def test_ctypes_prototypes_match_the_header():
+    """name, arity, and the class of the return value and of every argument (pointer / 32- / 64-bit integer / float)"""
+    from fibers_jl_amd import _lib
+    hdr = _header_prototypes()
+    assert sorted(hdr) == sorted(_lib._PROTOS)
+    for name, (res, args) in _lib._PROTOS.items():
+        got = (_ctypes_class(res), [_ctypes_class(a) for a in args])
+        assert got == hdr[name], "%s: ctypes %s, header %s" % (name, got, hdr[name])
+
+
+def test_julia_ccalls_match_the_header_and_ctypes():
+    """julia/FibersHIP.jl cannot be executed here (no Julia in the image), so its ccalls are parsed: every call names an exported
+    function and states the header's return class, arity and per-argument class; as many values are passed as types are declared.
+    Dropping or retyping an argument on either side fails this test."""
+    from fibers_jl_amd import _lib
+    hdr = _header_prototypes()
+    calls = _julia_ccalls(os.path.join(ROOT, "julia", "FibersHIP.jl"))
+    assert len(calls) >= 14
+    seen = set()
+    for name, ret, args, nvals in calls:
+        assert name in hdr, "FibersHIP.jl calls %s, which include/fibers_hip.h does not declare" % name
+        assert (ret, args) == hdr[name], "%s: Julia ccall %s, header %s" % (name, (ret, args), hdr[name])
+        res_c, args_c = _lib._PROTOS[name]
+        assert (ret, args) == (_ctypes_class(res_c), [_ctypes_class(a) for a in args_c])
+        assert nvals == len(args), "%s: %d argument types, %d values" % (name, len(args), nvals)
+        seen.add(name)
+    # the reference's surface (SURVEY 8b) is bound
+    for need in ("fib_init", "fib_dti_fit", "fib_adc_fit", "fib_gqi_rec", "fib_dsi_rec", "fib_find_peaks_work", "fib_stream", "fib_tract_free", "fib_last_error"):
+        assert need in seen, need
+
+
+def test_the_parser_notices_a_dropped_or_retyped_argument(tmp_path):
+    """the check above is only worth something if it can fail"""
+    hdr = _header_prototypes()
+    src = open(os.path.join(ROOT, "julia", "FibersHIP.jl")).read()
+    bad1 = tmp_path / "dropped.jl"
+    bad1.write_text(src.replace("(Cint, Ptr{Float32}, Cint, Cint, Cint, Cint, Ptr{Cvoid}, Cint, Ptr{Float32}, Ptr{Float32}, Ref{FibDtiOut})",
+                                "(Cint, Ptr{Float32}, Cint, Cint, Cint, Ptr{Cvoid}, Cint, Ptr{Float32}, Ptr{Float32}, Ref{FibDtiOut})"))
+    got = {n: (r, a) for n, r, a, _ in _julia_ccalls(str(bad1))}
+    assert got["fib_dti_fit"] != hdr["fib_dti_fit"]
+    bad2 = tmp_path / "retyped.jl"
+    bad2.write_text(src.replace("Ptr{Int32}, Cint, Cfloat, Ptr{Float32}, Ptr{Ptr{Float32}}, Ptr{Ptr{Float32}})", "Ptr{Int32}, Cint, Cdouble, Ptr{Float32}, Ptr{Ptr{Float32}}, Ptr{Ptr{Float32}})"))
+    got = {n: (r, a) for n, r, a, _ in _julia_ccalls(str(bad2))}
+    assert got["fib_gqi_rec"] != hdr["fib_gqi_rec"]
+
+
+def test_reference_fixture_script_only_uses_names_the_reference_defines():
+    """julia/make_reference_fixtures.jl calls into the reference as `F.<name>`; every such name must be defined by the reference's
+    sources (function / struct / const).  Runs in the build container only: /root/reference does not exist on the GPU box."""
+    ref = "/root/reference/src"
+    if not os.path.isdir(ref):
+        pytest.skip("the reference checkout is not present")
+    used = set(re.findall(r"\bF\.([A-Za-z_][A-Za-z0-9_!]*)", open(os.path.join(ROOT, "julia", "make_reference_fixtures.jl")).read()))
+    assert len(used) >= 10
+    text = "\n".join(open(os.path.join(ref, f)).read() for f in os.listdir(ref) if f.endswith(".jl"))
+    for name in sorted(used):
+        n = re.escape(name)
+        e = r"(?![A-Za-z0-9_!])"                                       # (a name may end in `!`: no \b there)
+        defined = re.search(r"(?m)^\s*(?:function\s+%s%s|%s\s*\(.*\)\s*=|(?:mutable\s+)?struct\s+%s%s|const\s+(?:global\s+)?%s%s|%s\s*=)" % (n, e, n, n, e, n, e, n), text)
+        assert defined, "make_reference_fixtures.jl uses F.%s, which the reference does not define" % name
+    # and the drop-in module shadows exactly functions the reference exports
+    exports = set(re.findall(r"[A-Za-z_][A-Za-z0-9_!]*", " ".join(re.findall(r"(?ms)^export\s+(.*?)(?=^\S|\Z)", text))))
+    for fn in ("dti_fit", "adc_fit", "gqi_rec", "dsi_rec", "stream"):
+        assert fn in exports, fn

@@ -54,14 +54,23 @@ def main():
         L.fib_debug_clock_clear()
         L.fib_profile_enable(1)
         L.fib_profile_reset()
+        from fibers_jl_amd import energy as en          # the SMU's view of the same seconds: board energy, reported shader clock
+        e0 = en.energy_joules()
         t0 = time.perf_counter()
         n = 0
+        smu = []
         while time.perf_counter() - t0 < args.seconds:
             for _ in range(20):
                 step()
             n += 20
+            if n % 100 == 0:
+                torch.cuda.synchronize()
+                smu.append(en.sclk_mhz())
         torch.cuda.synchronize()
-        wall = (time.perf_counter() - t0) / n
+        t1 = time.perf_counter()
+        e1 = en.energy_joules()
+        wall = (t1 - t0) / n
+        smu = [v for v in smu if v]
         L.fib_profile_enable(0)
         ms, cnt = C.c_double(0), C.c_int64(0)
         L.fib_profile_get(b"odf_gemm", C.byref(ms), C.byref(cnt))
@@ -74,7 +83,11 @@ def main():
         res[label] = dict(kernel=names.get(kid, "?"), workgroups=int(len(live)), clock_ghz_median=float(np.median(ghz)) if len(live) else None,
                           clock_ghz_min=float(ghz.min()) if len(live) else None, clock_ghz_max=float(ghz.max()) if len(live) else None,
                           loop_us_median=float(np.median(live[:, 1]) / 100.0) if len(live) else None,
-                          kernel_ms_hipevent=ms.value / max(cnt.value, 1), step_ms_wall=wall * 1e3, steps=n)
+                          kernel_ms_hipevent=ms.value / max(cnt.value, 1), step_ms_wall=wall * 1e3, steps=n,
+                          smu_sclk_mhz_mean=float(np.mean(smu)) if smu else None, smu_sclk_mhz_min=float(np.min(smu)) if smu else None,
+                          smu_sclk_mhz_max=float(np.max(smu)) if smu else None,
+                          board_watts=(e1 - e0) / (t1 - t0) if e0 is not None and e1 is not None else None,
+                          joules_per_step=(e1 - e0) / n if e0 is not None and e1 is not None else None)
         if kid == 8 and len(live):                      # odf_dsi2_kernel: workgroups with an even index on their XCD run the ODF tile, odd ones the pdf tile
             wg = np.nonzero(buf[:, 1] > 0)[0]
             par = (wg >> 3) & 1
