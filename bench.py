@@ -371,7 +371,7 @@ def main():
     value = nvox * args.steps / dt / 1e6
 
     fmt = plan.format                                         # what the plan's kernels run, read back from the library (not from the environment)
-    fused = os.environ.get("FIBERS_ODF_UNFUSED") is None and fmt != "f32"
+    fused = fmt != "f32"                                      # (sphere_642, aligned volume, a split format: the fused peak scan runs)
     flops = 2.0 * nvert * nvol * nloc                      # algorithmic: 173 340 flop/voxel, this rank's voxels per launch
     gemm_avg_ms = gemm_ms / max(gemm_n, 1)
     achieved = flops / (gemm_avg_ms * 1e-3) / 1e12 if gemm_n else 0.0
@@ -386,7 +386,7 @@ def main():
     exact = fmt == "bf16x3"
     nprod = 6 if exact else 3
     if split:
-        # every f32 product = 3 piece products of two fp16 pieces per operand (default; FIBERS_ODF_EXACT=1: 6 products of three
+        # every f32 product = 3 piece products of two fp16 pieces per operand (default; format bf16x3: 6 products of three
         # bf16 pieces): the matrix cores execute nprod x the algorithmic flops of 320 of the 321 rows (K padded 270 -> 272).  Two
         # floors: executed flops / 2500 TFLOP/s and algorithmic bytes / 8 TB/s; the line's roofline is the larger one (with
         # 3 products: HBM, 0.83 ms against 0.57 ms), the other is reported beside it
@@ -485,8 +485,8 @@ def main():
             del dwi_s, mask_s, out_s
         except Exception as e:                                                      # noqa: BLE001
             extra["gqi_slab_1of8"] = dict(error=str(e))
-        # ---- the headline step with the other operand format (a plan built under FIBERS_ODF_EXACT picks it up): the exact 3 x bf16 split
-        # when the line runs the default, the two-piece fp16 form when the line itself was run with FIBERS_ODF_EXACT=1 ------------------
+        # ---- the headline step with the other operand format (the format is a plan parameter): the exact 3 x bf16 split
+        # when the line runs the default, the two-piece fp16 form when the line itself was run with FIBERS_ODF_FORMAT=bf16x3 ------------------
         try:
             plan_x = fj.OdfPlan("gqi", bval, bvec, sph, sigma=1.25, device=dev.index, format="fp16x2" if exact else "bf16x3")
             assert plan_x.format == ("fp16x2" if exact else "bf16x3")
@@ -501,7 +501,7 @@ def main():
                 odf_max_difference_of_voxel_max=dmax, first_peak_identical_fraction=same_pk,
                 note="the same step, same inputs, with %s; differences between the two formats' outputs relative to each voxel's ODF maximum "
                      "(tests: <= 3e-6, peaks identical except ties; both are ~1e-6 from a float64 contraction, tools/gemm_accuracy.py)"
-                     % ("three exact bf16 pieces per operand, 6 MFMAs per block and 16 frames (FIBERS_ODF_EXACT=1)" if not exact else "two fp16 pieces per operand, 3 MFMAs per block and 16 frames (the default)"))
+                     % ("three exact bf16 pieces per operand, 6 MFMAs per block and 16 frames (format bf16x3)" if not exact else "two fp16 pieces per operand, 3 MFMAs per block and 16 frames (the default)"))
             del out_x
             plan_x.close()
         except Exception as e:                                                      # noqa: BLE001
@@ -881,7 +881,7 @@ def main():
                                                    "f32 (f32 in, f32 accumulate, f32 out; inside the contraction every operand travels as two fp16 pieces = 23 significant "
                                                    "bits with a per-voxel power-of-two scale, 3 exact piece products per f32 product on the f16 matrix cores; measured "
                                                    "against a float64 contraction the result is closer than the exact 3xbf16 split's and than an f32 fma chain's: "
-                                                   "profiles/r03/gemm_accuracy.txt; FIBERS_ODF_EXACT=1 selects the exact split, timed in extra.gqi_exact_split)"), data="synthetic",
+                                                   "profiles/r03/gemm_accuracy.txt; format bf16x3 (FIBERS_ODF_FORMAT) selects the exact split, timed in extra.gqi_exact_split)"), data="synthetic",
                     config=dict(workload="gqi_rec + find_peaks + qa normalisation, ONE %dx%dx%d x 270-frame volume "
                                          "(18 x b=5 + 84 dirs x {1000,2000,3000}), sphere_642, mask = all ones" % shape,
                                 voxels=nvox, voxels_per_gpu=nloc, frames=nvol, odf_vertices=nvert,

@@ -205,7 +205,7 @@ HostCtx &ctx() { static HostCtx *c = new HostCtx(); return *c; }
 int copy_threads(int nworkers) {
     unsigned hw = std::thread::hardware_concurrency();
     if (hw == 0) hw = 8;
-    if (const char *e = getenv("FIBERS_COPY_THREADS")) { const int t = atoi(e); if (t >= 1) return t; }
+    if (const char *e = fib::env("FIBERS_COPY_THREADS")) { const int t = atoi(e); if (t >= 1) return t; }
     int t = (int)hw / (2 * (nworkers > 0 ? nworkers : 1));
     return t < 2 ? 2 : (t > 16 ? 16 : t);                // 8-16 threads reach the host's copy bandwidth (tools/probes/host_probe.hip)
 }
@@ -296,7 +296,7 @@ constexpr double LIVE_PACK_BELOW = 0.9;
 // the slab's LiveMap where packing pays (*use = &lm), NULL where the mask keeps (nearly) everything.  FIBERS_HOST_PACK=0: never.
 int live_map_for(DevState &d, const void *mask, int mask_dtype, int64_t v0, int64_t v1, LiveMap &lm, const LiveMap **use) {
     *use = nullptr;
-    const char *e = getenv("FIBERS_HOST_PACK");
+    const char *e = fib::env("FIBERS_HOST_PACK");
     if ((e && e[0] == '0') || v1 <= v0) return FIB_OK;
     RC(build_live_map(*d.pool, mask, mask_dtype, v0, v1, lm));
     if ((double)lm.nlive < LIVE_PACK_BELOW * (double)(v1 - v0)) *use = &lm;
@@ -310,7 +310,7 @@ int64_t pick_chunk(int64_t nrange, int rows_in, int rows_out) {
     // tools/host_tier_sweep.py); the pinned ring is 3 x (rows_in + rows_out) x chunk x 4 bytes per device
     int64_t c = 262144;
     while (c > 8192 && c * rows * 4 > (int64_t)384 << 20) c >>= 1;
-    if (const char *e = getenv("FIBERS_HOST_CHUNK")) { const long long v = atoll(e); if (v >= 1024) c = v / 32 * 32; }
+    if (const char *e = fib::env("FIBERS_HOST_CHUNK")) { const long long v = atoll(e); if (v >= 1024) c = v / 32 * 32; }
     return c < nrange ? c : std::max<int64_t>((nrange + 3) / 4 * 4, 4);
 }
 

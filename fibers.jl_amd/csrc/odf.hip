@@ -99,13 +99,13 @@ struct fib_odf_plan {
 namespace {
 
 
-// FIB_ODF_FORMAT_DEFAULT -> what the environment asks for (FIBERS_ODF_GEMM=f32, FIBERS_ODF_EXACT=1), else two fp16 pieces
+// FIB_ODF_FORMAT_DEFAULT -> what the environment asks for (FIBERS_ODF_FORMAT = fp16x2 | bf16x3 | f32), else two fp16 pieces
 int resolve_format(int format) {
     if (format != FIB_ODF_FORMAT_DEFAULT) return format;
-    const char *e = getenv("FIBERS_ODF_GEMM");
+    const char *e = fib::env("FIBERS_ODF_FORMAT");
     if (e && (!strcmp(e, "f32") || !strcmp(e, "F32"))) return FIB_ODF_FORMAT_F32;
-    const char *ex = getenv("FIBERS_ODF_EXACT");
-    return (ex && ex[0] != '0' && ex[0] != 0) ? FIB_ODF_FORMAT_BF16X3 : FIB_ODF_FORMAT_FP16X2;
+    if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "BF16X3"))) return FIB_ODF_FORMAT_BF16X3;
+    return FIB_ODF_FORMAT_FP16X2;
 }
 
 int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *faces, int nfaces,
@@ -231,8 +231,7 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
         // folded DSI on sphere_642: ODF tile in the fused scan's row order + pdf tile (odf_dsi2_kernel)
         static const int mbbs[] = {5, 7, 9};
         for (int mbb : mbbs) if (p->MBB == 0 && p->gRow0 <= mbb * 32) p->MBB = mbb;
-        p->dsi2_shape = faces && p->folded && p->gRow0 > 0 && p->MBB > 0 && M == p->gRow0 + FQ_NV && p->scale_frame >= 0 && p->Kpad <= 512 && nst >= 2 &&
-                        !getenv("FIBERS_DSI_THREE_TILES");
+        p->dsi2_shape = faces && p->folded && p->gRow0 > 0 && p->MBB > 0 && M == p->gRow0 + FQ_NV && p->scale_frame >= 0 && p->Kpad <= 512 && nst >= 2;
         if (p->dsi2_shape) {
             const int r0 = p->gRow0;
             build_one(10, 1, [&](int r) { return r < FQ_NV ? r0 + fib_f642_pos_vertex[r] : -1; }, A3, AX);
@@ -270,7 +269,7 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
             if (u >= 0) nbr[(size_t)v * p->deg_pad + d] = u;
         }
     // the default tessellation has a scan specialised at compile time (sphere642_scan.inc): use it iff the tables agree
-    p->is_s642 = p->nvert == FIB_S642_NVERT && p->maxdeg <= FIB_S642_DEG && !getenv("FIBERS_PEAKS_GENERIC");
+    p->is_s642 = p->nvert == FIB_S642_NVERT && p->maxdeg <= FIB_S642_DEG;
     for (int v = 0; v < p->nvert && p->is_s642; v++) {
         std::vector<int32_t> mine, ref;
         for (int d = 0; d < p->maxdeg; d++) { const int32_t u = nbr32[(size_t)v * p->maxdeg + d]; if (u >= 0) mine.push_back(u); }
@@ -336,7 +335,7 @@ extern "C" int fib_odf_plan_format(const fib_odf_plan *plan) try {
 // 1 = aligned groups of 32 voxels ("octets" of quads: a wave's 128-byte row segments are whole cache lines), 0 = aligned groups of 4
 extern "C" int fib_odf_plan_list_unit(const fib_odf_plan *plan, void *stream) try {
     FIB_CHECK(plan != nullptr, FIB_ERR_INVALID, "plan is NULL");
-    { const char *e = getenv("FIBERS_ODF_LIST"); if (e && (e[0] == 'q' || e[0] == 'o')) return e[0] == 'o' ? 1 : 0; }
+    { const char *e = fib::ab_env("FIBERS_ODF_LIST"); if (e && (e[0] == 'q' || e[0] == 'o')) return e[0] == 'o' ? 1 : 0; }
     if (!plan->compact_mode.p) return 1;                       // (no call yet)
     fib::DeviceGuard guard;
     { const int rcd = fib::use_device(plan->device); if (rcd != FIB_OK) return rcd; }
@@ -600,7 +599,8 @@ int launch_mask_compact(const fib_odf_plan *plan, const uint8_t *mask, int64_t n
         }
         c.oct_bits = plan->compact_oct.p; c.oct_words = (int)noct;
     }
-    { const char *e = getenv("FIBERS_ODF_LIST"); c.force = !e ? -1 : (e[0] == 'q' ? 0 : (e[0] == 'o' ? 1 : -1)); }   // quads | octets | auto
+    { const char *e = fib::ab_env("FIBERS_COMPACT_UNKNOWN"); c.dbg_unknown = e ? atoi(e) : 0; }
+    { const char *e = fib::ab_env("FIBERS_ODF_LIST"); c.force = !e ? -1 : (e[0] == 'q' ? 0 : (e[0] == 'o' ? 1 : -1)); }   // quads | octets | auto
     fib::ProfScope prof("mask_compact", st);
     // with outputs to clear: helpers behind the compacting workgroups, so that a volume that is mostly outside the mask is cleared by the whole chip
     const int grid = nchunks + (z ? 256 : 0);
@@ -634,8 +634,8 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
     ga.At = plan->At.p; ga.At3 = (plan->split_bf16 && nvox <= ((int64_t)1 << 26)) ? plan->At3.p : nullptr; ga.S = dwi;
     ga.Aextra = plan->Aextra.p; ga.h2 = plan->h2 ? 1 : 0; ga.h2_inv_sa = 1.0f / plan->h2_sa;
 #ifdef FIB_CLOCK_STAMP
-    { const char *pi = getenv("FIBERS_PHASE_ITEM"); ga.phase_item = pi ? atoi(pi) : 2; }
-    { const char *pw = getenv("FIBERS_PHASE_WG"); ga.phase_wg = pw ? atoi(pw) : 8; }        // (odf_dsi2_kernel: 8 = an ODF-tile workgroup, 136 = a pdf-tile one)
+    { const char *pi = fib::ab_env("FIBERS_PHASE_ITEM"); ga.phase_item = pi ? atoi(pi) : 2; }
+    { const char *pw = fib::ab_env("FIBERS_PHASE_WG"); ga.phase_wg = pw ? atoi(pw) : 8; }        // (odf_dsi2_kernel: 8 = an ODF-tile workgroup, 136 = a pdf-tile one)
 #endif
     ga.vec_ok = (nvox % 4 == 0 && ((uintptr_t)odf & 15) == 0 && (pdf == nullptr || ((uintptr_t)pdf & 15) == 0)) ? 1 : 0; ga.vidx = plan->live_vox.p; ga.nlive = plan->live_counts.p; ga.mask = mask; ga.effbits = plan->effbits.p;
     ga.out0 = pdf; ga.out1 = odf; ga.nvox = nvox;
@@ -645,7 +645,7 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         ga.fix_count = plan->live_counts.p + 2; ga.fix_list = plan->inf_list.p; ga.fix_cap = (int)std::min<int64_t>(nvox, INT32_MAX);
     }
     // sphere_642 GQI plans: find_peaks! runs on the contraction kernel's accumulators (gemm3_epilogue_fused)
-    const bool sep = (flags & FIB_ODF_SEPARATE_PEAKS) != 0 || getenv("FIBERS_ODF_UNFUSED") != nullptr;
+    const bool sep = (flags & FIB_ODF_SEPARATE_PEAKS) != 0;
     const bool fuse = plan->fused && ga.At3 != nullptr && ga.vec_ok && !sep;
     {
         int rcm = plan->mean_hi.ensure((size_t)nvox + 4);
@@ -658,13 +658,13 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         for (int k = 0; k < 3; k++) { ga.peak[k] = peak[k]; ga.qa[k] = qa[k]; }
         ga.verts = plan->verts.p; ga.maxenc = plan->maxenc.p; ga.mean_hi = plan->mean_hi.p;
         ga.redo_count = plan->live_counts.p + 3; ga.redo_list = plan->redo_list.p; ga.redo_cap = (int)std::min<int64_t>(nvox, INT32_MAX);
-        { const char *pa = getenv("FIBERS_ODF_ANTI"); ga.anti = pa ? atoi(pa) : 3; }   // bit 0: anti-phase wave halves, bit 1: s_setprio around the MFMA block (default both; 0 = neither)
+        { const char *pa = fib::ab_env("FIBERS_ODF_ANTI"); ga.anti = pa ? atoi(pa) : 3; }   // bit 0: anti-phase wave halves, bit 1: s_setprio around the MFMA block (default both; 0 = neither)
         return FIB_OK;
     };
     if (fuse) { int rcf = setup_fused(); if (rcf != FIB_OK) return rcf; }
     ga.K = plan->gK; ga.Kpad = plan->Kpad; ga.M = plan->gM; ga.nrow0 = plan->gRow0; ga.ntile_m = plan->ntile_m;
     const bool fold_ok = plan->folded && ga.At3 != nullptr && plan->Kpad <= FKMAX && plan->scale_frame_raw >= 0 &&
-                         (int64_t)plan->fold_span_max * nvox * 4 < (int64_t)0xE0000000ll && !getenv("FIBERS_DSI_UNFUSED");
+                         (int64_t)plan->fold_span_max * nvox * 4 < (int64_t)0xE0000000ll;
     const bool fuse_fold = fold_ok && plan->MB <= FOLD_MB_MAX;
     // folded DSI on sphere_642: one launch of odf_dsi2_kernel does contraction, scale, ODF / pdf rows and find_peaks!
     const bool dsi2 = plan->dsi2 && fold_ok && ga.vec_ok && !sep;
@@ -714,10 +714,10 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
             // partner's item counter), so the samples are fetched from HBM once and the second reader finds them in the XCD's L2 --
             // [r4] for any split, not only 16 | 16 (FIBERS_DSI_NA=<n> sets the split, FIBERS_DSI_PAIR=0 switches the waiting off:
             // tools/dsi_na_sweep.py).
-            const char *ena = getenv("FIBERS_DSI_NA");
+            const char *ena = fib::ab_env("FIBERS_DSI_NA");
             if (ena) na = atoi(ena);
             g.dsi_na = std::max(1, std::min(nslot - 1, na));
-            const char *epair = getenv("FIBERS_DSI_PAIR");
+            const char *epair = fib::ab_env("FIBERS_DSI_PAIR");
             if (plan->pair_flags.p && nslot <= 32 && !(epair && epair[0] == '0')) g.pair_flags = plan->pair_flags.p;   // (the counters were cleared by mask_compact_kernel)
             switch (plan->MBB) {
                 case 5: if (g.h2) hipLaunchKernelGGL((odf_dsi2_kernel<5, true>), dim3(pg), dim3(512), 0, s, g); else hipLaunchKernelGGL((odf_dsi2_kernel<5, false>), dim3(pg), dim3(512), 0, s, g); break;

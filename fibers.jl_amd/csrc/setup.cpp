@@ -24,6 +24,9 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// the library's only reader of the process environment (common.h lists the names)
+const char *env(const char *name) { return std::getenv(name); }
+
 int fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);

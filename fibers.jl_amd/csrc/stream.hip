@@ -90,13 +90,6 @@ struct TraceArgs {
     float search_cosang;
     const int32_t *cell_start;  // [G^3 + 1]: the table is sorted by direction cell (x fastest); entries of cell i = [cell_start[i], cell_start[i+1])
     int G;                      // direction grid: cell (floor((v + 1) / h)) per axis, h = 2 / G
-    // second pass of the two-pass scheme (MODE 2): the lines are traced again and written where they belong
-    const Pair *excl, *block_off;   // exclusive scan of the kept lines / points (scan_block_kernel, scan_totals_kernel)
-    int32_t *out_npts;
-    int64_t *out_seed;
-    float *out_xyz;
-    int len_min, trk;
-    float vs[3];
 };
 
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -145,33 +138,18 @@ __device__ __forceinline__ int lcm_match_edge(int dx, int dy, int dz, int sd0, i
     return 0;
 }
 
-// MODE 0: points into the slot-major scratch + counts (packed later by stream_pack_kernel);  MODE 1: counts only;
-// MODE 2: the counts and their scan are known: trace again, every point goes straight to its place in the packed output
-// (forward points descending from nf-1, backward points ascending from nf: stream.jl:652), no scratch at all.
+// The points go into the slot-major scratch and the per-line counts beside them; the scan + pack kernels below give every kept
+// line its place.  ([r5] the two-pass form -- count, scan, trace again straight into the output -- was as slow as the copy it
+// saved (a trace without stores takes 0.50 of the 0.53 ms) and has been removed: profiles/r04/negative_results.txt.)
 // TRI (params.interp = 1, not in the reference): the direction followed is the trilinear blend of the eight voxels around the
 // tentative position instead of the nearest voxel's vector -- see the TRI block below for the exact definition.
-template <int NVEC, bool LCM = false, int MODE = 0, bool TRI = false>   // NVEC > 0: compile-time vector count; 0: runtime
+// WIDE: 64-bit voxel indices and gather offsets, for orientation fields of 2^28 vectors (4 GiB) or more -- the microscopy
+// regime's whole-slide sections (stream.jl:83,147-172); chosen at launch, bit-identical to the 32-bit form on small fields.
+template <int NVEC, bool LCM = false, bool TRI = false, bool WIDE = false>   // NVEC > 0: compile-time vector count; 0: runtime
 __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= a.nlines) return;
-    float *ofw = nullptr, *obw = nullptr;
-    if (MODE == 2) {
-        const int n = a.npts[li];
-        if (n < a.len_min) return;                                // stream.jl:769
-        const int nf0 = a.nfwd[li] & 0x3fffffff;
-        const Pair e = a.excl[li], bo = a.block_off[li / TRACE_SCAN_B];
-        const int64_t pt = e.pts + bo.pts, l0 = e.lines + bo.lines;
-        int64_t p0;
-        if (a.trk) {
-            reinterpret_cast<int32_t *>(a.out_xyz)[l0 + 3 * pt] = n;                  // write(io, Int32(npts)), trk.jl:472
-            p0 = pt * 3 + l0 + 1;
-        } else {
-            a.out_npts[l0] = n; a.out_seed[l0] = a.line0 + li;
-            p0 = pt * 3;
-        }
-        ofw = a.out_xyz + p0 + (int64_t)(nf0 - 1) * 3;
-        obw = a.out_xyz + p0 + (int64_t)nf0 * 3;
-    }
+    typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type vox_t;
     const int nvec = NVEC > 0 ? NVEC : a.nvec;
     const int64_t line = a.line0 + li;
     const int64_t iseed = line / a.nsub;
@@ -193,7 +171,7 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
     // 6.4 -> 6.0 ms; one vector (C4): nothing (tools/stream_c5_times.py, stream_kernel_times.py).
     constexpr int NCV = NVEC > 0 ? NVEC : 1;
     float4 cvec[NCV];
-    uint32_t cvox = 0xffffffffu;
+    vox_t cvox = ~(vox_t)0;
     float px = p0x, py = p0y, pz = p0z;
     float vx, vy, vz;
     {
@@ -208,8 +186,15 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
             const float nxp = px + vx * a.step, nyp = py + vy * a.step, nzp = pz + vz * a.step;   // stream.jl:512
             const float rx = rintf(nxp), ry = rintf(nyp), rz = rintf(nzp);                        // stream.jl:514
             if (!(rx >= 1.0f && rx <= fnx && ry >= 1.0f && ry <= fny && rz >= 1.0f && rz <= fnz)) return true;   // :517
-            const uint32_t vox = (uint32_t)(((int)rx - 1) + a.nx * (((int)ry - 1) + a.ny * ((int)rz - 1)));   // nvox < 2^28 / nvec
-            const float4 *cand = reinterpret_cast<const float4 *>(fbase + (size_t)(vox * (uint32_t)(nvec * 16)));
+            vox_t vox;
+            const float4 *cand;
+            if constexpr (WIDE) {
+                vox = (uint64_t)(((int64_t)rx - 1) + (int64_t)a.nx * (((int64_t)ry - 1) + (int64_t)a.ny * ((int64_t)rz - 1)));
+                cand = reinterpret_cast<const float4 *>(fbase + vox * (uint64_t)(nvec * 16));
+            } else {
+                vox = (uint32_t)(((int)rx - 1) + a.nx * (((int)ry - 1) + a.ny * ((int)rz - 1)));   // nvox < 2^28 / nvec: the byte offset fits 32 bits
+                cand = reinterpret_cast<const float4 *>(fbase + (size_t)(vox * (uint32_t)(nvec * 16)));
+            }
             float bx = 0.0f, by = 0.0f, bz = 0.0f, bestc = 0.0f, besta = 0.0f;
             int best = 0;
             if constexpr (NVEC > 0) {
@@ -250,15 +235,19 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
                 const bool xl = gx0 >= 1.0f && gx0 <= fnx, xh = gx0 + 1.0f >= 1.0f && gx0 + 1.0f <= fnx;
                 const bool yl = gy0 >= 1.0f && gy0 <= fny, yh = gy0 + 1.0f >= 1.0f && gy0 + 1.0f <= fny;
                 const bool zl = gz0 >= 1.0f && gz0 <= fnz, zh = gz0 + 1.0f >= 1.0f && gz0 + 1.0f <= fnz;
-                const int cbase = ((int)gx0 - 1) + a.nx * (((int)gy0 - 1) + a.ny * ((int)gz0 - 1));
+                const int64_t cbase = ((int64_t)gx0 - 1) + (int64_t)a.nx * (((int64_t)gy0 - 1) + (int64_t)a.ny * ((int64_t)gz0 - 1));
                 const float ax0 = 1.0f - tx, ay0 = 1.0f - ty, az0 = 1.0f - tz;
 #pragma unroll
                 for (int c = 0; c < 8; c++) {
                     const int cx = c & 1, cy = (c >> 1) & 1, cz = c >> 2;
                     if (!((cx ? xh : xl) && (cy ? yh : yl) && (cz ? zh : zl))) continue;
                     const float tc = ((cx ? tx : ax0) * (cy ? ty : ay0)) * (cz ? tz : az0);
-                    const uint32_t cv = (uint32_t)(cbase + cx + a.nx * (cy + a.ny * cz));
-                    const float4 *cc = reinterpret_cast<const float4 *>(fbase + (size_t)(cv * (uint32_t)(nvec * 16)));
+                    const float4 *cc;
+                    if constexpr (WIDE) cc = reinterpret_cast<const float4 *>(fbase + (uint64_t)(cbase + cx + (int64_t)a.nx * (cy + a.ny * cz)) * (uint64_t)(nvec * 16));
+                    else {
+                        const uint32_t cv = (uint32_t)((int)cbase + cx + a.nx * (cy + a.ny * cz));
+                        cc = reinterpret_cast<const float4 *>(fbase + (size_t)(cv * (uint32_t)(nvec * 16)));
+                    }
                     float ux = 0.0f, uy = 0.0f, uz = 0.0f, uc = 0.0f, ua = 0.0f;
 #pragma unroll
                     for (int k = 0; k < nvec; k++) {
@@ -340,17 +329,9 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
                 }
                 isdiff = ivec != ivec_ang;                        // :538
             }
-            if (MODE == 2) {
-                float *d = pass == 0 ? ofw : obw;
-                if (a.trk) {                                      // T.((xyz .+ .5) .* voxel_size), Float64 arithmetic (trk.jl:475-476)
-                    d[0] = (float)(((double)px + 0.5) * (double)a.vs[0]); d[1] = (float)(((double)py + 0.5) * (double)a.vs[1]);
-                    d[2] = (float)(((double)pz + 0.5) * (double)a.vs[2]);
-                } else store_point(d, px, py, pz);
-                if (pass == 0) ofw -= 3; else obw += 3;
-            } else if (MODE == 0) {   // push!/prepend! of pos_now (stream.jl:660): the slot of this trip
-                // LCM runs: the method-difference flag of the point (stream.jl:666) rides in the sign bit of x (x > 0)
-                store_point(dcur, (LCM && isdiff) ? -px : px, py, pz);
-            }
+            // push!/prepend! of pos_now (stream.jl:660): the slot of this trip
+            // LCM runs: the method-difference flag of the point (stream.jl:666) rides in the sign bit of x (x > 0)
+            store_point(dcur, (LCM && isdiff) ? -px : px, py, pz);
             emitted = true;
             npts++;
             if (pass == 0) nf++;
@@ -385,7 +366,7 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
     // point j in slot nf + gap + j, gap = 1 if the forward pass ended on a trip that emitted nothing (a failed step).
     for (;;) {
         const bool ended = step();
-        if (MODE == 0) dcur += slot_floats;
+        dcur += slot_floats;
         if (ended) {
             if (pass == 1) break;
             pass = 1;
@@ -395,7 +376,7 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
             vx = s.x * -1.0f; vy = s.y * -1.0f; vz = s.z * -1.0f;
         }
     }
-    if (MODE != 2) { a.npts[li] = npts; a.nfwd[li] = nf | (gap << 30); }
+    a.npts[li] = npts; a.nfwd[li] = nf | (gap << 30);
 }
 
 // Divergent termination (lines of a wave end at different steps: 30-53 % of the lane-steps idle on a phantom with a broad length
@@ -834,9 +815,6 @@ struct fib_stream_ws {
     size_t bytes = 0;
     bool busy = false, pending = false;
     hipEvent_t done = nullptr;
-    // fibd_stream_run: the stream its pack kernels run on and the events that order the batches (created on first use)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_traced[2] = {nullptr, nullptr}, ev_packed[2] = {nullptr, nullptr};
 };
 
 extern "C" int fibd_stream_ws_create(int device, fib_stream_ws **ws) try {
@@ -859,8 +837,6 @@ extern "C" void fibd_stream_ws_destroy(fib_stream_ws *ws) try {
     if (ws->pending) (void)hipEventSynchronize(ws->done);
     if (ws->p) (void)hipFree(ws->p);
     if (ws->done) (void)hipEventDestroy(ws->done);
-    for (int i = 0; i < 2; i++) { if (ws->ev_traced[i]) (void)hipEventDestroy(ws->ev_traced[i]); if (ws->ev_packed[i]) (void)hipEventDestroy(ws->ev_packed[i]); }
-    if (ws->side) (void)hipStreamDestroy(ws->side);
     delete ws;
 } FIB_API_CATCH_VOID
 
@@ -877,8 +853,6 @@ struct fib_stream_job {
     struct ViewP { Pair *p = nullptr; } excl, block_tot, total;
     int64_t kept_lines = 0, kept_pts = 0;
     bool lcm = false;               // LCM run: the method-difference flag rides in the sign bit of x until unpacked
-    bool two_pass = false;          // no point scratch: the pack call traces the kept lines again, straight into the output
-    TraceArgs ta{};                 // (two_pass) the arguments of the first pass
 };
 
 extern "C" void fib_stream_job_destroy(fib_stream_job *job) try {
@@ -917,6 +891,17 @@ extern "C" int fibd_stream_field(int32_t nvec, int64_t nvox, const float *const 
 } FIB_API_CATCH
 
 namespace {
+// 2^28 vectors of 16 bytes = 4 GiB: from there on the gather offsets need 64 bits (stream_trace_kernel<.., WIDE>)
+bool field_is_wide(const fib_stream_params *prm) { return (int64_t)prm->nx * prm->ny * prm->nz * prm->nvec >= ((int64_t)1 << 28); }
+// the one-lane-per-line tracer for (LCM, TRI); the vector count is a compile-time constant for 1 and 3 vectors per voxel, wide
+// fields take the run-time count (one instantiation per mode)
+template <bool LCM, bool TRI>
+void launch_trace(const TraceArgs &ta, int nvec, bool wide, unsigned grid, hipStream_t st) {
+    if (wide)           hipLaunchKernelGGL((stream_trace_kernel<0, LCM, TRI, true>), dim3(grid), dim3(256), 0, st, ta);
+    else if (nvec == 1) hipLaunchKernelGGL((stream_trace_kernel<1, LCM, TRI>), dim3(grid), dim3(256), 0, st, ta);
+    else if (nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, LCM, TRI>), dim3(grid), dim3(256), 0, st, ta);
+    else                hipLaunchKernelGGL((stream_trace_kernel<0, LCM, TRI>), dim3(grid), dim3(256), 0, st, ta);
+}
 struct LcmIn { const float *lcms = nullptr; float thresh = 0.0f; int sd0 = 0, sd1 = 1; unsigned long long seed = 0; };
 int stream_trace_impl(const fib_stream_params *prm, const float *field4, const LcmIn &lin, const int64_t *seeds, int64_t nseed,
                       const float *sublist, int32_t nsub, void *stream,
@@ -956,8 +941,8 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
     FIB_CHECK(prm->search_flat_axis >= 0 && prm->search_flat_axis <= 3, FIB_ERR_INVALID, "search_flat_axis must be 0 (none) or 1..3 (x, y, z)");
     FIB_CHECK(prm->interp == 0 || (prm->search_dist == 0 && !lin.lcms), FIB_ERR_UNSUPPORTED,
               "trilinear interpolation is an option of macro-scale angle-picked tracking only");
-    FIB_CHECK((int64_t)prm->nx * prm->ny * prm->nz * prm->nvec < ((int64_t)1 << 28), FIB_ERR_UNSUPPORTED,
-              "orientation fields of 2^28 vectors or more are not supported (32-bit gather offsets)");
+    FIB_CHECK((int64_t)prm->nx * prm->ny * prm->nz < ((int64_t)1 << 40), FIB_ERR_UNSUPPORTED, "volumes of 2^40 voxels or more are not supported");
+    const bool wide = field_is_wide(prm);
     int device = 0;
     FIB_HIP(hipGetDevice(&device));
     hipStream_t st = (hipStream_t)stream;
@@ -973,11 +958,7 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
     auto bail = [&](int code) { fib_stream_job_destroy(job); return code; };
     const int nblocks = (int)fib::cdiv(nl, SCAN_B);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    {
-        const char *e = getenv("FIBERS_STREAM_TWOPASS");
-        job->two_pass = prm->search_dist == 0 && !lin.lcms && e && e[0] == '1';
-    }
-    const size_t b_scratch = job->two_pass ? 0 : up((size_t)fib::cdiv(nl, SCR_TILE) * SCR_TILE * job->nslots * 3 * sizeof(float));
+    const size_t b_scratch = up((size_t)fib::cdiv(nl, SCR_TILE) * SCR_TILE * job->nslots * 3 * sizeof(float));
     const size_t b_i32 = up((size_t)nl * sizeof(int32_t)), b_excl = up((size_t)nl * sizeof(Pair));
     const size_t b_btot = up((size_t)nblocks * sizeof(Pair)), b_tot = 256;
     const size_t sbytes = b_scratch + 2 * b_i32 + b_excl + b_btot + b_tot;
@@ -1079,33 +1060,11 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
         ta.lcm = d_lcm.p; ta.sd0 = lin.sd0; ta.sd1 = lin.sd1; ta.rng_seed = lin.seed;
         job->lcm = true;
         fib::ProfScope prof("stream_trace_lcm", st);
-        if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1, true>), dim3(grid), dim3(256), 0, st, ta);
-        else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, true>), dim3(grid), dim3(256), 0, st, ta);
-        else                     hipLaunchKernelGGL((stream_trace_kernel<0, true>), dim3(grid), dim3(256), 0, st, ta);
-    } else
-    if (prm->interp) {                                  // trilinear option: one-lane-per-line kernels only
-        fib::ProfScope prof(job->two_pass ? "stream_count" : "stream_trace", st);
-        if (job->two_pass) {
-            if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1, false, 1, true>), dim3(grid), dim3(256), 0, st, ta);
-            else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, false, 1, true>), dim3(grid), dim3(256), 0, st, ta);
-            else                     hipLaunchKernelGGL((stream_trace_kernel<0, false, 1, true>), dim3(grid), dim3(256), 0, st, ta);
-        } else {
-            if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1, false, 0, true>), dim3(grid), dim3(256), 0, st, ta);
-            else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, false, 0, true>), dim3(grid), dim3(256), 0, st, ta);
-            else                     hipLaunchKernelGGL((stream_trace_kernel<0, false, 0, true>), dim3(grid), dim3(256), 0, st, ta);
-        }
-    } else
-    if (job->two_pass) {
-        fib::ProfScope prof("stream_count", st);
-        if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1, false, 1>), dim3(grid), dim3(256), 0, st, ta);
-        else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, false, 1>), dim3(grid), dim3(256), 0, st, ta);
-        else                     hipLaunchKernelGGL((stream_trace_kernel<0, false, 1>), dim3(grid), dim3(256), 0, st, ta);
-        job->ta = ta;
-    } else
-    { fib::ProfScope prof("stream_trace", st);
-    if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1>), dim3(grid), dim3(256), 0, st, ta);
-    else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3>), dim3(grid), dim3(256), 0, st, ta);
-    else                     hipLaunchKernelGGL((stream_trace_kernel<0>), dim3(grid), dim3(256), 0, st, ta);
+        launch_trace<true, false>(ta, prm->nvec, wide, grid, st);
+    } else {
+        fib::ProfScope prof("stream_trace", st);
+        if (prm->interp) launch_trace<false, true>(ta, prm->nvec, wide, grid, st);   // trilinear option
+        else launch_trace<false, false>(ta, prm->nvec, wide, grid, st);
     }
     { fib::ProfScope prof("stream_scan", st);
     hipLaunchKernelGGL(scan_block_kernel, dim3(nblocks), dim3(SCAN_T), 0, st, job->npts.p, nl, prm->len_min, job->excl.p, job->block_tot.p);
@@ -1137,8 +1096,7 @@ static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, f
 // whole-tile kernel while 16 (len_max + 2) points (+ the .trk headers and the alignment slack) fit in LDS
 static int launch_pack_n(const PackArgs &pa, int64_t nlines, int stride, hipStream_t st) {
     const size_t smem = ((size_t)PK_LINES * stride * 3 + PK_LINES + 8) * sizeof(float);
-    const char *e = getenv("FIBERS_PACK_KERNEL");
-    if (smem <= 120 * 1024 && !(e && e[0] == 'w')) {
+    if (smem <= 120 * 1024) {
         if (smem > 48 * 1024)
             FIB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stream_pack_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(stream_pack_tile_kernel, dim3((unsigned)fib::cdiv(nlines, PK_LINES)), dim3(256), smem, st, pa);
@@ -1150,28 +1108,6 @@ static int launch_pack_n(const PackArgs &pa, int64_t nlines, int stride, hipStre
 static int launch_pack(fib_stream_job *job, const PackArgs &pa, hipStream_t st) {
     job->last_stream = st;
     return launch_pack_n(pa, job->nlines, job->stride, st);
-}
-
-// second pass of a two-pass job: the same trace, every kept line written straight to its place (packed arrays or .trk body)
-static int retrace(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, const float *voxel_size, void *stream) {
-    TraceArgs ta = job->ta;
-    ta.excl = job->excl.p; ta.block_off = job->block_tot.p;
-    ta.out_npts = npts; ta.out_seed = seed_index; ta.out_xyz = xyz; ta.len_min = job->prm.len_min;
-    if (voxel_size) { ta.trk = 1; ta.vs[0] = voxel_size[0]; ta.vs[1] = voxel_size[1]; ta.vs[2] = voxel_size[2]; }
-    const unsigned grid = (unsigned)fib::cdiv(job->nlines, 256);
-    hipStream_t st = (hipStream_t)stream;
-    job->last_stream = st;
-    fib::ProfScope prof(voxel_size ? "stream_write_trk" : "stream_write", st);
-    if (job->prm.interp) {
-        if (ta.nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1, false, 2, true>), dim3(grid), dim3(256), 0, st, ta);
-        else if (ta.nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, false, 2, true>), dim3(grid), dim3(256), 0, st, ta);
-        else                   hipLaunchKernelGGL((stream_trace_kernel<0, false, 2, true>), dim3(grid), dim3(256), 0, st, ta);
-    } else
-    if (ta.nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1, false, 2>), dim3(grid), dim3(256), 0, st, ta);
-    else if (ta.nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, false, 2>), dim3(grid), dim3(256), 0, st, ta);
-    else                   hipLaunchKernelGGL((stream_trace_kernel<0, false, 2>), dim3(grid), dim3(256), 0, st, ta);
-    FIB_HIP(hipGetLastError());
-    return FIB_OK;
 }
 
 extern "C" int fibd_stream_pack_flags(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, uint8_t *flags, void *stream) try {
@@ -1195,7 +1131,6 @@ static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, f
     FIB_CHECK(npts && seed_index && xyz, FIB_ERR_INVALID, "NULL output buffer");
     fib::DeviceGuard guard;
     FIB_HIP(hipSetDevice(job->device));
-    if (job->two_pass) return retrace(job, npts, seed_index, xyz, nullptr, stream);
     PackArgs pa{};
     pa.scratch = job->scratch; pa.npts = job->npts.p; pa.nfwd = job->nfwd.p;
     pa.excl = job->excl.p; pa.block_off = job->block_tot.p;
@@ -1215,7 +1150,6 @@ extern "C" int fibd_stream_pack_trk(fib_stream_job *job, const float voxel_size[
     FIB_CHECK(body != nullptr, FIB_ERR_INVALID, "NULL output buffer");
     fib::DeviceGuard guard;
     FIB_HIP(hipSetDevice(job->device));
-    if (job->two_pass) return retrace(job, nullptr, nullptr, reinterpret_cast<float *>(body), voxel_size, stream);
     PackArgs pa{};
     pa.scratch = job->scratch; pa.npts = job->npts.p; pa.nfwd = job->nfwd.p;
     pa.excl = job->excl.p; pa.block_off = job->block_tot.p;
@@ -1229,13 +1163,10 @@ extern "C" int fibd_stream_pack_trk(fib_stream_job *job, const float voxel_size[
     return FIB_OK;
 } FIB_API_CATCH
 
-// stream (stream.jl:730-790) in ONE call, straight into the caller's buffers (no second call, no allocation by the library).
-// The lines can be traced in batches (FIBERS_STREAM_BATCHES, default 1), a batch being packed on the workspace's second stream
-// while the next one is traced on the caller's; two scratch buffers alternate and the offsets of a batch continue from the
-// running totals of the batches before it (device-resident: no host round trip in between).  MEASURED (tools/stream_run_ab.py,
-// profiles/r04/negative_results.txt): the overlap does not pay -- 1.30 ms for trace + pack one after the other, 1.33 / 1.37 / 1.44 /
-// 1.50 / 1.55 ms with 1 / 2 / 3 / 4 / 8 batches: since the flat trace loop both kernels are bound by the same HBM traffic
-// (2.4 GB + 3.2 GB per million lines at ~5 TB/s), and side by side each just gets half of it.  Hence the default of one batch.
+// stream (stream.jl:730-790) in ONE call, straight into the caller's buffers (no second call, no allocation by the library):
+// trace, scan and pack one after the other on the caller's stream.  ([r5] the batched form -- a batch packed on a second stream
+// while the next one is traced -- was measured slower for every batch count, 1.33 ... 1.55 ms against 1.30: both kernels are bound
+// by the same HBM traffic, profiles/r04/negative_results.txt; it and its side stream / events have been removed.)
 // Macro-scale angle picking only (nearest voxel or trilinear); the microscopy regime and LCM runs use fibd_stream_trace / _pack.
 extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4, const int64_t *seeds, int64_t nseed,
                                const float *sublist, int32_t nsub, int32_t *npts, int64_t *seed_index, int64_t lines_cap,
@@ -1248,25 +1179,20 @@ extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4
     FIB_CHECK(prm->len_max >= 0 && prm->len_max < (1 << 24), FIB_ERR_INVALID, "invalid len_max");
     FIB_CHECK(prm->search_dist == 0, FIB_ERR_UNSUPPORTED, "fibd_stream_run covers macro-scale tracking (search_dist 0); use fibd_stream_trace for the microscopy regime");
     FIB_CHECK(prm->interp == 0 || prm->interp == 1, FIB_ERR_INVALID, "interp must be 0 (nearest voxel, the reference) or 1 (trilinear)");
-    FIB_CHECK((int64_t)prm->nx * prm->ny * prm->nz * prm->nvec < ((int64_t)1 << 28), FIB_ERR_UNSUPPORTED,
-              "orientation fields of 2^28 vectors or more are not supported (32-bit gather offsets)");
+    FIB_CHECK((int64_t)prm->nx * prm->ny * prm->nz < ((int64_t)1 << 40), FIB_ERR_UNSUPPORTED, "volumes of 2^40 voxels or more are not supported");
     FIB_CHECK(lines_cap >= 0 && points_cap >= 0 && (lines_cap == 0 || (npts && seed_index)) && (points_cap == 0 || xyz), FIB_ERR_INVALID, "invalid output buffers");
     const int64_t nl = nseed * nsub;
     if (nl == 0) return FIB_OK;
+    const bool wide = field_is_wide(prm);
     int device = 0;
     FIB_HIP(hipGetDevice(&device));
     hipStream_t st = (hipStream_t)stream;
-    // batches: whole scan blocks; one by default (see above)
-    int64_t nbatch = 1;
-    if (const char *e = getenv("FIBERS_STREAM_BATCHES")) { const int v = atoi(e); if (v >= 1 && v <= 64) nbatch = v; }
-    const int64_t BL = fib::cdiv(fib::cdiv(nl, nbatch), SCAN_B) * SCAN_B;
-    nbatch = fib::cdiv(nl, BL);
     const int stride = prm->len_max + 2, nslots = prm->len_max + 4;
+    const int nblk = (int)fib::cdiv(nl, SCAN_B);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t b_scr = up((size_t)fib::cdiv(BL, SCR_TILE) * SCR_TILE * nslots * 3 * sizeof(float));
-    const size_t b_i32 = up((size_t)BL * sizeof(int32_t)), b_excl = up((size_t)BL * sizeof(Pair)), b_bt = up((size_t)fib::cdiv(BL, SCAN_B) * sizeof(Pair));
-    const size_t PB = b_scr + 2 * b_i32 + b_excl + b_bt;
-    const size_t sbytes = 2 * PB + up((size_t)(nbatch + 1) * sizeof(Pair));
+    const size_t b_scr = up((size_t)fib::cdiv(nl, SCR_TILE) * SCR_TILE * nslots * 3 * sizeof(float));
+    const size_t b_i32 = up((size_t)nl * sizeof(int32_t)), b_excl = up((size_t)nl * sizeof(Pair)), b_bt = up((size_t)nblk * sizeof(Pair));
+    const size_t sbytes = b_scr + 2 * b_i32 + b_excl + b_bt + 256;
     // the caller's workspace when it is free, else one of our own for the call
     fib_stream_ws *ws = reinterpret_cast<fib_stream_ws *>(prm->ws), *own = nullptr;
     bool have = false;
@@ -1280,7 +1206,7 @@ extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4
         ws = own; ws->busy = true;
     }
     auto release = [&](int code) {
-        if (own) { (void)hipStreamSynchronize(st); if (own->side) (void)hipStreamSynchronize(own->side); own->busy = false; fibd_stream_ws_destroy(own); }
+        if (own) { (void)hipStreamSynchronize(st); own->busy = false; fibd_stream_ws_destroy(own); }
         else {
             std::lock_guard<std::mutex> lk(ws->mu);
             ws->pending = hipEventRecord(ws->done, st) == hipSuccess;
@@ -1296,69 +1222,46 @@ extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4
         if (hipMalloc(&ws->p, sbytes) != hipSuccess) { ws->p = nullptr; return release(fib::fail(FIB_ERR_NOMEM, "cannot allocate %zu bytes of streamline scratch", sbytes)); }
         ws->bytes = sbytes;
     }
-    if (ws->pending) { (void)hipStreamWaitEvent(st, ws->done, 0); ws->pending = false; }
-    if (!ws->side) {
-        if (hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking) != hipSuccess) { ws->side = nullptr; return release(fib::fail(FIB_ERR_HIP, "hipStreamCreate failed")); }
-        for (int i = 0; i < 2; i++)
-            if (hipEventCreateWithFlags(&ws->ev_traced[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ws->ev_packed[i], hipEventDisableTiming) != hipSuccess)
-                return release(fib::fail(FIB_ERR_HIP, "hipEventCreate failed"));
+    if (ws->pending) {
+        if (hipStreamWaitEvent(st, ws->done, 0) != hipSuccess) (void)hipEventSynchronize(ws->done);
+        ws->pending = false;
     }
-    char *base = reinterpret_cast<char *>(ws->p);
-    Pair *running = reinterpret_cast<Pair *>(base + 2 * PB);           // [nbatch + 1]: totals of the batches before b
-    if (hipMemsetAsync(running, 0, sizeof(Pair), st) != hipSuccess) return release(fib::fail(FIB_ERR_HIP, "hipMemsetAsync failed"));
-    for (int64_t b = 0; b < nbatch; b++) {
-        const int buf = (int)(b & 1);
-        char *pb = base + (size_t)buf * PB;
-        float *scr = reinterpret_cast<float *>(pb);
-        int32_t *bn = reinterpret_cast<int32_t *>(pb + b_scr), *bf = reinterpret_cast<int32_t *>(pb + b_scr + b_i32);
-        Pair *bex = reinterpret_cast<Pair *>(pb + b_scr + 2 * b_i32), *bbt = reinterpret_cast<Pair *>(pb + b_scr + 2 * b_i32 + b_excl);
-        const int64_t l0 = b * BL, nb = std::min<int64_t>(BL, nl - l0);
-        if (b >= 2) (void)hipStreamWaitEvent(st, ws->ev_packed[buf], 0);       // the pack of batch b - 2 has left this buffer
-        TraceArgs ta{};
-        ta.field = reinterpret_cast<const float4 *>(field4); ta.seeds = seeds; ta.sublist = sublist;
-        ta.scratch = scr; ta.npts = bn; ta.nfwd = bf; ta.line0 = l0; ta.nlines = nb;
-        ta.nx = prm->nx; ta.ny = prm->ny; ta.nz = prm->nz; ta.nvec = prm->nvec; ta.nsub = nsub;
-        ta.len_max = prm->len_max; ta.stride = stride; ta.nslots = nslots;
-        ta.cosang = prm->cosang_thresh; ta.step = prm->step_size; ta.smooth = prm->smooth_coeff;
-        const unsigned grid = (unsigned)fib::cdiv(nb, 256);
-        {
-            fib::ProfScope prof("stream_trace", st);
-            if (prm->interp) {
-                if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1, false, 0, true>), dim3(grid), dim3(256), 0, st, ta);
-                else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, false, 0, true>), dim3(grid), dim3(256), 0, st, ta);
-                else                     hipLaunchKernelGGL((stream_trace_kernel<0, false, 0, true>), dim3(grid), dim3(256), 0, st, ta);
-            } else {
-                if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1>), dim3(grid), dim3(256), 0, st, ta);
-                else if (prm->nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3>), dim3(grid), dim3(256), 0, st, ta);
-                else                     hipLaunchKernelGGL((stream_trace_kernel<0>), dim3(grid), dim3(256), 0, st, ta);
-            }
-        }
-        const int nblk = (int)fib::cdiv(nb, SCAN_B);
-        {
-            fib::ProfScope prof("stream_scan", st);
-            hipLaunchKernelGGL(scan_block_kernel, dim3(nblk), dim3(SCAN_T), 0, st, bn, nb, prm->len_min, bex, bbt);
-            hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(SCAN_T), 0, st, bbt, nblk, running + b + 1, (const Pair *)(running + b));
-        }
-        if (hipGetLastError() != hipSuccess || hipEventRecord(ws->ev_traced[buf], st) != hipSuccess ||
-            hipStreamWaitEvent(ws->side, ws->ev_traced[buf], 0) != hipSuccess)
-            return release(fib::fail(FIB_ERR_HIP, "streamline trace launch failed"));
-        PackArgs pa{};
-        pa.scratch = scr; pa.npts = bn; pa.nfwd = bf; pa.excl = bex; pa.block_off = bbt;
-        pa.out_npts = npts; pa.out_seed = seed_index; pa.out_xyz = xyz;
-        pa.nlines = nb; pa.line0 = l0; pa.out_line0 = 0; pa.out_pt0 = 0;
-        pa.stride = stride; pa.nslots = nslots; pa.len_min = prm->len_min;
-        pa.lines_cap = lines_cap; pa.points_cap = points_cap; pa.capped = 1;
-        {
-            fib::ProfScope prof("stream_pack", ws->side);
-            const int rcl = launch_pack_n(pa, nb, stride, ws->side);
-            if (rcl != FIB_OK) return release(rcl);
-        }
-        if (hipEventRecord(ws->ev_packed[buf], ws->side) != hipSuccess) return release(fib::fail(FIB_ERR_HIP, "hipEventRecord failed"));
+    char *pb = reinterpret_cast<char *>(ws->p);
+    float *scr = reinterpret_cast<float *>(pb);
+    int32_t *bn = reinterpret_cast<int32_t *>(pb + b_scr), *bf = reinterpret_cast<int32_t *>(pb + b_scr + b_i32);
+    Pair *bex = reinterpret_cast<Pair *>(pb + b_scr + 2 * b_i32), *bbt = reinterpret_cast<Pair *>(pb + b_scr + 2 * b_i32 + b_excl);
+    Pair *total = reinterpret_cast<Pair *>(pb + b_scr + 2 * b_i32 + b_excl + b_bt);
+    TraceArgs ta{};
+    ta.field = reinterpret_cast<const float4 *>(field4); ta.seeds = seeds; ta.sublist = sublist;
+    ta.scratch = scr; ta.npts = bn; ta.nfwd = bf; ta.line0 = 0; ta.nlines = nl;
+    ta.nx = prm->nx; ta.ny = prm->ny; ta.nz = prm->nz; ta.nvec = prm->nvec; ta.nsub = nsub;
+    ta.len_max = prm->len_max; ta.stride = stride; ta.nslots = nslots;
+    ta.cosang = prm->cosang_thresh; ta.step = prm->step_size; ta.smooth = prm->smooth_coeff;
+    const unsigned grid = (unsigned)fib::cdiv(nl, 256);
+    {
+        fib::ProfScope prof("stream_trace", st);
+        if (prm->interp) launch_trace<false, true>(ta, prm->nvec, wide, grid, st);
+        else launch_trace<false, false>(ta, prm->nvec, wide, grid, st);
     }
-    (void)hipStreamWaitEvent(st, ws->ev_packed[(nbatch - 1) & 1], 0);          // the caller's stream continues behind the last packs
-    if (nbatch >= 2) (void)hipStreamWaitEvent(st, ws->ev_packed[(nbatch - 2) & 1], 0);
+    {
+        fib::ProfScope prof("stream_scan", st);
+        hipLaunchKernelGGL(scan_block_kernel, dim3(nblk), dim3(SCAN_T), 0, st, bn, nl, prm->len_min, bex, bbt);
+        hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(SCAN_T), 0, st, bbt, nblk, total, (const Pair *)nullptr);
+    }
+    if (hipGetLastError() != hipSuccess) return release(fib::fail(FIB_ERR_HIP, "streamline trace launch failed"));
+    PackArgs pa{};
+    pa.scratch = scr; pa.npts = bn; pa.nfwd = bf; pa.excl = bex; pa.block_off = bbt;
+    pa.out_npts = npts; pa.out_seed = seed_index; pa.out_xyz = xyz;
+    pa.nlines = nl; pa.line0 = 0; pa.out_line0 = 0; pa.out_pt0 = 0;
+    pa.stride = stride; pa.nslots = nslots; pa.len_min = prm->len_min;
+    pa.lines_cap = lines_cap; pa.points_cap = points_cap; pa.capped = 1;   // a line whose place lies beyond the buffers is dropped, the totals say what was needed
+    {
+        fib::ProfScope prof("stream_pack", st);
+        const int rcl = launch_pack_n(pa, nl, stride, st);
+        if (rcl != FIB_OK) return release(rcl);
+    }
     Pair tot{0, 0};
-    hipError_t e = hipMemcpyAsync(&tot, running + nbatch, sizeof(Pair), hipMemcpyDeviceToHost, st);
+    hipError_t e = hipMemcpyAsync(&tot, total, sizeof(Pair), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return release(fib::fail(FIB_ERR_HIP, "streamline run failed: %s", hipGetErrorString(e)));
     *nlines_out = tot.lines; *npoints_out = tot.pts;

@@ -64,7 +64,7 @@ def test_c2_dti_140cubed(fj, orc, dev):
 def _check_odf_sample(fj, orc, kind, out, dwi, mask, bval, bvec, dev, nsamp, odf_rtol):
     import torch
     rng = np.random.default_rng(11)
-    idx = np.sort(rng.choice(NVOX, nsamp, replace=False))
+    idx = np.sort(rng.choice(int(mask.numel()), nsamp, replace=False))
     tidx = torch.from_numpy(idx).to(dev)
     sub = _sample_volume(dwi, tidx)
     msub = mask[tidx].cpu().numpy().reshape(-1, 1, 1)
@@ -130,26 +130,6 @@ def test_c3_gqi_140cubed(fj, orc, dev):
     _odf_properties(fj, out, mask, plan, dwi, dev, 4.0)
 
 
-@pytest.mark.parametrize("env,val", [("FIBERS_ODF_ANTI", "0")])
-def test_c3_gqi_kernel_variants_bit_identical_140cubed(fj, dev, monkeypatch, env, val):
-    """the fused GQI kernel without its anti-phase wave halves against the default kernel on the full 140^3 x 270 volume (ball mask: partial work items, workgroups with different item counts): every output bit"""
-    import torch
-    from fibers_jl_amd import phantom
-    bval, bvec = phantom.scheme_gqi()
-    dwi, _ = phantom.make_dwi_torch(SHAPE, bval, bvec, seed=3, device=dev)
-    mask = phantom.ball_mask_torch(SHAPE, dev)
-    plan = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642, sigma=1.25, device=0)
-    res = []
-    for on in (False, True):
-        if on:
-            monkeypatch.setenv(env, val)
-        o = fj.odf_rec_device(plan, dwi, mask)
-        torch.cuda.synchronize()
-        res.append([o["odf"].clone()] + [t.clone() for t in o["peak"]] + [t.clone() for t in o["qa"]] + [o["odfmax"].clone()])
-    for x, y in zip(*res):
-        assert torch.equal(x, y)
-
-
 @pytest.fixture(scope="module")
 def dsi_result(fj, dev):
     import torch
@@ -168,6 +148,35 @@ def test_c5_dsi_140cubed(fj, orc, dev, dsi_result):
     r = dsi_result
     _check_odf_sample(fj, orc, "dsi", r["out"], r["dwi"], r["mask"], r["bval"], r["bvec"], dev, 300, 1e-4)
     _odf_properties(fj, r["out"], r["mask"], r["plan"], r["dwi"], dev, 1.0)
+
+
+def test_dsi_fold_prepass_in_front_of_the_split_kernels_past_the_fold_span_limit(fj, orc, dev):
+    """The split kernels fold the antipodal sample pairs inside their sample requests through ONE 32-bit buffer range per stage and
+    side; a stage whose 16 folded samples span more than 0xE0000000 / (4 nvox) frames does not fit it, and the step runs the fold
+    pre-pass (dsi_fold4_kernel) in front of the unfused split kernel + the separate peak finder instead.  A DSI table whose frames
+    come in a scrambled order reaches that at 140^3 (span ~ 500 of 515 frames): the pre-pass must have run, and the result meets the
+    oracle like every other path (dsi.jl:171-270; the reference does not care about the frame order either)."""
+    import ctypes as C
+    import torch
+    from fibers_jl_amd import phantom
+    bval, bvec = phantom.scheme_dsi()
+    perm = np.random.default_rng(23).permutation(len(bval))
+    bval, bvec = np.ascontiguousarray(bval[perm]), np.ascontiguousarray(bvec[perm])
+    dwi, _ = phantom.make_dwi_torch(SHAPE, bval, bvec, seed=6, device=dev)
+    mask = phantom.ball_mask_torch(SHAPE, dev)
+    plan = fj.OdfPlan("dsi", bval, bvec, fj.sphere_642, hann_width=32, device=0)
+    L = fj.lib()
+    L.fib_profile_enable(1); L.fib_profile_reset()
+    out = fj.odf_rec_device(plan, dwi, mask)
+    torch.cuda.synchronize()
+    ms, cnt = C.c_double(0), C.c_int64(0)
+    L.fib_profile_get(b"dsi_fold", C.byref(ms), C.byref(cnt))
+    L.fib_profile_enable(0)
+    assert cnt.value == 1, "the fold pre-pass did not run: the table's stages no longer exceed the span limit at this size"
+    assert plan.format == "fp16x2"
+    _check_odf_sample(fj, orc, "dsi", out, dwi, mask, bval, bvec, dev, 200, 1e-4)
+    live = mask.bool()
+    assert float(out["odf"][:, ~live].abs().max()) == 0.0 and float(out["pdf"][:, ~live].abs().max()) == 0.0
 
 
 def _check_tract(res, nvec_field, mask, nseed, nsub, step=0.5, len_min=3, len_max=140):

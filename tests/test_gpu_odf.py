@@ -244,15 +244,12 @@ FORMATS = ["fp16x2", "bf16x3", "f32"]        # the operand formats of the contra
 
 def _use_format(monkeypatch, fmt):
     """make `fmt` the default operand format of the plans built from here on (the host tier builds its plans with the default
-    format and keys its plan cache on it): fp16x2 = no switch, bf16x3 = FIBERS_ODF_EXACT=1, f32 = FIBERS_ODF_GEMM=f32"""
+    format and keys its plan cache on it): FIBERS_ODF_FORMAT = fp16x2 (or unset) | bf16x3 | f32"""
     import fibers_jl_amd as fj
     from fibers_jl_amd import _lib
-    monkeypatch.delenv("FIBERS_ODF_EXACT", raising=False)
-    monkeypatch.delenv("FIBERS_ODF_GEMM", raising=False)
-    if fmt == "bf16x3":
-        monkeypatch.setenv("FIBERS_ODF_EXACT", "1")
-    elif fmt == "f32":
-        monkeypatch.setenv("FIBERS_ODF_GEMM", "f32")
+    monkeypatch.delenv("FIBERS_ODF_FORMAT", raising=False)
+    if fmt != "fp16x2":
+        monkeypatch.setenv("FIBERS_ODF_FORMAT", fmt)
     assert _lib.lib().fib_odf_default_format() == fj.gqi.ODF_FORMATS[fmt]
 
 
@@ -429,9 +426,11 @@ def test_outputs_outside_the_mask_are_cleared_whatever_they_held(fj, kind, shape
     plan.close()
 
 
-def test_dsi_fused_fold_is_bit_identical_to_the_prepass(fj, monkeypatch):
-    """The split-bf16 kernel folding the antipodal pairs itself (default) and the separate fold pre-pass feed the same
-    numbers to the same contraction: identical pdf / odf / peaks, with a mask, a ragged voxel count and non-finite samples."""
+def test_dsi_fold_inside_the_kernel_and_fold_prepass_agree(fj):
+    """The split kernels fold the antipodal pairs themselves (default format); a plan in the f32 format takes the separate fold pre-pass
+    (dsi_fold_kernel) and the f32 MFMA chain.  Same folded numbers into two contractions: pdf / odf agree to the formats' rounding,
+    non-finite samples and voxels outside the mask behave identically -- with a mask, a ragged voxel count and non-finite samples.
+    (The pre-pass in front of the SPLIT kernels is what volumes past the fold-span limit run: tests/test_gpu_fullsize.py.)"""
     import torch
     from fibers_jl_amd import phantom
     dev = torch.device("cuda", 0)
@@ -441,24 +440,28 @@ def test_dsi_fused_fold_is_bit_identical_to_the_prepass(fj, monkeypatch):
     dwi, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=12, device=dev)
     dwi[100, 7] = float("nan"); dwi[400, 8] = float("inf"); dwi[33, 9] = -float("inf"); dwi[:, 10] = -1.0
     g = torch.Generator(device=dev); g.manual_seed(2)
-    res = {}
+    L = fj.lib()
     for mname, mask in (("ones", torch.ones(nvox, dtype=torch.uint8, device=dev)),
                         ("sparse", (torch.rand(nvox, device=dev, generator=g) < 0.6).to(torch.uint8))):
-        for mode in ("fused", "prepass"):
-            if mode == "prepass":
-                monkeypatch.setenv("FIBERS_DSI_UNFUSED", "1")
-            else:
-                monkeypatch.delenv("FIBERS_DSI_UNFUSED", raising=False)
-            plan = fj.OdfPlan("dsi", bval, bvec, fj.sphere_642, hann_width=32)
+        res = {}
+        for mode, fmt in (("fused", "fp16x2"), ("prepass", "f32")):
+            plan = fj.OdfPlan("dsi", bval, bvec, fj.sphere_642, hann_width=32, format=fmt)
+            L.fib_profile_enable(1); L.fib_profile_reset()
             o = fj.odf_rec_device(plan, dwi, mask)
             torch.cuda.synchronize()
+            import ctypes as C
+            ms, cnt = C.c_double(0), C.c_int64(0)
+            L.fib_profile_get(b"dsi_fold", C.byref(ms), C.byref(cnt))
+            L.fib_profile_enable(0)
+            assert (cnt.value > 0) == (mode == "prepass"), (mode, cnt.value)
             res[mode] = {k: (v.clone() if torch.is_tensor(v) else [t.clone() for t in v]) for k, v in o.items()}
             plan.close()
+        nn = lambda t: t.nan_to_num(nan=-7.0, posinf=-8.0, neginf=-9.0)
         for k in ("pdf", "odf"):
-            assert torch.equal(res["fused"][k].nan_to_num(nan=-7.0, posinf=-8.0, neginf=-9.0), res["prepass"][k].nan_to_num(nan=-7.0, posinf=-8.0, neginf=-9.0)), (mname, k)
-        for i in range(3):
-            assert torch.equal(res["fused"]["peak"][i], res["prepass"]["peak"][i]), (mname, i)
-            assert torch.equal(res["fused"]["qa"][i].nan_to_num(nan=-7.0), res["prepass"]["qa"][i].nan_to_num(nan=-7.0)), (mname, i)
+            a_, b_ = nn(res["fused"][k]), nn(res["prepass"][k])
+            scale = b_.abs().amax(dim=0).clamp_min(1e-30)
+            assert float(((a_ - b_).abs() / scale).max()) <= 4e-6, (mname, k)
+            assert torch.equal(a_ == -7.0, b_ == -7.0) and torch.equal(a_ == -8.0, b_ == -8.0), (mname, k)     # NaN / Inf in the same places
         assert bool(torch.isnan(res["fused"]["odf"][:, 7]).all()) and bool(torch.isnan(res["fused"]["odf"][:, 8]).all()) or mname == "sparse"
         assert bool((res["fused"]["odf"][:, 10] == 0).all())
 
@@ -573,9 +576,9 @@ def test_find_peaks_work_fills_the_whole_work_struct(fj, sphere):
 
 
 @pytest.mark.parametrize("case", ["full", "sparse", "poison"])
-def test_dsi_two_tile_kernel_against_the_three_tile_path(fj, case, monkeypatch):
+def test_dsi_two_tile_kernel_against_the_three_tile_path(fj, case):
     """odf_dsi2_kernel (default for folded lattices on sphere_642: fused ODF tile + pdf tile in one launch, find_peaks! on the
-    accumulators) against the path it replaced (FIBERS_DSI_THREE_TILES=1: three M tiles, then odf_peaks642_kernel on the stored
+    accumulators) against the path other tessellations and FIB_ODF_SEPARATE_PEAKS take (three M tiles, then odf_peaks642_kernel on the stored
     ODF), same device buffers: peaks identical, qa / odfmax to rounding, ODF rows bit-identical except the three rows whose
     role differs (the fused layout's pole row and the three-tile layout's two extra rows are f32 VALU rows), pdf to rounding."""
     import torch
@@ -591,13 +594,9 @@ def test_dsi_two_tile_kernel_against_the_three_tile_path(fj, case, monkeypatch):
     if case == "poison":
         dwi[5, 100] = float("nan"); dwi[7, 2000] = float("inf"); dwi[:, 3000] = 0.0; dwi[:, 3001] = -1.0; dwi[0, 3002] = 0.0
     res = {}
-    for name, env in (("two", None), ("three", "1")):
-        if env:
-            monkeypatch.setenv("FIBERS_DSI_THREE_TILES", env)
-        else:
-            monkeypatch.delenv("FIBERS_DSI_THREE_TILES", raising=False)
+    for name, sep in (("two", False), ("three", True)):
         plan = fj.OdfPlan("dsi", bval, bvec, fj.sphere_642, hann_width=32)
-        o = fj.odf_rec_device(plan, dwi, mask, normalize=True)
+        o = fj.odf_rec_device(plan, dwi, mask, normalize=True, separate_peaks=sep)
         torch.cuda.synchronize()
         res[name] = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in o.items()}
     a, b = res["two"], res["three"]
@@ -616,7 +615,7 @@ def test_dsi_two_tile_kernel_against_the_three_tile_path(fj, case, monkeypatch):
     assert int((a["peak"][0] != 0).any(0).sum()) > int(mask.sum()) // 2
 
 
-# ---- the two operand formats of the contraction: two fp16 pieces (default) / three exact bf16 pieces (FIBERS_ODF_EXACT=1) ----------
+# ---- the two operand formats of the contraction: two fp16 pieces (default) / three exact bf16 pieces (format="bf16x3") ----------
 def _rec_both_formats(fj, monkeypatch, kind, dwi, mask, bval, bvec, sph):
     """device tier with explicitly built plans (the host tier caches its plans; the format is chosen when a plan builds its matrix
     image): dict(odf [nvox, nvert], peak 3 x [nvox, 3], pdf) per format"""
@@ -708,7 +707,7 @@ def _rec_dict(out):
 
 
 @pytest.mark.parametrize("kind", ["gqi", "dsi"])
-def test_list_unit_does_not_change_results_and_follows_the_mask(fj, kind, monkeypatch):
+def test_list_unit_does_not_change_results_and_follows_the_mask(fj, kind):
     """The voxel list of the contraction kernels is made of aligned groups of 32 voxels by default (a wave's 128-byte row segments
     are whole cache lines whatever the mask's runs look like) and of aligned groups of 4 when the previous call's mask was sparse.
     Outputs are bit-identical either way (ragged ball mask, runs that start anywhere, isolated voxels, a volume that does not end on
@@ -727,12 +726,17 @@ def test_list_unit_does_not_change_results_and_follows_the_mask(fj, kind, monkey
     for a, b in ((3, 41), (77, 78), (130, 389), (1001, 1033), (nvox - 9, nvox)):
         runs[a:b] = 1
     plan = fj.OdfPlan(kind, bval, bvec, fj.sphere_642, device=0)
+    # the unit of a call is chosen by the mask of the call BEFORE it (no switch: the product library has none): a call on isolated voxels
+    # puts the next one on groups of 4, a call on one long run puts it on groups of 32
+    slab = torch.zeros(nvox, dtype=torch.uint8, device=dev)
+    slab[37:5000] = 1
+    prime = {"quads": sparse, "octets": slab}
     for name, mask in (("ball", ball), ("sparse", sparse), ("runs", runs)):
         res = {}
         for unit in ("quads", "octets"):
-            monkeypatch.setenv("FIBERS_ODF_LIST", unit)
+            fj.odf_rec_device(plan, dwi, prime[unit])
+            assert plan.list_unit() == unit, (name, unit)
             res[unit] = _rec_dict(fj.odf_rec_device(plan, dwi, mask))
-        monkeypatch.delenv("FIBERS_ODF_LIST")
         a, b = res["quads"], res["octets"]
         for k in a:
             if isinstance(a[k], list):
@@ -742,14 +746,28 @@ def test_list_unit_does_not_change_results_and_follows_the_mask(fj, kind, monkey
         dead = mask == 0
         assert float(a["odf"][:, dead].abs().max()) == 0.0, name
     # the plan follows the mask (one call behind): long runs -> groups of 32, isolated voxels -> groups of 4
-    slab = torch.zeros(nvox, dtype=torch.uint8, device=dev)
-    slab[37:5000] = 1
     fj.odf_rec_device(plan, dwi, slab)
     assert plan.list_unit() == "octets"
     fj.odf_rec_device(plan, dwi, sparse)
     assert plan.list_unit() == "quads"
     got = _rec_dict(fj.odf_rec_device(plan, dwi, slab))     # this call runs on groups of 4 ..
     assert plan.list_unit() == "octets"                     # .. and puts the next one back on groups of 32
-    monkeypatch.setenv("FIBERS_ODF_LIST", "octets")
-    want = _rec_dict(fj.odf_rec_device(plan, dwi, slab))
+    want = _rec_dict(fj.odf_rec_device(plan, dwi, slab))    # (this one runs on groups of 32)
     assert torch.equal(got["odf"], want["odf"]) and all(torch.equal(x, y) for x, y in zip(got["peak"], want["peak"]))
+
+
+def test_clearing_workgroups_whose_poll_times_out_cover_both_partitions():
+    """mask_compact_kernel: a mixture of per-workgroup decisions (whole arrays | span by span) must not leave values
+    outside the mask uncleared.  The forced time-out exists in the DIAGNOSTIC build only, so the check runs as a child process that
+    loads libfibers_hip_stamp.so (tools/compact_mixture_check.py: NaN-filled outputs, three masks, every 2nd / 3rd / 7th workgroup
+    forced 'unknown', GQI and DSI)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "fibers.jl_amd", "libfibers_hip_stamp.so")):
+        pytest.skip("the diagnostic build is absent (make -C fibers.jl_amd/csrc stamp)")
+    env = {k: v for k, v in os.environ.items() if k != "FIBERS_HIP_LIB"}
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "compact_mixture_check.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "compact mixture check: ok" in out.stdout

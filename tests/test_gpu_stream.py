@@ -106,9 +106,9 @@ def test_stream_device_tier(fj, orc):
 
 
 @pytest.mark.parametrize("len_max,nvec", [(None, 1), (40, 3), (3000, 1)])
-def test_stream_pack_paths_agree(fj, orc, monkeypatch, len_max, nvec):
-    """The three ways the points reach the packed arrays -- whole-tile LDS pack (default), wave pack (long lines), second
-    trace straight into the output (no point scratch) -- give the same bytes, at every 4-byte alignment of xyz."""
+def test_stream_pack_paths_agree(fj, orc, len_max, nvec):
+    """The two ways the points reach the packed arrays -- whole-tile LDS pack (lines that fit the LDS: the default len_max and 40),
+    wave pack (len_max 3000: a tile of 16 lines no longer fits) -- give the oracle's bytes, at every 4-byte alignment of xyz."""
     import torch
     n = 22
     F = _fields(n, 11)
@@ -124,11 +124,7 @@ def test_stream_pack_paths_agree(fj, orc, monkeypatch, len_max, nvec):
     kw = dict(len_max=len_max, ang_thresh=60 if len_max == 3000 else 45)
     ref = orc.stream(ovs if nvec > 1 else ovs[0], sub, mask=mask, nthreads=4, **kw)
     res = []
-    for env in ({}, {"FIBERS_PACK_KERNEL": "w"}, {"FIBERS_STREAM_TWOPASS": "1"}):
-        for k in ("FIBERS_PACK_KERNEL", "FIBERS_STREAM_TWOPASS"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for env in ({},):
         for shift in range(4):
             out = fj.stream_device(field, (n, n, n), seeds, subd, xyz_out=lambda npnt: torch.full((3 * npnt + 8,), -7.0, device="cuda")[shift:], **kw)
             torch.cuda.synchronize()
@@ -421,12 +417,11 @@ def test_stream_angle_inputs_lcm_exact(fj, orc):
     assert np.array_equal(tr.scalars, ref["flags"].astype(np.float32))
 
 
-# ---- fibd_stream_run: trace and pack in one call, batches overlapped on two streams ---------------------------------------------------
-@pytest.mark.parametrize("nvec,batches", [(1, 1), (1, 3), (3, 4), (2, 2)])
-def test_stream_run_matches_trace_plus_pack(fj, monkeypatch, nvec, batches):
-    """the one-call form (batches of lines, each packed on a second stream while the next is traced) returns exactly what
-    fibd_stream_trace + fibd_stream_pack return: same lines, order, seed indices and points; buffers are sized by a first call,
-    reused by the second, and a call with too little room says how much it needs"""
+# ---- fibd_stream_run: trace, scan and pack in one call into caller-kept buffers ---------------------------------------------------------
+@pytest.mark.parametrize("nvec", [1, 2, 3])
+def test_stream_run_matches_trace_plus_pack(fj, nvec):
+    """the one-call form returns exactly what fibd_stream_trace + fibd_stream_pack return: same lines, order, seed indices and
+    points; buffers are sized by a first call, reused by the second, and a call with too little room says how much it needs"""
     import torch
     n = 20
     dev = torch.device("cuda", 0)
@@ -439,7 +434,6 @@ def test_stream_run_matches_trace_plus_pack(fj, monkeypatch, nvec, batches):
     sub = torch.from_numpy(fj.make_sublist(2, np.random.default_rng(8))).to(dev)
     kw = dict(len_min=2, len_max=30, smooth_coeff=0.3)
     ref = fj.stream_device(field, (n, n, n), seeds, sub, **kw)
-    monkeypatch.setenv("FIBERS_STREAM_BATCHES", str(batches))
     bufs = fj.StreamBuffers(dev)
     got = fj.stream_device_run(field, (n, n, n), seeds, sub, buffers=bufs, **kw)          # first call: sizes the buffers (one retry)
     for k in ("npts", "seed_index", "xyz"):

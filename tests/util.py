@@ -2,17 +2,32 @@
 import numpy as np
 
 
+def solver_r(l1, l2, l3):
+    """the closed-form 3x3 solver's r = det((A - q I) / p) / 2 (StaticArrays eigen, dti.jl:311), recomputed in Float64 from a tensor's
+    eigenvalues: q = mean, p = sqrt(sum((l - q)^2) / 6), r = prod(l - q) / p^3 / 2; |r| -> 1 where two eigenvalues coincide (p == 0: 1)"""
+    l = np.stack([np.asarray(x, np.float64) for x in (l1, l2, l3)])
+    q = l.mean(0)
+    p = np.sqrt(((l - q) ** 2).sum(0) / 6.0)
+    with np.errstate(all="ignore"):
+        r = np.prod(l - q, axis=0) / (p ** 3) / 2.0
+    return np.where(p > 0, r, 1.0)
+
+
 def assert_dti_close(got, ref, mask, label="", s0_rtol=1e-4, ev_atol=1e-7, ev_rtol=1e-4, fa_atol=1e-4,
-                     vec_tol=1e-4, gap=1e-2, trig_rel=6e-4):
+                     vec_tol=1e-4, gap=1e-2, trig_rel=6e-4, trig_r=1e-3):
     """got/ref: dicts of arrays [nx,ny,nz(,3)].
 
-    Eigenvalue tolerance: abs 1e-7 + rel 1e-4 PLUS trig_rel*|eigval1|: the reference's
-    closed-form solver (StaticArrays, dti.jl:311) takes acos(r) with r -> +-1 for prolate/oblate tensors,
-    so a 1-ulp change of r moves the two near-degenerate eigenvalues by ~sqrt(eps32)*p ~ 3.5e-4*|eigval1|.
-    That is the reference algorithm's own conditioning (two libm's give two answers), not a kernel error."""
+    Eigenvalue tolerance: abs 1e-7 + rel 1e-4 -- PLUS trig_rel*|eigval1| ONLY in the voxels where the reference's
+    closed-form solver (StaticArrays, dti.jl:311) is ill-conditioned: it takes acos(r), and for |r| > 1 - trig_r (prolate / oblate
+    tensors: two eigenvalues nearly equal) a 1-ulp change of r moves the two near-degenerate eigenvalues by up to
+    ~sqrt(eps32)*p ~ 3.5e-4*|eigval1| -- the reference algorithm's own conditioning (two libm's give two answers), not a kernel
+    error.  r is recomputed here from the oracle's eigenvalues (solver_r); everywhere else SURVEY's tolerance applies as written."""
     m = np.asarray(mask).astype(bool)
     if m.ndim == 4:
         m = m[..., 0]
+    with np.errstate(all="ignore"):
+        illc = np.abs(solver_r(*(np.asarray(ref[k]).reshape(m.shape) for k in ("eigval1", "eigval2", "eigval3")))) > 1.0 - trig_r
+    illc = illc | ~np.isfinite(np.asarray(ref["eigval1"]).reshape(m.shape))
     for k in ("s0", "eigval1", "eigval2", "eigval3", "rd", "md", "fa"):
         g, r = np.asarray(got[k]).reshape(m.shape), np.asarray(ref[k]).reshape(m.shape)
         assert np.array_equal(np.isnan(g), np.isnan(r)), "%s %s: NaN pattern differs" % (label, k)
@@ -23,7 +38,7 @@ def assert_dti_close(got, ref, mask, label="", s0_rtol=1e-4, ev_atol=1e-7, ev_rt
             err = np.abs(g - r)[ok] <= fa_atol
         else:
             lam1 = np.abs(np.asarray(ref["eigval1"]).reshape(m.shape))
-            err = np.abs(g - r)[ok] <= ev_atol + ev_rtol * np.abs(r)[ok] + trig_rel * lam1[ok]
+            err = np.abs(g - r)[ok] <= ev_atol + ev_rtol * np.abs(r)[ok] + np.where(illc, trig_rel, 0.0)[ok] * lam1[ok]
         assert err.all(), "%s %s: %d voxels out of tolerance, max abs err %g" % (
             label, k, (~err).sum(), np.abs(g - r)[ok].max())
         assert (g[~m] == 0).all(), "%s %s: non-zero outside the mask" % (label, k)

@@ -1,6 +1,9 @@
+import os
 """DSI two-tile kernel: time per step against the number of workgroups per XCD that take ODF tiles (FIBERS_DSI_NA)."""
 import sys, os, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the switch this tool flips exists in the DIAGNOSTIC build only (csrc/common.h ab_env; make -C fibers.jl_amd/csrc stamp)
+os.environ.setdefault("FIBERS_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fibers.jl_amd", "libfibers_hip_stamp.so"))
 import torch
 import fibers_jl_amd as fj
 from fibers_jl_amd import phantom

@@ -1,6 +1,9 @@
+import os
 """DSI two-tile kernel: paired 16:16 workgroup split (default: samples fetched once) against the cost-balanced 17:15 split without pairing."""
 import sys, os, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the switch this tool flips exists in the DIAGNOSTIC build only (csrc/common.h ab_env; make -C fibers.jl_amd/csrc stamp)
+os.environ.setdefault("FIBERS_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fibers.jl_amd", "libfibers_hip_stamp.so"))
 import torch
 import fibers_jl_amd as fj
 from fibers_jl_amd import phantom

@@ -1,4 +1,4 @@
-"""DSI at 140^3 x 515: odf_dsi2_kernel (two M tiles, peaks on chip) against the three-tile path + separate peak kernel (FIBERS_DSI_THREE_TILES=1): step and kernel times, agreement of the outputs."""
+"""DSI at 140^3 x 515: odf_dsi2_kernel (two M tiles, peaks on chip) against the three-tile path + separate peak kernel (FIB_ODF_SEPARATE_PEAKS): step and kernel times, agreement of the outputs."""
 import sys, os, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
@@ -12,17 +12,15 @@ b5, g5 = phantom.scheme_dsi()
 d5, _ = phantom.make_dwi_torch(shape, b5, g5, seed=5, device=dev)
 mask = torch.ones(nvox, dtype=torch.uint8, device=dev)
 res = {}
-for name, env in (("two_tiles", None), ("three_tiles", "1")):
-    if env: os.environ["FIBERS_DSI_THREE_TILES"] = env
-    else: os.environ.pop("FIBERS_DSI_THREE_TILES", None)
+for name, sep in (("two_tiles", False), ("three_tiles", True)):
     p5 = fj.OdfPlan("dsi", b5, g5, fj.sphere_642, hann_width=32, device=0)
-    o5 = fj.odf_rec_device(p5, d5, mask)
-    for _ in range(3): fj.odf_rec_device(p5, d5, mask, out=o5)
+    o5 = fj.odf_rec_device(p5, d5, mask, separate_peaks=sep)
+    for _ in range(3): fj.odf_rec_device(p5, d5, mask, out=o5, separate_peaks=sep)
     torch.cuda.synchronize()
     L.fib_profile_enable(1); L.fib_profile_reset()
     t0 = time.perf_counter()
     n = 20
-    for _ in range(n): fj.odf_rec_device(p5, d5, mask, out=o5)
+    for _ in range(n): fj.odf_rec_device(p5, d5, mask, out=o5, separate_peaks=sep)
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / n * 1e3
     L.fib_profile_enable(0)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B check of the fused peak scan (gemm3_epilogue_fused) against the separate peak kernel (FIBERS_ODF_UNFUSED=1) on
+"""A/B check of the fused peak scan (gemm3_epilogue_fused) against the separate peak kernel (FIB_ODF_SEPARATE_PEAKS) on
 the same device buffers: ODF, peaks and raw qa must be bit-identical; odfmax must equal the sequential f32 mean."""
 import os
 import sys
@@ -13,11 +13,7 @@ from fibers_jl_amd import phantom  # noqa: E402
 
 
 def run(plan, dwi, mask, unfused):
-    if unfused:
-        os.environ["FIBERS_ODF_UNFUSED"] = "1"
-    else:
-        os.environ.pop("FIBERS_ODF_UNFUSED", None)
-    out = fj.odf_rec_device(plan, dwi, mask, normalize=False)
+    out = fj.odf_rec_device(plan, dwi, mask, normalize=False, separate_peaks=unfused)
     torch.cuda.synchronize()
     return out
 

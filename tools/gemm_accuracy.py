@@ -2,7 +2,7 @@
 """Accuracy of the ODF contraction kernels against a float64 contraction of the same float32 operands.
 
   f32     odf_gemm_kernel   v_mfma_f32_32x32x2_f32 (k-ordered f32 fma chain)
-  bf16x3  odf_gemm3_kernel  three exact bf16 pieces per operand, six v_mfma_f32_32x32x16_bf16 per 16 frames (FIBERS_ODF_EXACT=1)
+  bf16x3  odf_gemm3_kernel  three exact bf16 pieces per operand, six v_mfma_f32_32x32x16_bf16 per 16 frames (FIBERS_ODF_FORMAT=bf16x3)
   fp16x2  odf_gemm3_kernel  two fp16 pieces per operand (23 significant bits, per-voxel power-of-two sample scale), three
                             v_mfma_f32_32x32x16_f16 per 16 frames: the default
 
@@ -20,9 +20,8 @@ sys.path.insert(0, ROOT)
 
 def run(kind, mode, bval, bvec, dwi, mask, sph):
     import fibers_jl_amd as fj
-    os.environ.pop("FIBERS_ODF_GEMM", None); os.environ.pop("FIBERS_ODF_EXACT", None)
-    if mode == "f32": os.environ["FIBERS_ODF_GEMM"] = "f32"
-    if mode == "bf16x3": os.environ["FIBERS_ODF_EXACT"] = "1"
+    os.environ.pop("FIBERS_ODF_FORMAT", None)
+    if mode in ("f32", "bf16x3"): os.environ["FIBERS_ODF_FORMAT"] = mode
     plan = fj.OdfPlan(kind, bval, bvec, sph, sigma=1.25, hann_width=32, device=0)
     out = fj.odf_rec_device(plan, dwi, mask)
     A = plan.matrix()

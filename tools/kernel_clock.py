@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """In-kernel clock of the contraction kernels (MI355X_MICROARCH.md "DVFS give-back" item 6).
 
-Loads the DIAGNOSTIC build libfibers_hip_stamp.so (make -C fibers.jl_amd/csrc stamp: the product library with one
-s_memtime / s_memrealtime pair around each workgroup's whole work loop, written to a buffer nothing else reads), runs each
+Loads the DIAGNOSTIC build libfibers_hip_stamp.so (make -C fibers.jl_amd/csrc stamp: the product library with ONE
+s_memtime / s_memrealtime pair around each workgroup's whole work loop, written to a buffer nothing else reads -- [r5] and nothing
+else: the per-stage phase marks moved to the phase build, they made this kernel 14 % slower than the product's), runs each
 kernel back to back for >= 2 s on the random phantom of the benchmark, and prints per kernel
     clock = d(s_memtime) / d(s_memrealtime) x 100 MHz   (median / min / max over the workgroups of the last launch)
 next to the launch's wall time.  One JSON object on stdout.  The product library never executes a stamp.
@@ -105,13 +106,10 @@ def main():
         plan = fj.OdfPlan("gqi", bval, bvec, sph, sigma=1.25, device=0)
         out = fj.odf_rec_device(plan, dwi, mask, normalize=False)
         for k in kernels:
-            os.environ.pop("FIBERS_ODF_UNFUSED", None)
-            if k == "unfused":
-                os.environ["FIBERS_ODF_UNFUSED"] = "1"
-            elif k != "fused":
+            if k not in ("fused", "unfused"):
                 continue
-            measure("gqi_" + k, lambda: fj.odf_rec_device(plan, dwi, mask, out=out, normalize=True))
-        os.environ.pop("FIBERS_ODF_UNFUSED", None)
+            sep = k == "unfused"                        # FIB_ODF_SEPARATE_PEAKS: the unfused contraction + the separate peak kernel
+            measure("gqi_" + k, lambda: fj.odf_rec_device(plan, dwi, mask, out=out, normalize=True, separate_peaks=sep))
         del dwi, out, plan
         torch.cuda.empty_cache()
     if "dsi" in kernels:

@@ -1,5 +1,7 @@
 import os, sys
 sys.path.insert(0, os.getcwd())
+# the switch this tool flips exists in the DIAGNOSTIC build only (csrc/common.h ab_env; make -C fibers.jl_amd/csrc stamp)
+os.environ.setdefault("FIBERS_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fibers.jl_amd", "libfibers_hip_stamp.so"))
 import numpy as np, torch
 import fibers_jl_amd as fj
 from fibers_jl_amd import phantom

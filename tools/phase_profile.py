@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where a work item's cycles go in the fused contraction kernel: the DIAGNOSTIC build (make -C fibers.jl_amd/csrc stamp) marks the
+"""Where a work item's cycles go in the fused contraction kernel: the DIAGNOSTIC build (make -C fibers.jl_amd/csrc phase) marks the
 phases of the third work item of waves 0 (an "early" wave: MFMA block first, next split afterwards) and 4 (a "late" wave) of one
 workgroup with s_memtime (shader cycles at the constant 100 MHz x clock ratio ... s_memtime counts shader-clock cycles).
 Prints per stage: split | requests | MFMA block | second split | wait for loads | barrier, then the epilogue.
@@ -7,7 +7,7 @@ usage: python tools/phase_profile.py [gqi|dsi]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("FIBERS_HIP_LIB", os.path.join(ROOT, "fibers.jl_amd", "libfibers_hip_stamp.so"))
+os.environ.setdefault("FIBERS_HIP_LIB", os.path.join(ROOT, "fibers.jl_amd", "libfibers_hip_phase.so"))
 import numpy as np, torch
 import fibers_jl_amd as fj
 from fibers_jl_amd import phantom

@@ -256,6 +256,55 @@ __global__ __launch_bounds__(512, 2) void k_lds_wr(int iters, int slp, uint32_t 
     if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345u) sink[threadIdx.x] = 1;
 }
 
+// ---- the step's unavoidable work and nothing else: an empirical floor ------------------------------------------------------------------
+// One launch = one GQI step's algorithmic HBM bytes (2.975 GB read + 3.655 GB written, non-temporal) AND its executed matrix-core
+// work (three fp16 piece products: 1.433 PFLOP of v_mfma_f32_32x32x16_f16), side by side on every CU: waves 0-3 (one per SIMD) issue
+// the MFMAs from registers (FRAG: fragments re-read from LDS as the stage loop does, 20 KiB per 30 MFMAs), waves 4-7 stream.  No
+// sample split, no epilogue, no lists: what a kernel made of nothing but the unavoidable ingredients costs under the board's cap.
+template <bool FRAG>
+__global__ __launch_bounds__(512, 2) void k_essential(const u32x4_t *src, size_t nr16, u32x4_t *dst, size_t nw16, int mfma_trips, float *sink, Stamp *st) {
+    __shared__ __attribute__((aligned(16))) _Float16 lds[20 * 512];
+    uint32_t x = rnd(threadIdx.x * 7919u + blockIdx.x * 104729u + 17u);
+    for (int i = threadIdx.x; i < 20 * 512; i += 512) { x = rnd(x); lds[i] = (_Float16)(((int)(x & 0xffffu) - 32768) * (1.0f / 32768.0f)); }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    Stamp s; stamp_begin(s);
+    if (wave < 4) {
+        f16x8_t a[4], b[2];
+        for (int i = 0; i < 4; i++) a[i] = rnd_f16x8(x);
+        for (int i = 0; i < 2; i++) b[i] = rnd_f16x8(x);
+        f32x16 acc[10];
+        for (int m = 0; m < 10; m++) for (int r = 0; r < 16; r++) acc[m][r] = 0.0f;
+        const f16x8_t *LA = reinterpret_cast<const f16x8_t *>(lds) + lane;
+        for (int t = 0; t < mfma_trips; t++) {
+#pragma unroll
+            for (int m = 0; m < 10; m++) {
+                const f16x8_t a1 = FRAG ? LA[(10 + m) * 64] : a[(m + 1) & 3], a0 = FRAG ? LA[m * 64] : a[m & 3];
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[0], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[1], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[0], acc[m], 0, 0, 0);
+            }
+        }
+        float z = 0;
+        for (int m = 0; m < 10; m++) for (int r = 0; r < 16; r++) z += acc[m][r];
+        if (z == 123.456f) sink[threadIdx.x] = z;
+    } else {
+        u32x4_t acc = {0, 0, 0, 0};
+        const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + (threadIdx.x - 256);
+        const size_t nmax = nr16 > nw16 ? nr16 : nw16;
+        for (size_t i = i0; i < nmax; i += 2 * stride) {
+            u32x4_t v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
+            if (i < nr16) v0 = __builtin_nontemporal_load(src + i);
+            if (i + stride < nr16) v1 = __builtin_nontemporal_load(src + i + stride);
+            acc ^= v0 ^ v1;
+            if (i < nw16) { u32x4_t v = acc; v[0] += (uint32_t)i; __builtin_nontemporal_store(v, dst + i); }
+            if (i + stride < nw16) { u32x4_t v = acc; v[1] += (uint32_t)i; __builtin_nontemporal_store(v, dst + i + stride); }
+        }
+        if ((acc[0] ^ acc[1]) == 0x12345u) sink[threadIdx.x] = 1;
+    }
+    stamp_end(s, st);
+}
+
 // ---- host ---------------------------------------------------------------------------------------------------------------------------
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static double energy_j() {
@@ -349,6 +398,22 @@ int main(int argc, char **argv) {
         const size_t nr = (size_t)(2.975e9 / 16), nw = (size_t)(3.655e9 / 16);
         r = run_mode(sec, d_st, 2048, [&] { hipLaunchKernelGGL(k_hbm_rw, dim3(2048), dim3(512), 0, 0, d_a, nr, d_b, nw, d_st); });
         report("hbm_rw_gqi", "B", (double)(nr + nw) * 16.0, r, p_idle, "the GQI step's bytes: 2.975 GB read + 3.655 GB written per launch, non-temporal");
+        CK(hipFree(d_a)); CK(hipFree(d_b));
+    }
+    if (want("essential")) {
+        CK(hipMalloc(&d_a, NB)); CK(hipMalloc(&d_b, NB));
+        hipLaunchKernelGGL(k_hbm_write, dim3(2048), dim3(512), 0, 0, d_a, NB / 16, 1u, d_st);
+        CK(hipDeviceSynchronize());
+        const size_t nr = (size_t)(2.975e9 / 16), nw = (size_t)(3.655e9 / 16);
+        const double flops = 3.0 * 2.0 * 320 * 272 * 2744000.0;                     // executed per step
+        const int trips = (int)(flops / (30.0 * 2.0 * 32 * 32 * 16) / (OCC * 4.0) + 0.5);
+        for (int frag = 0; frag < 2; frag++) {
+            Result r = frag ? run_mode(sec, d_st, OCC, [&] { hipLaunchKernelGGL(k_essential<true>, dim3(OCC), dim3(512), 0, 0, d_a, nr, d_b, nw, trips, (float *)d_sink, d_st); })
+                            : run_mode(sec, d_st, OCC, [&] { hipLaunchKernelGGL(k_essential<false>, dim3(OCC), dim3(512), 0, 0, d_a, nr, d_b, nw, trips, (float *)d_sink, d_st); });
+            report(frag ? "essential_gqi_step_lds_fragments" : "essential_gqi_step", "step", 1.0, r, p_idle,
+                   frag ? "one launch = the GQI step's HBM bytes + its executed MFMAs with the fragments re-read from LDS (20 KiB per 30 MFMAs), nothing else"
+                        : "one launch = the GQI step's algorithmic HBM bytes (2.975 GB in, 3.655 GB out) + its executed MFMAs (1.433 PFLOP, operands in registers), nothing else");
+        }
         CK(hipFree(d_a)); CK(hipFree(d_b));
     }
     const int slps[4] = {0, 1, 3, 8};
