@@ -11,7 +11,11 @@
 //   * the only exchange step of the fits, odfmax = maximum(mean(odf, dims=4)) (gqi.jl:164, dsi.jl:263), is one float per
 //     chunk: reduced on the host, then qa ./= odfmax runs on every device before the qa volumes are copied out;
 //   * plans (the reference's work structs) are cached per device, keyed by the tables they were built from.
+#include <sched.h>
+#include <sys/mman.h>
+
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -71,11 +75,68 @@ int d2h(void *dst, const void *src, size_t bytes) {
     return FIB_OK;
 }
 
+// ---- NUMA: the host CPUs next to a device ---------------------------------------------------------------------------------------
+// [r5] The pinned ring a device's DMA engines read and write, and the threads that fill and drain it, belong on the NUMA node the device
+// hangs off (a two-socket box: the driver's run of fib_gqi_rec took 122 ms where a run whose pages happened to sit on the device's
+// node took 90).  The node's CPUs come from sysfs (local_cpulist of the device's PCI function), intersected with the CPUs this process
+// may use; an empty list (no sysfs, one node, a container without the file) leaves everything where the scheduler puts it.
+std::vector<int> device_local_cpus(int device) {
+    std::vector<int> cpus;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) return cpus;
+    for (char *c = bdf; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/local_cpulist";
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return cpus;
+    char line[4096] = {0};
+    const bool ok = fgets(line, sizeof line, f) != nullptr;
+    fclose(f);
+    if (!ok) return cpus;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return cpus;
+    for (const char *q = line; *q;) {                        // "0-63,128-191"
+        char *e = nullptr;
+        const long a = strtol(q, &e, 10);
+        if (e == q) break;
+        long b = a;
+        q = e;
+        if (*q == '-') { b = strtol(q + 1, &e, 10); q = e; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (CPU_ISSET((int)c, &allowed)) cpus.push_back((int)c);
+        if (*q == ',') q++; else break;
+    }
+    return cpus;
+}
+void bind_this_thread(const std::vector<int> &cpus) {
+    if (cpus.empty()) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : cpus) CPU_SET(c, &set);
+    (void)sched_setaffinity(0, sizeof set, &set);            // (best effort)
+}
+
+// a host-side phase, into the profile table while fib_profile_enable(1) is active
+struct HostTimer {
+    const char *name; std::chrono::steady_clock::time_point t0;
+    explicit HostTimer(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
+    ~HostTimer() { if (fib::profiling_on()) fib::profile_add_ms(name, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+};
+
+// Result arrays the library hands to the caller (fib_tract_free releases them with free()): large ones are 2-MB aligned and advised for
+// transparent huge pages -- C4 returns 1.5 GB of points, i.e. 377 000 first-touch faults of 4-KB pages inside the call otherwise.
+void *alloc_result(size_t bytes) {
+    if (bytes < ((size_t)32 << 20)) return malloc(bytes ? bytes : 1);
+    void *p = nullptr;
+    if (posix_memalign(&p, (size_t)2 << 20, bytes) != 0) return nullptr;
+    (void)madvise(p, bytes, MADV_HUGEPAGE);
+    return p;
+}
+
 // ---- a small pool for the row copies between the caller's arrays and the pinned ring --------------------------------------
 class CopyPool {
   public:
-    explicit CopyPool(int nthreads) {
-        for (int i = 0; i < nthreads; i++) th_.emplace_back([this] { work(); });
+    CopyPool(int nthreads, const std::vector<int> &cpus) {
+        for (int i = 0; i < nthreads; i++) th_.emplace_back([this, cpus] { bind_this_thread(cpus); work(); });
     }
     ~CopyPool() {
         { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
@@ -131,11 +192,19 @@ constexpr int NBUF = 3;                                  // ring depth: chunk k 
 
 struct PinBuf {                                          // grow-only pinned host buffer
     char *p = nullptr; size_t n = 0;
-    int ensure(size_t bytes) {
+    // cpus: the allocation (and the first touch of its pages) happens on a thread bound to these CPUs -- the device's NUMA node
+    int ensure(size_t bytes, int device, const std::vector<int> &cpus) {
         if (bytes <= n && p) return FIB_OK;
         if (p) (void)hipHostFree(p);
         p = nullptr; n = 0;
-        hipError_t e = hipHostMalloc((void **)&p, bytes ? bytes : 1, hipHostMallocDefault);
+        hipError_t e = hipSuccess;
+        auto body = [&] {
+            bind_this_thread(cpus);
+            (void)hipSetDevice(device);
+            e = hipHostMalloc((void **)&p, bytes ? bytes : 1, hipHostMallocDefault);
+            if (e == hipSuccess) for (size_t o = 0; o < bytes; o += 4096) p[o] = 0;    // (first touch, should the driver have left any page untouched)
+        };
+        if (cpus.empty()) body(); else { std::thread t(body); t.join(); }
         if (e != hipSuccess) { p = nullptr; return fib::fail(FIB_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
         n = bytes;
         return FIB_OK;
@@ -153,10 +222,19 @@ struct DevState {
     hipEvent_t e_in[NBUF] = {}, e_cmp[NBUF] = {}, e_out[NBUF] = {};
     PinBuf pin_in[NBUF], pin_out[NBUF];
     fib::DevBuf<char> dev_in[NBUF], dev_out[NBUF];
-    std::unique_ptr<CopyPool> pool;
+    std::vector<int> cpus;                               // the host CPUs on the device's NUMA node (empty: unknown / not bound)
+    std::unique_ptr<CopyPool> pool, pool_out;            // row copies into the ring (gather) | out of it (scatter): the two stages run side by side
     std::vector<CachedPlan> plans;
     uint64_t clock = 0;
     fib_stream_ws *ws = nullptr;
+    // device buffers of fib_stream, kept between calls (grow-only, like the ring and the tracer's workspace): a hipMalloc / hipFree pair
+    // per 1.5-GB result costs more than the tracking itself
+    struct StreamBufs {
+        fib::DevBuf<float> vec, f, fa, field, sub, lcms, xyz;
+        fib::DevBuf<uint8_t> mask, mout, flags;
+        fib::DevBuf<int64_t> seeds, sidx;
+        fib::DevBuf<int32_t> npts;
+    } sb;
 
     int init(int nthreads) {
         if (ready) return FIB_OK;
@@ -169,7 +247,9 @@ struct DevState {
             FIB_HIP(hipEventCreateWithFlags(&e_cmp[b], hipEventDisableTiming));
             FIB_HIP(hipEventCreateWithFlags(&e_out[b], hipEventDisableTiming));
         }
-        pool.reset(new CopyPool(nthreads));
+        { const char *e = fib::ab_env("FIBERS_HOST_NUMA"); if (!(e && e[0] == '0')) cpus = device_local_cpus(device); }
+        pool.reset(new CopyPool(nthreads, cpus));
+        pool_out.reset(new CopyPool(nthreads, cpus));
         ready = true;
         return FIB_OK;
     }
@@ -299,7 +379,10 @@ int live_map_for(DevState &d, const void *mask, int mask_dtype, int64_t v0, int6
     const char *e = fib::env("FIBERS_HOST_PACK");
     if ((e && e[0] == '0') || v1 <= v0) return FIB_OK;
     RC(build_live_map(*d.pool, mask, mask_dtype, v0, v1, lm));
-    if ((double)lm.nlive < LIVE_PACK_BELOW * (double)(v1 - v0)) *use = &lm;
+    // .. and whose runs are long enough: every run is a memcpy per row in both directions; below ~16 voxels (64 bytes) per run the
+    // per-run overhead outweighs the bytes saved (a noisy threshold mask), and the unpacked pipeline moves whole rows
+    const bool long_runs = lm.start.empty() || lm.nlive >= (int64_t)16 * (int64_t)lm.start.size();
+    if ((double)lm.nlive < LIVE_PACK_BELOW * (double)(v1 - v0) && long_runs) *use = &lm;
     return FIB_OK;
 }
 
@@ -313,6 +396,22 @@ int64_t pick_chunk(int64_t nrange, int rows_in, int rows_out) {
     if (const char *e = fib::env("FIBERS_HOST_CHUNK")) { const long long v = atoll(e); if (v >= 1024) c = v / 32 * 32; }
     return c < nrange ? c : std::max<int64_t>((nrange + 3) / 4 * 4, 4);
 }
+
+// [r5] The chunk schedule of a range of `total` voxels: 1/8, 1/4 and 1/2 of a chunk first, whole chunks after that.  The download stream
+// is the pipeline's long pole (fib_gqi_rec moves 3.66 GB out against 2.96 GB in), and it cannot start before the first chunk has been
+// gathered, uploaded and computed: with a small first chunk it starts after ~2 ms instead of ~8.  Offsets are multiples of 32 voxels.
+std::vector<int64_t> chunk_schedule(int64_t total, int64_t chunk) {
+    std::vector<int64_t> off;
+    int64_t o = 0;
+    for (int64_t c : {chunk / 8, chunk / 4, chunk / 2}) {
+        c = c / 32 * 32;
+        if (c >= 8192 && total - o > chunk + c) { off.push_back(o); o += c; }
+    }
+    while (o < total) { off.push_back(o); o += std::min(chunk, total - o); }
+    off.push_back(total);
+    return off;
+}
+int chunk_count(int64_t total, int64_t chunk) { return total > 0 ? (int)chunk_schedule(total, chunk).size() - 1 : 0; }
 
 // voxels [vbeg, vend) of a volume of nvox voxels through device d.  Blocking.  The caller holds d.mu.
 // lm != NULL: only the voxels inside the mask travel (LiveMap); fn then sees dense chunks whose mask is all ones (padded with voxels
@@ -335,16 +434,17 @@ int run_chunks(DevState &d, int64_t vbeg, int64_t vend, int64_t nvox, const std:
     if (lm) chunk = (chunk + 31) / 32 * 32;
     const size_t in_bytes = (size_t)rin * chunk * 4 + (size_t)chunk, out_bytes = (size_t)rout * chunk * 4;
     for (int b = 0; b < NBUF; b++) {
-        RC(d.pin_in[b].ensure(in_bytes));
-        RC(d.pin_out[b].ensure(out_bytes));
+        RC(d.pin_in[b].ensure(in_bytes, d.device, d.cpus));
+        RC(d.pin_out[b].ensure(out_bytes, d.device, d.cpus));
         RC(d.dev_in[b].ensure(in_bytes));
         RC(d.dev_out[b].ensure(out_bytes));
     }
-    const int nchunks = (int)fib::cdiv(total, chunk);
+    const std::vector<int64_t> coff = chunk_schedule(total, chunk);
+    const int nchunks = (int)coff.size() - 1;
     std::atomic<int> err{FIB_OK};
     // chunk k: `n` voxels that travel, `nd` voxels the device sees (lm: padded to a multiple of 32 so that its rows stay on cache lines)
     auto span = [&](int k, int64_t &o0, int64_t &n, int64_t &nd) {
-        o0 = (int64_t)k * chunk; n = std::min<int64_t>(chunk, total - o0);
+        o0 = coff[k]; n = coff[k + 1] - coff[k];
         nd = lm ? (n + 31) / 32 * 32 : n;
     };
     // lm: the pieces of the caller's rows that make up inside-voxels [l0, l0 + n): f(voxel, position in the chunk, count, run index, piece starts its run)
@@ -362,18 +462,26 @@ int run_chunks(DevState &d, int64_t vbeg, int64_t vend, int64_t nvox, const std:
         const int b = k % NBUF;
         int64_t o0, n, nd;
         span(k, o0, n, nd);
+        const auto tw0 = std::chrono::steady_clock::now();
         if (hipEventSynchronize(d.e_out[b]) != hipSuccess) { err = fib::fail(FIB_ERR_HIP, "device-to-host copy of chunk %d failed", k); return; }
+        const auto tw1 = std::chrono::steady_clock::now();
+        struct Timed { std::chrono::steady_clock::time_point t0, w0; ~Timed() {
+            if (!fib::profiling_on()) return;
+            const auto t1 = std::chrono::steady_clock::now();
+            fib::profile_add_ms("host_scatter", std::chrono::duration<double, std::milli>(t1 - t0).count());
+            fib::profile_add_ms("host_scatter_wait", std::chrono::duration<double, std::milli>(t0 - w0).count());
+        } } timed{tw1, tw0};
         std::vector<std::pair<float *, const float *>> rows;
         const float *src = reinterpret_cast<const float *>(d.pin_out[b].p);
         if (!lm) {
             const int64_t v0 = vbeg + o0;
             for (auto &r : outs) for (int i = 0; i < r.nrows; i++) { rows.emplace_back(r.out + (int64_t)i * nvox + v0, src); src += n; }
-            d.pool->run((int)rows.size(), [&](int i) { memcpy(rows[i].first, rows[i].second, (size_t)n * 4); });
+            d.pool_out->run((int)rows.size(), [&](int i) { memcpy(rows[i].first, rows[i].second, (size_t)n * 4); });
             return;
         }
         for (auto &r : outs) for (int i = 0; i < r.nrows; i++) { rows.emplace_back(r.out + (int64_t)i * nvox, src); src += nd; }
         const bool last = k == nchunks - 1;
-        d.pool->run((int)rows.size(), [&](int i) {
+        d.pool_out->run((int)rows.size(), [&](int i) {
             float *row = rows[i].first;
             const float *s = rows[i].second;
             size_t rl = 0;
@@ -396,7 +504,9 @@ int run_chunks(DevState &d, int64_t vbeg, int64_t vend, int64_t nvox, const std:
         int64_t o0, n, nd;
         span(k, o0, n, nd);
         // the pinned input buffer is free once the upload of chunk k - NBUF has completed
+        const auto tg0 = std::chrono::steady_clock::now();
         if (k >= NBUF) FIB_HIP(hipEventSynchronize(d.e_in[b]));
+        const auto tg1 = std::chrono::steady_clock::now();
         {
             std::vector<std::pair<float *, const float *>> rows;
             float *dst = reinterpret_cast<float *>(d.pin_in[b].p);
@@ -421,23 +531,65 @@ int run_chunks(DevState &d, int64_t vbeg, int64_t vend, int64_t nvox, const std:
             }
             if (merr != FIB_OK) return fib::fail(FIB_ERR_INVALID, "unknown mask dtype %d", mask_dtype);
         }
+        if (fib::profiling_on()) {
+            fib::profile_add_ms("host_gather", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg1).count());
+            fib::profile_add_ms("host_gather_wait", std::chrono::duration<double, std::milli>(tg1 - tg0).count());
+        }
         const size_t ib = (size_t)rin * nd * 4 + (size_t)nd;
         // device buffers of this ring slot: the kernels of chunk k - NBUF have read dev_in, its download has read dev_out
         if (k >= NBUF) { FIB_HIP(hipStreamWaitEvent(d.s_in, d.e_cmp[b], 0)); FIB_HIP(hipStreamWaitEvent(d.s_cmp, d.e_out[b], 0)); }
-        FIB_HIP(hipMemcpyAsync(d.dev_in[b].p, d.pin_in[b].p, ib, hipMemcpyHostToDevice, d.s_in));
+        {
+            fib::ProfScope prof("host_h2d", d.s_in);
+            FIB_HIP(hipMemcpyAsync(d.dev_in[b].p, d.pin_in[b].p, ib, hipMemcpyHostToDevice, d.s_in));
+        }
         FIB_HIP(hipEventRecord(d.e_in[b], d.s_in));
         FIB_HIP(hipStreamWaitEvent(d.s_cmp, d.e_in[b], 0));
         RC(fn(k, o0, nd, reinterpret_cast<const float *>(d.dev_in[b].p), reinterpret_cast<const uint8_t *>(d.dev_in[b].p) + (size_t)rin * nd * 4,
               reinterpret_cast<float *>(d.dev_out[b].p), d.s_cmp));
         FIB_HIP(hipEventRecord(d.e_cmp[b], d.s_cmp));
         FIB_HIP(hipStreamWaitEvent(d.s_out, d.e_cmp[b], 0));
-        FIB_HIP(hipMemcpyAsync(d.pin_out[b].p, d.dev_out[b].p, (size_t)rout * nd * 4, hipMemcpyDeviceToHost, d.s_out));
+        {
+            fib::ProfScope prof("host_d2h", d.s_out);
+            FIB_HIP(hipMemcpyAsync(d.pin_out[b].p, d.dev_out[b].p, (size_t)rout * nd * 4, hipMemcpyDeviceToHost, d.s_out));
+        }
         FIB_HIP(hipEventRecord(d.e_out[b], d.s_out));
         return FIB_OK;
     };
-    for (int k = 0; k < nchunks + 2 && err == FIB_OK; k++) {
-        if (k >= 2) scatter(k - 2);
-        if (k < nchunks && err == FIB_OK) { const int rc = enqueue(k); if (rc != FIB_OK) err = rc; }
+    // [r5] Two host stages side by side: this thread gathers chunk k into the ring and enqueues its upload, kernels and download; a second
+    // thread waits for downloads and scatters them into the caller's arrays (each stage has its own copy pool).  Before, one thread
+    // alternated scatter(k - 2) and gather(k): 47 ms of row copies in a row next to 68 ms of PCIe for fib_gqi_rec 140^3 x 270.
+    // Ring slot b = k % NBUF of the OUTPUT side is free for chunk k once chunk k - NBUF has been scattered.
+    {
+        std::mutex mu;
+        std::condition_variable cv;
+        int enq = 0, scat = 0;                               // chunks enqueued by this thread | scattered by the other
+        bool stop = false;
+        std::string smsg;
+        std::thread ts([&] {
+            try {
+                (void)hipSetDevice(d.device);
+                for (int k = 0; k < nchunks; k++) {
+                    { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return enq > k || stop; }); if (enq <= k) break; }
+                    scatter(k);
+                    if (err != FIB_OK) smsg = fib_last_error();                // (the message is thread-local: hand it over)
+                    { std::lock_guard<std::mutex> lk(mu); scat = k + 1; }
+                    cv.notify_all();
+                    if (err != FIB_OK) break;
+                }
+            } catch (...) { err = FIB_ERR_INVALID; smsg = "internal error in the scatter stage"; std::lock_guard<std::mutex> lk(mu); scat = nchunks; cv.notify_all(); }
+        });
+        for (int k = 0; k < nchunks && err == FIB_OK; k++) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return scat >= k - NBUF + 1 || err != FIB_OK; }); }
+            if (err != FIB_OK) break;
+            const int rc = enqueue(k);
+            if (rc != FIB_OK) { err = rc; break; }
+            { std::lock_guard<std::mutex> lk(mu); enq = k + 1; }
+            cv.notify_all();
+        }
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        ts.join();
+        if (err != FIB_OK && !smsg.empty()) fib::set_error("%s", smsg.c_str());
     }
     // leave the streams idle whatever happened (the ring buffers are reused by the next call)
     (void)hipStreamSynchronize(d.s_in); (void)hipStreamSynchronize(d.s_cmp); (void)hipStreamSynchronize(d.s_out);
@@ -664,7 +816,7 @@ int odf_rec_host(int device, const OdfSpec &spec, const float *dwi, int nx, int 
         RC(live_map_for(d, mask, mask_dtype, sl.v0, sl.v1, sl.lm, &sl.use));
         const int64_t ntr = sl.use ? sl.use->nlive : nr;        // voxels that travel
         const int64_t chunk = pick_chunk(ntr, nvol, rows_out);
-        const int nchunks = (int)fib::cdiv(ntr, chunk);
+        const int nchunks = chunk_count(ntr, chunk);
         sl.nq = (ntr + 31) / 32 * 32 + 32;                      // a plane of the qa kept on the device (a packed chunk is padded to 32 voxels)
         FIB_HIP(hipSetDevice(d.device));
         RC(sl.keep.alloc((size_t)3 * sl.nq + (size_t)2 * std::max(nchunks, 1)));
@@ -853,8 +1005,50 @@ struct StreamIn {
     const fib_stream_params *prm; const float *const *ovec; const float *const *f; float f_thresh; const float *fa; float fa_thresh;
     const float *sublist; int32_t nsub; const float *lcms; float lcm_thresh; uint64_t rng_seed; int strd0, strd1;
 };
-// what one worker traced: lines in (seed, sub) order of ITS seed shard; seed_index counts seeds of the whole list
-struct Shard { int64_t nl = 0, np = 0; std::vector<int32_t> npts; std::vector<int64_t> sidx; std::vector<float> xyz; std::vector<uint8_t> flags; };
+// what one worker traced: lines in (seed, sub) order of ITS seed shard; seed_index counts seeds of the whole list.  The arrays are
+// malloc'ed and never zero-filled ([r5]: C4 returns 1.5 GB of points -- a std::vector's value-initialisation and a second copy into the
+// result cost more than the PCIe transfer); with one worker they ARE the result (fib_tract_free releases them with free()).
+struct Shard {
+    int64_t nl = 0, np = 0;
+    int32_t *npts = nullptr; int64_t *sidx = nullptr; float *xyz = nullptr; uint8_t *flags = nullptr;
+    Shard() = default;
+    Shard(const Shard &) = delete;
+    Shard &operator=(const Shard &) = delete;
+    ~Shard() { free(npts); free(sidx); free(xyz); free(flags); }
+};
+
+// device -> pageable host memory, pipelined: pieces of up to 64 MB come down into two slots of the worker's pinned output ring while the
+// scatter pool copies the previous piece to its destination (a plain hipMemcpy into pageable memory stages through a small driver buffer
+// at a third of the link's rate, and the first touch of a freshly malloc'ed destination falls on one thread)
+int d2h_pipelined(DevState &d, void *dst, const void *src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return FIB_OK;
+    const size_t piece = std::min<size_t>(bytes, (size_t)64 << 20);
+    for (int b = 0; b < 2; b++) RC(d.pin_out[b].ensure(piece, d.device, d.cpus));
+    const size_t np = (bytes + piece - 1) / piece;
+    const int nt = 16;
+    auto drain = [&](size_t i) -> int {                  // piece i: ring -> destination
+        const int b = (int)(i & 1);
+        FIB_HIP(hipEventSynchronize(d.e_out[b]));
+        const size_t o = i * piece, n = std::min(piece, bytes - o);
+        const size_t part = ((n + nt - 1) / nt + 63) & ~(size_t)63;
+        d.pool_out->run(nt, [&](int t) {
+            const size_t a = (size_t)t * part;
+            if (a < n) memcpy((char *)dst + o + a, d.pin_out[b].p + a, std::min(part, n - a));
+        });
+        return FIB_OK;
+    };
+    for (size_t i = 0; i < np; i++) {
+        const int b = (int)(i & 1);
+        const size_t o = i * piece, n = std::min(piece, bytes - o);
+        {
+            fib::ProfScope prof("host_d2h", st);
+            FIB_HIP(hipMemcpyAsync(d.pin_out[b].p, (const char *)src + o, n, hipMemcpyDeviceToHost, st));
+        }
+        FIB_HIP(hipEventRecord(d.e_out[b], st));
+        if (i > 0) RC(drain(i - 1));
+    }
+    return drain(np - 1);
+}
 
 // seeds[i], i = w, w + nw, ... (round-robin: balances line length; the reference's contiguous chunks, stream.jl:757-759, do not)
 int stream_worker(DevState &d, int w, int nw, const StreamIn &in, const std::vector<uint8_t> *m8, const std::vector<int64_t> &seeds,
@@ -865,22 +1059,23 @@ int stream_worker(DevState &d, int w, int nw, const StreamIn &in, const std::vec
     FIB_HIP(hipSetDevice(d.device));
     if (!d.ws) RC(fibd_stream_ws_create(d.device, &d.ws));
     hipStream_t st = d.s_cmp;
-    fib::DevBuf<float> d_vec, d_f, d_fa, d_field, d_sub, d_lcms;
-    fib::DevBuf<uint8_t> d_mask, d_mout;
-    RC(d_vec.alloc((size_t)nvox * 3 * nvec));
-    RC(d_field.alloc((size_t)nvox * 4 * nvec));
-    RC(d_mout.alloc((size_t)nvox));
+    std::unique_ptr<HostTimer> tm(new HostTimer("stream_host_upload_field"));
+    auto &d_vec = d.sb.vec; auto &d_f = d.sb.f; auto &d_fa = d.sb.fa; auto &d_field = d.sb.field; auto &d_sub = d.sb.sub; auto &d_lcms = d.sb.lcms;
+    auto &d_mask = d.sb.mask; auto &d_mout = d.sb.mout;
+    RC(d_vec.ensure((size_t)nvox * 3 * nvec));
+    RC(d_field.ensure((size_t)nvox * 4 * nvec));
+    RC(d_mout.ensure((size_t)nvox));
     const float *dv[8] = {}, *df[8] = {};
     for (int k = 0; k < nvec; k++) {
         RC(h2d(d_vec.p + (size_t)k * nvox * 3, in.ovec[k], sizeof(float) * nvox * 3));
         dv[k] = d_vec.p + (size_t)k * nvox * 3;
     }
     if (in.f) {
-        RC(d_f.alloc((size_t)nvox * nvec));
+        RC(d_f.ensure((size_t)nvox * nvec));
         for (int k = 0; k < nvec; k++) { RC(h2d(d_f.p + (size_t)k * nvox, in.f[k], sizeof(float) * nvox)); df[k] = d_f.p + (size_t)k * nvox; }
     }
-    if (in.fa) { RC(d_fa.alloc((size_t)nvox)); RC(h2d(d_fa.p, in.fa, sizeof(float) * nvox)); }
-    if (m8) { RC(d_mask.alloc((size_t)nvox)); RC(h2d(d_mask.p, m8->data(), (size_t)nvox)); }
+    if (in.fa) { RC(d_fa.ensure((size_t)nvox)); RC(h2d(d_fa.p, in.fa, sizeof(float) * nvox)); }
+    if (m8) { RC(d_mask.ensure((size_t)nvox)); RC(h2d(d_mask.p, m8->data(), (size_t)nvox)); }
     RC(fibd_stream_field(nvec, nvox, dv, in.f ? df : nullptr, in.f_thresh, in.fa ? d_fa.p : nullptr, in.fa_thresh,
                          m8 ? d_mask.p : nullptr, d_field.p, d_mout.p, st));
     if (seed_mask_out) {                                 // first pass (no seed volume): the tracking mask back to the host
@@ -889,12 +1084,13 @@ int stream_worker(DevState &d, int w, int nw, const StreamIn &in, const std::vec
         RC(d2h(seed_mask_out->data(), d_mout.p, (size_t)nvox));
         return FIB_OK;
     }
+    tm.reset(new HostTimer("stream_host_seeds_trace"));
     std::vector<int64_t> mine;
     for (size_t i = (size_t)w; i < seeds.size(); i += (size_t)nw) mine.push_back(seeds[i]);
-    fib::DevBuf<int64_t> d_seeds;
-    RC(d_seeds.alloc(mine.size()));
+    auto &d_seeds = d.sb.seeds;
+    RC(d_seeds.ensure(mine.size()));
     if (!mine.empty()) RC(h2d(d_seeds.p, mine.data(), sizeof(int64_t) * mine.size()));
-    RC(d_sub.alloc((size_t)in.nsub * 3));
+    RC(d_sub.ensure((size_t)in.nsub * 3));
     RC(h2d(d_sub.p, in.sublist, sizeof(float) * 3 * in.nsub));
     fib_stream_params prm = prm0;
     prm.ws = d.ws;
@@ -903,7 +1099,7 @@ int stream_worker(DevState &d, int w, int nw, const StreamIn &in, const std::vec
     if (in.lcms) {
         // the uniforms of a line are a function of its index in the WHOLE list (the header's random-number contract), which a
         // shard of a round-robin split cannot express -> LCM runs use one worker (stream_host)
-        RC(d_lcms.alloc((size_t)nvox * 10));
+        RC(d_lcms.ensure((size_t)nvox * 10));
         RC(h2d(d_lcms.p, in.lcms, sizeof(float) * nvox * 10));
         RC(fibd_stream_trace_lcm(&prm, d_field.p, d_lcms.p, in.lcm_thresh, in.strd0, in.strd1, in.rng_seed, d_seeds.p, (int64_t)mine.size(),
                                  d_sub.p, in.nsub, st, &job, &nl, &np));
@@ -911,26 +1107,26 @@ int stream_worker(DevState &d, int w, int nw, const StreamIn &in, const std::vec
         RC(fibd_stream_trace(&prm, d_field.p, d_seeds.p, (int64_t)mine.size(), d_sub.p, in.nsub, st, &job, &nl, &np));
     }
     struct JobGuard { fib_stream_job *j; ~JobGuard() { fib_stream_job_destroy(j); } } jg{job};
+    tm.reset(new HostTimer("stream_host_results"));
     sh.nl = nl; sh.np = np;
-    sh.npts.resize((size_t)nl); sh.sidx.resize((size_t)nl); sh.xyz.resize((size_t)np * 3);
-    if (in.lcms) sh.flags.resize((size_t)np);
+    sh.npts = (int32_t *)alloc_result(sizeof(int32_t) * (size_t)std::max<int64_t>(nl, 1));
+    sh.sidx = (int64_t *)alloc_result(sizeof(int64_t) * (size_t)std::max<int64_t>(nl, 1));
+    sh.xyz = (float *)alloc_result(sizeof(float) * 3 * (size_t)std::max<int64_t>(np, 1));
+    if (in.lcms) sh.flags = (uint8_t *)alloc_result((size_t)std::max<int64_t>(np, 1));
+    if (!sh.npts || !sh.sidx || !sh.xyz || (in.lcms && !sh.flags)) return fib::fail(FIB_ERR_NOMEM, "out of host memory");
     if (nl > 0) {
-        fib::DevBuf<int32_t> d_npts;
-        fib::DevBuf<int64_t> d_sidx;
-        fib::DevBuf<float> d_xyz;
-        fib::DevBuf<uint8_t> d_flags;
-        RC(d_npts.alloc((size_t)nl));
-        RC(d_sidx.alloc((size_t)nl));
-        RC(d_xyz.alloc((size_t)np * 3));
-        if (in.lcms) RC(d_flags.alloc((size_t)np));
+        auto &d_npts = d.sb.npts; auto &d_sidx = d.sb.sidx; auto &d_xyz = d.sb.xyz; auto &d_flags = d.sb.flags;
+        RC(d_npts.ensure((size_t)nl));
+        RC(d_sidx.ensure((size_t)nl));
+        RC(d_xyz.ensure((size_t)np * 3));
+        if (in.lcms) RC(d_flags.ensure((size_t)np));
         RC(fibd_stream_pack_flags(job, d_npts.p, d_sidx.p, d_xyz.p, in.lcms ? d_flags.p : nullptr, st));
-        FIB_HIP(hipStreamSynchronize(st));
-        RC(d2h(sh.npts.data(), d_npts.p, sizeof(int32_t) * nl));
-        RC(d2h(sh.sidx.data(), d_sidx.p, sizeof(int64_t) * nl));
-        RC(d2h(sh.xyz.data(), d_xyz.p, sizeof(float) * 3 * np));
-        if (in.lcms) RC(d2h(sh.flags.data(), d_flags.p, (size_t)np));
+        RC(d2h_pipelined(d, sh.xyz, d_xyz.p, sizeof(float) * 3 * (size_t)np, st));     // (stream order: behind the pack kernels)
+        RC(d2h_pipelined(d, sh.npts, d_npts.p, sizeof(int32_t) * (size_t)nl, st));
+        RC(d2h_pipelined(d, sh.sidx, d_sidx.p, sizeof(int64_t) * (size_t)nl, st));
+        if (in.lcms) RC(d2h_pipelined(d, sh.flags, d_flags.p, (size_t)np, st));
         // seed_index = local seed * nsub + sub  ->  global: seed (w + nw * local) of the whole list
-        if (nw > 1) for (auto &s : sh.sidx) { const int64_t ls = s / in.nsub, sub = s % in.nsub; s = ((int64_t)w + (int64_t)nw * ls) * in.nsub + sub; }
+        if (nw > 1) for (int64_t i = 0; i < nl; i++) { const int64_t s = sh.sidx[i], ls = s / in.nsub, sub = s % in.nsub; sh.sidx[i] = ((int64_t)w + (int64_t)nw * ls) * in.nsub + sub; }
     }
     return FIB_OK;
 }
@@ -964,6 +1160,7 @@ int stream_host(int device, const fib_stream_params *prm, const float *const *ov
         FIB_CHECK(ns >= 2, FIB_ERR_INVALID, "LCM-guided tracking needs two in-plane dimensions with non-zero orientation components");
         in.strd0 = strd[0]; in.strd1 = strd[1];
     }
+    std::unique_ptr<HostTimer> tm(new HostTimer("stream_host_masks_first_pass"));
     std::vector<uint8_t> m8, s8;
     if (mask) RC(mask_convert(mask, mask_dtype, nvox, true, m8));   // mask.vol .> 0, stream.jl:102
     // seed voxels: findall(W.mask) (stream.jl:744) or findall(seed.vol .> 0) (stream.jl:751), column-major order
@@ -973,8 +1170,10 @@ int stream_host(int device, const fib_stream_params *prm, const float *const *ov
         std::vector<int64_t> noseeds;
         RC(for_each_worker({ws[0]}, [&](int, DevState &d) { return stream_worker(d, 0, 1, in, mask ? &m8 : nullptr, noseeds, &s8, none); }));
     }
+    tm.reset(new HostTimer("stream_host_seed_list"));
     std::vector<int64_t> seeds;
     for (int64_t i = 0; i < nvox; i++) if (s8[i]) seeds.push_back(i);
+    tm.reset();
     const int nw = (int)ws.size();
     std::vector<Shard> shards((size_t)nw);
     RC(for_each_worker(ws, [&](int w, DevState &d) { return stream_worker(d, w, nw, in, mask ? &m8 : nullptr, seeds, nullptr, shards[w]); }));
@@ -982,17 +1181,17 @@ int stream_host(int device, const fib_stream_params *prm, const float *const *ov
     int64_t nl = 0, np = 0;
     for (auto &s : shards) { nl += s.nl; np += s.np; }
     out->nlines = nl; out->npoints = np;
-    out->npts = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nl > 0 ? nl : 1));
-    out->seed_index = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nl > 0 ? nl : 1));
-    out->xyz = (float *)malloc(sizeof(float) * 3 * (size_t)(np > 0 ? np : 1));
-    if (lcms) out->flags = (uint8_t *)malloc((size_t)(np > 0 ? np : 1));
-    if (!out->npts || !out->seed_index || !out->xyz || (lcms && !out->flags)) { fib_tract_free(out); return fib::fail(FIB_ERR_NOMEM, "out of host memory"); }
-    if (nw == 1) {
+    if (nw == 1) {                                       // one worker: its arrays are the result
         Shard &s = shards[0];
-        if (nl) { memcpy(out->npts, s.npts.data(), sizeof(int32_t) * nl); memcpy(out->seed_index, s.sidx.data(), sizeof(int64_t) * nl); }
-        if (np) { memcpy(out->xyz, s.xyz.data(), sizeof(float) * 3 * np); if (lcms) memcpy(out->flags, s.flags.data(), (size_t)np); }
+        out->npts = s.npts; out->seed_index = s.sidx; out->xyz = s.xyz; out->flags = s.flags;
+        s.npts = nullptr; s.sidx = nullptr; s.xyz = nullptr; s.flags = nullptr;
         return FIB_OK;
     }
+    out->npts = (int32_t *)alloc_result(sizeof(int32_t) * (size_t)(nl > 0 ? nl : 1));
+    out->seed_index = (int64_t *)alloc_result(sizeof(int64_t) * (size_t)(nl > 0 ? nl : 1));
+    out->xyz = (float *)alloc_result(sizeof(float) * 3 * (size_t)(np > 0 ? np : 1));
+    if (lcms) out->flags = (uint8_t *)alloc_result((size_t)(np > 0 ? np : 1));
+    if (!out->npts || !out->seed_index || !out->xyz || (lcms && !out->flags)) { fib_tract_free(out); return fib::fail(FIB_ERR_NOMEM, "out of host memory"); }
     std::vector<int64_t> li((size_t)nw, 0), pi((size_t)nw, 0);
     int64_t ol = 0, op = 0;
     while (ol < nl) {
@@ -1002,7 +1201,7 @@ int stream_host(int device, const fib_stream_params *prm, const float *const *ov
         Shard &s = shards[best];
         const int32_t n = s.npts[li[best]];
         out->npts[ol] = n; out->seed_index[ol] = s.sidx[li[best]];
-        memcpy(out->xyz + 3 * op, s.xyz.data() + 3 * pi[best], sizeof(float) * 3 * n);
+        memcpy(out->xyz + 3 * op, s.xyz + 3 * pi[best], sizeof(float) * 3 * n);
         ol++; op += n; li[best]++; pi[best] += n;
     }
     return FIB_OK;

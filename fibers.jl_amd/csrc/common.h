@@ -84,6 +84,7 @@ static inline const char *ab_env(const char *) { return nullptr; }
 // hipEvent bracket around a kernel launch when fib_profile_enable(1) is active (no-op otherwise)
 bool profiling_on();
 void profile_push(const char *name, hipEvent_t a, hipEvent_t b);
+void profile_add_ms(const char *name, double ms);
 struct ProfScope {
     const char *name; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
     ProfScope(const char *n, hipStream_t s) : name(n), st(s) {

@@ -298,6 +298,15 @@ void profile_push(const char *name, hipEvent_t a, hipEvent_t b) {
     g_prof.back().pending.emplace_back(a, b);
 }
 
+// a host-side stage's duration (the host tier's gather / scatter stages), into the same table
+void profile_add_ms(const char *name, double ms) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &e : g_prof) if (e.name == name) { e.ms += ms; e.count++; return; }
+    g_prof.emplace_back();
+    g_prof.back().name = name;
+    g_prof.back().ms = ms; g_prof.back().count = 1;
+}
+
 }  // namespace fib
 
 extern "C" int fib_profile_enable(int on) { fib::g_prof_on = on != 0; return FIB_OK; }

@@ -78,6 +78,7 @@ struct TraceArgs {
     int32_t *npts, *nfwd;       // [nlines]; nfwd = forward points | gap << 30 (gap = 1: the forward pass ended on a trip that emitted nothing)
     int64_t line0, nlines;      // this batch covers global lines [line0, line0+nlines)
     int nx, ny, nz, nvec, nsub, len_max, stride, nslots;
+    int scratch_plain;          // diagnostic build only (FIBERS_STREAM_SCRATCH_PLAIN): the point scratch with the default cache policy instead of non-temporal
     float cosang, step, smooth;
     // microscopy regime (stream.jl:252-287, 547-619)
     // LCM-guided tracking (stream.jl:200-236, 380-495)
@@ -99,8 +100,14 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
 // default policy the 1.6 GB of scratch points of a million lines go through the XCDs' L2 and push the orientation field out of it:
 // the trace kernel took 0.69 ms, 0.55 with this store (and 0.50 with no store at all); the pack kernel gains 4 % too.
 typedef float f32x3_t __attribute__((ext_vector_type(3)));
-__device__ __forceinline__ void store_point(float *d, float x, float y, float z) {
+__device__ __forceinline__ void store_point(float *d, float x, float y, float z, bool plain = false) {
     const f32x3_t v = {x, y, z};
+#ifdef FIB_AB_VARIANTS
+    // (diagnostic build, FIBERS_STREAM_SCRATCH_PLAIN: the default cache policy, as inline assembly -- written as a second C++ store hipcc
+    // merges the two branches into ONE store without the non-temporal hint; tools/check_loop_waits.py asserts the hint on the product)
+    if (plain) { asm volatile("global_store_dwordx3 %0, %1, off" :: "v"(d), "v"(v) : "memory"); return; }
+#endif
+    (void)plain;
     __builtin_nontemporal_store(v, reinterpret_cast<f32x3_t *>(d));
 }
 
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
             }
             // push!/prepend! of pos_now (stream.jl:660): the slot of this trip
             // LCM runs: the method-difference flag of the point (stream.jl:666) rides in the sign bit of x (x > 0)
-            store_point(dcur, (LCM && isdiff) ? -px : px, py, pz);
+            store_point(dcur, (LCM && isdiff) ? -px : px, py, pz, a.scratch_plain != 0);
             emitted = true;
             npts++;
             if (pass == 0) nf++;
@@ -594,7 +601,7 @@ struct PackArgs {
     int64_t *out_seed;
     float *out_xyz;
     int64_t nlines, line0, out_line0, out_pt0;
-    int stride, nslots, len_min;
+    int stride, nslots, len_min, scratch_plain;
     int64_t lines_cap, points_cap;   // capped: a line whose place lies beyond the caller's buffers is dropped (fibd_stream_run reports the need)
     int capped;
     int trk;                    // 1: out_xyz is a .trk body: [Int32 npts, npts x 3 Float32 ((xyz+.5)*voxel_size)] per line
@@ -766,6 +773,10 @@ __global__ __launch_bounds__(256) void stream_pack_tile_kernel(const PackArgs a)
             }
             if (pos[i] >= 0) {                                  // read once: non-temporal (the orientation field should keep the Infinity Cache)
                 const float *src = reinterpret_cast<const float *>(tbase + (int64_t)c * (16 * PK_LINES));
+#ifdef FIB_AB_VARIANTS
+                if (a.scratch_plain) { f32x3_t q; asm volatile("global_load_dwordx3 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(src) : "memory"); v[i] = P3{q[0], q[1], q[2]}; }
+                else
+#endif
                 v[i] = P3{__builtin_nontemporal_load(src), __builtin_nontemporal_load(src + 1), __builtin_nontemporal_load(src + 2)};
             } else v[i] = P3{0.f, 0.f, 0.f};
         }
@@ -999,6 +1010,7 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
     ta.nx = prm->nx; ta.ny = prm->ny; ta.nz = prm->nz; ta.nvec = prm->nvec; ta.nsub = nsub;
     ta.len_max = prm->len_max; ta.stride = job->stride; ta.nslots = job->nslots;
     ta.cosang = prm->cosang_thresh; ta.step = prm->step_size; ta.smooth = prm->smooth_coeff;
+    ta.scratch_plain = fib::ab_env("FIBERS_STREAM_SCRATCH_PLAIN") != nullptr;
     const unsigned grid = (unsigned)fib::cdiv(nl, 256);
     fib::DevBuf<float4> d_search;
     fib::DevBuf<int32_t> d_cell;
@@ -1137,6 +1149,7 @@ static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, f
     pa.out_npts = npts; pa.out_seed = seed_index; pa.out_xyz = xyz;
     pa.nlines = job->nlines; pa.line0 = 0; pa.out_line0 = 0; pa.out_pt0 = 0;
     pa.stride = job->stride; pa.nslots = job->nslots; pa.len_min = job->prm.len_min;
+    pa.scratch_plain = fib::ab_env("FIBERS_STREAM_SCRATCH_PLAIN") != nullptr;
     fib::ProfScope prof("stream_pack", (hipStream_t)stream);
     { const int rcl = launch_pack(job, pa, (hipStream_t)stream); if (rcl != FIB_OK) return rcl; }
     FIB_HIP(hipGetLastError());
@@ -1156,6 +1169,7 @@ extern "C" int fibd_stream_pack_trk(fib_stream_job *job, const float voxel_size[
     pa.out_npts = nullptr; pa.out_seed = nullptr; pa.out_xyz = reinterpret_cast<float *>(body);
     pa.nlines = job->nlines; pa.line0 = 0; pa.out_line0 = 0; pa.out_pt0 = 0;
     pa.stride = job->stride; pa.nslots = job->nslots; pa.len_min = job->prm.len_min;
+    pa.scratch_plain = fib::ab_env("FIBERS_STREAM_SCRATCH_PLAIN") != nullptr;
     pa.trk = 1; pa.vs[0] = voxel_size[0]; pa.vs[1] = voxel_size[1]; pa.vs[2] = voxel_size[2];
     fib::ProfScope prof("stream_pack_trk", (hipStream_t)stream);
     { const int rcl = launch_pack(job, pa, (hipStream_t)stream); if (rcl != FIB_OK) return rcl; }
@@ -1237,6 +1251,7 @@ extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4
     ta.nx = prm->nx; ta.ny = prm->ny; ta.nz = prm->nz; ta.nvec = prm->nvec; ta.nsub = nsub;
     ta.len_max = prm->len_max; ta.stride = stride; ta.nslots = nslots;
     ta.cosang = prm->cosang_thresh; ta.step = prm->step_size; ta.smooth = prm->smooth_coeff;
+    ta.scratch_plain = fib::ab_env("FIBERS_STREAM_SCRATCH_PLAIN") != nullptr;
     const unsigned grid = (unsigned)fib::cdiv(nl, 256);
     {
         fib::ProfScope prof("stream_trace", st);
@@ -1254,6 +1269,7 @@ extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4
     pa.out_npts = npts; pa.out_seed = seed_index; pa.out_xyz = xyz;
     pa.nlines = nl; pa.line0 = 0; pa.out_line0 = 0; pa.out_pt0 = 0;
     pa.stride = stride; pa.nslots = nslots; pa.len_min = prm->len_min;
+    pa.scratch_plain = fib::ab_env("FIBERS_STREAM_SCRATCH_PLAIN") != nullptr;
     pa.lines_cap = lines_cap; pa.points_cap = points_cap; pa.capped = 1;   // a line whose place lies beyond the buffers is dropped, the totals say what was needed
     {
         fib::ProfScope prof("stream_pack", st);

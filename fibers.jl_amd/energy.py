@@ -108,3 +108,54 @@ def idle_watts(seconds=1.5, dev=0):
     time.sleep(seconds)
     e1, t1 = energy_joules(dev), time.perf_counter()
     return (e1 - e0) / (t1 - t0)
+
+
+# ---- the GQI step's energy by component (bench.py roofline.power, tools/energy_model.py) -------------------------------------------------
+def gqi_counts(nvox, nvol=270, nvert=321, valu_wave_instructions=None):
+    """what one fused GQI step (fp16 pieces) does, per launch.  VALU: SQ_INSTS_VALU of the launch minus its MFMAs at 140^3
+    (profiles/r04/summary.txt: 2.81e8 - 0.437e8), scaled by the voxel count"""
+    items = -(-nvox // 256)
+    nst = -(-nvol // 16)
+    if valu_wave_instructions is None:
+        valu_wave_instructions = 2.3727e8 * nvox / 2744000.0
+    return dict(
+        hbm_bytes=(4.0 * nvol + 1 + 4.0 * nvert + 48) * nvox,                 # algorithmic: DWI + mask in, ODF + peaks + qa out (SURVEY 8d)
+        mfma_flops=3 * 2.0 * 320 * (16 * nst) * nvox,                          # executed: three fp16 piece products, K padded to whole stages
+        lds_fragment_bytes=20.0 * 1024 * 8 * nst * items,                      # every wave re-reads the stage's 20 KiB of matrix pieces
+        l2_to_lds_bytes=(20.0 * 1024 * nst) * items + 4.0 * 16 * nst * nvox,   # the pieces per workgroup and item + the samples, by LDS-DMA
+        lds_other_bytes=(2 * 4.0 * 16 * nst + 2 * 4.0 * 320) * nvox,           # sample tiles read back + the epilogue's transposition (write + read)
+        valu_wave_instructions=valu_wave_instructions)
+
+
+UNAVOIDABLE = ("hbm_bytes", "mfma_flops")       # the algorithm's bytes and its (three-product) matrix-core work; the rest is this kernel's way of doing it
+
+
+def gqi_power_roofline(joules_per_unit, nvox, kernel_ms, step_ms, step_joules, idle_w, cap_w=1400.0, essential_ms=None, **count_kw):
+    """roofline.power: joules_by_component = counts x the probes' Joules per unit (above the idle board); two floors:
+    floor_ms            = unavoidable components' Joules / (cap - idle): what a kernel made of nothing else would take under the cap if the
+                          ingredients cost what they cost one at a time (each probe runs at its own clock: HBM, LDS and VALU probes at 2.4
+                          GHz and its voltage, the MFMA probe at the ~1.7 GHz the cap leaves it -- so this floor is on the high side);
+    floor_calibrated_ms = the same with every component scaled so that components + idle = the step's MEASURED Joules (the kernel runs
+                          at ~1.9 GHz: lower voltage than most probes) -- the low side;
+    essential_ms        = the measured time of a probe kernel that does one step's HBM bytes + MFMAs and nothing else (when available)."""
+    counts = gqi_counts(nvox, **count_kw)
+    joules = {k: (counts[k] * joules_per_unit[k] if joules_per_unit.get(k) is not None else None) for k in counts}
+    dyn = sum(v for v in joules.values() if v)
+    unavoidable = sum(joules[k] or 0.0 for k in UNAVOIDABLE)
+    budget = cap_w - idle_w
+    idle_j = idle_w * step_ms * 1e-3
+    out = dict(cap_w=cap_w, idle_w=idle_w, budget_w=budget, counts_per_step=counts, joules_per_unit=dict(joules_per_unit),
+               joules_by_component=joules, idle_joules_per_step=idle_j, modelled_joules_per_step=dyn + idle_j,
+               measured_joules_per_step=step_joules, model_over_measured=(dyn + idle_j) / step_joules if step_joules else None,
+               unavoidable_components=list(UNAVOIDABLE), floor_ms=unavoidable / budget * 1e3, kernel_ms=kernel_ms, step_ms=step_ms,
+               frac=(unavoidable / budget * 1e3) / kernel_ms if kernel_ms else None)
+    if step_joules and dyn > 0:
+        scale = max(0.0, step_joules - idle_j) / dyn
+        out["calibration_scale"] = scale
+        out["joules_by_component_calibrated"] = {k: (v * scale if v else v) for k, v in joules.items()}
+        out["floor_calibrated_ms"] = unavoidable * scale / budget * 1e3
+        out["frac_calibrated"] = out["floor_calibrated_ms"] / kernel_ms if kernel_ms else None
+    if essential_ms:
+        out["essential_ms"] = essential_ms
+        out["frac_of_essential"] = essential_ms / kernel_ms if kernel_ms else None
+    return out

@@ -20,3 +20,33 @@ def test_stage_loops_do_not_wait_on_the_loads_they_have_just_issued():
     # the kernel whose samples travel through LDS: its hand-counted vmcnt(2) waits follow exactly the two sample requests, and the
     # DRAIN wait sits directly in front of the first row store (tools/check_loop_waits.py check_slds)
     assert r.stdout.count("slds ok") >= 1, r.stdout[-2000:]
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_tracer_point_stores_and_pack_loads_keep_their_non_temporal_hint(tmp_path):
+    """stream.hip (stream.jl:660: every emitted point): the tracer's scratch stores and the pack kernel's scratch loads are NON-TEMPORAL
+    -- with the default policy 1.6 GB of points go through L2 and evict the orientation field (trace 0.53 -> 0.65 ms).  The hint is easy
+    to lose without a trace in the source: in round 5 a run-time `plain ? store : nontemporal_store` made hipcc merge both arms into one
+    plain store.  Compile the PRODUCT flags to assembly and look: every 12-byte point store of every stream_trace_kernel instantiation
+    carries `nt`, and the tile pack kernel loads with `nt`."""
+    import re
+    out = str(tmp_path / "stream.s")
+    src = os.path.join(ROOT, "fibers.jl_amd", "csrc", "stream.hip")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    subprocess.run([hipcc, "-std=c++17", "-O3", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-o", out, src], check=True, timeout=900,
+                   capture_output=True)
+    text = open(out).read()
+    funcs = re.split(r"\n(?=_Z\w+:)", text)
+    ntrace = 0
+    for f in funcs:
+        name = f.split(":", 1)[0]
+        body = f.split(".Lfunc_end", 1)[0]
+        if "stream_trace_kernel" in name:
+            st = re.findall(r"global_store_dwordx3[^\n]*", body)
+            assert st, name
+            assert all(" nt" in s for s in st), (name, [s for s in st if " nt" not in s][:3])
+            ntrace += 1
+        if "stream_pack_tile_kernel" in name:
+            ld = re.findall(r"global_load_dword[^\n]*", body)
+            assert sum(" nt" in s for s in ld) >= 3, (name, ld[:6])
+    assert ntrace >= 9, ntrace            # {1, 3, runtime} vectors x {plain, LCM, trilinear} + the wide forms

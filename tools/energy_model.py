@@ -90,42 +90,30 @@ def product_steps(seconds):
 
 
 def compose(probe, steps, clock):
-    """joules_by_component for the GQI step (fp16 pieces): counts x the probes' Joules per unit ABOVE the idle board"""
+    """roofline.power for the GQI step (fp16 pieces): fibers_jl_amd.energy.gqi_power_roofline on the probes' Joules per unit"""
+    from fibers_jl_amd import energy as en
     if not probe or not steps or not steps.get("gqi_fp16x2"):
         return None
     g = steps["gqi_fp16x2"]
     idle = steps.get("idle_watts") or probe.get("idle", {}).get("watts") or 260.0
-    cap = 1400.0
 
     def pj(mode):
         r = probe.get(mode)
         return r["pj_per_unit_above_idle"] * 1e-12 if r else None
-    items = -(-NVOX // 256)
-    counts = dict(
-        hbm_bytes=(4.0 * 270 + 1 + 4.0 * 321 + 48) * NVOX,                        # algorithmic: DWI + mask in, ODF + peaks + qa out
-        mfma_flops=3 * 2.0 * 320 * 272 * NVOX,                                     # executed: three piece products, K padded to 272
-        lds_fragment_bytes=20.0 * 1024 * 8 * 17 * items,                           # every wave re-reads the stage's 20 KiB of matrix pieces
-        l2_to_lds_bytes=(20.0 * 1024 * 17) * items + 4.0 * 272 * NVOX,             # piece fetch per workgroup and item + the samples by LDS-DMA
-        lds_other_bytes=(2 * 4.0 * 272 + 2 * 4.0 * 320) * NVOX,                    # sample tile read-back + the epilogue's transposition (write + read)
-        valu_wave_instructions=2.81e8 - 30.0 * 17 * 8 * items)                     # SQ_INSTS_VALU of the launch (profiles/r04/summary.txt) minus the MFMAs
     unit = dict(hbm_bytes=pj("hbm_rw_gqi"), mfma_flops=pj("mfma_reg_sleep0"), lds_fragment_bytes=pj("lds_read_sleep0"),
                 l2_to_lds_bytes=pj("ldsdma_l2"), lds_other_bytes=pj("lds_write_read"), valu_wave_instructions=pj("valu_sleep0"))
-    joules = {k: (counts[k] * unit[k] if unit[k] is not None else None) for k in counts}
-    dyn = sum(v for v in joules.values() if v)
-    measured = g["joules_per_step"]
-    t_ms = g["ms_per_step"]
-    unavoidable = (joules["hbm_bytes"] or 0) + (joules["mfma_flops"] or 0)
-    out = dict(
-        counts_per_step=counts, joules_per_unit=unit, joules_by_component=joules,
-        idle_joules_per_step=idle * t_ms * 1e-3, modelled_joules_per_step=dyn + idle * t_ms * 1e-3, measured_joules_per_step=measured,
-        model_over_measured=(dyn + idle * t_ms * 1e-3) / measured if measured else None,
-        board_watts=g["watts"], cap_w=cap, idle_w=idle, budget_w=cap - idle,
-        floor_ms=unavoidable / (cap - idle) * 1e3, floor_components="algorithmic HBM bytes + executed MFMA flops (three fp16 piece products) at the "
-        "probes' Joules per unit; everything else (fragment re-reads, piece fetch, vector ALU) counted as avoidable",
-        step_ms=t_ms, kernel_ms=g.get("kernel_ms"), frac=(unavoidable / (cap - idle) * 1e3) / g["kernel_ms"] if g.get("kernel_ms") else None)
+    ess = probe.get("essential_gqi_step")
+    out = en.gqi_power_roofline(unit, NVOX, g.get("kernel_ms"), g["ms_per_step"], g["joules_per_step"], idle,
+                                essential_ms=1e3 / ess["rate_per_s"] if ess and ess.get("rate_per_s") else None)
+    out["board_watts"] = g["watts"]
+    out["probe_operating_points"] = {m: dict(watts=probe[m]["watts"], in_kernel_clock_ghz=probe[m].get("in_kernel_clock_ghz"), smu_sclk_mhz=probe[m].get("sclk_smi_mhz"),
+                                               rate_per_s=probe[m].get("rate_per_s"), unit=probe[m].get("unit"))
+                                      for m in ("hbm_rw_gqi", "mfma_reg_sleep0", "lds_read_sleep0", "ldsdma_l2", "lds_write_read", "valu_sleep0", "essential_gqi_step",
+                                                "essential_gqi_step_lds_fragments", "mfma_lds2_sleep0", "mfma_lds1_sleep0", "spin") if m in probe}
     if clock and clock.get("gqi_fused"):
-        out["in_kernel_clock_ghz"] = clock["gqi_fused"].get("clock_ghz_median")
-        out["smu_sclk_mhz_mean"] = clock["gqi_fused"].get("smu_sclk_mhz_mean")
+        out["in_kernel_clock_ghz_diagnostic_build"] = clock["gqi_fused"].get("clock_ghz_median")
+        out["smu_sclk_mhz_same_seconds"] = clock["gqi_fused"].get("smu_sclk_mhz_mean")
+    out["smu_sclk_mhz_product_kernel"] = g.get("sclk_mhz_mean")
     return out
 
 

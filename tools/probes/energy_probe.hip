@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void k_lds_wr(int iters, int slp, uint32_t 
 
 // ---- the step's unavoidable work and nothing else: an empirical floor ------------------------------------------------------------------
 // One launch = one GQI step's algorithmic HBM bytes (2.975 GB read + 3.655 GB written, non-temporal) AND its executed matrix-core
-// work (three fp16 piece products: 1.433 PFLOP of v_mfma_f32_32x32x16_f16), side by side on every CU: waves 0-3 (one per SIMD) issue
+// work (three fp16 piece products: 1.433 PFLOP of v_mfma_f32_32x32x16_f16), side by side on every CU (two workgroups each): waves 0-3 of a workgroup issue
 // the MFMAs from registers (FRAG: fragments re-read from LDS as the stage loop does, 20 KiB per 30 MFMAs), waves 4-7 stream.  No
 // sample split, no epilogue, no lists: what a kernel made of nothing but the unavoidable ingredients costs under the board's cap.
 template <bool FRAG>
@@ -289,16 +289,19 @@ __global__ __launch_bounds__(512, 2) void k_essential(const u32x4_t *src, size_t
         for (int m = 0; m < 10; m++) for (int r = 0; r < 16; r++) z += acc[m][r];
         if (z == 123.456f) sink[threadIdx.x] = z;
     } else {
+        // eight 16-byte requests in flight per lane (a stream needs ~12 MB in flight chip-wide: latency x rate)
         u32x4_t acc = {0, 0, 0, 0};
         const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + (threadIdx.x - 256);
         const size_t nmax = nr16 > nw16 ? nr16 : nw16;
-        for (size_t i = i0; i < nmax; i += 2 * stride) {
-            u32x4_t v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
-            if (i < nr16) v0 = __builtin_nontemporal_load(src + i);
-            if (i + stride < nr16) v1 = __builtin_nontemporal_load(src + i + stride);
-            acc ^= v0 ^ v1;
-            if (i < nw16) { u32x4_t v = acc; v[0] += (uint32_t)i; __builtin_nontemporal_store(v, dst + i); }
-            if (i + stride < nw16) { u32x4_t v = acc; v[1] += (uint32_t)i; __builtin_nontemporal_store(v, dst + i + stride); }
+        for (size_t i = i0; i < nmax; i += 8 * stride) {
+            u32x4_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { v[u] = u32x4_t{0, 0, 0, 0}; if (i + u * stride < nr16) v[u] = __builtin_nontemporal_load(src + i + u * stride); }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                acc ^= v[u];
+                if (i + u * stride < nw16) { u32x4_t w = v[u]; w[0] += (uint32_t)i; __builtin_nontemporal_store(w, dst + i + u * stride); }
+            }
         }
         if ((acc[0] ^ acc[1]) == 0x12345u) sink[threadIdx.x] = 1;
     }
@@ -406,10 +409,11 @@ int main(int argc, char **argv) {
         CK(hipDeviceSynchronize());
         const size_t nr = (size_t)(2.975e9 / 16), nw = (size_t)(3.655e9 / 16);
         const double flops = 3.0 * 2.0 * 320 * 272 * 2744000.0;                     // executed per step
-        const int trips = (int)(flops / (30.0 * 2.0 * 32 * 32 * 16) / (OCC * 4.0) + 0.5);
+        const int EG = 2 * OCC;                                                      // two workgroups per CU: 8 MFMA waves (2 per SIMD, the product's occupancy) + 8 streaming waves
+        const int trips = (int)(flops / (30.0 * 2.0 * 32 * 32 * 16) / (EG * 4.0) + 0.5);
         for (int frag = 0; frag < 2; frag++) {
-            Result r = frag ? run_mode(sec, d_st, OCC, [&] { hipLaunchKernelGGL(k_essential<true>, dim3(OCC), dim3(512), 0, 0, d_a, nr, d_b, nw, trips, (float *)d_sink, d_st); })
-                            : run_mode(sec, d_st, OCC, [&] { hipLaunchKernelGGL(k_essential<false>, dim3(OCC), dim3(512), 0, 0, d_a, nr, d_b, nw, trips, (float *)d_sink, d_st); });
+            Result r = frag ? run_mode(sec, d_st, EG, [&] { hipLaunchKernelGGL(k_essential<true>, dim3(EG), dim3(512), 0, 0, d_a, nr, d_b, nw, trips, (float *)d_sink, d_st); })
+                            : run_mode(sec, d_st, EG, [&] { hipLaunchKernelGGL(k_essential<false>, dim3(EG), dim3(512), 0, 0, d_a, nr, d_b, nw, trips, (float *)d_sink, d_st); });
             report(frag ? "essential_gqi_step_lds_fragments" : "essential_gqi_step", "step", 1.0, r, p_idle,
                    frag ? "one launch = the GQI step's HBM bytes + its executed MFMAs with the fragments re-read from LDS (20 KiB per 30 MFMAs), nothing else"
                         : "one launch = the GQI step's algorithmic HBM bytes (2.975 GB in, 3.655 GB out) + its executed MFMAs (1.433 PFLOP, operands in registers), nothing else");
