@@ -430,6 +430,43 @@ def main():
     extra = {}
     extra["gqi_cold_start"] = dict(ms_per_step_blocks_of_5=cold, note="the headline step right after 0.5 s of idle, six blocks of five steps, before any "
                                                                         "preconditioning: the ramp the `preconditioning` field refers to")
+    if not args.no_extra and rank == 0 and world == 1:
+        # ---- the boundary a Julia caller pays for (SURVEY 8d "report both"): the fib_* entry points on pageable host arrays, PCIe both ways,
+        # every stage of the host tier timed apart (tools/host_tier_probe.py).  This process is the caller: its arrays are first touched by
+        # this thread wherever the scheduler put it; the library binds its pinned ring and copy threads to the GPU's NUMA node itself.
+        # FIRST among the extras: a process that has just released tens of GB of device memory (torch.cuda.empty_cache() between the legs
+        # below) sees its downloads run at 39 instead of 50 GB/s for a few seconds -- the driver is still busy with the released memory
+        # (tools/host_tier_state_check.py: 80.8 ms fresh, 101.7 ms right after 120 GB of allocations were released, 81 ms again later).
+        # A caller of fib_gqi_rec has not just done that; the legs run before this process has.
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import host_tier_probe as htp
+            ht = {}
+            ht["gqi_rec"] = htp.leg_odf("gqi", shape=shape, reps=4, dev=dev)
+            try:
+                mb = np.ascontiguousarray(phantom.ball_mask_torch(shape, dev).reshape(-1).cpu().numpy().astype(np.uint8))
+                r_b = htp.leg_odf("gqi", shape=shape, reps=3, mask=mb, dev=dev)
+                r_b["voxels_in_mask"] = int(mb.sum())
+                r_b["note"] = ("fib_gqi_rec, ball mask (36 % inside): the host tier packs the runs of the voxels inside the mask into the pinned ring and "
+                               "zero-fills the gaps on the way back; bytes_in / bytes_out count the voxels that travel")
+                ht["gqi_rec_ball_mask"] = r_b
+            except Exception as e:                                                          # noqa: BLE001
+                ht["gqi_rec_ball_mask"] = dict(error=str(e))
+            for name, fn in (("dti_fit", lambda: htp.leg_dti(shape=shape, reps=4, dev=dev)), ("dsi_rec", lambda: htp.leg_odf("dsi", shape=shape, reps=3, dev=dev)),
+                             ("stream_c4", lambda: htp.leg_stream(shape=shape, reps=3, dev=dev))):
+                try:
+                    ht[name] = fn()
+                except Exception as e:                                                      # noqa: BLE001
+                    ht[name] = dict(error=str(e))
+            ht["note"] = ("pcie_floor_ms = max(bytes in, bytes out) / 63 GB/s (Gen5 x16, one direction); with both directions busy this box's link "
+                          "moves ~97 GB/s in all (tools/probes/host_probe.hip), i.e. ~49 GB/s each way: the downloads are the pipeline's long pole")
+            extra["host_tier"] = ht
+            extra["gqi_host_tier"] = {k: v for k, v in ht["gqi_rec"].items() if not isinstance(v, dict)}   # (the key earlier rounds' lines carried)
+            if isinstance(ht.get("gqi_rec_ball_mask"), dict):
+                extra["gqi_host_tier"]["ball_mask"] = {k: v for k, v in ht["gqi_rec_ball_mask"].items() if not isinstance(v, (dict, list))}
+        except Exception as e:                                                              # noqa: BLE001
+            extra["host_tier"] = dict(error=str(e))
+
     if not args.no_extra and world == 1:
         # ---- in-kernel clock of the contraction kernels (MI355X_MICROARCH.md "DVFS give-back" item 6): a child process loads the
         # DIAGNOSTIC build (libfibers_hip_stamp.so: one s_memtime / s_memrealtime pair around each workgroup's work loop) and runs the
@@ -448,6 +485,40 @@ def main():
                         roofline["frac_of_clock_adjusted_peak"] = roofline["frac"] * 2.4 / ghz
         except Exception as e:                                                      # noqa: BLE001
             extra["in_kernel_clock"] = dict(error=str(e))
+        # ---- roofline.power: is "the 1 400 W cap binds" a measured bound?  The step's Joules, LIVE from the board's
+        # energy counter around ~2 s of back-to-back steps; the Joules per byte / flop / instruction of the step's ingredients, STORED
+        # (tools/energy_model.py runs tools/probes/energy_probe.hip, each ingredient alone under the same counter: profiles/energy_model.json)
+        try:
+            from fibers_jl_amd import energy as en
+            em = en.measure(gqi_step, torch.cuda.synchronize, seconds=2.0)
+            if em is None:
+                roofline["power"] = dict(error="no board energy counter (librocm_smi64 / rsmi_dev_energy_count_get)")
+            else:
+                torch.cuda.synchronize()
+                idle_w = en.idle_watts(1.2)
+                stored = json.load(open(os.path.join(ROOT, "profiles", "energy_model.json")))
+                gm = stored.get("gqi_model") or {}
+                pw = en.gqi_power_roofline(gm["joules_per_unit"], nloc, gemm_avg_ms, em["ms_per_step"], em["joules_per_step"], idle_w,
+                                           essential_ms=(gm.get("essential_ms") or 0.0) * nloc / float(SHAPE[0] * SHAPE[1] * SHAPE[2]) or None)
+                pw.update(board_watts_while_stepping=em["watts"], smu_sclk_mhz_while_stepping=em["sclk_mhz_mean"], steps_measured=em["steps"],
+                          source=("measured_joules_per_step, board_watts, idle_w: LIVE (energy counter, this run).  joules_per_unit, essential_ms: STORED, "
+                                  "from %s.  frac = floor_ms / the kernel's hipEvent time: the floor counts the algorithmic HBM bytes and the executed MFMA flops "
+                                  "at what each costs ALONE (HBM probe at 2.4 GHz and its voltage: the high side); frac_calibrated scales every component so "
+                                  "that components + idle = the measured Joules (the low side); frac_of_essential = a probe kernel that does one step's HBM "
+                                  "bytes + MFMAs and nothing else, timed under the same cap" % stored.get("source", "profiles/energy_model.json")))
+                roofline["power"] = pw
+                kc = extra.get("in_kernel_clock", {}).get("gqi_fused") if isinstance(extra.get("in_kernel_clock"), dict) else None
+                roofline["clock"] = dict(
+                    smu_sclk_mhz_product_kernel=em["sclk_mhz_mean"],
+                    in_kernel_ghz_diagnostic_build=kc.get("clock_ghz_median") if kc else None,
+                    smu_sclk_mhz_diagnostic_build_same_seconds=kc.get("smu_sclk_mhz_mean") if kc else None,
+                    diagnostic_kernel_ms=kc.get("kernel_ms_hipevent") if kc else None,
+                    note="the in-kernel clock (s_memtime / s_memrealtime around each workgroup's loop) and the SMU's reported shader clock agree within ~1 % "
+                         "when read in the SAME seconds on the SAME build; round 4's 1.875 GHz (in-kernel) against 1.62 GHz (smi) compared the diagnostic build -- "
+                         "whose phase marks made it 14 % slower and cooler -- with the product on another box.  The diagnostic build now carries one stamp "
+                         "pair per workgroup and runs at the product's speed")
+        except Exception as e:                                                      # noqa: BLE001
+            roofline["power"] = dict(error=str(e))
         # ---- the same step on the less flattering inputs of SURVEY §8d: ball mask (36 % of the volume inside) and ~1 % of the
         # samples non-positive (exercises the clamp and the mask compaction; the headline uses an all-ones mask, all positive) ----
         bm_h = phantom.ball_mask_torch(shape, dev)
@@ -799,70 +870,6 @@ def main():
                                                    "host sync for the line count); kernel_sum = device time of the three kernels on rank 0; seeds x offsets round-robin")
         del o5, r3, f3_loc, m3_loc, mout3, seeds3, xyz5
         torch.cuda.empty_cache()
-    if not args.no_extra and rank == 0 and world == 1:
-        # ---- the boundary a Julia caller pays for: fib_gqi_rec on host arrays (PCIe both ways, SURVEY §8d "report both") ------------
-        try:
-            import ctypes as C
-            from fibers_jl_amd import _lib
-            dh, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=3, device=dev)
-            host = np.ascontiguousarray(dh.cpu().numpy())                                  # [nvol, nvox] planar == MRI.vol memory
-            del dh
-            torch.cuda.empty_cache()
-            m8 = np.ones(nvox, np.uint8)
-            v = np.asfortranarray(sph.vertices, np.float32); f = np.asfortranarray(sph.faces, np.int32)
-            bv = np.ascontiguousarray(bval, np.float32); bg = np.asfortranarray(np.asarray(bvec, np.float32))
-            odf_h = np.ones((nvert, nvox), np.float32)
-            pk_h = [np.ones((3, nvox), np.float32) for _ in range(3)]
-            qa_h = [np.ones(nvox, np.float32) for _ in range(3)]
-
-            def call():
-                return L.fib_gqi_rec(0, host.ctypes.data, nx, ny, nz, nvol, m8.ctypes.data, 0, bv.ctypes.data, bg.ctypes.data,
-                                     v.ctypes.data, v.shape[0], f.ctypes.data, f.shape[0], 1.25, odf_h.ctypes.data,
-                                     _lib.P3(*[a.ctypes.data for a in pk_h]), _lib.P3(*[a.ctypes.data for a in qa_h]))
-            ts = []
-            for _ in range(4):
-                t0 = time.perf_counter()
-                _lib.check(call())
-                ts.append(time.perf_counter() - t0)
-            gb = (host.nbytes + odf_h.nbytes + sum(a.nbytes for a in pk_h + qa_h)) / 1e9
-            # the same call into FRESHLY zero-allocated outputs, as a Julia caller makes them (`zeros`, mri.jl:251-255): the first touch
-            # of 3.65 GB of output pages falls inside the call
-            tf = []
-            for _ in range(2):
-                del odf_h, pk_h, qa_h
-                odf_h = np.zeros((nvert, nvox), np.float32)
-                pk_h = [np.zeros((3, nvox), np.float32) for _ in range(3)]
-                qa_h = [np.zeros(nvox, np.float32) for _ in range(3)]
-                t0 = time.perf_counter()
-                _lib.check(call())
-                tf.append(time.perf_counter() - t0)
-            extra["gqi_host_tier"] = dict(e2e_pcie_ms=min(ts[1:]) * 1e3, mvoxels_per_s=nvox / min(ts[1:]) / 1e6, link_gbs=gb / min(ts[1:]),
-                                          e2e_pcie_first_touch_ms=min(tf) * 1e3, mvoxels_per_s_first_touch=nvox / min(tf) / 1e6,
-                                          bytes_over_link=gb * 1e9,
-                                          note="fib_gqi_rec on pageable host arrays (the call a Julia wrapper makes): gather -> pinned ring -> H2D || kernels "
-                                               "|| D2H -> scatter; PCIe Gen5 x16, both directions busy.  e2e_pcie_ms: outputs touched before the call; "
-                                               "e2e_pcie_first_touch_ms: outputs freshly zero-allocated (np.zeros = calloc), first touch inside the call")
-            # the same call with the ball mask (36 % of the volume inside): only the voxels inside cross PCIe (api.hip LiveMap)
-            try:
-                mb = np.ascontiguousarray(phantom.ball_mask_torch(shape, dev).reshape(-1).cpu().numpy().astype(np.uint8))
-                m8_keep = m8
-                m8 = mb
-                tb = []
-                for _ in range(3):
-                    t0 = time.perf_counter()
-                    _lib.check(call())
-                    tb.append(time.perf_counter() - t0)
-                m8 = m8_keep
-                extra["gqi_host_tier"]["ball_mask"] = dict(e2e_pcie_ms=min(tb[1:]) * 1e3, voxels_in_mask=int(mb.sum()),
-                                                           mvoxels_in_mask_per_s=float(mb.sum()) / min(tb[1:]) / 1e6,
-                                                           note="fib_gqi_rec, outputs touched before the call, ball mask: the host tier packs the runs of "
-                                                                "the voxels inside the mask into the pinned ring and zero-fills the gaps on the way back")
-            except Exception as e:                                                          # noqa: BLE001
-                extra["gqi_host_tier"]["ball_mask"] = dict(error=str(e))
-            del host, odf_h, pk_h, qa_h
-        except Exception as e:                                                              # noqa: BLE001
-            extra["gqi_host_tier"] = dict(error=str(e))
-
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline_gqi(bval, bvec, sph, seed=3)    # (rank 0 only; at N > 1 the other ranks wait at the barrier below)

@@ -64,14 +64,22 @@ def _torch_stream(stream):
     return torch.cuda.ExternalStream(handle)
 
 
-def allreduce_odfmax(odfmax, group=None, always=False):
+def allreduce_odfmax(odfmax, group=None, always=False, raw=True):
     """odfmax: tensor [2] = {local max of the per-voxel ODF means that are not NaN (-Inf if there is none), NaN flag} as
     fibd_odf_rec writes it with FIB_ODF_RAW_ODFMAX; in-place MAX over ranks: ONE 2-float all-reduce.  A NaN anywhere must win
     (Julia's maximum propagates NaN, gqi.jl:164): the flag is reduced with the maximum, and the consumers
-    (fibd_qa_normalize_dev, odfmax_value) turn {m, flag > 0} into NaN.
+    (fibd_qa_normalize_pair -- qa_normalize_device(raw=True) --, odfmax_value) turn {m, flag > 0} into NaN.
+    raw=True (default, what odf_rec_sharded passes): the input IS the raw pair (odf_rec_device(raw_odfmax=True)) and the collective is
+    the only device work.  raw=False: the plain form, whose element 0 may itself be NaN -- what a MAX all-reduce does with a NaN is
+    undefined, so it is moved into the flag first (three small torch kernels).
     always: run the collective even in a one-rank group (tests: exercises the RCCL path on a 1-GPU box)."""
+    import torch
     import torch.distributed as dist
     if dist.is_initialized() and (dist.get_world_size(group) > 1 or always):
+        if not raw:
+            isn = torch.isnan(odfmax[0])
+            odfmax[1] = torch.where(isn, torch.ones_like(odfmax[1]), odfmax[1])
+            odfmax[0] = torch.where(isn, torch.full_like(odfmax[0], float("-inf")), odfmax[0])
         dist.all_reduce(odfmax, op=dist.ReduceOp.MAX, group=group)
     return odfmax
 

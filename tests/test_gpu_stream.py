@@ -462,3 +462,51 @@ def test_stream_run_matches_trace_plus_pack(fj, nvec):
     assert (small_x[1000:] == -7.0).all()                                              # nothing written past the capacity
     kept = small_n != -7
     assert torch.equal(small_n[kept], ref["npts"][:100][kept[:100]])                    # what was written is right
+
+
+def test_stream_wide_field_past_the_32_bit_gather_limit(fj, orc):
+    """An orientation field of 2^28 vectors or more (4 GiB of float4: the microscopy regime's whole-slide sections, stream.jl:83,147-172) takes
+    the tracer's WIDE form -- 64-bit voxel indices and gather offsets, chosen at launch.  4096 x 4096 x 17 voxels, one vector each = 4.56 GB;
+    the orientations are in-plane (2-D angles, v_z = 0 exactly), so a line seeded in the LAST slice (voxel indices >= 2^28: every gather
+    lies past the 32-bit range) never leaves it, and the oracle can trace the same lines on that slice alone: x, y bit-identical, z = 17."""
+    import torch
+    dev = torch.device("cuda", 0)
+    nx, ny, nz = 4096, 4096, 17
+    nxy, nvox = nx * ny, nx * ny * nz
+    assert (nz - 1) * nxy == 1 << 28
+    lin = torch.arange(nxy, device=dev)
+    x, y = (lin % nx).float(), (lin // nx).float()
+
+    def plane(z):                                          # the slice's vectors [3, nxy]: angle a(x, y, z), (cos a, sin a, 0)
+        a = 0.9 * torch.sin(x / 97.0) + 0.7 * torch.cos(y / 131.0) + 0.11 * z
+        return torch.stack([torch.cos(a), torch.sin(a), torch.zeros_like(a)])
+    ov = torch.empty((3, nvox), dtype=torch.float32, device=dev)
+    for z in range(nz):
+        ov[:, z * nxy:(z + 1) * nxy] = plane(float(z))
+    mask = torch.ones(nvox, dtype=torch.uint8, device=dev)
+    hole = torch.rand(nxy, device=dev, generator=torch.Generator(device=dev).manual_seed(4)) < 0.002      # mask holes in the last slice: lines end there
+    mask[(nz - 1) * nxy:][hole] = 0
+    field, mout = fj.stream_field_device([ov], mask=mask)
+    assert field.numel() * 4 > (1 << 32)
+    del ov
+    rng = np.random.default_rng(12)
+    loc = np.sort(rng.choice(nxy, 400, replace=False)).astype(np.int64)
+    loc = loc[mout[(nz - 1) * nxy:][torch.from_numpy(loc).to(dev)].cpu().numpy() != 0]
+    seeds = torch.from_numpy(loc + (nz - 1) * nxy).to(dev)
+    sub = np.array([[0.25, -0.125, 0.0]], np.float32)
+    kw = dict(len_min=2, len_max=200, smooth_coeff=0.2)
+    got = fj.stream_device(field, (nx, ny, nz), seeds, torch.from_numpy(sub).to(dev), **kw)
+    torch.cuda.synchronize()
+    # the oracle on the last slice alone
+    last = plane(float(nz - 1)).cpu().numpy()                                             # [3, nxy]
+    ov2 = np.asfortranarray(last.T.reshape(nx, ny, 1, 3, order="F"))
+    m2 = np.asfortranarray(mask[(nz - 1) * nxy:].cpu().numpy().reshape(nx, ny, 1, order="F"))
+    seedvol = np.zeros((nx, ny, 1), np.uint8, order="F")
+    seedvol.reshape(-1, order="F")[loc] = 1
+    ref = orc.stream(ov2, sub, mask=m2, seed=seedvol, nthreads=4, **kw)
+    assert int(ref["npts"].sum()) > 20000
+    assert np.array_equal(got["npts"].cpu().numpy(), ref["npts"])
+    assert np.array_equal(got["seed_index"].cpu().numpy(), ref["seed_index"])
+    g = got["xyz"].cpu().numpy()
+    assert np.array_equal(g[:, :2], ref["xyz"][:, :2])
+    assert np.all(g[:, 2] == np.float32(nz)) and np.all(ref["xyz"][:, 2] == np.float32(1.0))

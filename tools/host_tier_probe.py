@@ -100,9 +100,8 @@ def _host_dwi(shape, bval, bvec, seed, dev, **kw):
     from fibers_jl_amd import phantom
     d, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=seed, device=dev, **kw)
     h = np.ascontiguousarray(d.cpu().numpy())                           # [nvol, nvox] planar == MRI.vol memory; first touched by THIS thread
-    del d
-    torch.cuda.empty_cache()
-    return h
+    del d                                                                # (back to torch's cache, NOT to the driver: releasing GBs of device memory
+    return h                                                             #  slows the next seconds' downloads -- tools/host_tier_state_check.py)
 
 
 def leg_odf(kind, shape=SHAPE, reps=4, mask=None, dev=None):
