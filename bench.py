@@ -657,8 +657,8 @@ def main():
                 fj.stream_device_run(f_once, shape, seeds_all, sub, buffers=sbuf)
                 t_run = timed(lambda: fj.stream_device_run(f_once, shape, seeds_all, sub, buffers=sbuf), nst, 1) / nst
                 extra["stream_dti_ball"]["one_call_form"] = dict(ms_per_step=t_run * 1e3, mpoints_per_s=npoints / t_run / 1e6,
-                                                                 note="fibd_stream_run, one batch (more batches -- trace and pack overlapped on two streams -- "
-                                                                      "are slower: profiles/r04/negative_results.txt)")
+                                                                 note="fibd_stream_run into kept buffers: trace + scan + pack in one call (1 M lines: below the 2^21 "
+                                                                      "lines from which the fused kernel is used -- tools/stream_fused_ab.py, profiles/r05/negative_results.txt)")
                 del sbuf, f_once
             except Exception as e:                                                  # noqa: BLE001
                 extra["stream_dti_ball"]["one_call_form"] = dict(error=str(e))
@@ -847,9 +847,14 @@ def main():
             return xyz5["t"]
         r3 = {}
 
+        sbuf5 = fj.StreamBuffers(dev) if not multi else None
+
         def c5_step():
             field3 = fd.allgather_slabs(f3_loc, counts, always=force_pg)       # the shared 3-peak field over xGMI (48 B / voxel)
-            r3["r"] = fd.stream_sharded(field3, shape, seeds3, sub10, xyz_out=xyz_out5)
+            if multi:
+                r3["r"] = fd.stream_sharded(field3, shape, seeds3, sub10, xyz_out=xyz_out5)
+            else:                                                              # one GPU: the one-call form into kept buffers (fibd_stream_run: 10 M lines ->
+                r3["r"] = fj.stream_device_run(field3, shape, seeds3, sub10, buffers=sbuf5)   # the fused trace + look-back + pack kernel)
         t3 = timed(c5_step, 3, 2) / 3
         tr_ms, tr_n = prof_get(L, "stream_trace")
         pk_ms, pk_n = prof_get(L, "stream_pack")
@@ -866,8 +871,10 @@ def main():
                                               roofline=dict(bound="hbm", achieved=49.0 * (np3 / world) / (ksum3 * 1e-3) / 1e9 if tr_n else 0.0, peak=PEAK_HBM_GBS, unit="GB/s",
                                                             frac=49.0 * (np3 / world) / (ksum3 * 1e-3) / 1e9 / PEAK_HBM_GBS if tr_n else 0.0,
                                                             note="49 B per emitted point (SURVEY 8d, nvec = 3) x rank 0's points / device time of trace + scan + pack"),
-                                              note="wall = field all-gather + trace + scan + pack into a pre-allocated buffer (+ npts / seed_index allocation and one "
-                                                   "host sync for the line count); kernel_sum = device time of the three kernels on rank 0; seeds x offsets round-robin")
+                                              note="wall = field all-gather + tracking into kept buffers (+ one host sync for the counts); one GPU: fibd_stream_run, which from "
+                                                   "2^21 lines on is ONE kernel (the workgroup that traced 512 lines packs them behind a decoupled look-back: no scan, no "
+                                                   "pack launch -- pack_kernel_ms 0); N > 1: trace + scan + pack per rank, seeds x offsets round-robin; kernel_sum = device "
+                                                   "time of the tracking kernels on rank 0")
         del o5, r3, f3_loc, m3_loc, mout3, seeds3, xyz5
         torch.cuda.empty_cache()
     cpu = None

@@ -67,6 +67,8 @@ __global__ __launch_bounds__(256) void stream_field_kernel(const FieldArgs a) {
 
 struct Pair { int64_t pts, lines; };
 constexpr int SCR_TILE = 16;         // lines per tile of the point scratch
+constexpr int FUSED_TILE = 16;       // .. in the fused trace + pack kernel (diagnostic build A/B; 8-line tiles -- 96-byte rows -- made the trace 3 x slower)
+constexpr int FUSED_BLOCK = 512;     // its workgroup: 8 waves, so that 4 workgroups of 35 KB of LDS keep the CU's 32 wave slots full
 constexpr int TRACE_SCAN_B = 2048;   // = SCAN_B (lines per block of the scan)
 struct TraceArgs {
     const float4 *field;        // [nvox][nvec]
@@ -79,6 +81,15 @@ struct TraceArgs {
     int64_t line0, nlines;      // this batch covers global lines [line0, line0+nlines)
     int nx, ny, nz, nvec, nsub, len_max, stride, nslots;
     int scratch_plain;          // diagnostic build only (FIBERS_STREAM_SCRATCH_PLAIN): the point scratch with the default cache policy instead of non-temporal
+    // FUSED (fibd_stream_run): the block that traced 256 lines also packs them -- a decoupled look-back over the blocks' kept-line / point
+    // totals gives it its place in the output
+    unsigned long long *fstate; // [blocks] granules: status << 62 | kept lines << 36 | points (zeroed before the launch)
+    int32_t *out_npts;
+    int64_t *out_seed;
+    float *out_xyz;
+    Pair *ftotal;               // the last block's inclusive prefix = the call's totals
+    int64_t lines_cap, points_cap;
+    int len_min;
     float cosang, step, smooth;
     // microscopy regime (stream.jl:252-287, 547-619)
     // LCM-guided tracking (stream.jl:200-236, 380-495)
@@ -152,13 +163,17 @@ __device__ __forceinline__ int lcm_match_edge(int dx, int dy, int dz, int sd0, i
 // tentative position instead of the nearest voxel's vector -- see the TRI block below for the exact definition.
 // WIDE: 64-bit voxel indices and gather offsets, for orientation fields of 2^28 vectors (4 GiB) or more -- the microscopy
 // regime's whole-slide sections (stream.jl:83,147-172); chosen at launch, bit-identical to the 32-bit form on small fields.
-template <int NVEC, bool LCM = false, bool TRI = false, bool WIDE = false>   // NVEC > 0: compile-time vector count; 0: runtime
-__global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
+struct FuseLds;   // (defined with the pack kernels below)
+template <int NVEC> __device__ void fused_pack_block(const TraceArgs &a, int64_t li, bool live, int npts, int nf, int gap);
+
+template <int NVEC, bool LCM = false, bool TRI = false, bool WIDE = false, bool FUSED = false>   // NVEC > 0: compile-time vector count; 0: runtime
+__global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel(const TraceArgs a) {
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= a.nlines) return;
+    if (!FUSED && li >= a.nlines) return;
+    const bool live_line = li < a.nlines;              // (FUSED: every thread of the block takes part in the pack)
     typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type vox_t;
     const int nvec = NVEC > 0 ? NVEC : a.nvec;
-    const int64_t line = a.line0 + li;
+    const int64_t line = a.line0 + (FUSED && !live_line ? a.nlines - 1 : li);   // (FUSED: a thread past the end shadows the last line and emits nothing)
     const int64_t iseed = line / a.nsub;
     const int isub = (int)(line - iseed * a.nsub);
     const int64_t lin = a.seeds[iseed];
@@ -166,8 +181,9 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
     const float p0x = (float)(sx + 1) + a.sublist[3 * isub];      // pos_now .= seed_vox .+ sub_vox, stream.jl:649
     const float p0y = (float)(sy + 1) + a.sublist[3 * isub + 1];
     const float p0z = (float)(sz + 1) + a.sublist[3 * isub + 2];
-    constexpr int64_t slot_floats = SCR_TILE * 3;
-    float *dcur = a.scratch + (li / SCR_TILE) * ((int64_t)a.nslots * slot_floats) + (li % SCR_TILE) * 3;   // this line's place in the slot of the current trip
+    constexpr int TILE = FUSED ? FUSED_TILE : SCR_TILE;   // lines per scratch tile (FUSED: half as wide, so that a tile's output range fits 14 KB of LDS)
+    constexpr int64_t slot_floats = TILE * 3;
+    float *dcur = a.scratch + (li / TILE) * ((int64_t)a.nslots * slot_floats) + (li % TILE) * 3;   // this line's place in the slot of the current trip
     const char *fbase = reinterpret_cast<const char *>(a.field);   // wave-uniform base; per-lane offsets are 32-bit
     const float fnx = (float)a.nx, fny = (float)a.ny, fnz = (float)a.nz;
     const float omc = 1.0f - a.smooth;
@@ -338,7 +354,7 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
             }
             // push!/prepend! of pos_now (stream.jl:660): the slot of this trip
             // LCM runs: the method-difference flag of the point (stream.jl:666) rides in the sign bit of x (x > 0)
-            store_point(dcur, (LCM && isdiff) ? -px : px, py, pz, a.scratch_plain != 0);
+            if (!FUSED || live_line) store_point(dcur, (LCM && isdiff) ? -px : px, py, pz, a.scratch_plain != 0);
             emitted = true;
             npts++;
             if (pass == 0) nf++;
@@ -383,7 +399,8 @@ __global__ __launch_bounds__(256) void stream_trace_kernel(const TraceArgs a) {
             vx = s.x * -1.0f; vy = s.y * -1.0f; vz = s.z * -1.0f;
         }
     }
-    a.npts[li] = npts; a.nfwd[li] = nf | (gap << 30);
+    if (!FUSED || live_line) { a.npts[li] = npts; a.nfwd[li] = nf | (gap << 30); }
+    if constexpr (FUSED) fused_pack_block<NVEC>(a, li, live_line, npts, nf, gap);
 }
 
 // Divergent termination (lines of a wave end at different steps: 30-53 % of the lane-steps idle on a phantom with a broad length
@@ -806,6 +823,163 @@ __global__ __launch_bounds__(256) void stream_pack_tile_kernel(const PackArgs a)
 #pragma unroll
             for (int j = 0; j < 4; j++) if (4 * k + j >= mis && 4 * k + j < mis + len) gbase[4 * k + j] = e[j];
         }
+    }
+}
+
+// ---- [r5] FUSED: the block that traced 256 lines packs them (fibd_stream_run) --------------------------------------
+// After its trace loop a block knows its kept lines and points; a decoupled look-back over the blocks' totals (one 64-bit granule per
+// block: status | kept lines | points -- the data is the flag, agent-scope atomics, no fence; blocks are dispatched in order, so every
+// block a block waits for is running or done) gives it its place in the packed output, and it then packs its own 16 scratch tiles
+// exactly as stream_pack_tile_kernel does: the tile's kept lines are ONE contiguous output range, assembled in LDS and streamed out with
+// aligned 16-byte non-temporal stores.  No scan kernels, no pack launch; the scratch is still written and read back (256 lines x 144
+// slots x 12 B = 442 KB per block: it does not stay on chip), but blocks that pack overlap with blocks that still trace.
+constexpr unsigned long long FG_PTS_MASK = (1ull << 36) - 1ull, FG_VAL_MASK = (1ull << 62) - 1ull;
+__device__ __forceinline__ unsigned long long shfl_up_u64(unsigned long long v, int off) {
+    return ((unsigned long long)(unsigned)__shfl_up((int)(v >> 32), off) << 32) | (unsigned)__shfl_up((int)(unsigned)v, off);
+}
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int off) {
+    return ((unsigned long long)(unsigned)__shfl_xor((int)(v >> 32), off) << 32) | (unsigned)__shfl_xor((int)(unsigned)v, off);
+}
+typedef __attribute__((address_space(1))) unsigned long long fib_gu64s;
+template <int NVEC>
+__device__ void fused_pack_block(const TraceArgs &a, int64_t li, bool live, int npts, int nf, int gap) {
+    extern __shared__ __attribute__((aligned(16))) float f_obuf[];              // [FT * stride * 3 + slack]: a tile's output range
+    __shared__ uint16_t f_nf[FUSED_BLOCK], f_nb[FUSED_BLOCK], f_bs[FUSED_BLOCK];                        // (16 bits: a tile of such lines fits the LDS, so len_max < 2^15)
+    __shared__ int64_t f_p0[FUSED_BLOCK];
+    constexpr int FB = FUSED_BLOCK, FW = FB / 64;
+    __shared__ unsigned long long f_wsum[FW], f_base;
+    constexpr int FT = FUSED_TILE, FSL = FB / FT;                               // lines per tile; slots a pass of the 256 threads covers
+    __shared__ int t_nf[FT], t_nb[FT], t_bs[FT], t_o[FT], t_cnt[4];
+    __shared__ int64_t t_g0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t b = blockIdx.x;
+    __builtin_amdgcn_s_setprio(3);                                               // the pack's few memory instructions go ahead of the neighbours' trace loops
+    const bool keep = live && npts >= a.len_min;                                 // stream.jl:769
+    const unsigned long long v = keep ? ((1ull << 36) | (unsigned long long)npts) : 0ull;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const unsigned long long o = shfl_up_u64(inc, off); if (lane >= off) inc += o; }
+    if (lane == 63) f_wsum[wave] = inc;
+    __syncthreads();
+    unsigned long long wbase = 0ull;
+    for (int w = 0; w < wave; w++) wbase += f_wsum[w];
+    unsigned long long agg = 0ull;
+    for (int w = 0; w < FW; w++) agg += f_wsum[w];
+    if (wave == 0) {
+        if (lane == 0)
+            __hip_atomic_store((fib_gu64s *)(a.fstate + b), ((b == 0 ? 2ull : 1ull) << 62) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long excl = 0ull;
+        int64_t j0 = b - 1;                                                     // lane l looks at block j0 - l
+        while (j0 >= 0) {
+            const int64_t j = j0 - lane;
+            unsigned long long g = 2ull << 62;                                   // (before block 0: an inclusive prefix of nothing)
+            if (j >= 0) {
+                for (;;) {
+                    g = __hip_atomic_load((fib_gu64s *)(a.fstate + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((g >> 62) != 0ull) break;
+                    __builtin_amdgcn_s_sleep(4);                                 // (a predecessor still tracing: do not take its issue slots)
+                }
+            }
+            const unsigned long long pre = __ballot((g >> 62) == 2ull);          // nearest predecessor that knows its inclusive prefix
+            const int first = pre ? __builtin_ctzll(pre) : 63;
+            unsigned long long c = lane <= first ? (g & FG_VAL_MASK) : 0ull;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) c += shfl_xor_u64(c, off);
+            excl += c;
+            if (pre) break;
+            j0 -= 64;
+        }
+        if (lane == 0) {
+            if (b > 0) __hip_atomic_store((fib_gu64s *)(a.fstate + b), (2ull << 62) | (excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            f_base = excl;
+            if (b == (int64_t)gridDim.x - 1) { const unsigned long long tot = excl + agg; a.ftotal->pts = (int64_t)(tot & FG_PTS_MASK); a.ftotal->lines = (int64_t)(tot >> 36); }
+        }
+    }
+    __syncthreads();
+    {
+        const unsigned long long ex = f_base + wbase + inc - v;                  // kept lines / points before this line
+        const int64_t l0 = (int64_t)(ex >> 36), pt = (int64_t)(ex & FG_PTS_MASK);
+        int mnf = 0, mnb = 0, mbs = 0;
+        int64_t p0 = 0;
+        if (keep && !(l0 >= a.lines_cap || pt + npts > a.points_cap)) {          // (no room: dropped; the totals say what was needed)
+            a.out_npts[l0] = npts; a.out_seed[l0] = a.line0 + li;
+            mnf = nf; mnb = npts - nf; mbs = nf + gap; p0 = pt * 3;
+        }
+        f_nf[tid] = (uint16_t)mnf; f_nb[tid] = (uint16_t)mnb; f_bs[tid] = (uint16_t)mbs; f_p0[tid] = p0;
+    }
+    __syncthreads();
+    struct P3 { float x, y, z; };
+    // per tile: [one wave: the tile's summary] barrier [gather the tile's points into its output range in LDS] barrier [stream the range out]
+    // barrier.  (Preparing the next tile's summary beside the stream-out -- two barriers per tile -- measured SLOWER: C4 1.18 against 1.05 ms.)
+    for (int t = 0; t < FB / FT; t++) {
+        if (tid < 64) {                                                         // the tile's summary (as stream_pack_tile_kernel)
+            int tnf = 0, tnb = 0, tbs = 0, n = 0;
+            int64_t p0 = 0, gs = INT64_MAX, ge = -1;
+            if (tid < FT) {
+                tnf = f_nf[t * FT + tid]; tnb = f_nb[t * FT + tid]; tbs = f_bs[t * FT + tid]; n = tnf + tnb; p0 = f_p0[t * FT + tid];
+                if (n > 0) { gs = p0; ge = p0 + (int64_t)n * 3; }
+            }
+            int mf = tnb > 0 ? tbs + tnb : tnf;
+            int64_t g0 = gs, g1 = ge;
+#pragma unroll
+            for (int o = 1; o < FT; o <<= 1) {
+                mf = max(mf, __shfl_xor(mf, o));
+                const int64_t og0 = (int64_t)shfl_xor_u64((unsigned long long)g0, o), og1 = (int64_t)shfl_xor_u64((unsigned long long)g1, o);
+                g0 = og0 < g0 ? og0 : g0; g1 = og1 > g1 ? og1 : g1;
+            }
+            const int mis = g1 >= 0 ? (int)((reinterpret_cast<uintptr_t>(a.out_xyz + g0) >> 2) & 3) : 0;
+            if (tid < FT) { t_nf[tid] = tnf; t_nb[tid] = tnb; t_bs[tid] = tbs; t_o[tid] = n > 0 ? (int)(p0 - g0) + mis : 0; }
+            if (tid == 0) { t_cnt[0] = mf; t_cnt[1] = g1 >= 0 ? (int)(g1 - g0) : 0; t_cnt[2] = mis; t_g0 = g0; }
+        }
+        __syncthreads();
+        const int cnt = t_cnt[0], len = t_cnt[1], mis = t_cnt[2];
+        if (len > 0) {
+            const int nch = (cnt + FSL - 1) / FSL;
+            const int l = tid % FT, sl = tid / FT;                              // thread = (line, slot within the pass): a pass reads FB x 12 contiguous bytes
+            const int lnf = t_nf[l], lnb = t_nb[l], lbs = t_bs[l], lo = t_o[l];
+            const P3 *tbase = reinterpret_cast<const P3 *>(a.scratch + (b * (FB / FT) + t) * ((int64_t)a.nslots * FT * 3)) + tid;
+            for (int c0 = 0; c0 < nch; c0 += 4) {
+                P3 q[4];
+                int pos[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int c = c0 + i, tt = c * FSL + sl;
+                    pos[i] = -1;                                                // forward points reversed, backward points behind them (stream.jl:652)
+                    if (c < nch) {
+                        if (tt < lnf) pos[i] = lnf - 1 - tt;
+                        else if (tt >= lbs && tt - lbs < lnb) pos[i] = lnf + (tt - lbs);
+                    }
+                    if (pos[i] >= 0) {
+                        const float *src = reinterpret_cast<const float *>(tbase + (int64_t)c * FB);
+                        q[i] = P3{__builtin_nontemporal_load(src), __builtin_nontemporal_load(src + 1), __builtin_nontemporal_load(src + 2)};
+                    } else q[i] = P3{0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (pos[i] < 0) continue;
+                    float *d = f_obuf + lo + pos[i] * 3;
+                    d[0] = q[i].x; d[1] = q[i].y; d[2] = q[i].z;
+                }
+            }
+        }
+        __syncthreads();
+        if (len > 0) {
+            float *gbase = a.out_xyz + t_g0 - mis;
+            const int nq = (mis + len + 3) >> 2;
+            for (int k = tid; k < nq; k += FB) {
+                const float4 qq = reinterpret_cast<const float4 *>(f_obuf)[k];
+                if (4 * k >= mis && 4 * k + 4 <= mis + len) {
+                    typedef float nt4_t __attribute__((ext_vector_type(4)));
+                    const nt4_t qn = {qq.x, qq.y, qq.z, qq.w};
+                    __builtin_nontemporal_store(qn, reinterpret_cast<nt4_t *>(gbase + 4 * k));
+                } else {
+                    const float e[4] = {qq.x, qq.y, qq.z, qq.w};
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) if (4 * k + jj >= mis && 4 * k + jj < mis + len) gbase[4 * k + jj] = e[jj];
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1253,6 +1427,25 @@ extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4
     ta.cosang = prm->cosang_thresh; ta.step = prm->step_size; ta.smooth = prm->smooth_coeff;
     ta.scratch_plain = fib::ab_env("FIBERS_STREAM_SCRATCH_PLAIN") != nullptr;
     const unsigned grid = (unsigned)fib::cdiv(nl, 256);
+    // [r5] FUSED (fused_pack_block): trace + look-back + pack in ONE launch, for nearest-voxel tracking with 1 or 3 vectors per voxel on fields
+    // below 2^28 vectors whose lines fit a 16-line LDS tile (len_max <= ~200) -- from 2^21 lines on: the fused kernel wins by overlapping
+    // workgroups that pack with workgroups that still trace, which needs several rounds of workgroups per CU (measured, tools/stream_fused_ab.py:
+    // 9.96 M lines x 3 vectors 9.7-10.6 ms against 11.5-11.8; 1 M lines 1.05-1.17 ms against 1.09-1.13: two rounds, no steady state).
+    // Everything else takes the three launches below.  (Diagnostic build: FIBERS_STREAM_UNFUSED=1 / FIBERS_STREAM_FUSED=1 force either.)
+    const size_t fsmem = ((size_t)FUSED_TILE * stride * 3 + FUSED_TILE + 8) * sizeof(float);
+    const bool fused_ok = !wide && !prm->interp && (prm->nvec == 1 || prm->nvec == 3) && fsmem <= 40 * 1024 &&
+                          nl < ((int64_t)1 << 26) && nl * (int64_t)(prm->len_max + 2) < ((int64_t)1 << 36) && b_excl >= (size_t)fib::cdiv(nl, FUSED_BLOCK) * sizeof(unsigned long long);
+    const bool fused = fused_ok && fib::ab_env("FIBERS_STREAM_UNFUSED") == nullptr && (nl >= ((int64_t)1 << 21) || fib::ab_env("FIBERS_STREAM_FUSED") != nullptr);
+    if (fused) {
+        const unsigned fgrid = (unsigned)fib::cdiv(nl, FUSED_BLOCK);
+        ta.fstate = reinterpret_cast<unsigned long long *>(bex);          // (the scan's array is free: no scan)
+        ta.out_npts = npts; ta.out_seed = seed_index; ta.out_xyz = xyz; ta.ftotal = total;
+        ta.lines_cap = lines_cap; ta.points_cap = points_cap; ta.len_min = prm->len_min;
+        if (hipMemsetAsync(ta.fstate, 0, (size_t)fgrid * sizeof(unsigned long long), st) != hipSuccess) return release(fib::fail(FIB_ERR_HIP, "hipMemsetAsync failed"));
+        fib::ProfScope prof("stream_trace", st);
+        if (prm->nvec == 1) hipLaunchKernelGGL((stream_trace_kernel<1, false, false, false, true>), dim3(fgrid), dim3(FUSED_BLOCK), fsmem, st, ta);
+        else                hipLaunchKernelGGL((stream_trace_kernel<3, false, false, false, true>), dim3(fgrid), dim3(FUSED_BLOCK), fsmem, st, ta);
+    } else {
     {
         fib::ProfScope prof("stream_trace", st);
         if (prm->interp) launch_trace<false, true>(ta, prm->nvec, wide, grid, st);
@@ -1276,6 +1469,8 @@ extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4
         const int rcl = launch_pack_n(pa, nl, stride, st);
         if (rcl != FIB_OK) return release(rcl);
     }
+    }   // (!fused)
+    if (hipGetLastError() != hipSuccess) return release(fib::fail(FIB_ERR_HIP, "streamline launch failed"));
     Pair tot{0, 0};
     hipError_t e = hipMemcpyAsync(&tot, total, sizeof(Pair), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);

@@ -367,9 +367,10 @@ class StreamBuffers:
 
 def stream_device_run(field, shape, seeds, sublist, buffers: StreamBuffers = None, len_min=3, len_max=None, ang_thresh=45, step_size=0.5,
                       smooth_coeff=0.2, stream=None, workspace="default", interp="nearest"):
-    """stream_device in ONE library call (fibd_stream_run): the lines are traced in batches and each batch is packed, on a second
-    stream, while the next is traced; results go straight into `buffers` (grown and the call repeated when they are too small:
-    a first call sizes them).  Same lines, order and layout as stream_device; macro-scale angle picking only.
+    """stream_device in ONE library call (fibd_stream_run): trace, scan and pack without a host round trip in between -- from 2^21
+    lines on (nearest-voxel tracking, 1 or 3 vectors per voxel) as ONE kernel in which the workgroup that traced 512 lines packs them
+    behind a decoupled look-back; results go straight into `buffers` (grown and the call repeated when they are too small: a first
+    call sizes them).  Same lines, order and layout as stream_device; macro-scale angle picking only.
     Returns dict(npts, seed_index, xyz) -- views of the buffers, valid until the next call with them."""
     import torch
     _chk_dev(field, torch.float32, "field")

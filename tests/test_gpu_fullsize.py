@@ -278,6 +278,38 @@ def test_c5_stream_three_peaks_10m(fj, dev, dsi_result):
         i = pos[int(pick[sd]) * 10 + so]
         assert np.array_equal(xyz[off[i]:off[i + 1]].cpu().numpy(), ref["xyz"][roff[j]:roff[j + 1]]), (j, rs)
     assert len(ref["npts"]) == sum(1 for sd in pick for so in range(10) if int(sd) * 10 + so in pos)   # and no line more or less
+    # [r5] the one-call form (fibd_stream_run): from 2^21 lines on the workgroup that traced 512 lines packs them itself behind a decoupled
+    # look-back (fused_pack_block) -- the same lines, order, seed indices and points, bit for bit, as trace + scan + pack above; also into
+    # buffers that are too small (the totals come back, nothing is written past the capacity, what is written is right)
+    import ctypes as C
+    L = fj.lib()
+    L.fib_profile_enable(1); L.fib_profile_reset()
+    bufs = fj.StreamBuffers(dev)
+    one = fj.stream_device_run(field, SHAPE, seeds, sub, buffers=bufs)
+    torch.cuda.synchronize()
+    ms, cnt = C.c_double(0), C.c_int64(0)
+    L.fib_profile_get(b"stream_pack", C.byref(ms), C.byref(cnt))
+    L.fib_profile_enable(0)
+    assert cnt.value == 0, "the fused kernel was expected to run (no separate pack launch)"
+    for k in ("npts", "seed_index", "xyz"):
+        assert torch.equal(one[k], res[k]), k
+    small = fj.StreamBuffers(dev)
+    small.reserve(1000, 100000)
+    small.xyz.fill_(-7.0)
+    import sys
+    smod = sys.modules[fj.stream_device_run.__module__]
+    from fibers_jl_amd import _lib
+    prm = smod._params(SHAPE, 3, 3, None, 45, 0.5, 0.2, 0, 10, smod.default_workspace(0))
+    nl2, np2 = C.c_int64(0), C.c_int64(0)
+    rc = L.fibd_stream_run(C.byref(prm), field.data_ptr(), seeds.data_ptr(), seeds.numel(), sub.data_ptr(), sub.shape[0], small.npts.data_ptr(),
+                           small.seed_index.data_ptr(), 1000, small.xyz.data_ptr(), 100000, C.byref(nl2), C.byref(np2), None)
+    torch.cuda.synchronize()
+    assert rc == _lib.FIB_ERR_CAPACITY and nl2.value == res["npts"].numel() and np2.value == res["xyz"].shape[0]
+    nfit = int((torch.cumsum(res["npts"][:1000].long(), 0) <= 100000).sum())
+    assert nfit > 100 and torch.equal(small.npts[:nfit], res["npts"][:nfit])
+    npf = int(res["npts"][:nfit].sum())
+    assert torch.equal(small.xyz[:npf], res["xyz"][:npf])
+    assert bool((small.xyz[100000:] == -7.0).all())
 
 
 # ---- the one-launch mask compaction at sizes where a chunk holds several sub-chunks and the helper workgroups take every path --------
