@@ -498,14 +498,13 @@ def main():
                 idle_w = en.idle_watts(1.2)
                 stored = json.load(open(os.path.join(ROOT, "profiles", "energy_model.json")))
                 gm = stored.get("gqi_model") or {}
-                pw = en.gqi_power_roofline(gm["joules_per_unit"], nloc, gemm_avg_ms, em["ms_per_step"], em["joules_per_step"], idle_w,
-                                           essential_ms=(gm.get("essential_ms") or 0.0) * nloc / float(SHAPE[0] * SHAPE[1] * SHAPE[2]) or None)
+                pw = en.gqi_power_roofline(gm["joules_per_unit"], nloc, gemm_avg_ms, em["ms_per_step"], em["joules_per_step"], idle_w)
                 pw.update(board_watts_while_stepping=em["watts"], smu_sclk_mhz_while_stepping=em["sclk_mhz_mean"], steps_measured=em["steps"],
-                          source=("measured_joules_per_step, board_watts, idle_w: LIVE (energy counter, this run).  joules_per_unit, essential_ms: STORED, "
-                                  "from %s.  frac = floor_ms / the kernel's hipEvent time: the floor counts the algorithmic HBM bytes and the executed MFMA flops "
-                                  "at what each costs ALONE (HBM probe at 2.4 GHz and its voltage: the high side); frac_calibrated scales every component so "
-                                  "that components + idle = the measured Joules (the low side); frac_of_essential = a probe kernel that does one step's HBM "
-                                  "bytes + MFMAs and nothing else, timed under the same cap" % stored.get("source", "profiles/energy_model.json")))
+                          source=("measured_joules_per_step, board_watts, idle_w: LIVE (energy counter, this run).  joules_per_unit: STORED, from %s.  "
+                                  "floor_ms = (algorithmic HBM bytes + executed MFMA flops, in Joules) / (cap - idle), frac = floor_ms / the kernel's hipEvent "
+                                  "time, with every component scaled by calibration_scale so that components + idle = the MEASURED Joules (the probes ran at "
+                                  "2.4 GHz and its voltage, the kernel at 1.8-1.9 GHz); floor_raw_ms / frac_raw: the same at what each ingredient costs ALONE at "
+                                  "its own clock -- an over-count by ~25 %%, an upper estimate that can exceed 1" % stored.get("source", "profiles/energy_model.json")))
                 roofline["power"] = pw
                 kc = extra.get("in_kernel_clock", {}).get("gqi_fused") if isinstance(extra.get("in_kernel_clock"), dict) else None
                 roofline["clock"] = dict(

@@ -130,32 +130,30 @@ def gqi_counts(nvox, nvol=270, nvert=321, valu_wave_instructions=None):
 UNAVOIDABLE = ("hbm_bytes", "mfma_flops")       # the algorithm's bytes and its (three-product) matrix-core work; the rest is this kernel's way of doing it
 
 
-def gqi_power_roofline(joules_per_unit, nvox, kernel_ms, step_ms, step_joules, idle_w, cap_w=1400.0, essential_ms=None, **count_kw):
-    """roofline.power: joules_by_component = counts x the probes' Joules per unit (above the idle board); two floors:
-    floor_ms            = unavoidable components' Joules / (cap - idle): what a kernel made of nothing else would take under the cap if the
-                          ingredients cost what they cost one at a time (each probe runs at its own clock: HBM, LDS and VALU probes at 2.4
-                          GHz and its voltage, the MFMA probe at the ~1.7 GHz the cap leaves it -- so this floor is on the high side);
-    floor_calibrated_ms = the same with every component scaled so that components + idle = the step's MEASURED Joules (the kernel runs
-                          at ~1.9 GHz: lower voltage than most probes) -- the low side;
-    essential_ms        = the measured time of a probe kernel that does one step's HBM bytes + MFMAs and nothing else (when available)."""
+def gqi_power_roofline(joules_per_unit, nvox, kernel_ms, step_ms, step_joules, idle_w, cap_w=1400.0, **count_kw):
+    """roofline.power: joules_by_component = counts x the probes' Joules per unit (above the idle board), and the floor a kernel made of
+    nothing but the unavoidable components (the algorithm's HBM bytes and its executed MFMA flops) would reach under the cap:
+    floor_ms / frac          (the figures to quote) every component scaled by ONE factor so that components + idle = the step's MEASURED
+                             Joules -- the probes for HBM, LDS and the vector ALU ran at 2.4 GHz and its voltage, the kernel runs at 1.8-1.9 GHz
+                             where every operation costs less -- then unavoidable Joules / (cap - idle).  Conservative: a shorter kernel would
+                             run at a higher clock and pay more per operation than this assumes;
+    floor_raw_ms / frac_raw  the same without the scaling: each ingredient at what it costs ALONE at its own clock.  An over-count (the model
+                             then exceeds the measured Joules by ~25 %), so this 'floor' can exceed the kernel's time: an upper estimate."""
     counts = gqi_counts(nvox, **count_kw)
     joules = {k: (counts[k] * joules_per_unit[k] if joules_per_unit.get(k) is not None else None) for k in counts}
     dyn = sum(v for v in joules.values() if v)
     unavoidable = sum(joules[k] or 0.0 for k in UNAVOIDABLE)
     budget = cap_w - idle_w
     idle_j = idle_w * step_ms * 1e-3
+    scale = max(0.0, step_joules - idle_j) / dyn if (step_joules and dyn > 0) else None
     out = dict(cap_w=cap_w, idle_w=idle_w, budget_w=budget, counts_per_step=counts, joules_per_unit=dict(joules_per_unit),
-               joules_by_component=joules, idle_joules_per_step=idle_j, modelled_joules_per_step=dyn + idle_j,
+               joules_by_component_raw=joules, idle_joules_per_step=idle_j, modelled_joules_per_step_raw=dyn + idle_j,
                measured_joules_per_step=step_joules, model_over_measured=(dyn + idle_j) / step_joules if step_joules else None,
-               unavoidable_components=list(UNAVOIDABLE), floor_ms=unavoidable / budget * 1e3, kernel_ms=kernel_ms, step_ms=step_ms,
-               frac=(unavoidable / budget * 1e3) / kernel_ms if kernel_ms else None)
-    if step_joules and dyn > 0:
-        scale = max(0.0, step_joules - idle_j) / dyn
+               unavoidable_components=list(UNAVOIDABLE), kernel_ms=kernel_ms, step_ms=step_ms,
+               floor_raw_ms=unavoidable / budget * 1e3, frac_raw=(unavoidable / budget * 1e3) / kernel_ms if kernel_ms else None)
+    if scale is not None:
         out["calibration_scale"] = scale
-        out["joules_by_component_calibrated"] = {k: (v * scale if v else v) for k, v in joules.items()}
-        out["floor_calibrated_ms"] = unavoidable * scale / budget * 1e3
-        out["frac_calibrated"] = out["floor_calibrated_ms"] / kernel_ms if kernel_ms else None
-    if essential_ms:
-        out["essential_ms"] = essential_ms
-        out["frac_of_essential"] = essential_ms / kernel_ms if kernel_ms else None
+        out["joules_by_component"] = {k: (v * scale if v else v) for k, v in joules.items()}
+        out["floor_ms"] = unavoidable * scale / budget * 1e3
+        out["frac"] = out["floor_ms"] / kernel_ms if kernel_ms else None
     return out
