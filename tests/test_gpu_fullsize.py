@@ -241,6 +241,24 @@ def test_c4_stream_1m_seeds(fj, orc, dev):
     for j, rs in enumerate(ref["seed_index"]):                 # oracle numbers its 400 seeds 0..399 in findall order
         i = pos[int(pick[int(rs)])]
         assert np.array_equal(xyz[off[i]:off[i + 1]], ref["xyz"][roff[j]:roff[j + 1]])
+    # [r5] the one-call form on the same field: 1 M lines take trace + scan + pack (below the fused kernel's 2^21 lines), 3 M lines (three
+    # offsets) take the fused trace + look-back + pack kernel with ONE vector per voxel -- both bit-identical to the two-call form
+    one = fj.stream_device_run(field, SHAPE, seeds, sub, buffers=fj.StreamBuffers(dev))
+    for k in ("npts", "seed_index", "xyz"):
+        assert torch.equal(one[k], res[k]), k
+    sub3 = torch.tensor([[0.1, -0.2, 0.3], [-0.3, 0.25, 0.0], [0.0, 0.4, -0.45]], dtype=torch.float32, device=dev)
+    two3 = fj.stream_device(field, SHAPE, seeds, sub3)
+    import ctypes as C
+    L = fj.lib()
+    L.fib_profile_enable(1); L.fib_profile_reset()
+    one3 = fj.stream_device_run(field, SHAPE, seeds, sub3, buffers=fj.StreamBuffers(dev))
+    torch.cuda.synchronize()
+    ms, cnt = C.c_double(0), C.c_int64(0)
+    L.fib_profile_get(b"stream_pack", C.byref(ms), C.byref(cnt))
+    L.fib_profile_enable(0)
+    assert cnt.value == 0 and int(seeds.numel()) * 3 >= (1 << 21)          # (no separate pack launch: the fused kernel ran)
+    for k in ("npts", "seed_index", "xyz"):
+        assert torch.equal(one3[k], two3[k]), k
 
 
 def test_c5_stream_three_peaks_10m(fj, dev, dsi_result):
