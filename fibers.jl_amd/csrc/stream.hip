@@ -164,11 +164,20 @@ __device__ __forceinline__ int lcm_match_edge(int dx, int dy, int dz, int sd0, i
 // WIDE: 64-bit voxel indices and gather offsets, for orientation fields of 2^28 vectors (4 GiB) or more -- the microscopy
 // regime's whole-slide sections (stream.jl:83,147-172); chosen at launch, bit-identical to the 32-bit form on small fields.
 struct FuseLds;   // (defined with the pack kernels below)
-template <int NVEC> __device__ void fused_pack_block(const TraceArgs &a, int64_t li, bool live, int npts, int nf, int gap);
+template <int NVEC> __device__ void fused_pack_block(const TraceArgs &a, int64_t b, int64_t li, bool live, int npts, int nf, int gap);
 
 template <int NVEC, bool LCM = false, bool TRI = false, bool WIDE = false, bool FUSED = false>   // NVEC > 0: compile-time vector count; 0: runtime
 __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel(const TraceArgs a) {
-    const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // FUSED: the workgroup's place in the line order is a TICKET, not blockIdx: whatever order workgroups are dispatched in, everything a
+    // workgroup later waits for in the look-back (tickets below its own) was drawn by a workgroup that is already running
+    int64_t wg = blockIdx.x;
+    if constexpr (FUSED) {
+        __shared__ unsigned s_ticket;
+        if (threadIdx.x == 0) s_ticket = atomicAdd(reinterpret_cast<unsigned *>(a.fstate + gridDim.x), 1u);
+        __syncthreads();
+        wg = s_ticket;
+    }
+    const int64_t li = wg * blockDim.x + threadIdx.x;
     if (!FUSED && li >= a.nlines) return;
     const bool live_line = li < a.nlines;              // (FUSED: every thread of the block takes part in the pack)
     typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type vox_t;
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
         }
     }
     if (!FUSED || live_line) { a.npts[li] = npts; a.nfwd[li] = nf | (gap << 30); }
-    if constexpr (FUSED) fused_pack_block<NVEC>(a, li, live_line, npts, nf, gap);
+    if constexpr (FUSED) fused_pack_block<NVEC>(a, wg, li, live_line, npts, nf, gap);
 }
 
 // Divergent termination (lines of a wave end at different steps: 30-53 % of the lane-steps idle on a phantom with a broad length
@@ -842,7 +851,7 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 }
 typedef __attribute__((address_space(1))) unsigned long long fib_gu64s;
 template <int NVEC>
-__device__ void fused_pack_block(const TraceArgs &a, int64_t li, bool live, int npts, int nf, int gap) {
+__device__ void fused_pack_block(const TraceArgs &a, int64_t b, int64_t li, bool live, int npts, int nf, int gap) {
     extern __shared__ __attribute__((aligned(16))) float f_obuf[];              // [FT * stride * 3 + slack]: a tile's output range
     __shared__ uint16_t f_nf[FUSED_BLOCK], f_nb[FUSED_BLOCK], f_bs[FUSED_BLOCK];                        // (16 bits: a tile of such lines fits the LDS, so len_max < 2^15)
     __shared__ int64_t f_p0[FUSED_BLOCK];
@@ -852,7 +861,6 @@ __device__ void fused_pack_block(const TraceArgs &a, int64_t li, bool live, int 
     __shared__ int t_nf[FT], t_nb[FT], t_bs[FT], t_o[FT], t_cnt[4];
     __shared__ int64_t t_g0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t b = blockIdx.x;
     __builtin_amdgcn_s_setprio(3);                                               // the pack's few memory instructions go ahead of the neighbours' trace loops
     const bool keep = live && npts >= a.len_min;                                 // stream.jl:769
     const unsigned long long v = keep ? ((1ull << 36) | (unsigned long long)npts) : 0ull;
@@ -1434,14 +1442,15 @@ extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4
     // Everything else takes the three launches below.  (Diagnostic build: FIBERS_STREAM_UNFUSED=1 / FIBERS_STREAM_FUSED=1 force either.)
     const size_t fsmem = ((size_t)FUSED_TILE * stride * 3 + FUSED_TILE + 8) * sizeof(float);
     const bool fused_ok = !wide && !prm->interp && (prm->nvec == 1 || prm->nvec == 3) && fsmem <= 40 * 1024 &&
-                          nl < ((int64_t)1 << 26) && nl * (int64_t)(prm->len_max + 2) < ((int64_t)1 << 36) && b_excl >= (size_t)fib::cdiv(nl, FUSED_BLOCK) * sizeof(unsigned long long);
+                          nl < ((int64_t)1 << 26) && nl * (int64_t)(prm->len_max + 2) < ((int64_t)1 << 36) && b_excl >= ((size_t)fib::cdiv(nl, FUSED_BLOCK) + 1) * sizeof(unsigned long long);
     const bool fused = fused_ok && fib::ab_env("FIBERS_STREAM_UNFUSED") == nullptr && (nl >= ((int64_t)1 << 21) || fib::ab_env("FIBERS_STREAM_FUSED") != nullptr);
     if (fused) {
         const unsigned fgrid = (unsigned)fib::cdiv(nl, FUSED_BLOCK);
         ta.fstate = reinterpret_cast<unsigned long long *>(bex);          // (the scan's array is free: no scan)
         ta.out_npts = npts; ta.out_seed = seed_index; ta.out_xyz = xyz; ta.ftotal = total;
         ta.lines_cap = lines_cap; ta.points_cap = points_cap; ta.len_min = prm->len_min;
-        if (hipMemsetAsync(ta.fstate, 0, (size_t)fgrid * sizeof(unsigned long long), st) != hipSuccess) return release(fib::fail(FIB_ERR_HIP, "hipMemsetAsync failed"));
+        if (hipMemsetAsync(ta.fstate, 0, ((size_t)fgrid + 1) * sizeof(unsigned long long), st) != hipSuccess)      // (+ the ticket counter behind the granules)
+            return release(fib::fail(FIB_ERR_HIP, "hipMemsetAsync failed"));
         fib::ProfScope prof("stream_trace", st);
         if (prm->nvec == 1) hipLaunchKernelGGL((stream_trace_kernel<1, false, false, false, true>), dim3(fgrid), dim3(FUSED_BLOCK), fsmem, st, ta);
         else                hipLaunchKernelGGL((stream_trace_kernel<3, false, false, false, true>), dim3(fgrid), dim3(FUSED_BLOCK), fsmem, st, ta);
