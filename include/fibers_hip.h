@@ -98,7 +98,7 @@ int fib_dsi_plan_create(int device, const float *bval, const float *bvec, int nv
  *   FIB_ODF_FORMAT_FP16X2  two fp16 pieces per f32 operand (23 of 24 significant bits, three piece products; the default)
  *   FIB_ODF_FORMAT_BF16X3  three bf16 pieces per operand, six piece products: every f32 product exact
  *   FIB_ODF_FORMAT_F32     v_mfma_f32_32x32x2_f32: a k-ordered f32 fma chain
- *   FIB_ODF_FORMAT_DEFAULT what the environment selects (FIBERS_ODF_GEMM=f32, FIBERS_ODF_EXACT=1), else FP16X2.
+ *   FIB_ODF_FORMAT_DEFAULT what the environment selects (FIBERS_ODF_FORMAT = fp16x2 | bf16x3 | f32), else FP16X2.
  * A plan may fall back to a wider form when its matrix does not fit a narrower one (non-finite entries, < 2 stages):
  * fib_odf_plan_format reports what the plan's kernels actually run; fib_odf_default_format what DEFAULT resolves to now. */
 #define FIB_ODF_FORMAT_DEFAULT 0
@@ -115,7 +115,7 @@ int fib_odf_plan_format(const fib_odf_plan *plan);   /* FIB_ODF_FORMAT_* (> 0) o
 /* Diagnostic: the unit of the voxel list the plan's next fibd_odf_rec call will use -- 1: aligned groups of 32 voxels (a wave's
  * 128-byte row segments are whole cache lines whatever the mask's runs look like; the default), 0: aligned groups of 4 (chosen by
  * the previous call when groups of 32 would list more than 1.5 x the voxels: sparse masks).  Results do not depend on it.
- * Waits for `stream`.  FIBERS_ODF_LIST=quads|octets pins it. */
+ * Waits for `stream`. */
 int fib_odf_plan_list_unit(const fib_odf_plan *plan, void *stream);
 int fib_odf_default_format(void);
 void fib_odf_plan_destroy(fib_odf_plan *plan);
@@ -278,8 +278,8 @@ int fibd_stream_field(int32_t nvec, int64_t nvox, const float *const *ovec, cons
  * in the reference's findall order; sublist [nsub*3] (xyz per offset; caller-generated, stream.jl:176-181).
  * Traces into library-owned scratch, applies len_min (stream.jl:769) and computes output offsets.
  * Synchronises `stream`; returns the number of kept lines and their total point count.
- * field4, seeds and sublist must stay valid and unchanged until the job has been packed (the low-memory
- * mode FIBERS_STREAM_TWOPASS=1 keeps no point scratch: the pack call traces the kept lines again). */
+ * field4, seeds and sublist must stay valid and unchanged until the job has been packed.  Orientation fields of 2^28 vectors
+ * (4 GiB) or more take a form of the tracer with 64-bit gather offsets, chosen at launch. */
 int fibd_stream_trace(const fib_stream_params *prm, const float *field4, const int64_t *seeds, int64_t nseed,
                       const float *sublist, int32_t nsub, void *stream,
                       fib_stream_job **job, int64_t *nlines, int64_t *npoints);
@@ -290,9 +290,9 @@ int fibd_stream_pack(fib_stream_job *job, int32_t *npts, int64_t *seed_index, fl
 
 /* trace + pack in ONE call into caller-provided device buffers (npts [lines_cap] int32, seed_index [lines_cap] int64, xyz
  * [3*points_cap] float): the same lines, order and layout as fibd_stream_trace + fibd_stream_pack without the second call and
- * without any allocation on the caller's side of the boundary between them.  (FIBERS_STREAM_BATCHES=n traces the lines in n
- * batches and packs each on a second stream while the next is traced; measured slower than one batch: both kernels are bound by
- * the same HBM traffic.)  *nlines / *npoints receive the totals; when they exceed the capacities the call
+ * without any allocation on the caller's side of the boundary between them.  From 2^21 lines on (nearest-voxel tracking, 1 or 3
+ * vectors per voxel, lines that fit a 16-line LDS tile) it is ONE kernel: the workgroup that traced 512 lines packs them behind a
+ * decoupled look-back over the workgroups' totals.  *nlines / *npoints receive the totals; when they exceed the capacities the call
  * returns FIB_ERR_CAPACITY (lines that did not fit are missing from the buffers; call again with larger ones).  Macro-scale angle
  * picking only (prm->search_dist == 0, no LCMs); synchronises `stream`. */
 int fibd_stream_run(const fib_stream_params *prm, const float *field4, const int64_t *seeds, int64_t nseed,
