@@ -1085,7 +1085,10 @@ extern "C" int fibd_stream_field(int32_t nvec, int64_t nvox, const float *const 
 
 namespace {
 // 2^28 vectors of 16 bytes = 4 GiB: from there on the gather offsets need 64 bits (stream_trace_kernel<.., WIDE>)
-bool field_is_wide(const fib_stream_params *prm) { return (int64_t)prm->nx * prm->ny * prm->nz * prm->nvec >= ((int64_t)1 << 28); }
+// (diagnostic build: FIBERS_STREAM_WIDE=1 takes the wide form on any field -- tools/stream_wide_check.py compares it with the 32-bit form)
+bool field_is_wide(const fib_stream_params *prm) {
+    return (int64_t)prm->nx * prm->ny * prm->nz * prm->nvec >= ((int64_t)1 << 28) || fib::ab_env("FIBERS_STREAM_WIDE") != nullptr;
+}
 // the one-lane-per-line tracer for (LCM, TRI); the vector count is a compile-time constant for 1 and 3 vectors per voxel, wide
 // fields take the run-time count (one instantiation per mode)
 template <bool LCM, bool TRI>

@@ -510,3 +510,19 @@ def test_stream_wide_field_past_the_32_bit_gather_limit(fj, orc):
     g = got["xyz"].cpu().numpy()
     assert np.array_equal(g[:, :2], ref["xyz"][:, :2])
     assert np.all(g[:, 2] == np.float32(nz)) and np.all(ref["xyz"][:, 2] == np.float32(1.0))
+
+
+def test_wide_tracer_forms_match_the_32_bit_forms_on_small_fields():
+    """stream_trace_kernel<.., WIDE> for nearest-voxel (1 / 2 / 3 vectors), trilinear and LCM-guided tracking against the 32-bit forms, bit for
+    bit, on small fields -- where only the DIAGNOSTIC build can force the wide form, so the check runs as a child process that loads
+    libfibers_hip_stamp.so (tools/stream_wide_check.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "fibers.jl_amd", "libfibers_hip_stamp.so")):
+        pytest.skip("the diagnostic build is absent (make -C fibers.jl_amd/csrc stamp)")
+    env = {k: v for k, v in os.environ.items() if k != "FIBERS_HIP_LIB"}
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stream_wide_check.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "stream wide check: ok" in out.stdout
