@@ -66,21 +66,37 @@ __global__ __launch_bounds__(256) void stream_field_kernel(const FieldArgs a) {
 }
 
 struct Pair { int64_t pts, lines; };
-constexpr int SCR_TILE = 16;         // lines per tile of the point scratch
-constexpr int FUSED_TILE = 16;       // .. in the fused trace + pack kernel (diagnostic build A/B; 8-line tiles -- 96-byte rows -- made the trace 3 x slower)
+constexpr int SCR_TILE = 16;         // lines per pack tile: the unit whose output range a pack workgroup assembles in LDS
+constexpr int FUSED_TILE = 16;       // .. in the fused trace + pack kernel
 constexpr int FUSED_BLOCK = 512;     // its workgroup: 8 waves, so that 4 workgroups of 35 KB of LDS keep the CU's 32 wave slots full
+// Lines that share a ROW of the point scratch (a row = one slot of SCR_ROW lines, SCR_ROW x 12 bytes).  [r5] The tracer is bound by these
+// stores (tools/stream_bound_probe.py: without them the trace takes 0.43 of 0.50 ms, without the field gathers nothing less), and
+// non-temporal stores that end in the middle of a 128-byte line are slow: 192-byte rows (16 lines) reach 4.1 TB/s alone, 384-byte rows
+// (32 lines = three whole lines) 5.1 (tools/probes/write_probe.hip), and the trace kernel went 0.54 -> 0.49 ms with them.  But then the
+// pack side pays the same back: 16-line tiles that read 192 of every 384 bytes 0.54 -> 0.63 ms, 32-line tiles (55 KB of LDS, two
+// workgroups per CU) 0.60 (1 024 threads) / 0.64 (512), the fused kernel 10.6 -> 11.7 ms (half rows) / 13.3 (32-line tiles, 1 024
+// threads): profiles/r05/negative_results.txt.  So the row stays the pack tile.  (8-line rows, 96 B: the trace 3 x slower.)
+constexpr int SCR_ROW = 16;
+static_assert(SCR_ROW % SCR_TILE == 0 && SCR_ROW % FUSED_TILE == 0, "pack tiles are whole fractions of a scratch row");
+constexpr int SCR_SLOT_FLOATS = SCR_ROW * 3;                       // from one slot of a line to its next
+// first float of line li's slot 0:  [row = li / SCR_ROW][slot][li % SCR_ROW][3]
+__host__ __device__ __forceinline__ int64_t scratch_line_base(int64_t li, int nslots) {
+    return (li / SCR_ROW) * ((int64_t)nslots * SCR_SLOT_FLOATS) + (li % SCR_ROW) * 3;
+}
 constexpr int TRACE_SCAN_B = 2048;   // = SCAN_B (lines per block of the scan)
 struct TraceArgs {
     const float4 *field;        // [nvox][nvec]
     const int64_t *seeds;       // [nseed] 0-based linear voxel index
     const float *sublist;       // [nsub][3]
-    float *scratch;             // [nlines/16 tiles][nslots][16 lines][3]: the point a line emits at loop trip t -> slot t: forward point i in slot i,
-                                // backward point j in slot nf + gap + j (a tile is one contiguous run that the pack kernel streams; a wave of the
-                                // trace kernel writes 4 x 192 B per trip)
+    float *scratch;             // [nlines/16 rows][nslots][16 lines][3]: the point a line emits at loop trip t -> slot t: forward point i in slot i,
+                                // backward point j in slot nf + gap + j (a row's slots are one contiguous run that the pack kernel streams; a wave
+                                // of the trace kernel writes 4 x 192 B per trip)
     int32_t *npts, *nfwd;       // [nlines]; nfwd = forward points | gap << 30 (gap = 1: the forward pass ended on a trip that emitted nothing)
     int64_t line0, nlines;      // this batch covers global lines [line0, line0+nlines)
     int nx, ny, nz, nvec, nsub, len_max, stride, nslots;
     int scratch_plain;          // diagnostic build only (FIBERS_STREAM_SCRATCH_PLAIN): the point scratch with the default cache policy instead of non-temporal
+    int norm_generic;           // diagnostic build only (FIBERS_STREAM_NORM_GENERIC): normalise3's generic expansion for every vector
+    int dbg;                    // diagnostic build only (FIBERS_STREAM_DBG bit mask; WRONG RESULTS, timing experiments): 1 = no gather after the seed's, 2 = no point stores
     // FUSED (fibd_stream_run): the block that traced 256 lines also packs them -- a decoupled look-back over the blocks' kept-line / point
     // totals gives it its place in the output
     unsigned long long *fstate; // [blocks] granules: status << 62 | kept lines << 36 | points (zeroed before the launch)
@@ -111,15 +127,74 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
 // default policy the 1.6 GB of scratch points of a million lines go through the XCDs' L2 and push the orientation field out of it:
 // the trace kernel took 0.69 ms, 0.55 with this store (and 0.50 with no store at all); the pack kernel gains 4 % too.
 typedef float f32x3_t __attribute__((ext_vector_type(3)));
-__device__ __forceinline__ void store_point(float *d, float x, float y, float z, bool plain = false) {
+__device__ __forceinline__ void store_point(float *d, float x, float y, float z, int plain = 0) {
     const f32x3_t v = {x, y, z};
 #ifdef FIB_AB_VARIANTS
     // (diagnostic build, FIBERS_STREAM_SCRATCH_PLAIN: the default cache policy, as inline assembly -- written as a second C++ store hipcc
     // merges the two branches into ONE store without the non-temporal hint; tools/check_loop_waits.py asserts the hint on the product)
-    if (plain) { asm volatile("global_store_dwordx3 %0, %1, off" :: "v"(d), "v"(v) : "memory"); return; }
+    if (plain == 1) { asm volatile("global_store_dwordx3 %0, %1, off" :: "v"(d), "v"(v) : "memory"); return; }
+    if (plain == 2) { asm volatile("global_store_dwordx3 %0, %1, off sc1" :: "v"(d), "v"(v) : "memory"); return; }
+    if (plain == 3) { asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1" :: "v"(d), "v"(v) : "memory"); return; }
+    if (plain == 4) { asm volatile("global_store_dwordx3 %0, %1, off sc1 nt" :: "v"(d), "v"(v) : "memory"); return; }
+    if (plain == 5) { asm volatile("global_store_dwordx3 %0, %1, off sc0 nt" :: "v"(d), "v"(v) : "memory"); return; }
+    if (plain == 6) { asm volatile("global_store_dwordx3 %0, %1, off sc0" :: "v"(d), "v"(v) : "memory"); return; }
 #endif
     (void)plain;
     __builtin_nontemporal_store(v, reinterpret_cast<f32x3_t *>(d));
+}
+
+// w ./= norm(w)  (stream.jl:680).  LinearAlgebra.norm on a 3-vector is generic_norm2: the largest magnitude first (zero / Inf / NaN return
+// it), then the squares in Float32, their sum and the square root in Float64, the result converted to Float32; then three IEEE divisions.
+// [r5] Written out as `(float)sqrt(acc)` and `w / n` this is ~60 of the tracer's ~125 vector instructions per step (the loop is bound by
+// vector-ALU issue): hipcc expands the f64 square root with a range-scaling prologue / special-value epilogue and each division with two
+// v_div_scale, a reciprocal, its refinement, v_div_fmas and v_div_fixup.  Where every component is 0 or within 2^-40 .. 2^40 -- any
+// orientation field -- none of the scaling or fix-up can trigger, and the SAME instruction sequences without them give the same bits:
+// the Goldschmidt square root of llvm's f64 lowering, ONE refined reciprocal for the three divisions, two residual corrections per
+// quotient.  Anything outside that range takes the generic expansion.  tests/test_gpu_stream.py compares the two over random and edge inputs.
+__device__ __forceinline__ void normalise3(float &wx, float &wy, float &wz, bool generic = false) {
+    const float m = fmaxf(fabsf(wx), fmaxf(fabsf(wy), fabsf(wz)));
+    const float lo = fminf(fabsf(wx), fminf(fabsf(wy), fabsf(wz)));
+    bool plain = lo >= 0x1p-40f && m <= 0x1p40f;                   // (NaN fails)
+#ifdef FIB_AB_VARIANTS
+    if (generic) plain = false;                                    // diagnostic build, FIBERS_STREAM_NORM_GENERIC: hipcc's expansions throughout
+    else
+#endif
+    if (!plain && m <= 0x1p40f && m >= 0x1p-40f)                   // components that are exactly zero (2-D sections) are fine too
+        plain = (wx == 0.0f || fabsf(wx) >= 0x1p-40f) && (wy == 0.0f || fabsf(wy) >= 0x1p-40f) && (wz == 0.0f || fabsf(wz) >= 0x1p-40f);
+    if (plain) {
+        double acc = (double)(wx * wx);
+        acc += (double)(wy * wy);
+        acc += (double)(wz * wz);
+        const double y = __builtin_amdgcn_rsq(acc);
+        double g = acc * y, h = y * 0.5;
+        const double r = fma(-h, g, 0.5);
+        g = fma(g, r, g);
+        double d = fma(-g, g, acc);
+        h = fma(h, r, h);
+        g = fma(d, h, g);
+        d = fma(-g, g, acc);
+        g = fma(d, h, g);
+        const float n = (float)g;
+        float rc = __builtin_amdgcn_rcpf(n);
+        rc = fmaf(fmaf(-n, rc, 1.0f), rc, rc);
+        auto quot = [&](float x) {
+            float q = x * rc;
+            q = fmaf(fmaf(-n, q, x), rc, q);
+            q = fmaf(fmaf(-n, q, x), rc, q);
+            return __builtin_copysignf(q, x);                     // (-0 / n = -0; the residual steps give +0)
+        };
+        wx = quot(wx); wy = quot(wy); wz = quot(wz);
+        return;
+    }
+    float n;
+    if (m == 0.0f || !(m < INFINITY)) n = m;
+    else {
+        double acc = (double)(wx * wx);
+        acc += (double)(wy * wy);
+        acc += (double)(wz * wz);
+        n = (float)sqrt(acc);
+    }
+    wx = wx / n; wy = wy / n; wz = wz / n;
 }
 
 // The random-number contract of LCM-guided tracking (include/fibers_hip.h): the k-th uniform of streamline `line` is
@@ -190,9 +265,8 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
     const float p0x = (float)(sx + 1) + a.sublist[3 * isub];      // pos_now .= seed_vox .+ sub_vox, stream.jl:649
     const float p0y = (float)(sy + 1) + a.sublist[3 * isub + 1];
     const float p0z = (float)(sz + 1) + a.sublist[3 * isub + 2];
-    constexpr int TILE = FUSED ? FUSED_TILE : SCR_TILE;   // lines per scratch tile (FUSED: half as wide, so that a tile's output range fits 14 KB of LDS)
-    constexpr int64_t slot_floats = TILE * 3;
-    float *dcur = a.scratch + (li / TILE) * ((int64_t)a.nslots * slot_floats) + (li % TILE) * 3;   // this line's place in the slot of the current trip
+    constexpr int64_t slot_floats = SCR_SLOT_FLOATS;
+    float *dcur = a.scratch + scratch_line_base(li, a.nslots);   // this line's place in the slot of the current trip
     const char *fbase = reinterpret_cast<const char *>(a.field);   // wave-uniform base; per-lane offsets are 32-bit
     const float fnx = (float)a.nx, fny = (float)a.ny, fnz = (float)a.nz;
     const float omc = 1.0f - a.smooth;
@@ -230,6 +304,9 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
             float bx = 0.0f, by = 0.0f, bz = 0.0f, bestc = 0.0f, besta = 0.0f;
             int best = 0;
             if constexpr (NVEC > 0) {
+#ifdef FIB_AB_VARIANTS
+                if (a.dbg & 1) { if (cvox == ~(vox_t)0) { for (int k = 0; k < NVEC; k++) cvec[k] = cand[k]; } cvox = vox; }
+#endif
                 if (vox != cvox) {
 #pragma unroll
                     for (int k = 0; k < NVEC; k++) cvec[k] = cand[k];
@@ -295,11 +372,8 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
                 }
                 const float m = fmaxf(fabsf(sx), fmaxf(fabsf(sy), fabsf(sz)));
                 if (m == 0.0f || !(m < INFINITY)) return true;
-                double acc = (double)(sx * sx);
-                acc += (double)(sy * sy);
-                acc += (double)(sz * sz);
-                const float n = (float)sqrt(acc);
-                wx = sx / n; wy = sy / n; wz = sz / n;
+                wx = sx; wy = sy; wz = sz;
+                normalise3(wx, wy, wz, a.norm_generic != 0);
             }
             bool isdiff = false;
             if (LCM) {
@@ -363,7 +437,10 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
             }
             // push!/prepend! of pos_now (stream.jl:660): the slot of this trip
             // LCM runs: the method-difference flag of the point (stream.jl:666) rides in the sign bit of x (x > 0)
-            if (!FUSED || live_line) store_point(dcur, (LCM && isdiff) ? -px : px, py, pz, a.scratch_plain != 0);
+#ifdef FIB_AB_VARIANTS
+            if (!(a.dbg & 2))
+#endif
+            if (!FUSED || live_line) store_point(dcur, (LCM && isdiff) ? -px : px, py, pz, a.scratch_plain);
             emitted = true;
             npts++;
             if (pass == 0) nf++;
@@ -373,17 +450,7 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
                 wx = a.smooth * vx + omc * wx;
                 wy = a.smooth * vy + omc * wy;
                 wz = a.smooth * vz + omc * wz;
-                // LinearAlgebra.norm (generic_norm2): squares in Float32, sum and sqrt in Float64
-                const float m = fmaxf(fabsf(wx), fmaxf(fabsf(wy), fabsf(wz)));
-                float n;
-                if (m == 0.0f || !(m < INFINITY)) n = m;
-                else {
-                    double acc = (double)(wx * wx);
-                    acc += (double)(wy * wy);
-                    acc += (double)(wz * wz);
-                    n = (float)sqrt(acc);
-                }
-                wx = wx / n; wy = wy / n; wz = wz / n;
+                normalise3(wx, wy, wz, a.norm_generic != 0);
             }
             px = nxp; py = nyp; pz = nzp;                         // stream.jl:684-685
             vx = wx; vy = wy; vz = wz;
@@ -447,7 +514,7 @@ __global__ __launch_bounds__(1024) void stream_trace_micro_kernel(const TraceArg
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int dx = a.sdx, dy = a.sdy, dz = a.sdz, Sx = 2 * dx + 1, Sy = 2 * dy + 1, Sz = 2 * dz + 1;
     const unsigned lin_centre = (unsigned)(dx + Sx * (dy + Sy * dz)), lin_last = (unsigned)(Sx * Sy * Sz - 1);
-    constexpr int64_t slot_floats = SCR_TILE * 3;
+    constexpr int64_t slot_floats = SCR_SLOT_FLOATS;
     const float fnx = (float)a.nx, fny = (float)a.ny, fnz = (float)a.nz;
     const float omc = 1.0f - a.smooth;
     for (int64_t li = wave0; li < a.nlines; li += nwaves) {
@@ -459,7 +526,7 @@ __global__ __launch_bounds__(1024) void stream_trace_micro_kernel(const TraceArg
         const float p0x = (float)(sx + 1) + a.sublist[3 * isub];
         const float p0y = (float)(sy + 1) + a.sublist[3 * isub + 1];
         const float p0z = (float)(sz + 1) + a.sublist[3 * isub + 2];
-        float *dcur = a.scratch + (li / SCR_TILE) * ((int64_t)a.nslots * slot_floats) + (li % SCR_TILE) * 3;   // next slot: the line's points one after the other (gap 0)
+        float *dcur = a.scratch + scratch_line_base(li, a.nslots);   // next slot: the line's points one after the other (gap 0)
         int npts = 0, nf = 0;
         for (int pass = 0; pass < 2; pass++) {
             const float fwd = pass == 0 ? 1.0f : -1.0f;
@@ -539,16 +606,7 @@ __global__ __launch_bounds__(1024) void stream_trace_micro_kernel(const TraceArg
                     wx = a.smooth * vx + omc * wx;
                     wy = a.smooth * vy + omc * wy;
                     wz = a.smooth * vz + omc * wz;
-                    const float m = fmaxf(fabsf(wx), fmaxf(fabsf(wy), fabsf(wz)));
-                    float n;
-                    if (m == 0.0f || !(m < INFINITY)) n = m;
-                    else {
-                        double acc = (double)(wx * wx);
-                        acc += (double)(wy * wy);
-                        acc += (double)(wz * wz);
-                        n = (float)sqrt(acc);
-                    }
-                    wx = wx / n; wy = wy / n; wz = wz / n;
+                    normalise3(wx, wy, wz, a.norm_generic != 0);
                 }
                 px = (float)(bx + 1); py = (float)(by + 1); pz = (float)(bz + 1);   // the position snaps to the voxel found, :612-614
                 vx = wx; vy = wy; vz = wz;
@@ -684,16 +742,15 @@ __global__ __launch_bounds__(PK_WAVES * 64) void stream_pack_kernel(const PackAr
         wnf[j] = __shfl(nf, lg + 4 * j); wnb[j] = __shfl(nb, lg + 4 * j); wbs[j] = __shfl(bs, lg + 4 * j);
         wp0[j] = ((int64_t)__shfl((int)(p0 >> 32), lg + 4 * j) << 32) | (uint32_t)__shfl((int)(uint32_t)p0, lg + 4 * j);
     }
-    const float4 *tbase = reinterpret_cast<const float4 *>(a.scratch + tix * ((int64_t)a.nslots * PK_LINES * 3));
+    const float4 *tbase = reinterpret_cast<const float4 *>(a.scratch + scratch_line_base(line0, a.nslots));
     float4 v[3];
-    auto fetch = [&](int c) {                                   // 3 KiB of contiguous scratch: 16 slots
+    auto fetch = [&](int c) {                                   // 16 slots of the tile
         const int s0 = c * PK_SLOTS;
-        const float4 *src = tbase + (int64_t)s0 * (PK_LINES * 3 / 4) + lane;
         const int live = cnt - s0;                              // live slots of the chunk
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            const int f = lane + 64 * i;                        // float4 index within the chunk: slot f / 12
-            v[i] = (f < live * 12) ? src[64 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int f = lane + 64 * i;                        // float4 index within the chunk: slot f / 12 (rows of 16 lines: one contiguous 3-KiB run)
+            v[i] = (f < live * 12) ? tbase[(int64_t)(s0 + f / 12) * (SCR_SLOT_FLOATS / 4) + f % 12] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     if (nch > 0) fetch(0);
@@ -735,18 +792,19 @@ __global__ __launch_bounds__(PK_WAVES * 64) void stream_pack_kernel(const PackAr
 // out with 16-byte stores aligned to the output address (fill-like: 12-byte stores in 192-byte runs reached 2.7 TB/s,
 // aligned 16-byte stores of whole lines reach twice that).  LDS = 16 (len_max + 2) points; longer lines than the LDS
 // holds go through stream_pack_kernel above.
-__global__ __launch_bounds__(256) void stream_pack_tile_kernel(const PackArgs a) {
+template <int TL, int SPC>   // TL lines per tile (a whole fraction of a scratch row); SPC slots per pass of the workgroup's SPC x TL threads
+__global__ __launch_bounds__(SPC * TL) void stream_pack_tile_kernel(const PackArgs a) {
     extern __shared__ __attribute__((aligned(16))) float obuf[];
-    __shared__ int s_nf[PK_LINES], s_nb[PK_LINES], s_bs[PK_LINES], s_o[PK_LINES];   // per line: forward / backward counts (0 if dropped), first backward slot, offset in obuf
+    __shared__ int s_nf[TL], s_nb[TL], s_bs[TL], s_o[TL];   // per line: forward / backward counts (0 if dropped), first backward slot, offset in obuf
     __shared__ int s_cnt[4];                                        // slots in use, -, range length (floats), misalignment
     __shared__ int64_t s_g0;                                        // first float of the range in out_xyz
     const int tid = threadIdx.x;
-    const int64_t line0 = (int64_t)blockIdx.x * PK_LINES;
+    const int64_t line0 = (int64_t)blockIdx.x * TL;
     if (tid < 64) {
         const int64_t li = line0 + tid;
         int nf = 0, nb = 0, bs = 0, n = 0;
         int64_t p0 = 0, gs = INT64_MAX, ge = -1;
-        if (tid < PK_LINES && li < a.nlines) {
+        if (tid < TL && li < a.nlines) {
             n = a.npts[li];
             if (n >= a.len_min) {                               // stream.jl:769
                 const int nfr = a.nfwd[li];
@@ -764,14 +822,14 @@ __global__ __launch_bounds__(256) void stream_pack_tile_kernel(const PackArgs a)
         int mf = nb > 0 ? bs + nb : nf;                        // slots of the tile that hold points of kept lines
         int64_t g0 = gs, g1 = ge;
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
+        for (int o = 1; o < TL; o <<= 1) {
             mf = max(mf, __shfl_xor(mf, o));
             const int64_t og0 = ((int64_t)__shfl_xor((int)(g0 >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)g0, o);
             const int64_t og1 = ((int64_t)__shfl_xor((int)(g1 >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)g1, o);
             g0 = og0 < g0 ? og0 : g0; g1 = og1 > g1 ? og1 : g1;
         }
         const int mis = g1 >= 0 ? (int)((reinterpret_cast<uintptr_t>(a.out_xyz + g0) >> 2) & 3) : 0;
-        if (tid < PK_LINES) {
+        if (tid < TL) {
             s_nf[tid] = nf; s_nb[tid] = nb; s_bs[tid] = bs; s_o[tid] = n > 0 ? (int)(p0 - g0) + mis : 0;
             if (a.trk && n > 0) obuf[(int)(p0 - g0) + mis - 1] = __int_as_float(n);
         }
@@ -780,25 +838,25 @@ __global__ __launch_bounds__(256) void stream_pack_tile_kernel(const PackArgs a)
     __syncthreads();
     const int cnt = s_cnt[0], len = s_cnt[2], mis = s_cnt[3];
     if (len == 0) return;
-    const int nch = (cnt + 15) >> 4;
-    const int l = tid & 15, sl = tid >> 4;                      // thread = (line, slot within the 16-slot chunk)
+    const int nch = (cnt + SPC - 1) / SPC;
+    const int l = tid % TL, sl = tid / TL;                      // thread = (line, slot within the SPC-slot chunk)
     const int nf = s_nf[l], nb = s_nb[l], bs = s_bs[l], o = s_o[l];
     struct P3 { float x, y, z; };
-    const P3 *tbase = reinterpret_cast<const P3 *>(a.scratch + (int64_t)blockIdx.x * ((int64_t)a.nslots * PK_LINES * 3)) + tid;
+    const P3 *tbase = reinterpret_cast<const P3 *>(a.scratch + scratch_line_base(line0, a.nslots)) + l + sl * SCR_ROW;
     for (int c0 = 0; c0 < nch; c0 += 4) {
         P3 v[4];
         int pos[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int c = c0 + i;
-            const int t = (c << 4) + sl;                        // the slot = the loop trip that emitted the point
+            const int t = c * SPC + sl;                         // the slot = the loop trip that emitted the point
             pos[i] = -1;                                        // forward points reversed, backward points behind them (stream.jl:652)
             if (c < nch) {
                 if (t < nf) pos[i] = nf - 1 - t;
                 else if (t >= bs && t - bs < nb) pos[i] = nf + (t - bs);
             }
             if (pos[i] >= 0) {                                  // read once: non-temporal (the orientation field should keep the Infinity Cache)
-                const float *src = reinterpret_cast<const float *>(tbase + (int64_t)c * (16 * PK_LINES));
+                const float *src = reinterpret_cast<const float *>(tbase + (int64_t)c * (SPC * SCR_ROW));
 #ifdef FIB_AB_VARIANTS
                 if (a.scratch_plain) { f32x3_t q; asm volatile("global_load_dwordx3 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(src) : "memory"); v[i] = P3{q[0], q[1], q[2]}; }
                 else
@@ -820,7 +878,7 @@ __global__ __launch_bounds__(256) void stream_pack_tile_kernel(const PackArgs a)
     // obuf[mis .. mis + len) -> out_xyz[g0 .. g0 + len): obuf[4k..4k+3] lands on a 16-byte aligned address
     float *gbase = a.out_xyz + s_g0 - mis;
     const int nq = (mis + len + 3) >> 2;
-    for (int k = tid; k < nq; k += 256) {
+    for (int k = tid; k < nq; k += SPC * TL) {
         const float4 q = reinterpret_cast<const float4 *>(obuf)[k];
         if (4 * k >= mis && 4 * k + 4 <= mis + len) {            // written once, read by nobody on the device: non-temporal
             typedef float nt4_t __attribute__((ext_vector_type(4)));
@@ -945,7 +1003,7 @@ __device__ void fused_pack_block(const TraceArgs &a, int64_t b, int64_t li, bool
             const int nch = (cnt + FSL - 1) / FSL;
             const int l = tid % FT, sl = tid / FT;                              // thread = (line, slot within the pass): a pass reads FB x 12 contiguous bytes
             const int lnf = t_nf[l], lnb = t_nb[l], lbs = t_bs[l], lo = t_o[l];
-            const P3 *tbase = reinterpret_cast<const P3 *>(a.scratch + (b * (FB / FT) + t) * ((int64_t)a.nslots * FT * 3)) + tid;
+            const P3 *tbase = reinterpret_cast<const P3 *>(a.scratch + scratch_line_base((b * (FB / FT) + t) * FT, a.nslots)) + l + sl * SCR_ROW;
             for (int c0 = 0; c0 < nch; c0 += 4) {
                 P3 q[4];
                 int pos[4];
@@ -958,7 +1016,7 @@ __device__ void fused_pack_block(const TraceArgs &a, int64_t b, int64_t li, bool
                         else if (tt >= lbs && tt - lbs < lnb) pos[i] = lnf + (tt - lbs);
                     }
                     if (pos[i] >= 0) {
-                        const float *src = reinterpret_cast<const float *>(tbase + (int64_t)c * FB);
+                        const float *src = reinterpret_cast<const float *>(tbase + (int64_t)c * (FSL * SCR_ROW));
                         q[i] = P3{__builtin_nontemporal_load(src), __builtin_nontemporal_load(src + 1), __builtin_nontemporal_load(src + 2)};
                     } else q[i] = P3{0.f, 0.f, 0.f};
                 }
@@ -1154,7 +1212,7 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
     auto bail = [&](int code) { fib_stream_job_destroy(job); return code; };
     const int nblocks = (int)fib::cdiv(nl, SCAN_B);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t b_scratch = up((size_t)fib::cdiv(nl, SCR_TILE) * SCR_TILE * job->nslots * 3 * sizeof(float));
+    const size_t b_scratch = up((size_t)fib::cdiv(nl, SCR_ROW) * SCR_ROW * job->nslots * 3 * sizeof(float));
     const size_t b_i32 = up((size_t)nl * sizeof(int32_t)), b_excl = up((size_t)nl * sizeof(Pair));
     const size_t b_btot = up((size_t)nblocks * sizeof(Pair)), b_tot = 256;
     const size_t sbytes = b_scratch + 2 * b_i32 + b_excl + b_btot + b_tot;
@@ -1195,7 +1253,9 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
     ta.nx = prm->nx; ta.ny = prm->ny; ta.nz = prm->nz; ta.nvec = prm->nvec; ta.nsub = nsub;
     ta.len_max = prm->len_max; ta.stride = job->stride; ta.nslots = job->nslots;
     ta.cosang = prm->cosang_thresh; ta.step = prm->step_size; ta.smooth = prm->smooth_coeff;
-    ta.scratch_plain = fib::ab_env("FIBERS_STREAM_SCRATCH_PLAIN") != nullptr;
+    { const char *e = fib::ab_env("FIBERS_STREAM_SCRATCH_PLAIN"); ta.scratch_plain = e ? std::atoi(e) : 0; }
+    ta.norm_generic = fib::ab_env("FIBERS_STREAM_NORM_GENERIC") != nullptr;
+    { const char *e = fib::ab_env("FIBERS_STREAM_DBG"); ta.dbg = e ? std::atoi(e) : 0; }
     const unsigned grid = (unsigned)fib::cdiv(nl, 256);
     fib::DevBuf<float4> d_search;
     fib::DevBuf<int32_t> d_cell;
@@ -1295,8 +1355,8 @@ static int launch_pack_n(const PackArgs &pa, int64_t nlines, int stride, hipStre
     const size_t smem = ((size_t)PK_LINES * stride * 3 + PK_LINES + 8) * sizeof(float);
     if (smem <= 120 * 1024) {
         if (smem > 48 * 1024)
-            FIB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stream_pack_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(stream_pack_tile_kernel, dim3((unsigned)fib::cdiv(nlines, PK_LINES)), dim3(256), smem, st, pa);
+            FIB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stream_pack_tile_kernel<PK_LINES, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((stream_pack_tile_kernel<PK_LINES, 16>), dim3((unsigned)fib::cdiv(nlines, PK_LINES)), dim3(16 * PK_LINES), smem, st, pa);
     } else
         hipLaunchKernelGGL(stream_pack_kernel, dim3((unsigned)fib::cdiv(nlines, PK_LINES * PK_WAVES)), dim3(PK_WAVES * 64), 0, st, pa);
     FIB_HIP(hipGetLastError());
@@ -1334,7 +1394,7 @@ static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, f
     pa.out_npts = npts; pa.out_seed = seed_index; pa.out_xyz = xyz;
     pa.nlines = job->nlines; pa.line0 = 0; pa.out_line0 = 0; pa.out_pt0 = 0;
     pa.stride = job->stride; pa.nslots = job->nslots; pa.len_min = job->prm.len_min;
-    pa.scratch_plain = fib::ab_env("FIBERS_STREAM_SCRATCH_PLAIN") != nullptr;
+    pa.scratch_plain = fib::ab_env("FIBERS_STREAM_PACK_PLAIN") != nullptr;
     fib::ProfScope prof("stream_pack", (hipStream_t)stream);
     { const int rcl = launch_pack(job, pa, (hipStream_t)stream); if (rcl != FIB_OK) return rcl; }
     FIB_HIP(hipGetLastError());
@@ -1354,7 +1414,7 @@ extern "C" int fibd_stream_pack_trk(fib_stream_job *job, const float voxel_size[
     pa.out_npts = nullptr; pa.out_seed = nullptr; pa.out_xyz = reinterpret_cast<float *>(body);
     pa.nlines = job->nlines; pa.line0 = 0; pa.out_line0 = 0; pa.out_pt0 = 0;
     pa.stride = job->stride; pa.nslots = job->nslots; pa.len_min = job->prm.len_min;
-    pa.scratch_plain = fib::ab_env("FIBERS_STREAM_SCRATCH_PLAIN") != nullptr;
+    pa.scratch_plain = fib::ab_env("FIBERS_STREAM_PACK_PLAIN") != nullptr;
     pa.trk = 1; pa.vs[0] = voxel_size[0]; pa.vs[1] = voxel_size[1]; pa.vs[2] = voxel_size[2];
     fib::ProfScope prof("stream_pack_trk", (hipStream_t)stream);
     { const int rcl = launch_pack(job, pa, (hipStream_t)stream); if (rcl != FIB_OK) return rcl; }
@@ -1389,7 +1449,7 @@ extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4
     const int stride = prm->len_max + 2, nslots = prm->len_max + 4;
     const int nblk = (int)fib::cdiv(nl, SCAN_B);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t b_scr = up((size_t)fib::cdiv(nl, SCR_TILE) * SCR_TILE * nslots * 3 * sizeof(float));
+    const size_t b_scr = up((size_t)fib::cdiv(nl, SCR_ROW) * SCR_ROW * nslots * 3 * sizeof(float));
     const size_t b_i32 = up((size_t)nl * sizeof(int32_t)), b_excl = up((size_t)nl * sizeof(Pair)), b_bt = up((size_t)nblk * sizeof(Pair));
     const size_t sbytes = b_scr + 2 * b_i32 + b_excl + b_bt + 256;
     // the caller's workspace when it is free, else one of our own for the call
@@ -1436,7 +1496,9 @@ extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4
     ta.nx = prm->nx; ta.ny = prm->ny; ta.nz = prm->nz; ta.nvec = prm->nvec; ta.nsub = nsub;
     ta.len_max = prm->len_max; ta.stride = stride; ta.nslots = nslots;
     ta.cosang = prm->cosang_thresh; ta.step = prm->step_size; ta.smooth = prm->smooth_coeff;
-    ta.scratch_plain = fib::ab_env("FIBERS_STREAM_SCRATCH_PLAIN") != nullptr;
+    { const char *e = fib::ab_env("FIBERS_STREAM_SCRATCH_PLAIN"); ta.scratch_plain = e ? std::atoi(e) : 0; }
+    ta.norm_generic = fib::ab_env("FIBERS_STREAM_NORM_GENERIC") != nullptr;
+    { const char *e = fib::ab_env("FIBERS_STREAM_DBG"); ta.dbg = e ? std::atoi(e) : 0; }
     const unsigned grid = (unsigned)fib::cdiv(nl, 256);
     // [r5] FUSED (fused_pack_block): trace + look-back + pack in ONE launch, for nearest-voxel tracking with 1 or 3 vectors per voxel on fields
     // below 2^28 vectors whose lines fit a 16-line LDS tile (len_max <= ~200) -- from 2^21 lines on: the fused kernel wins by overlapping
@@ -1454,6 +1516,12 @@ extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4
         ta.lines_cap = lines_cap; ta.points_cap = points_cap; ta.len_min = prm->len_min;
         if (hipMemsetAsync(ta.fstate, 0, ((size_t)fgrid + 1) * sizeof(unsigned long long), st) != hipSuccess)      // (+ the ticket counter behind the granules)
             return release(fib::fail(FIB_ERR_HIP, "hipMemsetAsync failed"));
+        if (fsmem > 48 * 1024) {
+            const void *fk = prm->nvec == 1 ? reinterpret_cast<const void *>(stream_trace_kernel<1, false, false, false, true>)
+                                            : reinterpret_cast<const void *>(stream_trace_kernel<3, false, false, false, true>);
+            if (hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsmem) != hipSuccess)
+                return release(fib::fail(FIB_ERR_HIP, "hipFuncSetAttribute failed"));
+        }
         fib::ProfScope prof("stream_trace", st);
         if (prm->nvec == 1) hipLaunchKernelGGL((stream_trace_kernel<1, false, false, false, true>), dim3(fgrid), dim3(FUSED_BLOCK), fsmem, st, ta);
         else                hipLaunchKernelGGL((stream_trace_kernel<3, false, false, false, true>), dim3(fgrid), dim3(FUSED_BLOCK), fsmem, st, ta);
@@ -1474,7 +1542,7 @@ extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4
     pa.out_npts = npts; pa.out_seed = seed_index; pa.out_xyz = xyz;
     pa.nlines = nl; pa.line0 = 0; pa.out_line0 = 0; pa.out_pt0 = 0;
     pa.stride = stride; pa.nslots = nslots; pa.len_min = prm->len_min;
-    pa.scratch_plain = fib::ab_env("FIBERS_STREAM_SCRATCH_PLAIN") != nullptr;
+    pa.scratch_plain = fib::ab_env("FIBERS_STREAM_PACK_PLAIN") != nullptr;
     pa.lines_cap = lines_cap; pa.points_cap = points_cap; pa.capped = 1;   // a line whose place lies beyond the buffers is dropped, the totals say what was needed
     {
         fib::ProfScope prof("stream_pack", st);

@@ -526,3 +526,21 @@ def test_wide_tracer_forms_match_the_32_bit_forms_on_small_fields():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "stream_wide_check.py")], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "stream wide check: ok" in out.stdout
+
+
+def test_plain_normalisation_sequences_match_the_generic_expansions():
+    """normalise3's scaling-free square root / shared-reciprocal divisions (what every ordinary vector takes) against hipcc's generic
+    expansions, bit for bit, over smoothing coefficients, angle thresholds, 1 / 3 vectors, trilinear, LCM-guided (a component exactly zero),
+    the microscopy regime and vectors scaled to the ends of the plain range and past them -- the DIAGNOSTIC build forces the generic
+    form (tools/stream_norm_check.py, a child process that loads libfibers_hip_stamp.so).  The oracle comparisons of this file and of
+    test_gpu_fullsize.py check the same sequences against IEEE arithmetic on the CPU."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "fibers.jl_amd", "libfibers_hip_stamp.so")):
+        pytest.skip("the diagnostic build is absent (make -C fibers.jl_amd/csrc stamp)")
+    env = {k: v for k, v in os.environ.items() if k != "FIBERS_HIP_LIB"}
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stream_norm_check.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "stream norm check: ok" in out.stdout

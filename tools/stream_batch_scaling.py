@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Would a point scratch that stays in cache pay?  (the scratch round trip is 3.3 of the tracker's 5.2 GB of HBM
 traffic.)  Trace + scan + pack on the first n lines of the C4 workload, n = 32 K ... 1 M: kernel time per million lines, with the scratch
-written / read non-temporally (the product) and with the default cache policy (DIAGNOSTIC build: FIBERS_STREAM_SCRATCH_PLAIN=1).  If small
+written / read non-temporally (the product) and with the default cache policy (DIAGNOSTIC build: FIBERS_STREAM_SCRATCH_PLAIN=1 + FIBERS_STREAM_PACK_PLAIN=1).  If small
 batches with a cacheable scratch (32 K lines = 56 MB: inside the 256-MB Infinity Cache) ran well below the 1-M-line figure, tracing the
 lines in sequential batches that reuse ONE scratch region would beat the single pass.  usage: stream_batch_scaling.py"""
 import ctypes as C
@@ -43,8 +43,10 @@ rows = []
 for plain in (False, True):
     if plain:
         os.environ["FIBERS_STREAM_SCRATCH_PLAIN"] = "1"
+        os.environ["FIBERS_STREAM_PACK_PLAIN"] = "1"
     else:
         os.environ.pop("FIBERS_STREAM_SCRATCH_PLAIN", None)
+        os.environ.pop("FIBERS_STREAM_PACK_PLAIN", None)
     for n in (32768, 65536, 131072, 262144, 524288, int(seeds_all.numel())):
         seeds = seeds_all[perm[:n]].sort().values.contiguous()
         bufs = fj.StreamBuffers(dev)
