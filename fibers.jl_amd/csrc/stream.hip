@@ -75,7 +75,8 @@ constexpr int FUSED_BLOCK = 512;     // its workgroup: 8 waves, so that 4 workgr
 // (32 lines = three whole lines) 5.1 (tools/probes/write_probe.hip), and the trace kernel went 0.54 -> 0.49 ms with them.  But then the
 // pack side pays the same back: 16-line tiles that read 192 of every 384 bytes 0.54 -> 0.63 ms, 32-line tiles (55 KB of LDS, two
 // workgroups per CU) 0.60 (1 024 threads) / 0.64 (512), the fused kernel 10.6 -> 11.7 ms (half rows) / 13.3 (32-line tiles, 1 024
-// threads): profiles/r05/negative_results.txt.  So the row stays the pack tile.  (8-line rows, 96 B: the trace 3 x slower.)
+// threads): profiles/r05/negative_results.txt.  So the row stays the pack tile, and the trace kernel gets its whole lines another way:
+// it parks four trips' points in LDS and stores the four rows together (see there).  (8-line rows, 96 B: the trace 3 x slower.)
 constexpr int SCR_ROW = 16;
 static_assert(SCR_ROW % SCR_TILE == 0 && SCR_ROW % FUSED_TILE == 0, "pack tiles are whole fractions of a scratch row");
 constexpr int SCR_SLOT_FLOATS = SCR_ROW * 3;                       // from one slot of a line to its next
@@ -89,8 +90,8 @@ struct TraceArgs {
     const int64_t *seeds;       // [nseed] 0-based linear voxel index
     const float *sublist;       // [nsub][3]
     float *scratch;             // [nlines/16 rows][nslots][16 lines][3]: the point a line emits at loop trip t -> slot t: forward point i in slot i,
-                                // backward point j in slot nf + gap + j (a row's slots are one contiguous run that the pack kernel streams; a wave
-                                // of the trace kernel writes 4 x 192 B per trip)
+                                // backward point j in slot nf + gap + j (a row's slots are one contiguous run that the pack kernel streams; the
+                                // trace kernel stores four trips' rows of a tile together, as whole 128-byte lines)
     int32_t *npts, *nfwd;       // [nlines]; nfwd = forward points | gap << 30 (gap = 1: the forward pass ended on a trip that emitted nothing)
     int64_t line0, nlines;      // this batch covers global lines [line0, line0+nlines)
     int nx, ny, nz, nvec, nsub, len_max, stride, nslots;
@@ -142,6 +143,18 @@ __device__ __forceinline__ void store_point(float *d, float x, float y, float z,
     (void)plain;
     __builtin_nontemporal_store(v, reinterpret_cast<f32x3_t *>(d));
 }
+
+#ifdef FIB_AB_VARIANTS
+typedef float fib_f4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_x4_variant(fib_f4_t *d, fib_f4_t v, int flavour) {   // FIBERS_STREAM_SCRATCH_PLAIN = 1..6 (timing experiments)
+    if (flavour == 1) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(d), "v"(v) : "memory");
+    else if (flavour == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(d), "v"(v) : "memory");
+    else if (flavour == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(d), "v"(v) : "memory");
+    else if (flavour == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(d), "v"(v) : "memory");
+    else if (flavour == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" :: "v"(d), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(d), "v"(v) : "memory");
+}
+#endif
 
 // w ./= norm(w)  (stream.jl:680).  LinearAlgebra.norm on a 3-vector is generic_norm2: the largest magnitude first (zero / Inf / NaN return
 // it), then the squares in Float32, their sum and the square root in Float64, the result converted to Float32; then three IEEE divisions.
@@ -253,11 +266,10 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
         wg = s_ticket;
     }
     const int64_t li = wg * blockDim.x + threadIdx.x;
-    if (!FUSED && li >= a.nlines) return;
-    const bool live_line = li < a.nlines;              // (FUSED: every thread of the block takes part in the pack)
+    const bool live_line = li < a.nlines;              // (every thread takes part in the scratch stores and, FUSED, in the pack)
     typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type vox_t;
     const int nvec = NVEC > 0 ? NVEC : a.nvec;
-    const int64_t line = a.line0 + (FUSED && !live_line ? a.nlines - 1 : li);   // (FUSED: a thread past the end shadows the last line and emits nothing)
+    const int64_t line = a.line0 + (!live_line ? a.nlines - 1 : li);   // (a thread past the end borrows the last line's seed and traces nothing)
     const int64_t iseed = line / a.nsub;
     const int isub = (int)(line - iseed * a.nsub);
     const int64_t lin = a.seeds[iseed];
@@ -265,8 +277,25 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
     const float p0x = (float)(sx + 1) + a.sublist[3 * isub];      // pos_now .= seed_vox .+ sub_vox, stream.jl:649
     const float p0y = (float)(sy + 1) + a.sublist[3 * isub + 1];
     const float p0z = (float)(sz + 1) + a.sublist[3 * isub + 2];
-    constexpr int64_t slot_floats = SCR_SLOT_FLOATS;
-    float *dcur = a.scratch + scratch_line_base(li, a.nslots);   // this line's place in the slot of the current trip
+    // [r5] The points leave in GROUPS OF FOUR TRIPS as whole 128-byte lines.  A trip's points of a tile are a 192-byte row, and a
+    // non-temporal store instruction that ends in the middle of a line is slow (such stores alone: 4.1 TB/s; whole lines: 5.1 --
+    // tools/probes/write_probe.hip), and these stores bound the kernel (tools/stream_bound_probe.py).  So a lane parks its point in LDS
+    // (768 B per tile: 4 slots x 16 lines x 12 B) and after every fourth trip the tile's 16 lanes store the 48 float4 of those four rows --
+    // 3 instructions per wave, each 4 runs of 256 contiguous bytes -- instead of 4 instructions of 4 x 192 B.  Same scratch layout, same
+    // bytes; lanes whose line has ended stay in the loop (switched off) to do their share of the stores.
+    static_assert(SCR_ROW == 16, "the grouped scratch stores map a tile's 16 lanes to its 48 float4 per four slots");
+    float *stage;                                                 // this lane's tile: [4 slots][16 lines][3]
+    if constexpr (FUSED) {
+        extern __shared__ __attribute__((aligned(16))) float f_obuf[];   // (the pack phase's tile buffer: free until the trace loop is over)
+        stage = f_obuf + (threadIdx.x >> 4) * (4 * SCR_SLOT_FLOATS);
+    } else {
+        __shared__ __attribute__((aligned(16))) float s_stage[256 / 16][4 * SCR_SLOT_FLOATS];
+        stage = s_stage[threadIdx.x >> 4];
+    }
+    const int tj = threadIdx.x & 15;                              // this line's place in its tile
+    float *const tile0 = a.scratch + scratch_line_base(li - tj, a.nslots);   // the tile's slot 0
+    const bool tile_ok = li - tj < a.nlines;                      // (a tile wholly past the end has no scratch)
+    int trip = 0;                                                 // wave-uniform: the slot the current trip writes
     const char *fbase = reinterpret_cast<const char *>(a.field);   // wave-uniform base; per-lane offsets are 32-bit
     const float fnx = (float)a.nx, fny = (float)a.ny, fnz = (float)a.nz;
     const float omc = 1.0f - a.smooth;
@@ -437,10 +466,10 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
             }
             // push!/prepend! of pos_now (stream.jl:660): the slot of this trip
             // LCM runs: the method-difference flag of the point (stream.jl:666) rides in the sign bit of x (x > 0)
-#ifdef FIB_AB_VARIANTS
-            if (!(a.dbg & 2))
-#endif
-            if (!FUSED || live_line) store_point(dcur, (LCM && isdiff) ? -px : px, py, pz, a.scratch_plain);
+            {
+                float *sp = stage + (trip & 3) * SCR_SLOT_FLOATS + tj * 3;
+                sp[0] = (LCM && isdiff) ? -px : px; sp[1] = py; sp[2] = pz;
+            }
             emitted = true;
             npts++;
             if (pass == 0) nf++;
@@ -461,21 +490,48 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
     // stream.jl:649-650 with dir = -1) while its neighbours go on, so a wave runs max(forward + backward trips) over its lanes --
     // with one loop per pass it ran max(forward) + max(backward): 1.5 x the trips on the benchmark field, whose lines all use up
     // len_max but split it differently between the two directions.  The trip counter is wave-uniform, and so is the scratch slot
-    // a trip writes (all 64 lanes store into the same 4 x 192-byte rows, as before): forward point i sits in slot i, backward
+    // a trip writes (the 64 lanes' points of a trip are 4 x 192-byte rows): forward point i sits in slot i, backward
     // point j in slot nf + gap + j, gap = 1 if the forward pass ended on a trip that emitted nothing (a failed step).
-    for (;;) {
-        const bool ended = step();
-        dcur += slot_floats;
-        if (ended) {
-            if (pass == 1) break;
-            pass = 1;
-            gap = emitted ? 0 : 1;
-            px = p0x; py = p0y; pz = p0z;
-            const float4 s = a.field[lin * nvec + ivec];          // view(W.ovecs, :, ivec_next, seed...), stream.jl:650
-            vx = s.x * -1.0f; vy = s.y * -1.0f; vz = s.z * -1.0f;
+    auto flush = [&](int t0) {                                   // slots t0 .. t0 + 3 of the wave's four tiles: whole lines
+        typedef float nt4_t __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_wave_barrier();                          // (LDS is in order within a wave: the lanes' points are there)
+#ifdef FIB_AB_VARIANTS
+        if (!(a.dbg & 2))
+#endif
+        if (tile_ok) {
+            nt4_t *g = reinterpret_cast<nt4_t *>(tile0 + (int64_t)t0 * SCR_SLOT_FLOATS);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const nt4_t q = reinterpret_cast<const nt4_t *>(stage)[tj + 16 * k];
+#ifdef FIB_AB_VARIANTS
+                if (a.scratch_plain) { store_x4_variant(g + tj + 16 * k, q, a.scratch_plain); continue; }
+#endif
+                __builtin_nontemporal_store(q, g + tj + 16 * k);
+            }
         }
+        __builtin_amdgcn_wave_barrier();
+    };
+    bool dead = !live_line;
+    for (;;) {
+        if (!dead) {
+            const bool ended = step();
+            if (ended) {
+                if (pass == 1) dead = true;
+                else {
+                    pass = 1;
+                    gap = emitted ? 0 : 1;
+                    px = p0x; py = p0y; pz = p0z;
+                    const float4 s = a.field[lin * nvec + ivec];  // view(W.ovecs, :, ivec_next, seed...), stream.jl:650
+                    vx = s.x * -1.0f; vy = s.y * -1.0f; vz = s.z * -1.0f;
+                }
+            }
+        }
+        if ((trip & 3) == 3) flush(trip - 3);
+        trip++;
+        if (__ballot(!dead) == 0ull) break;                       // (wave-uniform)
     }
-    if (!FUSED || live_line) { a.npts[li] = npts; a.nfwd[li] = nf | (gap << 30); }
+    if (trip & 3) flush(trip & ~3);                               // (the last, partial group: its unused slots carry stale points nobody reads)
+    if (live_line) { a.npts[li] = npts; a.nfwd[li] = nf | (gap << 30); }
     if constexpr (FUSED) fused_pack_block<NVEC>(a, wg, li, live_line, npts, nf, gap);
 }
 
@@ -1204,7 +1260,7 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
     FIB_CHECK(job != nullptr, FIB_ERR_NOMEM, "out of host memory");
     job->device = device; job->prm = *prm; job->nseed = nseed; job->nsub = nsub;
     job->nlines = nseed * nsub; job->stride = prm->len_max + 2;
-    job->nslots = prm->len_max + 4;                     // trips of a line's loop: <= len_max + 1 points + two failed steps
+    job->nslots = (prm->len_max + 4 + 3) & ~3;          // trips of a line's loop: <= len_max + 1 points + two failed steps; whole groups of four (the tracer stores four slots together)
     const int64_t nl = job->nlines;
     *nlines_out = 0; *npoints_out = 0;
     if (nl == 0) { *job_out = job; return FIB_OK; }
@@ -1446,7 +1502,7 @@ extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4
     int device = 0;
     FIB_HIP(hipGetDevice(&device));
     hipStream_t st = (hipStream_t)stream;
-    const int stride = prm->len_max + 2, nslots = prm->len_max + 4;
+    const int stride = prm->len_max + 2, nslots = (prm->len_max + 4 + 3) & ~3;   // (whole groups of four slots: the tracer stores them together)
     const int nblk = (int)fib::cdiv(nl, SCAN_B);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t b_scr = up((size_t)fib::cdiv(nl, SCR_ROW) * SCR_ROW * nslots * 3 * sizeof(float));
@@ -1505,7 +1561,7 @@ extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4
     // workgroups that pack with workgroups that still trace, which needs several rounds of workgroups per CU (measured, tools/stream_fused_ab.py:
     // 9.96 M lines x 3 vectors 9.7-10.6 ms against 11.5-11.8; 1 M lines 1.05-1.17 ms against 1.09-1.13: two rounds, no steady state).
     // Everything else takes the three launches below.  (Diagnostic build: FIBERS_STREAM_UNFUSED=1 / FIBERS_STREAM_FUSED=1 force either.)
-    const size_t fsmem = ((size_t)FUSED_TILE * stride * 3 + FUSED_TILE + 8) * sizeof(float);
+    const size_t fsmem = std::max(((size_t)FUSED_TILE * stride * 3 + FUSED_TILE + 8) * sizeof(float), (size_t)(FUSED_BLOCK / 16) * 4 * SCR_SLOT_FLOATS * sizeof(float));   // the pack's tile buffer; the trace loop parks four trips of points there
     const bool fused_ok = !wide && !prm->interp && (prm->nvec == 1 || prm->nvec == 3) && fsmem <= 40 * 1024 &&
                           nl < ((int64_t)1 << 26) && nl * (int64_t)(prm->len_max + 2) < ((int64_t)1 << 36) && b_excl >= ((size_t)fib::cdiv(nl, FUSED_BLOCK) + 1) * sizeof(unsigned long long);
     const bool fused = fused_ok && fib::ab_env("FIBERS_STREAM_UNFUSED") == nullptr && (nl >= ((int64_t)1 << 21) || fib::ab_env("FIBERS_STREAM_FUSED") != nullptr);

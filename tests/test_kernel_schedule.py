@@ -27,8 +27,9 @@ def test_tracer_point_stores_and_pack_loads_keep_their_non_temporal_hint(tmp_pat
     """stream.hip (stream.jl:660: every emitted point): the tracer's scratch stores and the pack kernel's scratch loads are NON-TEMPORAL
     -- with the default policy 1.6 GB of points go through L2 and evict the orientation field (trace 0.53 -> 0.65 ms).  The hint is easy
     to lose without a trace in the source: in round 5 a run-time `plain ? store : nontemporal_store` made hipcc merge both arms into one
-    plain store.  Compile the PRODUCT flags to assembly and look: every 12-byte point store of every stream_trace_kernel instantiation
-    carries `nt`, and the tile pack kernel loads with `nt`."""
+    plain store.  Compile the PRODUCT flags to assembly and look: every stream_trace_kernel instantiation stores its points as whole
+    lines -- 16-byte stores, three per group of four trips, in the loop and once behind it -- every one with `nt`, no 12-byte store is
+    left in it, and the tile pack kernel loads with `nt`."""
     import re
     out = str(tmp_path / "stream.s")
     src = os.path.join(ROOT, "fibers.jl_amd", "csrc", "stream.hip")
@@ -42,10 +43,16 @@ def test_tracer_point_stores_and_pack_loads_keep_their_non_temporal_hint(tmp_pat
         name = f.split(":", 1)[0]
         body = f.split(".Lfunc_end", 1)[0]
         if "stream_trace_kernel" in name:
-            st = re.findall(r"global_store_dwordx3[^\n]*", body)
-            assert st, name
-            assert all(" nt" in s for s in st), (name, [s for s in st if " nt" not in s][:3])
+            st = re.findall(r"global_store_dwordx4[^\n]*", body)
+            plain = [x for x in st if " nt" not in x]
+            fused = "ELb1EEEv" in name                          # (the fused kernel also stores its 16-byte totals record: one plain store)
+            assert len(st) - len(plain) >= 6, (name, len(st))
+            assert len(plain) <= (1 if fused else 0), (name, plain[:3])
+            assert not re.findall(r"global_store_dwordx3[^\n]*", body), name
             ntrace += 1
+        if "stream_trace_micro_kernel" in name:                 # (one lane of the wave stores the line's point: 12 bytes, nt)
+            st = re.findall(r"global_store_dwordx3[^\n]*", body)
+            assert st and all(" nt" in s for s in st), (name, st[:3])
         if "stream_pack_tile_kernel" in name:
             ld = re.findall(r"global_load_dword[^\n]*", body)
             assert sum(" nt" in s for s in ld) >= 3, (name, ld[:6])

@@ -82,6 +82,35 @@ __global__ __launch_bounds__(256) void k_store12_paired(float *dst, size_t ntile
     }
 }
 
+// 16-line tiles, 192-byte rows, but the wave parks four trips' points in LDS and stores them as whole lines: per tile 4 slots = 768 B =
+// 48 float4, lane j of the tile's 16 stores float4 j, j + 16, j + 32 -> every store instruction writes 4 runs of 256 contiguous bytes
+template <int NT>
+__global__ __launch_bounds__(256) void k_store12_grouped(float *dst, size_t ntiles, int nslots, uint32_t seed) {
+    __shared__ __attribute__((aligned(16))) float stage[4][4][192];           // [wave][tile of the wave][4 slots x 16 lines x 3]
+    const size_t li = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (li / 16 >= ntiles) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tl = lane >> 4, j = lane & 15;
+    float *tile = dst + (li / 16) * ((size_t)nslots * 48);
+    float *st = &stage[wave][tl][0];
+    float x = (float)seed, y = (float)threadIdx.x, z = 1.0f;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (int t = 0; t < nslots; t++) {
+        x += 1.0f;
+        float *p = st + (t & 3) * 48 + j * 3;
+        p[0] = x; p[1] = y; p[2] = z;
+        if ((t & 3) == 3) {
+            __builtin_amdgcn_wave_barrier();
+            f4 *g = reinterpret_cast<f4 *>(tile + (size_t)(t - 3) * 48);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const f4 q = reinterpret_cast<const f4 *>(st)[j + 16 * k];
+                if (NT) __builtin_nontemporal_store(q, g + j + 16 * k); else g[j + 16 * k] = q;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 int main() {
     const size_t NB = (size_t)4 << 30;
     void *buf;
@@ -131,6 +160,8 @@ int main() {
         time("12 B per lane, 16-line tiles, trips stored in pairs, nt", bytes, [&] { hipLaunchKernelGGL((k_store12_paired<1, 16, 2>), g, b, 0, 0, f, nl / 16, nslots, 1u); });
         time("12 B per lane, 16-line tiles, trips stored in fours, nt", bytes, [&] { hipLaunchKernelGGL((k_store12_paired<1, 16, 4>), g, b, 0, 0, f, nl / 16, nslots, 1u); });
         time("12 B per lane, 32-line tiles, trips stored in pairs, nt", bytes, [&] { hipLaunchKernelGGL((k_store12_paired<1, 32, 2>), g, b, 0, 0, f, nl / 32, nslots, 1u); });
+        time("16-line tiles, four trips parked in LDS, whole-line dwordx4 stores, nt", bytes, [&] { hipLaunchKernelGGL((k_store12_grouped<1>), g, b, 0, 0, f, nl / 16, nslots, 1u); });
+        time("16-line tiles, four trips parked in LDS, whole-line dwordx4 stores, plain", bytes, [&] { hipLaunchKernelGGL((k_store12_grouped<0>), g, b, 0, 0, f, nl / 16, nslots, 1u); });
         time("3 x 4 B per lane, 16-line tiles, planes, nt", bytes, [&] { hipLaunchKernelGGL((k_store4x3_tiles<1, 16>), g, b, 0, 0, f, nl / 16, nslots, 1u); });
         time("3 x 4 B per lane, 32-line tiles, planes, nt", bytes, [&] { hipLaunchKernelGGL((k_store4x3_tiles<1, 32>), g, b, 0, 0, f, nl / 32, nslots, 1u); });
         time("3 x 4 B per lane, 64-line tiles, planes, nt", bytes, [&] { hipLaunchKernelGGL((k_store4x3_tiles<1, 64>), g, b, 0, 0, f, nl / 64, nslots, 1u); });
