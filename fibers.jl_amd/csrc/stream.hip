@@ -121,6 +121,18 @@ struct TraceArgs {
     int G;                      // direction grid: cell (floor((v + 1) / h)) per axis, h = 2 / G
 };
 
+// iszero(v) on a 3-view (stream.jl:353): all three components == 0, -0.0 included.  One OR of the three bit patterns and one class
+// test (a pattern with no magnitude bit set is +-0) instead of three compares.
+__device__ __forceinline__ bool is_zero3(float x, float y, float z) {
+    const unsigned u = __float_as_uint(x) | __float_as_uint(y) | __float_as_uint(z);
+    return __builtin_amdgcn_classf(__uint_as_float(u), 0x60);     // (v_cmp_class: -0 | +0)
+}
+// v_cvt_i32_f32 itself (NaN -> 0, out of range -> INT_MIN / INT_MAX): what the bounds test below wants, and not what C++ promises
+__device__ __forceinline__ int cvt_i32_sat(float x) {
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
     return ax * bx + ay * by + az * bz;                           // (x+y)+z, no fma
 }
@@ -320,14 +332,16 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
         {
             const float nxp = px + vx * a.step, nyp = py + vy * a.step, nzp = pz + vz * a.step;   // stream.jl:512
             const float rx = rintf(nxp), ry = rintf(nyp), rz = rintf(nzp);                        // stream.jl:514
-            if (!(rx >= 1.0f && rx <= fnx && ry >= 1.0f && ry <= fny && rz >= 1.0f && rz <= fnz)) return true;   // :517
+            // x in axes(mask, 1) ... (:517) on the 0-based integers: one unsigned compare per axis (NaN -> 0 - 1, +-huge -> saturated: outside)
+            const int ix = cvt_i32_sat(rx) - 1, iy = cvt_i32_sat(ry) - 1, iz = cvt_i32_sat(rz) - 1;
+            if (!(((unsigned)ix < (unsigned)a.nx) & ((unsigned)iy < (unsigned)a.ny) & ((unsigned)iz < (unsigned)a.nz))) return true;
             vox_t vox;
             const float4 *cand;
             if constexpr (WIDE) {
-                vox = (uint64_t)(((int64_t)rx - 1) + (int64_t)a.nx * (((int64_t)ry - 1) + (int64_t)a.ny * ((int64_t)rz - 1)));
+                vox = (uint64_t)((int64_t)ix + (int64_t)a.nx * ((int64_t)iy + (int64_t)a.ny * (int64_t)iz));
                 cand = reinterpret_cast<const float4 *>(fbase + vox * (uint64_t)(nvec * 16));
             } else {
-                vox = (uint32_t)(((int)rx - 1) + a.nx * (((int)ry - 1) + a.ny * ((int)rz - 1)));   // nvox < 2^28 / nvec: the byte offset fits 32 bits
+                vox = (uint32_t)(ix + a.nx * (iy + a.ny * iz));   // nvox < 2^28 / nvec: the byte offset fits 32 bits
                 cand = reinterpret_cast<const float4 *>(fbase + (size_t)(vox * (uint32_t)(nvec * 16)));
             }
             float bx = 0.0f, by = 0.0f, bz = 0.0f, bestc = 0.0f, besta = 0.0f;
@@ -346,7 +360,7 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
             for (int k = 0; k < nvec; k++) {                      // stream_pick_by_angle!, stream.jl:350-361
                 const float4 w = NVEC > 0 ? cvec[k < NCV ? k : 0] : cand[k];
                 float c, ca;
-                if (w.x == 0.0f && w.y == 0.0f && w.z == 0.0f) { c = -INFINITY; ca = -INFINITY; }
+                if (is_zero3(w.x, w.y, w.z)) { c = -INFINITY; ca = -INFINITY; }
                 else { c = dot3(vx, vy, vz, w.x, w.y, w.z); ca = fabsf(c); }
                 // argmax: first maximum, NaN wins over everything
                 if (k == 0 || (!(besta != besta) && ((ca != ca) || ca > besta))) {
@@ -391,7 +405,7 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
                     for (int k = 0; k < nvec; k++) {
                         const float4 w = cc[k];
                         float cs, ca;
-                        if (w.x == 0.0f && w.y == 0.0f && w.z == 0.0f) { cs = -INFINITY; ca = -INFINITY; }
+                        if (is_zero3(w.x, w.y, w.z)) { cs = -INFINITY; ca = -INFINITY; }
                         else { cs = dot3(vx, vy, vz, w.x, w.y, w.z); ca = fabsf(cs); }
                         if (k == 0 || (!(ua != ua) && ((ca != ca) || ca > ua))) { ua = ca; uc = cs; ux = w.x; uy = w.y; uz = w.z; }
                     }
@@ -408,8 +422,7 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
             if (LCM) {
                 // stream_pick_by_lcm! (stream.jl:380-495), after the angle pick above set W.ivec_next (stream.jl:530-531)
                 const int ivec_ang = ivec;
-                const int ix = (int)rx, iy = (int)ry, iz = (int)rz;
-                int dvx = (int)rintf(px) - ix, dvy = (int)rintf(py) - iy, dvz = (int)rintf(pz) - iz;   // :394-398
+                int dvx = (int)rintf(px) - (ix + 1), dvy = (int)rintf(py) - (iy + 1), dvz = (int)rintf(pz) - (iz + 1);   // :394-398
                 if (dvx == 0 && dvy == 0 && dvz == 0) {           // not entering a new voxel, :400-413
                     const float4 w = cand[ivec];
                     if (dot3(vx, vy, vz, w.x, w.y, w.z) > 0.0f) { wx = w.x; wy = w.y; wz = w.z; } else { wx = -w.x; wy = -w.y; wz = -w.z; }
@@ -454,7 +467,7 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
                     for (int k = 0; k < nvec; k++) {              // :462-472
                         const float4 w = cand[k];
                         float c, ca;
-                        if (w.x == 0.0f && w.y == 0.0f && w.z == 0.0f) { c = -INFINITY; ca = -INFINITY; }
+                        if (is_zero3(w.x, w.y, w.z)) { c = -INFINITY; ca = -INFINITY; }
                         else { c = dot3(ex, ey, ez, w.x, w.y, w.z); ca = fabsf(c); }
                         if (k == 0 || (!(la != la) && ((ca != ca) || ca > la))) { lb = k; la = ca; lc = c; lx = w.x; ly = w.y; lz = w.z; }
                     }
@@ -471,8 +484,7 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
                 sp[0] = (LCM && isdiff) ? -px : px; sp[1] = py; sp[2] = pz;
             }
             emitted = true;
-            npts++;
-            if (pass == 0) nf++;
+            npts++;                                               // (nf = the count when the forward pass ends: below)
             if (!LCM && dot3(vx, vy, vz, wx, wy, wz) < a.cosang) return true;   // stream.jl:670 (not used with LCMs, :668)
             if (npts > a.len_max) return true;                    // stream.jl:674
             if (a.smooth != 0.0f) {                               // stream.jl:677-681
@@ -519,6 +531,7 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
                 if (pass == 1) dead = true;
                 else {
                     pass = 1;
+                    nf = npts;                                    // the forward pass's points
                     gap = emitted ? 0 : 1;
                     px = p0x; py = p0y; pz = p0z;
                     const float4 s = a.field[lin * nvec + ivec];  // view(W.ovecs, :, ivec_next, seed...), stream.jl:650
