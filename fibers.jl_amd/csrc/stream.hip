@@ -97,6 +97,7 @@ struct TraceArgs {
     int nx, ny, nz, nvec, nsub, len_max, stride, nslots;
     int scratch_plain;          // diagnostic build only (FIBERS_STREAM_SCRATCH_PLAIN): the point scratch with the default cache policy instead of non-temporal
     int norm_generic;           // diagnostic build only (FIBERS_STREAM_NORM_GENERIC): normalise3's generic expansion for every vector
+    int lcm_plain;              // LCM runs: lcm_thresh >= 2^-40 (every entry of the thresholded matrices is 0 or at least that)
     int dbg;                    // diagnostic build only (FIBERS_STREAM_DBG bit mask; WRONG RESULTS, timing experiments): 1 = no gather after the seed's, 2 = no point stores
     // FUSED (fibd_stream_run): the block that traced 256 lines also packs them -- a decoupled look-back over the blocks' kept-line / point
     // totals gives it its place in the output
@@ -449,8 +450,23 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
                     float sum = lcm[0];
 #pragma unroll
                     for (int j = 1; j < 10; j++) sum += lcm[j];
+                    // lcm ./ sum (:450): ten IEEE divisions by one divisor.  Every entry is 0 or >= lcm_thresh (lcm_prepare_kernel), so with a threshold
+                    // >= 2^-40 and a sum <= 2^40 neither operand nor quotient comes near the ends of the exponent range and the
+                    // division's expansion without scaling and fix-up gives the same bits (as normalise3): ONE refined reciprocal, two
+                    // residual corrections per quotient -- 5 instructions each instead of 11.
+                    if (a.lcm_plain && sum <= 0x1p40f) {
+                        float rc = __builtin_amdgcn_rcpf(sum);
+                        rc = fmaf(fmaf(-sum, rc, 1.0f), rc, rc);
 #pragma unroll
-                    for (int j = 0; j < 10; j++) lcm[j] = lcm[j] / sum;      // :450
+                        for (int j = 0; j < 10; j++) {
+                            float q = lcm[j] * rc;
+                            q = fmaf(fmaf(-sum, q, lcm[j]), rc, q);
+                            lcm[j] = fmaf(fmaf(-sum, q, lcm[j]), rc, q);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 10; j++) lcm[j] = lcm[j] / sum;
+                    }
                     const float u = fib_uniform(a.rng_seed, (unsigned long long)line, ndraw++);
                     int il = 0;                                   // rand(Categorical(lcm)): first index whose running sum exceeds u
                     float cp = lcm[0];
@@ -1384,6 +1400,7 @@ int stream_trace_impl(const fib_stream_params *prm, const float *field4, const L
         if ((rc = d_lcm.alloc((size_t)nvox * 10)) != FIB_OK) return bail(rc);
         hipLaunchKernelGGL(lcm_prepare_kernel, dim3((unsigned)fib::cdiv(nvox, 256)), dim3(256), 0, st, lin.lcms, lin.thresh, nvox, d_lcm.p);
         ta.lcm = d_lcm.p; ta.sd0 = lin.sd0; ta.sd1 = lin.sd1; ta.rng_seed = lin.seed;
+        ta.lcm_plain = lin.thresh >= 0x1p-40f && !ta.norm_generic;
         job->lcm = true;
         fib::ProfScope prof("stream_trace_lcm", st);
         launch_trace<true, false>(ta, prm->nvec, wide, grid, st);
