@@ -775,6 +775,11 @@ struct PackArgs {
     int capped;
     int trk;                    // 1: out_xyz is a .trk body: [Int32 npts, npts x 3 Float32 ((xyz+.5)*voxel_size)] per line
     float vs[3];
+    // LCM runs (the tile kernel; not with trk): the method-difference flag of a point rides in the sign bit of its x (stream.jl:666) -- the pack
+    // strips it and, if flags != NULL, writes it out as one byte per point ([r5] a second pass over the packed points did this: 3.0 of
+    // the 17 ms of the 2048^2 benchmark section)
+    int lcm;
+    uint8_t *out_flags;
 };
 
 // One wave per scratch tile (16 lines), four independent waves per workgroup: no workgroup barriers.  A chunk = 16 slots of
@@ -923,6 +928,7 @@ __global__ __launch_bounds__(SPC * TL) void stream_pack_tile_kernel(const PackAr
     __syncthreads();
     const int cnt = s_cnt[0], len = s_cnt[2], mis = s_cnt[3];
     if (len == 0) return;
+    uint8_t *fbuf = reinterpret_cast<uint8_t *>(obuf + ((size_t)TL * a.stride * 3 + TL + 8));   // [TL * stride] flags of the range's points (LCM runs)
     const int nch = (cnt + SPC - 1) / SPC;
     const int l = tid % TL, sl = tid / TL;                      // thread = (line, slot within the SPC-slot chunk)
     const int nf = s_nf[l], nb = s_nb[l], bs = s_bs[l], o = s_o[l];
@@ -956,10 +962,17 @@ __global__ __launch_bounds__(SPC * TL) void stream_pack_tile_kernel(const PackAr
             if (a.trk) {                                        // T.((xyz .+ .5) .* voxel_size), Float64 arithmetic (trk.jl:475-476)
                 d[0] = (float)(((double)v[i].x + 0.5) * (double)a.vs[0]); d[1] = (float)(((double)v[i].y + 0.5) * (double)a.vs[1]);
                 d[2] = (float)(((double)v[i].z + 0.5) * (double)a.vs[2]);
+            } else if (a.lcm) {
+                d[0] = fabsf(v[i].x); d[1] = v[i].y; d[2] = v[i].z;
+                fbuf[(o - mis) / 3 + pos[i]] = (uint8_t)(__float_as_uint(v[i].x) >> 31);
             } else { d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; }
         }
     }
     __syncthreads();
+    if (a.lcm && a.out_flags) {                                 // the range's flags: one byte per point, in the order of the points
+        uint8_t *fg = a.out_flags + s_g0 / 3;
+        for (int k = tid; k < len / 3; k += SPC * TL) fg[k] = fbuf[k];
+    }
     // obuf[mis .. mis + len) -> out_xyz[g0 .. g0 + len): obuf[4k..4k+3] lands on a 16-byte aligned address
     float *gbase = a.out_xyz + s_g0 - mis;
     const int nq = (mis + len + 3) >> 2;
@@ -1434,11 +1447,14 @@ __global__ __launch_bounds__(256) void stream_unpack_flags_kernel(float *xyz, ui
     xyz[3 * i] = fabsf(x);
 }
 
-static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, void *stream);
+static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, uint8_t *flags, bool *flags_done, void *stream);
 
 // whole-tile kernel while 16 (len_max + 2) points (+ the .trk headers and the alignment slack) fit in LDS
-static int launch_pack_n(const PackArgs &pa, int64_t nlines, int stride, hipStream_t st) {
-    const size_t smem = ((size_t)PK_LINES * stride * 3 + PK_LINES + 8) * sizeof(float);
+static int launch_pack_n(const PackArgs &pa_in, int64_t nlines, int stride, hipStream_t st, bool *flags_done = nullptr) {
+    PackArgs pa = pa_in;
+    const size_t smem = ((size_t)PK_LINES * stride * 3 + PK_LINES + 8) * sizeof(float) + (pa.lcm ? (((size_t)PK_LINES * stride + 15) & ~(size_t)15) : 0);
+    if (flags_done) *flags_done = smem <= 120 * 1024;          // (the wave-per-tile kernel below leaves the flag bit in x: the caller strips it)
+    if (smem > 120 * 1024) { pa.lcm = 0; pa.out_flags = nullptr; }
     if (smem <= 120 * 1024) {
         if (smem > 48 * 1024)
             FIB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(stream_pack_tile_kernel<PK_LINES, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -1448,14 +1464,16 @@ static int launch_pack_n(const PackArgs &pa, int64_t nlines, int stride, hipStre
     FIB_HIP(hipGetLastError());
     return FIB_OK;
 }
-static int launch_pack(fib_stream_job *job, const PackArgs &pa, hipStream_t st) {
+static int launch_pack(fib_stream_job *job, const PackArgs &pa, hipStream_t st, bool *flags_done = nullptr) {
     job->last_stream = st;
-    return launch_pack_n(pa, job->nlines, job->stride, st);
+    return launch_pack_n(pa, job->nlines, job->stride, st, flags_done);
 }
 
 extern "C" int fibd_stream_pack_flags(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, uint8_t *flags, void *stream) try {
-    int rc = pack_plain(job, npts, seed_index, xyz, stream);
+    bool done = false;
+    int rc = pack_plain(job, npts, seed_index, xyz, flags, &done, stream);
     if (rc != FIB_OK || job->kept_pts == 0) return rc;
+    if (job->lcm && done) return FIB_OK;                        // (the pack kernel stripped the flag bits and wrote the flags)
     if (job->lcm)
         hipLaunchKernelGGL(stream_unpack_flags_kernel, dim3((unsigned)fib::cdiv(job->kept_pts, 256)), dim3(256), 0, (hipStream_t)stream, xyz, flags, job->kept_pts);
     else if (flags) FIB_HIP(hipMemsetAsync(flags, 0, (size_t)job->kept_pts, (hipStream_t)stream));
@@ -1468,7 +1486,7 @@ extern "C" int fibd_stream_pack(fib_stream_job *job, int32_t *npts, int64_t *see
     return fibd_stream_pack_flags(job, npts, seed_index, xyz, nullptr, stream);   // (strips the flag bit of LCM runs)
 } FIB_API_CATCH
 
-static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, void *stream) {
+static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, float *xyz, uint8_t *flags, bool *flags_done, void *stream) {
     FIB_CHECK(job != nullptr, FIB_ERR_INVALID, "job is NULL");
     if (job->kept_lines == 0) return FIB_OK;
     FIB_CHECK(npts && seed_index && xyz, FIB_ERR_INVALID, "NULL output buffer");
@@ -1481,10 +1499,11 @@ static int pack_plain(fib_stream_job *job, int32_t *npts, int64_t *seed_index, f
     pa.nlines = job->nlines; pa.line0 = 0; pa.out_line0 = 0; pa.out_pt0 = 0;
     pa.stride = job->stride; pa.nslots = job->nslots; pa.len_min = job->prm.len_min;
     pa.scratch_plain = fib::ab_env("FIBERS_STREAM_PACK_PLAIN") != nullptr;
+    pa.lcm = job->lcm ? 1 : 0; pa.out_flags = job->lcm ? flags : nullptr;
     fib::ProfScope prof("stream_pack", (hipStream_t)stream);
-    { const int rcl = launch_pack(job, pa, (hipStream_t)stream); if (rcl != FIB_OK) return rcl; }
+    { const int rcl = launch_pack(job, pa, (hipStream_t)stream, flags_done); if (rcl != FIB_OK) return rcl; }
     FIB_HIP(hipGetLastError());
-    return FIB_OK;                                      // (LCM jobs: x still carries the flag bit; the caller strips it)
+    return FIB_OK;                                      // (LCM jobs whose lines do not fit the tile kernel: x still carries the flag bit; the caller strips it)
 }
 
 extern "C" int fibd_stream_pack_trk(fib_stream_job *job, const float voxel_size[3], void *body, void *stream) try {
