@@ -334,8 +334,9 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
             const float nxp = px + vx * a.step, nyp = py + vy * a.step, nzp = pz + vz * a.step;   // stream.jl:512
             const float rx = rintf(nxp), ry = rintf(nyp), rz = rintf(nzp);                        // stream.jl:514
             // x in axes(mask, 1) ... (:517) on the 0-based integers: one unsigned compare per axis (NaN -> 0 - 1, +-huge -> saturated: outside)
-            const int ix = cvt_i32_sat(rx) - 1, iy = cvt_i32_sat(ry) - 1, iz = cvt_i32_sat(rz) - 1;
-            if (!(((unsigned)ix < (unsigned)a.nx) & ((unsigned)iy < (unsigned)a.ny) & ((unsigned)iz < (unsigned)a.nz))) return true;
+            const unsigned ux = (unsigned)cvt_i32_sat(rx) - 1u, uy = (unsigned)cvt_i32_sat(ry) - 1u, uz = (unsigned)cvt_i32_sat(rz) - 1u;   // (unsigned: no overflow to reason about)
+            if (!((ux < (unsigned)a.nx) & (uy < (unsigned)a.ny) & (uz < (unsigned)a.nz))) return true;
+            const int ix = (int)ux, iy = (int)uy, iz = (int)uz;
             vox_t vox;
             const float4 *cand;
             if constexpr (WIDE) {
