@@ -141,25 +141,15 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
 // default policy the 1.6 GB of scratch points of a million lines go through the XCDs' L2 and push the orientation field out of it:
 // the trace kernel took 0.69 ms, 0.55 with this store (and 0.50 with no store at all); the pack kernel gains 4 % too.
 typedef float f32x3_t __attribute__((ext_vector_type(3)));
-__device__ __forceinline__ void store_point(float *d, float x, float y, float z, int plain = 0) {
+__device__ __forceinline__ void store_point(float *d, float x, float y, float z) {   // (the microscopy tracer: one lane per line stores)
     const f32x3_t v = {x, y, z};
-#ifdef FIB_AB_VARIANTS
-    // (diagnostic build, FIBERS_STREAM_SCRATCH_PLAIN: the default cache policy, as inline assembly -- written as a second C++ store hipcc
-    // merges the two branches into ONE store without the non-temporal hint; tools/check_loop_waits.py asserts the hint on the product)
-    if (plain == 1) { asm volatile("global_store_dwordx3 %0, %1, off" :: "v"(d), "v"(v) : "memory"); return; }
-    if (plain == 2) { asm volatile("global_store_dwordx3 %0, %1, off sc1" :: "v"(d), "v"(v) : "memory"); return; }
-    if (plain == 3) { asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1" :: "v"(d), "v"(v) : "memory"); return; }
-    if (plain == 4) { asm volatile("global_store_dwordx3 %0, %1, off sc1 nt" :: "v"(d), "v"(v) : "memory"); return; }
-    if (plain == 5) { asm volatile("global_store_dwordx3 %0, %1, off sc0 nt" :: "v"(d), "v"(v) : "memory"); return; }
-    if (plain == 6) { asm volatile("global_store_dwordx3 %0, %1, off sc0" :: "v"(d), "v"(v) : "memory"); return; }
-#endif
-    (void)plain;
     __builtin_nontemporal_store(v, reinterpret_cast<f32x3_t *>(d));
 }
-
 #ifdef FIB_AB_VARIANTS
 typedef float fib_f4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_x4_variant(fib_f4_t *d, fib_f4_t v, int flavour) {   // FIBERS_STREAM_SCRATCH_PLAIN = 1..6 (timing experiments)
+// (diagnostic build, FIBERS_STREAM_SCRATCH_PLAIN = 1..6: the scratch stores with another cache policy, as inline assembly -- written as a second
+// C++ store hipcc once merged the two branches into ONE store without the non-temporal hint; tests/test_kernel_schedule.py asserts the hint)
+__device__ __forceinline__ void store_x4_variant(fib_f4_t *d, fib_f4_t v, int flavour) {
     if (flavour == 1) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(d), "v"(v) : "memory");
     else if (flavour == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(d), "v"(v) : "memory");
     else if (flavour == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(d), "v"(v) : "memory");
@@ -171,8 +161,8 @@ __device__ __forceinline__ void store_x4_variant(fib_f4_t *d, fib_f4_t v, int fl
 
 // w ./= norm(w)  (stream.jl:680).  LinearAlgebra.norm on a 3-vector is generic_norm2: the largest magnitude first (zero / Inf / NaN return
 // it), then the squares in Float32, their sum and the square root in Float64, the result converted to Float32; then three IEEE divisions.
-// [r5] Written out as `(float)sqrt(acc)` and `w / n` this is ~60 of the tracer's ~125 vector instructions per step (the loop is bound by
-// vector-ALU issue): hipcc expands the f64 square root with a range-scaling prologue / special-value epilogue and each division with two
+// [r5] Written out as `(float)sqrt(acc)` and `w / n` this is ~60 of the tracer's ~125 vector instructions per step (which bound the
+// three-vector tracer and, once its stores leave as whole lines, the one-vector tracer too): hipcc expands the f64 square root with a range-scaling prologue / special-value epilogue and each division with two
 // v_div_scale, a reciprocal, its refinement, v_div_fmas and v_div_fixup.  Where every component is 0 or within 2^-40 .. 2^40 -- any
 // orientation field -- none of the scaling or fix-up can trigger, and the SAME instruction sequences without them give the same bits:
 // the Goldschmidt square root of llvm's f64 lowering, ONE refined reciprocal for the three divisions, two residual corrections per
