@@ -645,7 +645,7 @@ def main():
                                                       peak=PEAK_HBM_GBS, unit="GB/s",
                                                       frac=25.0 * (npoints / world) / ((tr_ms + pk_ms + sc_ms) / max(tr_n, 1) * 1e-3) / 1e9 / PEAK_HBM_GBS if tr_n else 0.0,
                                                       note="25 B per emitted point (SURVEY 8d, nvec = 1) x rank 0's points / device time of trace + scan + pack; the "
-                                                           "integrator is a dependent chain of gathers from the Infinity-Cache-resident field, VALU-bound by its exact f64 norm"),
+                                                           "trace bound by its point stores and vector-ALU issue, pack by HBM (DESIGN.md K6 [r5])"),
                                         note="one volume; wall = field all-gather + trace + scan + pack into a pre-allocated buffer (+ one host sync for "
                                              "the line count); seeds dealt round-robin over the ranks")
         # the one-call form (fibd_stream_run: straight into buffers kept between calls) on the same field and seeds, for the record
@@ -658,6 +658,18 @@ def main():
                 extra["stream_dti_ball"]["one_call_form"] = dict(ms_per_step=t_run * 1e3, mpoints_per_s=npoints / t_run / 1e6,
                                                                  note="fibd_stream_run into kept buffers: trace + scan + pack in one call (1 M lines: below the 2^21 "
                                                                       "lines from which the fused kernel is used -- tools/stream_fused_ab.py, profiles/r05/negative_results.txt)")
+                # .. and without the host round trip at the end of every call (fibd_stream_run_enqueue: the counts stay on the device)
+                cnt2 = torch.zeros(2, dtype=torch.int64, device=dev)
+                t_enq = timed(lambda: fj.stream_device_run_enqueue(f_once, shape, seeds_all, sub, sbuf, counts=cnt2), nst, 1) / nst
+                torch.cuda.synchronize()
+                ke_ms, ke_n = prof_get(L, "stream_trace")
+                kp_ms, kp_n = prof_get(L, "stream_pack")
+                ks_ms, _ = prof_get(L, "stream_scan")
+                extra["stream_dti_ball"]["enqueue_form"] = dict(ms_per_step=t_enq * 1e3, mpoints_per_s=int(cnt2[1]) / t_enq / 1e6, lines=int(cnt2[0]), points=int(cnt2[1]),
+                                                                kernel_sum_ms=(ke_ms + kp_ms + ks_ms) / max(ke_n, 1),
+                                                                note="fibd_stream_run_enqueue: the same launches, {lines, points} written by the stream to device memory, no "
+                                                                     "synchronisation inside the call -- back-to-back calls keep the GPU busy (the synchronising forms idle it for "
+                                                                     "the 16-byte download of the counts and the next call's launch latency)")
                 del sbuf, f_once
             except Exception as e:                                                  # noqa: BLE001
                 extra["stream_dti_ball"]["one_call_form"] = dict(error=str(e))
@@ -874,6 +886,17 @@ def main():
                                                    "2^21 lines on is ONE kernel (the workgroup that traced 512 lines packs them behind a decoupled look-back: no scan, no "
                                                    "pack launch -- pack_kernel_ms 0); N > 1: trace + scan + pack per rank, seeds x offsets round-robin; kernel_sum = device "
                                                    "time of the tracking kernels on rank 0")
+        if not multi:                                                          # the same without the host round trip at the end of every call
+            try:
+                field3e = fd.allgather_slabs(f3_loc, counts)
+                cnt5 = torch.zeros(2, dtype=torch.int64, device=dev)
+                t5e = timed(lambda: fj.stream_device_run_enqueue(field3e, shape, seeds3, sub10, sbuf5, counts=cnt5), 3, 1) / 3
+                torch.cuda.synchronize()
+                extra["stream_dsi_3peaks_10M"]["enqueue_form"] = dict(ms_per_step=t5e * 1e3, mpoints_per_s=int(cnt5[1]) / t5e / 1e6, lines=int(cnt5[0]), points=int(cnt5[1]),
+                                                                      note="fibd_stream_run_enqueue on the gathered field: {lines, points} stay on the device, no synchronisation inside the call")
+                del field3e
+            except Exception as e:                                                  # noqa: BLE001
+                extra["stream_dsi_3peaks_10M"]["enqueue_form"] = dict(error=str(e))
         del o5, r3, f3_loc, m3_loc, mout3, seeds3, xyz5
         torch.cuda.empty_cache()
     cpu = None

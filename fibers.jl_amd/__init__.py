@@ -14,7 +14,7 @@ from .rumba import RUMBASD, RumbaPlan, rumba_rec, rumba_rec_device  # noqa: F401
 from .structens import st_eigen, st_eigen_device  # noqa: F401
 from .tract import Tract  # noqa: F401
 from .stream import (StreamBuffers, StreamWorkspace, angles_to_vectors, angles_to_vectors_device, make_sublist, stream,  # noqa: F401
-                     stream_device, stream_device_run, stream_field_device)
+                     stream_device, stream_device_run, stream_device_run_enqueue, stream_field_device)
 from .nifti import (dsi_write, dti_write, gqi_write, load_nifti, mri_read, mri_read_bfiles, mri_write, rumba_write,  # noqa: F401
                     read_struct)
 from .trk import str_add, stream_to_trk, tract_header, trk_read, trk_write  # noqa: F401

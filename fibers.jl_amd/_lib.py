@@ -80,6 +80,7 @@ _PROTOS = {
     "fibd_stream_trace": (i32, [C.POINTER(StreamParams), vp, vp, i64, vp, i32, vp,
                                 C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]),
     "fibd_stream_run": (i32, [C.POINTER(StreamParams), vp, vp, i64, vp, i32, vp, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64), vp]),
+    "fibd_stream_run_enqueue": (i32, [C.POINTER(StreamParams), vp, vp, i64, vp, i32, vp, vp, i64, vp, i64, vp, vp]),
     "fibd_stream_ws_create": (i32, [i32, C.POINTER(vp)]),
     "fibd_stream_ws_destroy": (None, [vp]),
     "fibd_stream_pack": (i32, [vp, vp, vp, vp, vp]),

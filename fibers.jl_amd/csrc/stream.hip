@@ -1523,11 +1523,13 @@ extern "C" int fibd_stream_pack_trk(fib_stream_job *job, const float voxel_size[
 // while the next one is traced -- was measured slower for every batch count, 1.33 ... 1.55 ms against 1.30: both kernels are bound
 // by the same HBM traffic, profiles/r04/negative_results.txt; it and its side stream / events have been removed.)
 // Macro-scale angle picking only (nearest voxel or trilinear); the microscopy regime and LCM runs use fibd_stream_trace / _pack.
-extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4, const int64_t *seeds, int64_t nseed,
-                               const float *sublist, int32_t nsub, int32_t *npts, int64_t *seed_index, int64_t lines_cap,
-                               float *xyz, int64_t points_cap, int64_t *nlines_out, int64_t *npoints_out, void *stream) try {
-    FIB_CHECK(prm && field4 && nlines_out && npoints_out, FIB_ERR_INVALID, "NULL argument");
-    *nlines_out = 0; *npoints_out = 0;
+// counts_dev != NULL (fibd_stream_run_enqueue): the call returns once everything is enqueued; the stream writes {lines, points} there.
+static int stream_run_impl(const fib_stream_params *prm, const float *field4, const int64_t *seeds, int64_t nseed,
+                           const float *sublist, int32_t nsub, int32_t *npts, int64_t *seed_index, int64_t lines_cap,
+                           float *xyz, int64_t points_cap, int64_t *nlines_out, int64_t *npoints_out, int64_t *counts_dev, void *stream) {
+    FIB_CHECK(prm && field4 && (counts_dev || (nlines_out && npoints_out)), FIB_ERR_INVALID, "NULL argument");
+    if (nlines_out) *nlines_out = 0;
+    if (npoints_out) *npoints_out = 0;
     FIB_CHECK(nseed >= 0 && (nseed == 0 || seeds), FIB_ERR_INVALID, "invalid seed list");
     FIB_CHECK(nsub >= 1 && sublist, FIB_ERR_INVALID, "sublist must hold at least one offset (use [0,0,0] for nsub=0, stream.jl:180)");
     FIB_CHECK(prm->nx > 0 && prm->ny > 0 && prm->nz > 0 && prm->nvec >= 1 && prm->nvec <= 8, FIB_ERR_INVALID, "invalid volume / nvec");
@@ -1537,11 +1539,14 @@ extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4
     FIB_CHECK((int64_t)prm->nx * prm->ny * prm->nz < ((int64_t)1 << 40), FIB_ERR_UNSUPPORTED, "volumes of 2^40 voxels or more are not supported");
     FIB_CHECK(lines_cap >= 0 && points_cap >= 0 && (lines_cap == 0 || (npts && seed_index)) && (points_cap == 0 || xyz), FIB_ERR_INVALID, "invalid output buffers");
     const int64_t nl = nseed * nsub;
-    if (nl == 0) return FIB_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (nl == 0) {
+        if (counts_dev) FIB_HIP(hipMemsetAsync(counts_dev, 0, 2 * sizeof(int64_t), st));
+        return FIB_OK;
+    }
     const bool wide = field_is_wide(prm);
     int device = 0;
     FIB_HIP(hipGetDevice(&device));
-    hipStream_t st = (hipStream_t)stream;
     const int stride = prm->len_max + 2, nslots = (prm->len_max + 4 + 3) & ~3;   // (whole groups of four slots: the tracer stores them together)
     const int nblk = (int)fib::cdiv(nl, SCAN_B);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1647,6 +1652,12 @@ extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4
     }
     }   // (!fused)
     if (hipGetLastError() != hipSuccess) return release(fib::fail(FIB_ERR_HIP, "streamline launch failed"));
+    if (counts_dev) {                                             // {lines, points} behind the kernels, no host round trip
+        if (hipMemcpyAsync(counts_dev, &total->lines, sizeof(int64_t), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(counts_dev + 1, &total->pts, sizeof(int64_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return release(fib::fail(FIB_ERR_HIP, "streamline run: copying the counts failed"));
+        return release(FIB_OK);
+    }
     Pair tot{0, 0};
     hipError_t e = hipMemcpyAsync(&tot, total, sizeof(Pair), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1656,6 +1667,22 @@ extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4
         return release(fib::fail(FIB_ERR_CAPACITY, "output buffers too small: %lld lines / %lld points needed, %lld / %lld given",
                                  (long long)tot.lines, (long long)tot.pts, (long long)lines_cap, (long long)points_cap));
     return release(FIB_OK);
+}
+
+extern "C" int fibd_stream_run(const fib_stream_params *prm, const float *field4, const int64_t *seeds, int64_t nseed,
+                               const float *sublist, int32_t nsub, int32_t *npts, int64_t *seed_index, int64_t lines_cap,
+                               float *xyz, int64_t points_cap, int64_t *nlines_out, int64_t *npoints_out, void *stream) try {
+    FIB_CHECK(nlines_out && npoints_out, FIB_ERR_INVALID, "NULL argument");
+    return stream_run_impl(prm, field4, seeds, nseed, sublist, nsub, npts, seed_index, lines_cap, xyz, points_cap, nlines_out, npoints_out, nullptr, stream);
+} FIB_API_CATCH
+
+// [r5] fibd_stream_run without its host round trip: a step of a stream of volumes ends with a 16-byte download and a synchronisation
+// during which the GPU idles (~45 us of C4's 1.03 ms between back-to-back calls); here the counts stay on the device.
+extern "C" int fibd_stream_run_enqueue(const fib_stream_params *prm, const float *field4, const int64_t *seeds, int64_t nseed,
+                                       const float *sublist, int32_t nsub, int32_t *npts, int64_t *seed_index, int64_t lines_cap,
+                                       float *xyz, int64_t points_cap, int64_t *counts_dev, void *stream) try {
+    FIB_CHECK(counts_dev != nullptr, FIB_ERR_INVALID, "NULL argument");
+    return stream_run_impl(prm, field4, seeds, nseed, sublist, nsub, npts, seed_index, lines_cap, xyz, points_cap, nullptr, nullptr, counts_dev, stream);
 } FIB_API_CATCH
 
 extern "C" int fibd_stream_all_npts(fib_stream_job *job, int32_t *all_npts, void *stream) try {

@@ -397,3 +397,27 @@ def stream_device_run(field, shape, seeds, sublist, buffers: StreamBuffers = Non
         _lib.check(rc)
         break
     return dict(npts=buffers.npts[: nl.value], seed_index=buffers.seed_index[: nl.value], xyz=buffers.xyz[: npnt.value], buffers=buffers)
+
+
+def stream_device_run_enqueue(field, shape, seeds, sublist, buffers: StreamBuffers, counts=None, len_min=3, len_max=None, ang_thresh=45,
+                              step_size=0.5, smooth_coeff=0.2, stream=None, workspace="default", interp="nearest"):
+    """stream_device_run without the host round trip at its end (fibd_stream_run_enqueue): returns as soon as the work is enqueued.
+    `buffers` must already be large enough (a stream_device_run call sizes them); `counts` (int64 CUDA tensor of 2 elements, made if
+    None) receives {lines, points} from the stream -- read it after synchronising; values above the buffers' capacities mean that
+    lines were dropped for lack of room.  Returns (buffers, counts)."""
+    import torch
+    _chk_dev(field, torch.float32, "field")
+    _chk_dev(seeds, torch.int64, "seeds")
+    _chk_dev(sublist, torch.float32, "sublist")
+    if buffers is None or buffers.npts is None or buffers.npts.numel() == 0:
+        raise ValueError("stream_device_run_enqueue needs sized buffers (call stream_device_run once)")
+    if counts is None:
+        counts = torch.zeros(2, dtype=torch.int64, device=field.device)
+    _chk_dev(counts, torch.int64, "counts")
+    nvec = field.shape[1]
+    ws = default_workspace(field.device.index or 0) if isinstance(workspace, str) else workspace
+    prm = _params(shape, nvec, len_min, len_max, ang_thresh, step_size, smooth_coeff, 0, 10, ws, interp)
+    _lib.check(_lib.lib().fibd_stream_run_enqueue(C.byref(prm), field.data_ptr(), seeds.data_ptr(), seeds.numel(), sublist.data_ptr(),
+                                                  sublist.shape[0], buffers.npts.data_ptr(), buffers.seed_index.data_ptr(), buffers.npts.numel(),
+                                                  buffers.xyz.data_ptr(), buffers.xyz.shape[0], counts.data_ptr(), _stream_ptr(stream)))
+    return buffers, counts

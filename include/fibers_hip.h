@@ -299,6 +299,15 @@ int fibd_stream_run(const fib_stream_params *prm, const float *field4, const int
                     const float *sublist, int32_t nsub, int32_t *npts, int64_t *seed_index, int64_t lines_cap,
                     float *xyz, int64_t points_cap, int64_t *nlines, int64_t *npoints, void *stream);
 
+/* fibd_stream_run without the host round trip at its end: returns once the work is enqueued on `stream`, which also writes
+ * counts_dev[0] = lines, counts_dev[1] = points (DEVICE memory, 2 x int64; the totals the run NEEDED: larger than the capacities when
+ * lines were dropped for lack of room -- compare after synchronising, there is no FIB_ERR_CAPACITY here).  The buffers and the
+ * workspace of prm->ws stay in use until `stream` has passed the call.  For callers that keep a stream of volumes in flight: the
+ * synchronising form idles the GPU for the download of its two counts between consecutive calls. */
+int fibd_stream_run_enqueue(const fib_stream_params *prm, const float *field4, const int64_t *seeds, int64_t nseed,
+                            const float *sublist, int32_t nsub, int32_t *npts, int64_t *seed_index, int64_t lines_cap,
+                            float *xyz, int64_t points_cap, int64_t *counts_dev, void *stream);
+
 /* LCM-guided tracking (stream(...; lcms, lcm_thresh), stream.jl:200-236, 380-495, 526-538): when a line enters a new
  * voxel the exit edge is drawn from the voxel's local connection matrix restricted to the entry edge, and the
  * orientation vector best aligned with a jump towards that edge is followed; the angle threshold is not applied

@@ -464,6 +464,47 @@ def test_stream_run_matches_trace_plus_pack(fj, nvec):
     assert torch.equal(small_n[kept], ref["npts"][:100][kept[:100]])                    # what was written is right
 
 
+def test_stream_run_enqueue_leaves_the_counts_on_the_device(fj):
+    """fibd_stream_run_enqueue: the same lines as fibd_stream_run, no host round trip -- three calls back to back on one stream, then
+    one synchronisation: the counts tensor holds {lines, points}, the buffers the last call's lines; with buffers that are too small
+    the counts still say what was needed and nothing is written past the capacities"""
+    import torch
+    n = 24
+    dev = torch.device("cuda", 0)
+    f = _fields(n, 4)
+    ov = [torch.from_numpy(np.ascontiguousarray(f[k].reshape(-1, 3, order="F").T)).to(dev) for k in ("wavy", "circ", "noisy")]
+    mask = torch.from_numpy((np.random.default_rng(3).random(n ** 3) < 0.9).astype(np.uint8)).to(dev)
+    field, mout = fj.stream_field_device(ov, mask=mask)
+    seeds = torch.nonzero(mout).flatten()
+    sub = torch.from_numpy(fj.make_sublist(3, np.random.default_rng(8))).to(dev)
+    kw = dict(len_min=2, len_max=40, smooth_coeff=0.3)
+    bufs = fj.StreamBuffers(dev)
+    ref = fj.stream_device_run(field, (n, n, n), seeds, sub, buffers=bufs, **kw)
+    ref = {k: ref[k].clone() for k in ("npts", "seed_index", "xyz")}
+    counts = torch.full((2,), -1, dtype=torch.int64, device=dev)
+    for rep in range(3):
+        bufs.xyz.fill_(-1.0); bufs.npts.fill_(-1)
+        fj.stream_device_run_enqueue(field, (n, n, n), seeds, sub, bufs, counts=counts, **kw)
+    torch.cuda.synchronize()
+    nl, npnt = int(counts[0]), int(counts[1])
+    assert nl == ref["npts"].numel() and npnt == ref["xyz"].shape[0] and nl > 1000
+    assert torch.equal(bufs.npts[:nl], ref["npts"]) and torch.equal(bufs.seed_index[:nl], ref["seed_index"]) and torch.equal(bufs.xyz[:npnt], ref["xyz"])
+    small = fj.StreamBuffers(dev)
+    small.reserve(100, 1000)
+    small.xyz.fill_(-7.0); small.npts.fill_(-7)
+    cap_pts = small.xyz.shape[0]
+    fj.stream_device_run_enqueue(field, (n, n, n), seeds, sub, small, counts=counts, **kw)
+    torch.cuda.synchronize()
+    assert int(counts[0]) == nl and int(counts[1]) == npnt                              # what the run needed
+    kept = small.npts != -7
+    assert torch.equal(small.npts[kept], ref["npts"][: small.npts.numel()][kept])
+    assert cap_pts < npnt
+    # no seeds: the stream writes zeros
+    fj.stream_device_run_enqueue(field, (n, n, n), seeds[:0], sub, bufs, counts=counts, **kw)
+    torch.cuda.synchronize()
+    assert counts.tolist() == [0, 0]
+
+
 def test_stream_wide_field_past_the_32_bit_gather_limit(fj, orc):
     """An orientation field of 2^28 vectors or more (4 GiB of float4: the microscopy regime's whole-slide sections, stream.jl:83,147-172) takes
     the tracer's WIDE form -- 64-bit voxel indices and gather offsets, chosen at launch.  4096 x 4096 x 17 voxels, one vector each = 4.56 GB;
