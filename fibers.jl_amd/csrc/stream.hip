@@ -106,6 +106,7 @@ struct TraceArgs {
     int64_t *out_seed;
     float *out_xyz;
     Pair *ftotal;               // the last block's inclusive prefix = the call's totals
+    int64_t *fcounts;           // .. and, fibd_stream_run_enqueue, {lines, points} for the caller
     int64_t lines_cap, points_cap;
     int len_min;
     float cosang, step, smooth;
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(SCAN_T) void scan_block_kernel(const int32_t *npts,
 
 // exclusive scan of the per-block totals in place (single workgroup, chunks of SCAN_T with a running carry)
 // base (optional): the totals of everything before this batch of lines -- the offsets start there and *total continues from it
-__global__ __launch_bounds__(SCAN_T) void scan_totals_kernel(Pair *block_tot, int nblocks, Pair *total, const Pair *base = nullptr) {
+__global__ __launch_bounds__(SCAN_T) void scan_totals_kernel(Pair *block_tot, int nblocks, Pair *total, const Pair *base = nullptr, int64_t *counts = nullptr) {
     __shared__ Pair sh[SCAN_T];
     Pair carry = base ? *base : Pair{0, 0};
     for (int base = 0; base < nblocks; base += SCAN_T) {
@@ -750,7 +751,10 @@ __global__ __launch_bounds__(SCAN_T) void scan_totals_kernel(Pair *block_tot, in
         carry.pts += last.pts; carry.lines += last.lines;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = carry;
+    if (threadIdx.x == 0) {
+        *total = carry;
+        if (counts) { counts[0] = carry.lines; counts[1] = carry.pts; }   // (fibd_stream_run_enqueue: {lines, points} for the caller)
+    }
 }
 
 struct PackArgs {
@@ -1047,7 +1051,11 @@ __device__ void fused_pack_block(const TraceArgs &a, int64_t b, int64_t li, bool
         if (lane == 0) {
             if (b > 0) __hip_atomic_store((fib_gu64s *)(a.fstate + b), (2ull << 62) | (excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             f_base = excl;
-            if (b == (int64_t)gridDim.x - 1) { const unsigned long long tot = excl + agg; a.ftotal->pts = (int64_t)(tot & FG_PTS_MASK); a.ftotal->lines = (int64_t)(tot >> 36); }
+            if (b == (int64_t)gridDim.x - 1) {
+                const unsigned long long tot = excl + agg;
+                a.ftotal->pts = (int64_t)(tot & FG_PTS_MASK); a.ftotal->lines = (int64_t)(tot >> 36);
+                if (a.fcounts) { a.fcounts[0] = (int64_t)(tot >> 36); a.fcounts[1] = (int64_t)(tot & FG_PTS_MASK); }
+            }
         }
     }
     __syncthreads();
@@ -1613,7 +1621,7 @@ static int stream_run_impl(const fib_stream_params *prm, const float *field4, co
     if (fused) {
         const unsigned fgrid = (unsigned)fib::cdiv(nl, FUSED_BLOCK);
         ta.fstate = reinterpret_cast<unsigned long long *>(bex);          // (the scan's array is free: no scan)
-        ta.out_npts = npts; ta.out_seed = seed_index; ta.out_xyz = xyz; ta.ftotal = total;
+        ta.out_npts = npts; ta.out_seed = seed_index; ta.out_xyz = xyz; ta.ftotal = total; ta.fcounts = counts_dev;
         ta.lines_cap = lines_cap; ta.points_cap = points_cap; ta.len_min = prm->len_min;
         if (hipMemsetAsync(ta.fstate, 0, ((size_t)fgrid + 1) * sizeof(unsigned long long), st) != hipSuccess)      // (+ the ticket counter behind the granules)
             return release(fib::fail(FIB_ERR_HIP, "hipMemsetAsync failed"));
@@ -1635,7 +1643,7 @@ static int stream_run_impl(const fib_stream_params *prm, const float *field4, co
     {
         fib::ProfScope prof("stream_scan", st);
         hipLaunchKernelGGL(scan_block_kernel, dim3(nblk), dim3(SCAN_T), 0, st, bn, nl, prm->len_min, bex, bbt);
-        hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(SCAN_T), 0, st, bbt, nblk, total, (const Pair *)nullptr);
+        hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(SCAN_T), 0, st, bbt, nblk, total, (const Pair *)nullptr, counts_dev);
     }
     if (hipGetLastError() != hipSuccess) return release(fib::fail(FIB_ERR_HIP, "streamline trace launch failed"));
     PackArgs pa{};
@@ -1652,12 +1660,7 @@ static int stream_run_impl(const fib_stream_params *prm, const float *field4, co
     }
     }   // (!fused)
     if (hipGetLastError() != hipSuccess) return release(fib::fail(FIB_ERR_HIP, "streamline launch failed"));
-    if (counts_dev) {                                             // {lines, points} behind the kernels, no host round trip
-        if (hipMemcpyAsync(counts_dev, &total->lines, sizeof(int64_t), hipMemcpyDeviceToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(counts_dev + 1, &total->pts, sizeof(int64_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
-            return release(fib::fail(FIB_ERR_HIP, "streamline run: copying the counts failed"));
-        return release(FIB_OK);
-    }
+    if (counts_dev) return release(FIB_OK);                       // ({lines, points} were written by the scan / the last workgroup: no host round trip)
     Pair tot{0, 0};
     hipError_t e = hipMemcpyAsync(&tot, total, sizeof(Pair), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
