@@ -8,6 +8,7 @@ LIB_PATH = os.environ.get("FIBERS_HIP_LIB") or os.path.join(_HERE, "libfibers_hi
 
 FIB_OK = 0
 FIB_ERR_CAPACITY = -9
+FIB_MASK_OUTPUTS_ZEROED = 0x100     # OR-ed into mask_dtype: the output arrays are freshly zero-allocated (include/fibers_hip.h)
 DTYPES = {"uint8": 0, "int8": 1, "int16": 2, "uint16": 3, "int32": 4, "uint32": 5,
           "float32": 6, "float64": 7, "int64": 8, "bool": 9}
 

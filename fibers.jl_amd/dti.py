@@ -86,7 +86,7 @@ def dti_fit(dwi: MRI, mask: MRI, device: int = 0) -> DTI:
     m, mdt = _mask_checked(mask, (nx, ny, nz))
     outs = {k: MRI.like(mask if isinstance(mask, MRI) else dwi, 3 if "vec" in k else 1) for k in DTI_FIELDS}
     o = _lib.DtiOut(*[outs[k].vol.ctypes.data for k in DTI_FIELDS])
-    _lib.check(L.fib_dti_fit(device, vol.ctypes.data, nx, ny, nz, nvol, m.ctypes.data, mdt,
+    _lib.check(L.fib_dti_fit(device, vol.ctypes.data, nx, ny, nz, nvol, m.ctypes.data, mdt | _lib.FIB_MASK_OUTPUTS_ZEROED,
                              bval.ctypes.data, bvec.ctypes.data, C.byref(o)))
     return DTI(**outs)
 
@@ -100,7 +100,7 @@ def adc_fit(dwi: MRI, mask: MRI, device: int = 0):
     m, mdt = _mask_checked(mask, (nx, ny, nz))
     ref = mask if isinstance(mask, MRI) else dwi
     adc, s0 = MRI.like(ref, 1), MRI.like(ref, 1)
-    _lib.check(L.fib_adc_fit(device, vol.ctypes.data, nx, ny, nz, nvol, m.ctypes.data, mdt,
+    _lib.check(L.fib_adc_fit(device, vol.ctypes.data, nx, ny, nz, nvol, m.ctypes.data, mdt | _lib.FIB_MASK_OUTPUTS_ZEROED,
                              bval.ctypes.data, adc.vol.ctypes.data, s0.vol.ctypes.data))
     return adc, s0
 

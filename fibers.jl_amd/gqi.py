@@ -50,7 +50,7 @@ def gqi_rec(dwi: MRI, mask: MRI, odf_dirs: ODF = sphere_642, sigma: float = 1.25
     odf = MRI.like(ref, odf_dirs.nvert)
     peak = [MRI.like(ref, 3) for _ in range(3)]
     qa = [MRI.like(ref, 1) for _ in range(3)]
-    _lib.check(_lib.lib().fib_gqi_rec(device, vol.ctypes.data, nx, ny, nz, nvol, m.ctypes.data, mdt,
+    _lib.check(_lib.lib().fib_gqi_rec(device, vol.ctypes.data, nx, ny, nz, nvol, m.ctypes.data, mdt | _lib.FIB_MASK_OUTPUTS_ZEROED,
                                       bval.ctypes.data, bvec.ctypes.data,
                                       v.ctypes.data, v.shape[0], f.ctypes.data, f.shape[0], float(sigma),
                                       odf.vol.ctypes.data, _p3(peak), _p3(qa)))
@@ -69,7 +69,7 @@ def dsi_rec(dwi: MRI, mask: MRI, odf_dirs: ODF = sphere_642, hann_width: int = 3
     odf = MRI.like(ref, odf_dirs.nvert)
     peak = [MRI.like(ref, 3) for _ in range(3)]
     qa = [MRI.like(ref, 1) for _ in range(3)]
-    _lib.check(_lib.lib().fib_dsi_rec(device, vol.ctypes.data, nx, ny, nz, nvol, m.ctypes.data, mdt,
+    _lib.check(_lib.lib().fib_dsi_rec(device, vol.ctypes.data, nx, ny, nz, nvol, m.ctypes.data, mdt | _lib.FIB_MASK_OUTPUTS_ZEROED,
                                       bval.ctypes.data, bvec.ctypes.data,
                                       v.ctypes.data, v.shape[0], f.ctypes.data, f.shape[0], int(hann_width),
                                       pdf.vol.ctypes.data, odf.vol.ctypes.data, _p3(peak), _p3(qa)))

@@ -349,6 +349,12 @@ void fib_stream_job_destroy(fib_stream_job *job);
  * fib_init(ndev, devs): devs[i] may repeat (two pipelines on one GPU); ndev == 0 selects every visible device (also
  * the default of FIB_DEVICE_ALL without fib_init).  fib_shutdown releases every cached plan, stream and buffer. */
 #define FIB_DEVICE_ALL (-1)
+/* May be OR-ed into the mask_dtype of fib_dti_fit / fib_adc_fit / fib_gqi_rec / fib_dsi_rec: the caller's output arrays are zero already
+ * (freshly allocated -- what the reference does itself: MRI(mask, n, Float32) -> zeros, mri.jl:251-255).  Voxels outside the mask
+ * need then not be written, and where only the voxels inside the mask travel (a mask that keeps < 90 % of the volume in runs of 16
+ * voxels or more) they are not: with a mask that keeps a third of the volume the scatter stage of the transfer pipeline writes a
+ * third of the bytes.  Without the flag every output voxel is written (outside the mask: 0). */
+#define FIB_MASK_OUTPUTS_ZEROED 0x100
 int fib_init(int ndev, const int *devs);
 void fib_shutdown(void);
 

@@ -11,6 +11,9 @@ const libfibers = get(ENV, "FIBERS_HIP_LIB", "libfibers_hip.so")
 
 const FIB_DTYPE = Dict(UInt8=>0, Int8=>1, Int16=>2, UInt16=>3, Int32=>4, UInt32=>5,
                        Float32=>6, Float64=>7, Int64=>8, Bool=>9)
+# OR-ed into mask_dtype by the fits below: their outputs are MRI(mask, n, Float32) = zeros (mri.jl:251-255), so the library need not
+# write the voxels outside the mask (include/fibers_hip.h)
+const FIB_MASK_OUTPUTS_ZEROED = Cint(0x100)
 
 # Multi-GPU: `device = FIB_DEVICE_ALL` shards a call over the device set declared here (contiguous voxel slabs for the fits,
 # as Threads.@threads shards the z loop in dti.jl:258 / gqi.jl:132 / dsi.jl:197; round-robin seeds for stream).  Without
@@ -47,7 +50,7 @@ function dti_fit(dwi::MRI, mask::MRI; device::Integer=0)
                         pointer(RD.vol), pointer(MD.vol), pointer(FA.vol)))
     fib_check(ccall((:fib_dti_fit, libfibers), Cint,
                     (Cint, Ptr{Float32}, Cint, Cint, Cint, Cint, Ptr{Cvoid}, Cint, Ptr{Float32}, Ptr{Float32}, Ref{FibDtiOut}),
-                    device, vol, nx, ny, nz, nvol, m, FIB_DTYPE[eltype(m)], dwi.bval, dwi.bvec, out))
+                    device, vol, nx, ny, nz, nvol, m, FIB_DTYPE[eltype(m)] | FIB_MASK_OUTPUTS_ZEROED, dwi.bval, dwi.bvec, out))
   end
   return DTI(S0, E1, E2, E3, V1, V2, V3, RD, MD, FA)
 end
@@ -60,7 +63,7 @@ function adc_fit(dwi::MRI, mask::MRI; device::Integer=0)
   vol = dwi.vol::Array{Float32,4}; m = mask.vol
   GC.@preserve vol m adc s0 fib_check(ccall((:fib_adc_fit, libfibers), Cint,
       (Cint, Ptr{Float32}, Cint, Cint, Cint, Cint, Ptr{Cvoid}, Cint, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
-      device, vol, nx, ny, nz, nvol, m, FIB_DTYPE[eltype(m)], dwi.bval, adc.vol, s0.vol))
+      device, vol, nx, ny, nz, nvol, m, FIB_DTYPE[eltype(m)] | FIB_MASK_OUTPUTS_ZEROED, dwi.bval, adc.vol, s0.vol))
   return adc, s0
 end
 
@@ -115,7 +118,7 @@ function gqi_rec(dwi::MRI, mask::MRI, odf_dirs::ODF=sphere_642, σ::Float32=Floa
   GC.@preserve vol m odf peak qa faces verts fib_check(ccall((:fib_gqi_rec, libfibers), Cint,
       (Cint, Ptr{Float32}, Cint, Cint, Cint, Cint, Ptr{Cvoid}, Cint, Ptr{Float32}, Ptr{Float32},
        Ptr{Float32}, Cint, Ptr{Int32}, Cint, Cfloat, Ptr{Float32}, Ptr{Ptr{Float32}}, Ptr{Ptr{Float32}}),
-      device, vol, nx, ny, nz, nvol, m, FIB_DTYPE[eltype(m)], dwi.bval, dwi.bvec,
+      device, vol, nx, ny, nz, nvol, m, FIB_DTYPE[eltype(m)] | FIB_MASK_OUTPUTS_ZEROED, dwi.bval, dwi.bvec,
       verts, size(verts, 1), faces, size(faces, 1), σ, odf.vol, pk, pq))
   return GQI(odf, peak, qa)
 end
@@ -133,7 +136,7 @@ function dsi_rec(dwi::MRI, mask::MRI, odf_dirs::ODF=sphere_642, hann_width::Int=
   GC.@preserve vol m pdf odf peak qa faces verts fib_check(ccall((:fib_dsi_rec, libfibers), Cint,
       (Cint, Ptr{Float32}, Cint, Cint, Cint, Cint, Ptr{Cvoid}, Cint, Ptr{Float32}, Ptr{Float32},
        Ptr{Float32}, Cint, Ptr{Int32}, Cint, Cint, Ptr{Float32}, Ptr{Float32}, Ptr{Ptr{Float32}}, Ptr{Ptr{Float32}}),
-      device, vol, nx, ny, nz, nvol, m, FIB_DTYPE[eltype(m)], dwi.bval, dwi.bvec,
+      device, vol, nx, ny, nz, nvol, m, FIB_DTYPE[eltype(m)] | FIB_MASK_OUTPUTS_ZEROED, dwi.bval, dwi.bvec,
       verts, size(verts, 1), faces, size(faces, 1), hann_width, pdf.vol, odf.vol, pk, pq))
   return DSI(pdf, odf, peak, qa)
 end

@@ -250,6 +250,47 @@ def test_packing_the_voxels_inside_the_mask_does_not_change_results(fj, monkeypa
         assert np.array_equal(out["0"].peak[k].vol, out["1"].peak[k].vol) and np.array_equal(out["0"].qa[k].vol, out["1"].qa[k].vol, equal_nan=True)
 
 
+def test_outputs_zeroed_flag_leaves_the_voxels_outside_the_mask_alone(fj, monkeypatch):
+    """FIB_MASK_OUTPUTS_ZEROED in mask_dtype (what the Julia / Python wrappers pass: they allocate zeros, as the reference does): the scatter
+    stage writes the runs inside the mask only.  Without the flag every output voxel is written -- arrays that held garbage read 0 outside
+    the mask; with it the same arrays keep their garbage there (when the voxels inside travel packed -- the flag is a permission: a mask
+    that keeps most of the volume, or in short runs, goes through whole and its rows are written whole), and the voxels inside are identical."""
+    import ctypes as C
+    from fibers_jl_amd import _lib, phantom
+    shape = (64, 13, 9)                                              # (long rows: runs of >= 16 voxels on average, so the voxels inside travel packed)
+    nx, ny, nz = shape
+    nvox = nx * ny * nz
+    x, y, z = np.meshgrid(*[np.arange(n) - (n - 1) / 2 for n in shape], indexing="ij")
+    ball = ((x / 30.0) ** 2 + (y / 5.5) ** 2 + (z / 3.5) ** 2 <= 1.0)
+    m8 = np.ascontiguousarray(ball.reshape(-1, order="F").astype(np.uint8))
+    bg, gg = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3)
+    dg, _, _ = phantom.make_volume(shape, bg, gg, seed=5, crossing=True)
+    host = np.ascontiguousarray(np.asarray(dg, np.float32).reshape(nvox, -1, order="F").T)           # [nvol][nvox]
+    sph = fj.sphere_642
+    v = np.asfortranarray(sph.vertices, np.float32); f = np.asfortranarray(sph.faces, np.int32)
+    bv = np.ascontiguousarray(bg, np.float32); bvec = np.asfortranarray(np.asarray(gg, np.float32))
+    nvol, nvert = len(bg), sph.nvert
+    monkeypatch.setenv("FIBERS_HOST_CHUNK", "1024")
+    L = _lib.lib()
+
+    def run(flag):
+        odf = np.full((nvert, nvox), 7.5, np.float32)
+        pk = [np.full((3, nvox), 7.5, np.float32) for _ in range(3)]
+        qa = [np.full(nvox, 7.5, np.float32) for _ in range(3)]
+        _lib.check(L.fib_gqi_rec(0, host.ctypes.data, nx, ny, nz, nvol, m8.ctypes.data, 0 | flag, bv.ctypes.data, bvec.ctypes.data, v.ctypes.data,
+                                 v.shape[0], f.ctypes.data, f.shape[0], 1.25, odf.ctypes.data, _lib.P3(*[a.ctypes.data for a in pk]),
+                                 _lib.P3(*[a.ctypes.data for a in qa])))
+        return odf, pk, qa
+    o0, p0, q0 = run(0)
+    o1, p1, q1 = run(_lib.FIB_MASK_OUTPUTS_ZEROED)
+    inside = m8 != 0
+    assert inside.sum() > 500 and (~inside).sum() > 500
+    assert not o0[:, ~inside].any() and not any(p[:, ~inside].any() for p in p0)                        # every voxel written
+    assert np.array_equal(o0[:, inside], o1[:, inside]) and all(np.array_equal(a[:, inside], b[:, inside]) for a, b in zip(p0, p1))
+    assert (o1[:, ~inside] == 7.5).all() and all((p[:, ~inside] == 7.5).all() for p in p1)             # left alone
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(q0, q1))                            # (the qa planes are written in full either way)
+
+
 def test_gqi_unaligned_volume_does_not_depend_on_chunks_or_device_set(fj, orc, monkeypatch):
     """nvox % 4 != 0 (13 x 11 x 9 = 1287): the same kernel choice for every chunk, so chunk size and device set do not change
     a bit (the fused peak kernel needs 16-byte aligned rows; the choice is made from the whole volume, not per chunk)"""
