@@ -309,6 +309,9 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
     // lane that does not need the gather is switched off for it.  Same data, same arithmetic.  Three vectors per voxel (C5): trace
     // 6.4 -> 6.0 ms; one vector (C4): nothing (tools/stream_c5_times.py, stream_kernel_times.py).
     constexpr int NCV = NVEC > 0 ? NVEC : 1;
+    constexpr int NTRI = (TRI && NVEC == 1) ? 8 : 1;             // the trilinear option's cell of corner vectors (one vector per voxel)
+    float tri_x[NTRI], tri_y[NTRI], tri_z[NTRI];
+    float tri_gx = __builtin_nanf(""), tri_gy = 0.0f, tri_gz = 0.0f;   // (NaN: no cell yet)
     float4 cvec[NCV];
     vox_t cvox = ~(vox_t)0;
     float px = p0x, py = p0y, pz = p0z;
@@ -372,7 +375,8 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
                 // against the current direction (corners without a vector contribute nothing), s_c = sign of its cosine; products
                 // and sums in Float32 in corner order x fastest, the norm as LinearAlgebra.norm does it (below).  A zero or
                 // non-finite blend ends the line.  The 8 x nvec float4 loads of a step hit L2 / the vector cache (the stencil moves
-                // by half a voxel per step); an LDS copy per lane (128 B x nvec x 256 lanes) was not worth its LDS traffic.
+                // by half a voxel per step); an LDS copy per lane (128 B x nvec x 256 lanes) was not worth its LDS traffic.  [r5] With one
+                // vector per voxel the cell's eight vectors are kept in REGISTERS between the steps that stay in it (trace 2.39 -> 1.82 ms).
                 const float gx0 = floorf(nxp), gy0 = floorf(nyp), gz0 = floorf(nzp);
                 const float tx = nxp - gx0, ty = nyp - gy0, tz = nzp - gz0;
                 float sx = 0.0f, sy = 0.0f, sz = 0.0f;
@@ -382,6 +386,35 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
                 const bool zl = gz0 >= 1.0f && gz0 <= fnz, zh = gz0 + 1.0f >= 1.0f && gz0 + 1.0f <= fnz;
                 const int64_t cbase = ((int64_t)gx0 - 1) + (int64_t)a.nx * (((int64_t)gy0 - 1) + (int64_t)a.ny * ((int64_t)gz0 - 1));
                 const float ax0 = 1.0f - tx, ay0 = 1.0f - ty, az0 = 1.0f - tz;
+                if constexpr (NVEC == 1) {
+                    // [r5] one vector per voxel: the eight corner vectors stay in registers while the position stays in the cell (a step is
+                    // half a voxel: ~40 % of the steps do) -- the lanes that changed cell reload, corners outside the volume count as
+                    // "no vector".  Same data, same arithmetic.
+                    if (gx0 != tri_gx || gy0 != tri_gy || gz0 != tri_gz) {
+#pragma unroll
+                        for (int c = 0; c < 8; c++) {
+                            const int cx = c & 1, cy = (c >> 1) & 1, cz = c >> 2;
+                            float4 w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            if ((cx ? xh : xl) && (cy ? yh : yl) && (cz ? zh : zl)) {
+                                if constexpr (WIDE) w = *reinterpret_cast<const float4 *>(fbase + (uint64_t)(cbase + cx + (int64_t)a.nx * (cy + a.ny * cz)) * (uint64_t)16);
+                                else w = *reinterpret_cast<const float4 *>(fbase + (size_t)((uint32_t)((int)cbase + cx + a.nx * (cy + a.ny * cz)) * 16u));
+                            }
+                            tri_x[c] = w.x; tri_y[c] = w.y; tri_z[c] = w.z;
+                        }
+                        tri_gx = gx0; tri_gy = gy0; tri_gz = gz0;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const int cx = c & 1, cy = (c >> 1) & 1, cz = c >> 2;
+                        const float ux = tri_x[c], uy = tri_y[c], uz = tri_z[c];
+                        if (is_zero3(ux, uy, uz)) continue;           // (no vector there, or a corner outside the volume)
+                        const float tc = ((cx ? tx : ax0) * (cy ? ty : ay0)) * (cz ? tz : az0);
+                        const float uc = dot3(vx, vy, vz, ux, uy, uz);
+                        if (!(fabsf(uc) < INFINITY)) continue;
+                        const float sg = uc > 0.0f ? tc : -tc;
+                        sx = sx + sg * ux; sy = sy + sg * uy; sz = sz + sg * uz;
+                    }
+                } else
 #pragma unroll
                 for (int c = 0; c < 8; c++) {
                     const int cx = c & 1, cy = (c >> 1) & 1, cz = c >> 2;
