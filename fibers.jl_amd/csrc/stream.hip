@@ -450,7 +450,9 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
                 const int ivec_ang = ivec;
                 int dvx = (int)rintf(px) - (ix + 1), dvy = (int)rintf(py) - (iy + 1), dvz = (int)rintf(pz) - (iz + 1);   // :394-398
                 if (dvx == 0 && dvy == 0 && dvz == 0) {           // not entering a new voxel, :400-413
-                    const float4 w = cand[ivec];
+                    float4 w;                                     // (the voxel's vectors are in registers when their count is a template constant)
+                    if constexpr (NVEC > 0) { w = cvec[0]; for (int k = 1; k < NVEC; k++) if (ivec == k) w = cvec[k]; }
+                    else w = cand[ivec];
                     if (dot3(vx, vy, vz, w.x, w.y, w.z) > 0.0f) { wx = w.x; wy = w.y; wz = w.z; } else { wx = -w.x; wy = -w.y; wz = -w.z; }
                 } else {
                     int entry = lcm_match_edge(dvx, dvy, dvz, a.sd0, a.sd1);                         // :416-422
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
                     int lb = 0;
 #pragma unroll
                     for (int k = 0; k < nvec; k++) {              // :462-472
-                        const float4 w = cand[k];
+                        const float4 w = NVEC > 0 ? cvec[k < NCV ? k : 0] : cand[k];
                         float c, ca;
                         if (is_zero3(w.x, w.y, w.z)) { c = -INFINITY; ca = -INFINITY; }
                         else { c = dot3(ex, ey, ez, w.x, w.y, w.z); ca = fabsf(c); }
