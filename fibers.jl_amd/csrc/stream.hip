@@ -358,8 +358,10 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
                 float c, ca;
                 if (is_zero3(w.x, w.y, w.z)) { c = -INFINITY; ca = -INFINITY; }
                 else { c = dot3(vx, vy, vz, w.x, w.y, w.z); ca = fabsf(c); }
-                // argmax: first maximum, NaN wins over everything
-                if (k == 0 || (!(besta != besta) && ((ca != ca) || ca > besta))) {
+                // argmax: first maximum, NaN wins over everything -- as ONE signed compare of the bit patterns: ca is -Inf, >= +0 or a NaN
+                // with its sign cleared, and as integers -Inf < +0 <= .. <= +Inf < every such NaN.  (A later NaN with a larger payload
+                // replaces an earlier one where the reference keeps the first: both end the line, below, before `best` is used.)
+                if (k == 0 || __float_as_int(ca) > __float_as_int(besta)) {
                     best = k; besta = ca; bestc = c; bx = w.x; by = w.y; bz = w.z;
                 }
             }
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
                         float cs, ca;
                         if (is_zero3(w.x, w.y, w.z)) { cs = -INFINITY; ca = -INFINITY; }
                         else { cs = dot3(vx, vy, vz, w.x, w.y, w.z); ca = fabsf(cs); }
-                        if (k == 0 || (!(ua != ua) && ((ca != ca) || ca > ua))) { ua = ca; uc = cs; ux = w.x; uy = w.y; uz = w.z; }
+                        if (k == 0 || __float_as_int(ca) > __float_as_int(ua)) { ua = ca; uc = cs; ux = w.x; uy = w.y; uz = w.z; }
                     }
                     if (!(fabsf(uc) < INFINITY)) continue;
                     const float sg = uc > 0.0f ? tc : -tc;
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(FUSED ? FUSED_BLOCK : 256) void stream_trace_kernel
                         float c, ca;
                         if (is_zero3(w.x, w.y, w.z)) { c = -INFINITY; ca = -INFINITY; }
                         else { c = dot3(ex, ey, ez, w.x, w.y, w.z); ca = fabsf(c); }
-                        if (k == 0 || (!(la != la) && ((ca != ca) || ca > la))) { lb = k; la = ca; lc = c; lx = w.x; ly = w.y; lz = w.z; }
+                        if (k == 0 || __float_as_int(ca) > __float_as_int(la)) { lb = k; la = ca; lc = c; lx = w.x; ly = w.y; lz = w.z; }
                     }
                     if (!(fabsf(lc) < INFINITY)) return true;     // :476
                     if (lc > 0.0f) { wx = lx; wy = ly; wz = lz; } else { wx = -lx; wy = -ly; wz = -lz; }   // :480-484
