@@ -622,9 +622,14 @@ def main():
             return xyz_buf["t"]
         res = {}
 
+        sbuf4 = fj.StreamBuffers(dev) if not multi else None
+
         def stream_step():
             field = fd.allgather_slabs(field_loc, counts, always=force_pg)   # shared peak field over xGMI
-            res["r"] = fd.stream_sharded(field, shape, seeds_all, sub, xyz_out=xyz_out)
+            if multi:
+                res["r"] = fd.stream_sharded(field, shape, seeds_all, sub, xyz_out=xyz_out)
+            else:                                                            # one GPU: the one-call form into kept buffers (as the C5 section below)
+                res["r"] = fj.stream_device_run(field, shape, seeds_all, sub, buffers=sbuf4)
         nst = max(2, args.steps // 2)
         t_st = timed(stream_step, nst, 2)
         r = res["r"]
@@ -646,8 +651,8 @@ def main():
                                                       frac=25.0 * (npoints / world) / ((tr_ms + pk_ms + sc_ms) / max(tr_n, 1) * 1e-3) / 1e9 / PEAK_HBM_GBS if tr_n else 0.0,
                                                       note="25 B per emitted point (SURVEY 8d, nvec = 1) x rank 0's points / device time of trace + scan + pack; the "
                                                            "trace bound by its point stores and vector-ALU issue, pack by HBM (DESIGN.md K6 [r5])"),
-                                        note="one volume; wall = field all-gather + trace + scan + pack into a pre-allocated buffer (+ one host sync for "
-                                             "the line count); seeds dealt round-robin over the ranks")
+                                        note="one volume; wall = field all-gather + trace + scan + pack into kept buffers (+ one host sync for the counts): one GPU "
+                                             "fibd_stream_run, N > 1 trace + pack per rank with the seeds dealt round-robin")
         # the one-call form (fibd_stream_run: straight into buffers kept between calls) on the same field and seeds, for the record
         if rank == 0 and world == 1:
             try:
