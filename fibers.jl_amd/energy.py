@@ -31,6 +31,33 @@ def _smi():
     return _lib
 
 
+def rsmi_index_of(hip_device=0):
+    """The rocm_smi index of a HIP / torch device.  rsmi enumerates every board and ignores HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES,
+    so `cuda:0` need not be rsmi's board 0: match the PCI bus address (torch's device properties against rsmi_dev_pci_id_get, whose id
+    is (domain << 32) | (bus << 8) | (device << 3) | function).  Raises if no board matches: a reading from another board must never be
+    reported as this run's."""
+    lib = _smi()
+    if lib is None:
+        return 0                                                     # (no library: every reader returns None anyway)
+    import torch
+    p = torch.cuda.get_device_properties(hip_device)
+    want = (int(p.pci_domain_id), int(p.pci_bus_id), int(p.pci_device_id))
+    n = C.c_uint32(0)
+    if lib.rsmi_num_monitor_devices(C.byref(n)) != 0:
+        raise RuntimeError("rsmi_num_monitor_devices failed")
+    seen = []
+    for i in range(n.value):
+        bdf = C.c_uint64(0)
+        if lib.rsmi_dev_pci_id_get(C.c_uint32(i), C.byref(bdf)) != 0:
+            continue
+        v = bdf.value
+        got = ((v >> 32) & 0xFFFFFFFF, (v >> 8) & 0xFF, (v >> 3) & 0x1F)
+        seen.append(got)
+        if got == want:
+            return i
+    raise RuntimeError("no rocm_smi board at PCI %04x:%02x:%02x (boards seen: %s)" % (want + (seen,)))
+
+
 def energy_joules(dev=0):
     """Accumulated board energy in Joules (monotonic), or None"""
     lib = _smi()
