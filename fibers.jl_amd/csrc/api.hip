@@ -24,41 +24,19 @@
 #include <thread>
 
 #include "common.h"
+#include "host_tier.h"
 
 namespace {
 
+using fibh::bind_this_thread; using fibh::chunk_count; using fibh::CopyPool; using fibh::dtype_size; using fibh::LiveMap; using fibh::NBUF; using fibh::Rows;
+using fibh::slab;
+
 #define RC(x) do { int _rc = (x); if (_rc != FIB_OK) return _rc; } while (0)
 
-// mask.vol[...] == 0 && continue (dti.jl:261, gqi.jl:135, dsi.jl:200)  -> nonzero test
-// mask.vol .> 0 (stream.jl:102), seed.vol .> 0 (stream.jl:751)         -> positive test
-template <typename T>
-void mask_convert_t(const T *m, int64_t n, bool positive, uint8_t *out) {
-    if (positive) for (int64_t i = 0; i < n; i++) out[i] = m[i] > (T)0 ? 1 : 0;
-    else          for (int64_t i = 0; i < n; i++) out[i] = m[i] != (T)0 ? 1 : 0;
-}
-int dtype_size(int dtype) {
-    switch (dtype) {
-        case FIB_U8: case FIB_BOOL: case FIB_I8: return 1;
-        case FIB_I16: case FIB_U16: return 2;
-        case FIB_I32: case FIB_U32: case FIB_F32: return 4;
-        case FIB_I64: case FIB_F64: return 8;
-        default: return 0;
-    }
-}
-// elements [i0, i0 + n) of a mask / seed volume of any numeric type -> bytes
+// (mask element types, the copy pool, live maps, the chunk schedule and the chunk pipeline itself: host_tier.h -- pure host code, also built
+// under the sanitizers by tests/test_host_sanitizers.py)
 int mask_convert_range(const void *m, int dtype, int64_t i0, int64_t n, bool positive, uint8_t *out) {
-    switch (dtype) {
-        case FIB_U8: case FIB_BOOL: mask_convert_t((const uint8_t *)m + i0, n, positive, out); break;
-        case FIB_I8:  mask_convert_t((const int8_t *)m + i0, n, positive, out); break;
-        case FIB_I16: mask_convert_t((const int16_t *)m + i0, n, positive, out); break;
-        case FIB_U16: mask_convert_t((const uint16_t *)m + i0, n, positive, out); break;
-        case FIB_I32: mask_convert_t((const int32_t *)m + i0, n, positive, out); break;
-        case FIB_U32: mask_convert_t((const uint32_t *)m + i0, n, positive, out); break;
-        case FIB_I64: mask_convert_t((const int64_t *)m + i0, n, positive, out); break;
-        case FIB_F32: mask_convert_t((const float *)m + i0, n, positive, out); break;
-        case FIB_F64: mask_convert_t((const double *)m + i0, n, positive, out); break;
-        default: return fib::fail(FIB_ERR_INVALID, "unknown mask dtype %d", dtype);
-    }
+    if (!fibh::mask_convert_range(m, dtype, i0, n, positive, out)) return fib::fail(FIB_ERR_INVALID, "unknown mask dtype %d", dtype);
     return FIB_OK;
 }
 int mask_convert(const void *m, int dtype, int64_t n, bool positive, std::vector<uint8_t> &out) {
@@ -107,14 +85,6 @@ std::vector<int> device_local_cpus(int device) {
     }
     return cpus;
 }
-void bind_this_thread(const std::vector<int> &cpus) {
-    if (cpus.empty()) return;
-    cpu_set_t set;
-    CPU_ZERO(&set);
-    for (int c : cpus) CPU_SET(c, &set);
-    (void)sched_setaffinity(0, sizeof set, &set);            // (best effort)
-}
-
 // a host-side phase, into the profile table while fib_profile_enable(1) is active
 struct HostTimer {
     const char *name; std::chrono::steady_clock::time_point t0;
@@ -132,64 +102,7 @@ void *alloc_result(size_t bytes) {
     return p;
 }
 
-// ---- a small pool for the row copies between the caller's arrays and the pinned ring --------------------------------------
-class CopyPool {
-  public:
-    CopyPool(int nthreads, const std::vector<int> &cpus) {
-        for (int i = 0; i < nthreads; i++) th_.emplace_back([this, cpus] { bind_this_thread(cpus); work(); });
-    }
-    ~CopyPool() {
-        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
-        cv_.notify_all();
-        for (auto &t : th_) t.join();
-    }
-    // runs fn(0..n-1), the caller takes part; returns when all are done
-    void run(int n, const std::function<void(int)> &fn) {
-        if (n <= 0) return;
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            fn_ = &fn; n_ = n; next_ = 0; left_ = n;
-        }
-        cv_.notify_all();
-        for (;;) {
-            int i;
-            { std::lock_guard<std::mutex> lk(mu_); if (next_ >= n_) break; i = next_++; }
-            fn(i);
-            std::lock_guard<std::mutex> lk(mu_);
-            if (--left_ == 0) done_.notify_all();
-        }
-        std::unique_lock<std::mutex> lk(mu_);
-        done_.wait(lk, [this] { return left_ == 0; });
-        fn_ = nullptr;
-    }
-
-  private:
-    void work() {
-        for (;;) {
-            int i;
-            const std::function<void(int)> *fn;
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [this] { return stop_ || (fn_ && next_ < n_); });
-                if (stop_) return;
-                i = next_++; fn = fn_;
-            }
-            (*fn)(i);
-            std::lock_guard<std::mutex> lk(mu_);
-            if (--left_ == 0) done_.notify_all();
-        }
-    }
-    std::vector<std::thread> th_;
-    std::mutex mu_;
-    std::condition_variable cv_, done_;
-    const std::function<void(int)> *fn_ = nullptr;
-    int n_ = 0, next_ = 0, left_ = 0;
-    bool stop_ = false;
-};
-
 // ---- per-device state of the host tier -----------------------------------------------------------------------------------
-constexpr int NBUF = 3;                                  // ring depth: chunk k uploads while k-1 computes and k-2 downloads
-
 struct PinBuf {                                          // grow-only pinned host buffer
     char *p = nullptr; size_t n = 0;
     // cpus: the allocation (and the first touch of its pages) happens on a thread bound to these CPUs -- the device's NUMA node
@@ -287,7 +200,9 @@ int copy_threads(int nworkers) {
     if (hw == 0) hw = 8;
     if (const char *e = fib::env("FIBERS_COPY_THREADS")) { const int t = atoi(e); if (t >= 1) return t; }
     int t = (int)hw / (2 * (nworkers > 0 ? nworkers : 1));
-    return t < 2 ? 2 : (t > 16 ? 16 : t);                // 8-16 threads reach the host's copy bandwidth (tools/probes/host_probe.hip)
+    // 8-16 threads reach the host's copy bandwidth on whole rows (tools/probes/host_probe.hip); the runs of a masked volume are a few hundred
+    // bytes each; [r6] 32 or 64 threads per stage were measured and are WORSE, dense and masked (profiles/r06/host_tier_threads.txt)
+    return t < 2 ? 2 : (t > 16 ? 16 : t);
 }
 
 // workers of a call: the fib_init set for FIB_DEVICE_ALL, else the (lazily created) worker of that device
@@ -330,280 +245,73 @@ int cached_plan(DevState &d, int kind, const std::string &key, MakeFn make, void
     return FIB_OK;
 }
 
-// ---- the chunk pipeline --------------------------------------------------------------------------------------------------------
-struct Rows { const float *in; float *out; int nrows; };   // a planar host array: nrows rows of nvox floats (row stride = nvox)
-
+// ---- the chunk pipeline (host_tier.h: fibh::run_chunks) on HIP streams ------------------------------------------------------------
 // what a fit does with one chunk, all pointers on the device: din = the input rows back to back (row stride n), dmask = n
 // bytes, dout = the output rows back to back (row stride n)
 using ChunkFn = std::function<int(int chunk, int64_t rel, int64_t n, const float *din, const uint8_t *dmask, float *dout, hipStream_t st)>;
 
-// [r4] The voxels of [vbeg, vend) inside the mask as runs.  With a mask that leaves a good part of the volume out, the host tier moves the
-// voxels inside only: the gather stage packs their runs densely into the pinned ring, the device works on a dense all-inside chunk (whose
-// rows are aligned whatever the mask looks like), the scatter stage puts the runs back and zero-fills the gaps.  A ball mask (36 % inside)
-// moves 36 % of the bytes over PCIe.  Voxels are independent (dti.jl:258, gqi.jl:132, dsi.jl:197): results do not depend on it.
-struct LiveMap {
-    std::vector<int64_t> start, len, off;                // run i: voxels [start, start + len), `off` voxels inside the mask before it
-    int64_t nlive = 0, vbeg = 0, vend = 0;
-    size_t run_at(int64_t l) const { return (size_t)(std::upper_bound(off.begin(), off.end(), l) - off.begin()) - 1; }   // the run that holds inside-voxel l
-};
-int build_live_map(CopyPool &pool, const void *mask, int mask_dtype, int64_t vbeg, int64_t vend, LiveMap &m) {
-    m = LiveMap{};
-    m.vbeg = vbeg; m.vend = vend;
-    const int64_t n = vend - vbeg;
-    if (n <= 0) return FIB_OK;
-    std::vector<uint8_t> m8((size_t)n);
-    const int64_t piece = 1 << 18;
-    std::atomic<int> merr{FIB_OK};
-    pool.run((int)fib::cdiv(n, piece), [&](int i) {
-        const int64_t a = (int64_t)i * piece, c = std::min<int64_t>(piece, n - a);
-        if (mask_convert_range(mask, mask_dtype, vbeg + a, c, false, m8.data() + a) != FIB_OK) merr = FIB_ERR_INVALID;
-    });
-    if (merr != FIB_OK) return fib::fail(FIB_ERR_INVALID, "unknown mask dtype %d", mask_dtype);
-    for (int64_t i = 0; i < n;) {
-        const uint8_t *p = (const uint8_t *)memchr(m8.data() + i, 1, (size_t)(n - i));      // (mask_convert_range writes 0 / 1)
-        if (!p) break;
-        const int64_t a = p - m8.data();
-        const uint8_t *q = (const uint8_t *)memchr(p, 0, (size_t)(n - a));
-        const int64_t b = q ? q - m8.data() : n;
-        m.start.push_back(vbeg + a); m.len.push_back(b - a); m.off.push_back(m.nlive);
-        m.nlive += b - a;
-        i = b;
-    }
-    return FIB_OK;
-}
-// a mask that keeps less than this share of a slab is worth the packing
-constexpr double LIVE_PACK_BELOW = 0.9;
 // the slab's LiveMap where packing pays (*use = &lm), NULL where the mask keeps (nearly) everything.  FIBERS_HOST_PACK=0: never.
 int live_map_for(DevState &d, const void *mask, int mask_dtype, int64_t v0, int64_t v1, LiveMap &lm, const LiveMap **use) {
     *use = nullptr;
     const char *e = fib::env("FIBERS_HOST_PACK");
     if ((e && e[0] == '0') || v1 <= v0) return FIB_OK;
-    RC(build_live_map(*d.pool, mask, mask_dtype, v0, v1, lm));
-    // .. and whose runs are long enough: every run is a memcpy per row in both directions; below ~16 voxels (64 bytes) per run the
-    // per-run overhead outweighs the bytes saved (a noisy threshold mask), and the unpacked pipeline moves whole rows
-    const bool long_runs = lm.start.empty() || lm.nlive >= (int64_t)16 * (int64_t)lm.start.size();
-    if ((double)lm.nlive < LIVE_PACK_BELOW * (double)(v1 - v0) && long_runs) *use = &lm;
+    if (!fibh::build_live_map(*d.pool, mask, mask_dtype, v0, v1, lm)) return fib::fail(FIB_ERR_INVALID, "unknown mask dtype %d", mask_dtype);
+    if (fibh::live_pack_pays(lm, v0, v1)) *use = &lm;
     return FIB_OK;
 }
+int64_t pick_chunk(int64_t nrange, int rows_in, int rows_out) { return fibh::pick_chunk(nrange, rows_in, rows_out, fib::env("FIBERS_HOST_CHUNK")); }
 
-int64_t pick_chunk(int64_t nrange, int rows_in, int rows_out) {
-    const int rows = rows_in > rows_out ? rows_in : rows_out;
-    // [r4] 262 144 voxels (four 256-voxel work items per CU for the contraction kernel) as long as a ring slot stays below 384 MB: fib_gqi_rec
-    // 140^3 x 270 takes 103 ms with chunks of 131 072 voxels, 90-93 ms with 262 144 (95 with 524 288: fewer chunks to overlap;
-    // tools/host_tier_sweep.py); the pinned ring is 3 x (rows_in + rows_out) x chunk x 4 bytes per device
-    int64_t c = 262144;
-    while (c > 8192 && c * rows * 4 > (int64_t)384 << 20) c >>= 1;
-    if (const char *e = fib::env("FIBERS_HOST_CHUNK")) { const long long v = atoll(e); if (v >= 1024) c = v / 32 * 32; }
-    return c < nrange ? c : std::max<int64_t>((nrange + 3) / 4 * 4, 4);
-}
-
-// [r5] The chunk schedule of a range of `total` voxels: 1/8, 1/4 and 1/2 of a chunk first, whole chunks after that.  The download stream
-// is the pipeline's long pole (fib_gqi_rec moves 3.66 GB out against 2.96 GB in), and it cannot start before the first chunk has been
-// gathered, uploaded and computed: with a small first chunk it starts after ~2 ms instead of ~8.  Offsets are multiples of 32 voxels.
-std::vector<int64_t> chunk_schedule(int64_t total, int64_t chunk) {
-    std::vector<int64_t> off;
-    int64_t o = 0;
-    for (int64_t c : {chunk / 8, chunk / 4, chunk / 2}) {
-        c = c / 32 * 32;
-        if (c >= 8192 && total - o > chunk + c) { off.push_back(o); o += c; }
+// the device back end of fibh::run_chunks: the worker's pinned ring, its three streams (upload | kernels | download) and one event per
+// ring slot and stage
+struct HipDev {
+    DevState &d;
+    const ChunkFn &fn;
+    hipStream_t st(fibh::Stream s) const { return s == fibh::S_IN ? d.s_in : (s == fibh::S_CMP ? d.s_cmp : d.s_out); }
+    hipEvent_t ev(fibh::Event e, int b) const { return e == fibh::E_IN ? d.e_in[b] : (e == fibh::E_CMP ? d.e_cmp[b] : d.e_out[b]); }
+    int ensure(size_t in_bytes, size_t out_bytes) {
+        for (int b = 0; b < NBUF; b++) {
+            RC(d.pin_in[b].ensure(in_bytes, d.device, d.cpus));
+            RC(d.pin_out[b].ensure(out_bytes, d.device, d.cpus));
+            RC(d.dev_in[b].ensure(in_bytes));
+            RC(d.dev_out[b].ensure(out_bytes));
+        }
+        return FIB_OK;
     }
-    while (o < total) { off.push_back(o); o += std::min(chunk, total - o); }
-    off.push_back(total);
-    return off;
-}
-int chunk_count(int64_t total, int64_t chunk) { return total > 0 ? (int)chunk_schedule(total, chunk).size() - 1 : 0; }
+    char *pin_in(int b) { return d.pin_in[b].p; }
+    char *pin_out(int b) { return d.pin_out[b].p; }
+    int upload(int b, size_t bytes) {
+        fib::ProfScope prof("host_h2d", d.s_in);
+        FIB_HIP(hipMemcpyAsync(d.dev_in[b].p, d.pin_in[b].p, bytes, hipMemcpyHostToDevice, d.s_in));
+        return FIB_OK;
+    }
+    int compute(int k, int b, int64_t rel, int64_t nd, int rin) {
+        return fn(k, rel, nd, reinterpret_cast<const float *>(d.dev_in[b].p), reinterpret_cast<const uint8_t *>(d.dev_in[b].p) + (size_t)rin * nd * 4,
+                  reinterpret_cast<float *>(d.dev_out[b].p), d.s_cmp);
+    }
+    int download(int b, size_t bytes) {
+        fib::ProfScope prof("host_d2h", d.s_out);
+        FIB_HIP(hipMemcpyAsync(d.pin_out[b].p, d.dev_out[b].p, bytes, hipMemcpyDeviceToHost, d.s_out));
+        return FIB_OK;
+    }
+    int record(fibh::Event e, int b) { FIB_HIP(hipEventRecord(ev(e, b), st((fibh::Stream)e))); return FIB_OK; }      // (event kinds and streams are numbered alike)
+    int stream_wait(fibh::Stream s, fibh::Event e, int b) { FIB_HIP(hipStreamWaitEvent(st(s), ev(e, b), 0)); return FIB_OK; }
+    int host_wait(fibh::Event e, int b) { (void)hipSetDevice(d.device); return hipEventSynchronize(ev(e, b)) == hipSuccess ? FIB_OK : FIB_ERR_HIP; }
+    void drain() { (void)hipStreamSynchronize(d.s_in); (void)hipStreamSynchronize(d.s_cmp); (void)hipStreamSynchronize(d.s_out); }
+    void prof(const char *name, double ms) { if (fib::profiling_on()) fib::profile_add_ms(name, ms); }
+    int fail(int code, const char *msg) { return fib::fail(code, "%s", msg); }
+    std::string last_error() { return fib_last_error(); }
+    void set_error(const std::string &m) { fib::set_error("%s", m.c_str()); }
+};
 
-// voxels [vbeg, vend) of a volume of nvox voxels through device d.  Blocking.  The caller holds d.mu.
-// lm != NULL: only the voxels inside the mask travel (LiveMap); fn then sees dense chunks whose mask is all ones (padded with voxels
-// outside to a multiple of 32) and `rel` counts voxels inside the mask.  rel = the chunk's offset in that numbering (lm) or from vbeg.
-// outputs_zeroed (FIB_MASK_OUTPUTS_ZEROED): the caller's output arrays are zero already -- the gaps between the runs are left alone (the
-// scatter stage then writes the 36 % of a ball mask's rows instead of all of them: 35 -> 15 ms of its 50 for fib_gqi_rec 140^3 x 270)
+// voxels [vbeg, vend) of a volume of nvox voxels through device d.  Blocking.  The caller holds d.mu.  (lm, outputs_zeroed: fibh::run_chunks)
 int run_chunks(DevState &d, int64_t vbeg, int64_t vend, int64_t nvox, const std::vector<Rows> &ins, const void *mask, int mask_dtype,
                const std::vector<Rows> &outs, int64_t chunk, const ChunkFn &fn, const LiveMap *lm = nullptr, bool outputs_zeroed = false) {
     if (vend <= vbeg) return FIB_OK;
     FIB_HIP(hipSetDevice(d.device));
-    int rin = 0, rout = 0;
-    for (auto &r : ins) rin += r.nrows;
-    for (auto &r : outs) rout += r.nrows;
-    const int64_t total = lm ? lm->nlive : vend - vbeg;
-    auto zero_rows = [&](int64_t a, int64_t b2) {         // every output row, voxels [a, b2)
-        if (b2 <= a || outputs_zeroed) return;
-        std::vector<float *> rows;
-        for (auto &r : outs) for (int i = 0; i < r.nrows; i++) rows.push_back(r.out + (int64_t)i * nvox);
-        d.pool->run((int)rows.size(), [&](int i) { memset(rows[i] + a, 0, (size_t)(b2 - a) * 4); });
-    };
-    if (lm && total == 0) { zero_rows(vbeg, vend); return FIB_OK; }
-    if (lm) chunk = (chunk + 31) / 32 * 32;
-    const size_t in_bytes = (size_t)rin * chunk * 4 + (size_t)chunk, out_bytes = (size_t)rout * chunk * 4;
-    for (int b = 0; b < NBUF; b++) {
-        RC(d.pin_in[b].ensure(in_bytes, d.device, d.cpus));
-        RC(d.pin_out[b].ensure(out_bytes, d.device, d.cpus));
-        RC(d.dev_in[b].ensure(in_bytes));
-        RC(d.dev_out[b].ensure(out_bytes));
-    }
-    const std::vector<int64_t> coff = chunk_schedule(total, chunk);
-    const int nchunks = (int)coff.size() - 1;
-    std::atomic<int> err{FIB_OK};
-    // chunk k: `n` voxels that travel, `nd` voxels the device sees (lm: padded to a multiple of 32 so that its rows stay on cache lines)
-    auto span = [&](int k, int64_t &o0, int64_t &n, int64_t &nd) {
-        o0 = coff[k]; n = coff[k + 1] - coff[k];
-        nd = lm ? (n + 31) / 32 * 32 : n;
-    };
-    // lm: the pieces of the caller's rows that make up inside-voxels [l0, l0 + n): f(voxel, position in the chunk, count, run index, piece starts its run)
-    auto for_pieces = [&](int64_t l0, int64_t n, const std::function<void(int64_t, int64_t, int64_t, size_t, bool)> &f) {
-        size_t ri = lm->run_at(l0);
-        int64_t done = 0;
-        while (done < n) {
-            const int64_t inrun = l0 + done - lm->off[ri];
-            const int64_t c = std::min<int64_t>(lm->len[ri] - inrun, n - done);
-            f(lm->start[ri] + inrun, done, c, ri, inrun == 0);
-            done += c; ri++;
-        }
-    };
-    auto scatter = [&](int k) {                          // chunk k: pinned ring -> the caller's arrays
-        const int b = k % NBUF;
-        int64_t o0, n, nd;
-        span(k, o0, n, nd);
-        const auto tw0 = std::chrono::steady_clock::now();
-        if (hipEventSynchronize(d.e_out[b]) != hipSuccess) { err = fib::fail(FIB_ERR_HIP, "device-to-host copy of chunk %d failed", k); return; }
-        const auto tw1 = std::chrono::steady_clock::now();
-        struct Timed { std::chrono::steady_clock::time_point t0, w0; ~Timed() {
-            if (!fib::profiling_on()) return;
-            const auto t1 = std::chrono::steady_clock::now();
-            fib::profile_add_ms("host_scatter", std::chrono::duration<double, std::milli>(t1 - t0).count());
-            fib::profile_add_ms("host_scatter_wait", std::chrono::duration<double, std::milli>(t0 - w0).count());
-        } } timed{tw1, tw0};
-        std::vector<std::pair<float *, const float *>> rows;
-        const float *src = reinterpret_cast<const float *>(d.pin_out[b].p);
-        if (!lm) {
-            const int64_t v0 = vbeg + o0;
-            for (auto &r : outs) for (int i = 0; i < r.nrows; i++) { rows.emplace_back(r.out + (int64_t)i * nvox + v0, src); src += n; }
-            d.pool_out->run((int)rows.size(), [&](int i) { memcpy(rows[i].first, rows[i].second, (size_t)n * 4); });
-            return;
-        }
-        for (auto &r : outs) for (int i = 0; i < r.nrows; i++) { rows.emplace_back(r.out + (int64_t)i * nvox, src); src += nd; }
-        const bool last = k == nchunks - 1;
-        d.pool_out->run((int)rows.size(), [&](int i) {
-            float *row = rows[i].first;
-            const float *s = rows[i].second;
-            size_t rl = 0;
-            for_pieces(o0, n, [&](int64_t vox, int64_t pos, int64_t c, size_t ri, bool first) {
-                if (first && !outputs_zeroed) {          // the gap in front of the run: voxels outside the mask read 0
-                    const int64_t g0 = ri == 0 ? lm->vbeg : lm->start[ri - 1] + lm->len[ri - 1];
-                    if (vox > g0) memset(row + g0, 0, (size_t)(vox - g0) * 4);
-                }
-                memcpy(row + vox, s + pos, (size_t)c * 4);
-                rl = ri;
-            });
-            if (last && !outputs_zeroed) {
-                const int64_t g0 = lm->start[rl] + lm->len[rl];
-                if (lm->vend > g0) memset(row + g0, 0, (size_t)(lm->vend - g0) * 4);
-            }
-        });
-    };
-    auto enqueue = [&](int k) -> int {                   // chunk k: gather, upload, compute, download (asynchronous from the upload on)
-        const int b = k % NBUF;
-        int64_t o0, n, nd;
-        span(k, o0, n, nd);
-        // the pinned input buffer is free once the upload of chunk k - NBUF has completed
-        const auto tg0 = std::chrono::steady_clock::now();
-        if (k >= NBUF) FIB_HIP(hipEventSynchronize(d.e_in[b]));
-        const auto tg1 = std::chrono::steady_clock::now();
-        {
-            std::vector<std::pair<float *, const float *>> rows;
-            float *dst = reinterpret_cast<float *>(d.pin_in[b].p);
-            uint8_t *m8 = reinterpret_cast<uint8_t *>(d.pin_in[b].p) + (size_t)rin * nd * 4;
-            std::atomic<int> merr{FIB_OK};
-            if (!lm) {
-                const int64_t v0 = vbeg + o0;
-                for (auto &r : ins) for (int i = 0; i < r.nrows; i++) { rows.emplace_back(dst, r.in + (int64_t)i * nvox + v0); dst += n; }
-                d.pool->run((int)rows.size() + 1, [&](int i) {
-                    if (i < (int)rows.size()) memcpy(rows[i].first, rows[i].second, (size_t)n * 4);
-                    else if (mask_convert_range(mask, mask_dtype, v0, n, false, m8) != FIB_OK) merr = FIB_ERR_INVALID;
-                });
-            } else {
-                for (auto &r : ins) for (int i = 0; i < r.nrows; i++) { rows.emplace_back(dst, r.in + (int64_t)i * nvox); dst += nd; }
-                d.pool->run((int)rows.size() + 1, [&](int i) {
-                    if (i == (int)rows.size()) { memset(m8, 1, (size_t)n); memset(m8 + n, 0, (size_t)(nd - n)); return; }
-                    float *o = rows[i].first;
-                    const float *row = rows[i].second;
-                    for_pieces(o0, n, [&](int64_t vox, int64_t pos, int64_t c, size_t, bool) { memcpy(o + pos, row + vox, (size_t)c * 4); });
-                    if (nd > n) memset(o + n, 0, (size_t)(nd - n) * 4);
-                });
-            }
-            if (merr != FIB_OK) return fib::fail(FIB_ERR_INVALID, "unknown mask dtype %d", mask_dtype);
-        }
-        if (fib::profiling_on()) {
-            fib::profile_add_ms("host_gather", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg1).count());
-            fib::profile_add_ms("host_gather_wait", std::chrono::duration<double, std::milli>(tg1 - tg0).count());
-        }
-        const size_t ib = (size_t)rin * nd * 4 + (size_t)nd;
-        // device buffers of this ring slot: the kernels of chunk k - NBUF have read dev_in, its download has read dev_out
-        if (k >= NBUF) { FIB_HIP(hipStreamWaitEvent(d.s_in, d.e_cmp[b], 0)); FIB_HIP(hipStreamWaitEvent(d.s_cmp, d.e_out[b], 0)); }
-        {
-            fib::ProfScope prof("host_h2d", d.s_in);
-            FIB_HIP(hipMemcpyAsync(d.dev_in[b].p, d.pin_in[b].p, ib, hipMemcpyHostToDevice, d.s_in));
-        }
-        FIB_HIP(hipEventRecord(d.e_in[b], d.s_in));
-        FIB_HIP(hipStreamWaitEvent(d.s_cmp, d.e_in[b], 0));
-        RC(fn(k, o0, nd, reinterpret_cast<const float *>(d.dev_in[b].p), reinterpret_cast<const uint8_t *>(d.dev_in[b].p) + (size_t)rin * nd * 4,
-              reinterpret_cast<float *>(d.dev_out[b].p), d.s_cmp));
-        FIB_HIP(hipEventRecord(d.e_cmp[b], d.s_cmp));
-        FIB_HIP(hipStreamWaitEvent(d.s_out, d.e_cmp[b], 0));
-        {
-            fib::ProfScope prof("host_d2h", d.s_out);
-            FIB_HIP(hipMemcpyAsync(d.pin_out[b].p, d.dev_out[b].p, (size_t)rout * nd * 4, hipMemcpyDeviceToHost, d.s_out));
-        }
-        FIB_HIP(hipEventRecord(d.e_out[b], d.s_out));
-        return FIB_OK;
-    };
-    // [r5] Two host stages side by side: this thread gathers chunk k into the ring and enqueues its upload, kernels and download; a second
-    // thread waits for downloads and scatters them into the caller's arrays (each stage has its own copy pool).  Before, one thread
-    // alternated scatter(k - 2) and gather(k): 47 ms of row copies in a row next to 68 ms of PCIe for fib_gqi_rec 140^3 x 270.
-    // Ring slot b = k % NBUF of the OUTPUT side is free for chunk k once chunk k - NBUF has been scattered.
-    {
-        std::mutex mu;
-        std::condition_variable cv;
-        int enq = 0, scat = 0;                               // chunks enqueued by this thread | scattered by the other
-        bool stop = false;
-        std::string smsg;
-        std::thread ts([&] {
-            try {
-                (void)hipSetDevice(d.device);
-                for (int k = 0; k < nchunks; k++) {
-                    { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return enq > k || stop; }); if (enq <= k) break; }
-                    scatter(k);
-                    if (err != FIB_OK) smsg = fib_last_error();                // (the message is thread-local: hand it over)
-                    { std::lock_guard<std::mutex> lk(mu); scat = k + 1; }
-                    cv.notify_all();
-                    if (err != FIB_OK) break;
-                }
-            } catch (...) { err = FIB_ERR_INVALID; smsg = "internal error in the scatter stage"; std::lock_guard<std::mutex> lk(mu); scat = nchunks; cv.notify_all(); }
-        });
-        for (int k = 0; k < nchunks && err == FIB_OK; k++) {
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return scat >= k - NBUF + 1 || err != FIB_OK; }); }
-            if (err != FIB_OK) break;
-            const int rc = enqueue(k);
-            if (rc != FIB_OK) { err = rc; break; }
-            { std::lock_guard<std::mutex> lk(mu); enq = k + 1; }
-            cv.notify_all();
-        }
-        { std::lock_guard<std::mutex> lk(mu); stop = true; }
-        cv.notify_all();
-        ts.join();
-        if (err != FIB_OK && !smsg.empty()) fib::set_error("%s", smsg.c_str());
-    }
-    // leave the streams idle whatever happened (the ring buffers are reused by the next call)
-    (void)hipStreamSynchronize(d.s_in); (void)hipStreamSynchronize(d.s_cmp); (void)hipStreamSynchronize(d.s_out);
-    return err;
-}
-
-// contiguous slab of voxels for worker i of n (the reference's z-slice blocks, here at 4-voxel granularity so that rows
-// stay 16-byte aligned on the device)
-void slab(int64_t nvox, int n, int i, int64_t &v0, int64_t &v1) {
-    const int64_t q = (nvox + 3) / 4, per = q / n, rem = q % n;
-    const int64_t a = per * i + std::min<int64_t>(i, rem), b = a + per + (i < rem ? 1 : 0);
-    v0 = std::min(a * 4, nvox); v1 = std::min(b * 4, nvox);
+    HipDev dev{d, fn};
+    const char *ent = fib::env("FIBERS_HOST_NT");        // streaming stores in the row copies: on unless FIBERS_HOST_NT=0
+    const bool nt = !(ent && ent[0] == '0');
+    return fibh::run_chunks(dev, *d.pool, *d.pool_out, vbeg, vend, nvox, ins, mask, mask_dtype, outs, chunk, lm, outputs_zeroed, nt);
 }
 
 // runs job(worker index, worker) on every worker of the set, one host thread each; the first error wins

@@ -92,7 +92,9 @@ struct fib_odf_plan {
     mutable fib::DevBuf<unsigned> compact_mode;              // .. and the unit of the next calls [2] (mask_compact_kernel)
     mutable fib::DevBuf<unsigned long long> compact_oct;     // .. which octets hold a voxel inside the mask (granules of 32 octets), for the clearing workgroups
     mutable unsigned compact_epoch = 0;              // .. and the call counter they are tagged with
-    fib::DevBuf<unsigned> tickets;                   // [4]: chunk dispenser of mask_compact_kernel, arrival counter of odf_post_kernel (both 0 between calls)
+    fib::DevBuf<unsigned> tickets;                   // [4]: chunk dispenser of mask_compact_kernel, arrival counter of odf_post_kernel (both 0 between calls), odf_post_kernel's divisor granule
+    fib::DevBuf<unsigned> selctr;                    // [2] head / tail of odf_post_kernel's list of voxels whose exact mean is wanted (0 between calls)
+    fib::DevBuf<unsigned long long> sellist;         // [POST_SELCAP] its entries, tagged with the call's epoch
     mutable fib::DevBuf<float> odfmax;
 };
 
@@ -297,6 +299,10 @@ int finish_plan(fib_odf_plan *p, const float *verts, int nverts, const int32_t *
     if ((rc = p->live_counts.alloc(4)) != FIB_OK) return rc;
     if ((rc = p->tickets.alloc(4)) != FIB_OK) return rc;
     FIB_HIP(hipMemset(p->tickets.p, 0, 4 * sizeof(unsigned)));
+    if ((rc = p->selctr.alloc(2)) != FIB_OK) return rc;
+    FIB_HIP(hipMemset(p->selctr.p, 0, 2 * sizeof(unsigned)));
+    if ((rc = p->sellist.alloc(POST_SELCAP)) != FIB_OK) return rc;
+    FIB_HIP(hipMemset(p->sellist.p, 0, POST_SELCAP * sizeof(unsigned long long)));
     if ((rc = p->odfmax.alloc(2)) != FIB_OK) return rc;
     FIB_HIP(hipMemcpy(p->At.p, At.data(), At.size() * sizeof(float), hipMemcpyHostToDevice));
     FIB_HIP(hipMemcpy(p->effbits.p, effbits.data(), effbits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -756,12 +762,13 @@ extern "C" int fibd_odf_rec(const fib_odf_plan *plan, const float *dwi, const ui
         pa.G = (fused_scan && ga.fix_list) ? plan->Gdev.p : nullptr; pa.S = dwi; pa.out = odf; pa.M = plan->gM; pa.K = plan->gK;
         pa.refine = RefineArgs{odf, nvox, nvox, plan->nvert, plan->live_vox.p, plan->live_counts.p, plan->mean_hi.p, plan->maxenc.p};
         pa.arrive = plan->tickets.p + 1; pa.odfmax = om; pa.raw = (flags & FIB_ODF_RAW_ODFMAX) ? 1 : 0;
+        pa.selctr = plan->selctr.p; pa.sellist = plan->sellist.p; pa.selcap = POST_SELCAP; pa.epoch = plan->compact_epoch;
+        if (flags & FIB_ODF_NORMALIZE) {                // [r6] qa ./= odfmax in the same launch (gqi.jl:166-168)
+            for (int k = 0; k < 3; k++) pa.nq[k] = qa[k];
+            pa.nq_n = nvox; pa.done = reinterpret_cast<unsigned long long *>(plan->tickets.p + 2); pa.epoch = plan->compact_epoch;
+        }
+        { const char *e = fib::ab_env("FIBERS_POST_SKIP"); pa.dbg = e ? atoi(e) : 0; }
         hipLaunchKernelGGL(odf_post_kernel, dim3(384), dim3(256), 0, st, pa);
-        FIB_HIP(hipGetLastError());
-    }
-    if (flags & FIB_ODF_NORMALIZE) {
-        fib::ProfScope prof("qa_normalize", st);
-        hipLaunchKernelGGL(qa_normalize_kernel, dim3(2048), dim3(256), 0, st, qa[0], qa[1], qa[2], nvox, om, 0.0f, (flags & FIB_ODF_RAW_ODFMAX) ? 1 : 0);   // launch 4
         FIB_HIP(hipGetLastError());
     }
     return FIB_OK;

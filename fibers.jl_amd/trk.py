@@ -134,8 +134,11 @@ def str_add(tr: Tract, lines) -> Tract:
     return tr
 
 
-def stream_to_trk(outfile, field, shape, seeds, sublist, ref: MRI, stream=None, **kw) -> dict:
-    """GPU path: trace, then let the pack kernel emit the .trk body directly (device tier)."""
+def stream_to_trk(outfile, field, shape, seeds, sublist, ref: MRI, stream=None, timings=None, **kw) -> dict:
+    """GPU path: trace, then let the pack kernel emit the .trk body directly (device tier: fibd_stream_pack_trk, trk.jl:471-482), one
+    download into pinned host memory and one write.  timings (optional dict): perf_counter stamps `device_done` (trace + pack finished)
+    and `file_done`."""
+    import time
     import torch
     from .stream import _params, default_workspace
     from .dti import _stream_ptr, _sync
@@ -152,11 +155,16 @@ def stream_to_trk(outfile, field, shape, seeds, sublist, ref: MRI, stream=None, 
         body = torch.empty(nl.value + 3 * npnt.value, dtype=torch.float32, device=field.device)
         vs = (C.c_float * 3)(*[float(np.float32(v)) for v in ref.volres[:3]])
         _lib.check(L.fibd_stream_pack_trk(job, C.byref(vs), body.data_ptr(), sp))
-        _sync(stream)                                   # the pack ran on `stream`: .cpu() only orders against the current one
-        host = body.cpu().numpy()
+        _sync(stream)                                   # the pack ran on `stream`: a copy only orders against the current one
+        if timings is not None:
+            timings["device_done"] = time.perf_counter()
+        host = torch.empty(body.shape, dtype=torch.float32, pin_memory=True)   # (torch's caching host allocator keeps it for the next call)
+        host.copy_(body)
     finally:
         L.fib_stream_job_destroy(job)
     with open(outfile, "wb") as fh:
         fh.write(tract_header(ref, n_count=nl.value))
-        fh.write(host.tobytes())
+        fh.write(memoryview(host.numpy()).cast("B"))
+    if timings is not None:
+        timings["file_done"] = time.perf_counter()
     return dict(nlines=nl.value, npoints=npnt.value)

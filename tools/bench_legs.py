@@ -68,7 +68,7 @@ def in_kernel_clock(ctx):
     build (libfibers_hip_stamp.so: one s_memtime / s_memrealtime pair around each workgroup's work loop) and runs the GQI and DSI
     steps for 2 s each; the product library never executes a stamp"""
     if not os.path.exists(os.path.join(ROOT, "fibers.jl_amd", "libfibers_hip_stamp.so")) or ctx.shape != (140, 140, 140):
-        return dict(error="no diagnostic build / reduced shape")
+        return dict(skipped=1)                                                   # (no diagnostic build / reduced shape)
     o = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_clock.py"), "--seconds", "2.0", "--kernels", "fused,dsi"],
                        capture_output=True, text=True, timeout=300)
     kc = json.loads([ln for ln in o.stdout.splitlines() if ln.startswith("{")][-1])
@@ -432,3 +432,15 @@ def c5(ctx):
         except Exception as e:                                                  # noqa: BLE001
             res["stream_dsi_3peaks_10M"]["enqueue_form"] = dict(error=str(e))
     return res
+
+
+def pipeline(ctx):
+    """the drop-in path file to file on the tutorial's shape (tools/pipeline.py): .nii (mmap) -> dti_fit + gqi_rec -> tracking on eigvec1 / FA
+    and on GQI peaks / QA -> .trk through the GPU serialiser, wall time per stage; host_path_*: the same with a volume read into memory,
+    fib_stream into host arrays and the NumPy trk_write.  The two ways' .trk files are compared byte for byte."""
+    import pipeline as pl
+    shape = pl.TUTORIAL_SHAPE if ctx.shape == (140, 140, 140) else (ctx.shape[0], ctx.shape[1], max(4, ctx.shape[2] * 92 // 140))
+    r = pl.measure(shape, ctx.dev)
+    if not r["trk_files_identical"]:
+        raise RuntimeError("the device and host paths wrote different .trk files")
+    return r

@@ -22,9 +22,20 @@ if what == "gqi":
     bval, bvec = phantom.scheme_gqi()
     dwi, _ = phantom.make_dwi_torch(SHAPE, bval, bvec, 3, dev)
     plan = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642)
+    if os.environ.get("PROF_SLAB"):                         # rank 0 of 8's z-slab through the sharded driver (no collective with one rank)
+        from fibers_jl_amd import dist as fd
+        z0, z1 = fd.slab_bounds(140, 8, 0, 19600)
+        ns = (z1 - z0) * 19600
+        counts8 = [(b - a) * 19600 for a, b in (fd.slab_bounds(140, 8, r, 19600) for r in range(8))]
+        dwi_s, mask_s = dwi[:, :ns].contiguous(), mask[:ns].contiguous()
+        out = fj.odf_rec_device(plan, dwi_s, mask_s, normalize=False)
+        for _ in range(steps):
+            fd.odf_rec_sharded(plan, dwi_s, mask_s, out=out, counts=counts8, out_prezeroed=bool(os.environ.get("PROF_PREZEROED")))
+        torch.cuda.synchronize()
+        sys.exit(0)
     out = fj.odf_rec_device(plan, dwi, mask)
     for _ in range(steps):
-        fj.odf_rec_device(plan, dwi, mask, out=out)
+        fj.odf_rec_device(plan, dwi, mask, out=out, out_prezeroed=bool(os.environ.get("PROF_PREZEROED")))
 elif what == "dsi":
     bval, bvec = phantom.scheme_dsi()
     dwi, _ = phantom.make_dwi_torch(SHAPE, bval, bvec, 5, dev)
