@@ -4,7 +4,7 @@ Host-side mirror of the reference's exported surface for that path (same names, 
 error behaviour): `MRI`, `ODF`, `sphere_362/642/724`, `DTI`, `dti_fit`, `adc_fit`, ... on top of the
 C ABI in include/fibers_hip.h.  All compute happens in libfibers_hip.so (hand-written HIP); there is
 no CPU path in this package."""
-from ._lib import DEVICE_ALL, FibersError, LIB_PATH, init, lib, shutdown  # noqa: F401
+from ._lib import DEVICE_ALL, FibersError, LIB_PATH, init, lib, shutdown, trim  # noqa: F401
 from .mri import MRI  # noqa: F401
 from .odf import ODF, sphere_362, sphere_642, sphere_724  # noqa: F401
 from .dti import DTI, DtiPlan, adc_fit, adc_fit_device, dti_fit, dti_fit_device  # noqa: F401

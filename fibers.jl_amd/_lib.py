@@ -92,6 +92,7 @@ _PROTOS = {
     "fibd_stream_all_npts": (i32, [vp, vp, vp]),
     "fib_stream_job_destroy": (None, [vp]),
     "fib_init": (i32, [i32, vp]),
+    "fib_trim": (i32, []),
     "fib_shutdown": (None, []),
     "fib_dti_fit": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, C.POINTER(DtiOut)]),
     "fib_adc_fit": (i32, [i32, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp]),
@@ -158,6 +159,12 @@ def init(devices=None):
 
 def shutdown():
     lib().fib_shutdown()
+
+
+def trim():
+    """fib_trim: the host tier's buffers kept between calls (pinned ring, its device mirror, fib_stream's device buffers, the tracer's
+    workspace) go back to the driver; plans stay"""
+    check(lib().fib_trim())
 
 
 def check(rc):

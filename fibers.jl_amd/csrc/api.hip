@@ -122,7 +122,8 @@ struct PinBuf {                                          // grow-only pinned hos
         n = bytes;
         return FIB_OK;
     }
-    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+    ~PinBuf() { release(); }
 };
 
 struct CachedPlan { std::string key; void *plan = nullptr; int kind = 0; uint64_t stamp = 0; };   // kind 0: dti/adc, 1: odf
@@ -165,6 +166,18 @@ struct DevState {
         pool_out.reset(new CopyPool(nthreads, cpus));
         ready = true;
         return FIB_OK;
+    }
+    // fib_trim: everything this worker keeps BETWEEN calls to make the next call cheap -- the pinned ring and its device mirror, fib_stream's
+    // device buffers (C4: 1.5 GB of points), the tracer's workspace -- goes back to the driver; plans stay (they are small and costly to
+    // rebuild).  The caller holds `mu`: no call is in flight on this worker.
+    void trim() {
+        if (!ready) return;
+        (void)hipSetDevice(device);
+        (void)hipStreamSynchronize(s_in); (void)hipStreamSynchronize(s_cmp); (void)hipStreamSynchronize(s_out);
+        for (int b = 0; b < NBUF; b++) { pin_in[b].release(); pin_out[b].release(); dev_in[b].release(); dev_out[b].release(); }
+        sb.vec.release(); sb.f.release(); sb.fa.release(); sb.field.release(); sb.sub.release(); sb.lcms.release(); sb.xyz.release();
+        sb.mask.release(); sb.mout.release(); sb.flags.release(); sb.seeds.release(); sb.sidx.release(); sb.npts.release();
+        if (ws) { fibd_stream_ws_destroy(ws); ws = nullptr; }
     }
     void drop_plans() {
         for (auto &c : plans) {
@@ -356,6 +369,15 @@ extern "C" int fib_init(int ndev, const int *devs) try {
     c.devs.clear();
     const int n = ndev > 0 ? ndev : have;
     for (int i = 0; i < n; i++) { c.devs.emplace_back(new DevState()); c.devs.back()->device = ndev > 0 ? devs[i] : i; }
+    return FIB_OK;
+} FIB_API_CATCH
+
+extern "C" int fib_trim(void) try {
+    HostCtx &c = ctx();
+    std::lock_guard<std::mutex> lk(c.mu);
+    fib::DeviceGuard guard;
+    for (auto *set : {&c.devs, &c.single})
+        for (auto &d : *set) { std::lock_guard<std::mutex> lk2(d->mu); d->trim(); }     // (waits for a call in flight on that worker)
     return FIB_OK;
 } FIB_API_CATCH
 

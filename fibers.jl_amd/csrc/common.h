@@ -68,9 +68,10 @@ struct DevBuf {  // RAII device allocation
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// Environment variables.  The product library reads FIVE names, none of which selects a kernel variant: FIBERS_ODF_FORMAT (what
-// FIB_ODF_FORMAT_DEFAULT means: fp16x2 | bf16x3 | f32 -- the format itself is a plan-creation parameter) and the host tier's pipeline
-// shape (FIBERS_HOST_CHUNK, FIBERS_HOST_PACK, FIBERS_COPY_THREADS), through env() below.  The A/B partners of the shipped kernels
+// Environment variables.  The product library reads these names, none of which selects a kernel variant: FIBERS_ODF_FORMAT (what
+// FIB_ODF_FORMAT_DEFAULT means: fp16x2 | bf16x3 | f32 -- the format itself is a plan-creation parameter; its former spellings
+// FIBERS_ODF_GEMM=f32 / FIBERS_ODF_EXACT=1 are still honoured) and the host tier's pipeline shape (FIBERS_HOST_CHUNK, FIBERS_HOST_PACK,
+// FIBERS_COPY_THREADS, FIBERS_HOST_NT), through env() below.  The A/B partners of the shipped kernels
 // and the knobs of the measurement tools (schedule variants, the split of an XCD's workgroups, the list unit, the phase stamps) exist
 // in the DIAGNOSTIC build only (`make stamp`: -DFIB_CLOCK_STAMP -DFIB_AB_VARIANTS -> libfibers_hip_stamp.so, which tools/ load
 // through FIBERS_HIP_LIB): ab_env() is a constant nullptr in the product.

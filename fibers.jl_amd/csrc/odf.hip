@@ -3,7 +3,7 @@
 //   K2/K5  odf_gemm3_kernel  O[M x Nvox] = A[M x K] * clamp(S[K x Nvox]) as an exact f32 contraction on the bf16 matrix
 //                            cores (three bf16 pieces per operand, v_mfma_f32_32x32x16_bf16; default), with the DSI
 //                            antipodal fold fused into the sample load (FOLD)
-//          odf_gemm_kernel   the same contraction on v_mfma_f32_32x32x2_f32 (FIBERS_ODF_GEMM=f32 and every plan the
+//          odf_gemm_kernel   the same contraction on v_mfma_f32_32x32x2_f32 (format f32 -- FIBERS_ODF_FORMAT=f32 -- and every plan the
 //                            split kernel does not take)
 //                            (gqi.jl:139-145 `mul!(o, A, s)`; dsi.jl:204-246 recast as two dense maps)
 //          mask_compact_kernel, odf_post_kernel, odf_inf_fix_kernel: voxel-list compaction + outputs outside the mask (one launch),
@@ -68,7 +68,7 @@ struct fib_odf_plan {
     fib::DevBuf<float> Gdev;                         // G, column-major [gM x gK] (odf_inf_fix_kernel)
     mutable fib::DevBuf<int32_t> inf_list;           // [nvox] voxels with a +Inf sample (GQI, split-bf16 kernel; grow-only)
     bool split_bf16 = false;
-    bool h2 = false;                                 // .. with two fp16 pieces per element (default) instead of three bf16 pieces (FIBERS_ODF_EXACT=1)
+    bool h2 = false;                                 // .. with two fp16 pieces per element (default) instead of three bf16 pieces (format bf16x3)
     float h2_sa = 1.0f;                              // power of two the matrix is scaled by before it is split into fp16 pieces
     bool fused_shape = false;                        // (GQI, 10 blocks + 1 extra row: the shape the fused scan is generated for)
     bool fused = false;                              // sphere_642 GQI plan: the contraction kernel finds the peaks on its accumulators
@@ -102,9 +102,15 @@ namespace {
 
 
 // FIB_ODF_FORMAT_DEFAULT -> what the environment asks for (FIBERS_ODF_FORMAT = fp16x2 | bf16x3 | f32), else two fp16 pieces
+// (the names rounds 2-4 used, FIBERS_ODF_GEMM=f32 and FIBERS_ODF_EXACT=1, are honoured: a stale setup must not change numerics silently)
 int resolve_format(int format) {
     if (format != FIB_ODF_FORMAT_DEFAULT) return format;
     const char *e = fib::env("FIBERS_ODF_FORMAT");
+    if (!e) {
+        const char *g = fib::env("FIBERS_ODF_GEMM"), *x = fib::env("FIBERS_ODF_EXACT");
+        if (g && (!strcmp(g, "f32") || !strcmp(g, "F32"))) return FIB_ODF_FORMAT_F32;
+        if (x && x[0] != '\0' && x[0] != '0') return FIB_ODF_FORMAT_BF16X3;
+    }
     if (e && (!strcmp(e, "f32") || !strcmp(e, "F32"))) return FIB_ODF_FORMAT_F32;
     if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "BF16X3"))) return FIB_ODF_FORMAT_BF16X3;
     return FIB_ODF_FORMAT_FP16X2;

@@ -1281,12 +1281,13 @@ namespace {
 bool field_is_wide(const fib_stream_params *prm) {
     return (int64_t)prm->nx * prm->ny * prm->nz * prm->nvec >= ((int64_t)1 << 28) || fib::ab_env("FIBERS_STREAM_WIDE") != nullptr;
 }
-// the one-lane-per-line tracer for (LCM, TRI); the vector count is a compile-time constant for 1 and 3 vectors per voxel, wide
+// the one-lane-per-line tracer for (LCM, TRI); the vector count is a compile-time constant for 1, 2 and 3 vectors per voxel, wide
 // fields take the run-time count (one instantiation per mode)
 template <bool LCM, bool TRI>
 void launch_trace(const TraceArgs &ta, int nvec, bool wide, unsigned grid, hipStream_t st) {
     if (wide)           hipLaunchKernelGGL((stream_trace_kernel<0, LCM, TRI, true>), dim3(grid), dim3(256), 0, st, ta);
     else if (nvec == 1) hipLaunchKernelGGL((stream_trace_kernel<1, LCM, TRI>), dim3(grid), dim3(256), 0, st, ta);
+    else if (nvec == 2) hipLaunchKernelGGL((stream_trace_kernel<2, LCM, TRI>), dim3(grid), dim3(256), 0, st, ta);
     else if (nvec == 3) hipLaunchKernelGGL((stream_trace_kernel<3, LCM, TRI>), dim3(grid), dim3(256), 0, st, ta);
     else                hipLaunchKernelGGL((stream_trace_kernel<0, LCM, TRI>), dim3(grid), dim3(256), 0, st, ta);
 }
@@ -1646,13 +1647,13 @@ static int stream_run_impl(const fib_stream_params *prm, const float *field4, co
     ta.norm_generic = fib::ab_env("FIBERS_STREAM_NORM_GENERIC") != nullptr;
     { const char *e = fib::ab_env("FIBERS_STREAM_DBG"); ta.dbg = e ? std::atoi(e) : 0; }
     const unsigned grid = (unsigned)fib::cdiv(nl, 256);
-    // [r5] FUSED (fused_pack_block): trace + look-back + pack in ONE launch, for nearest-voxel tracking with 1 or 3 vectors per voxel on fields
+    // [r5] FUSED (fused_pack_block): trace + look-back + pack in ONE launch, for nearest-voxel tracking with 1, 2 or 3 vectors per voxel on fields
     // below 2^28 vectors whose lines fit a 16-line LDS tile (len_max <= ~200) -- from 2^21 lines on: the fused kernel wins by overlapping
     // workgroups that pack with workgroups that still trace, which needs several rounds of workgroups per CU (measured, tools/stream_fused_ab.py:
     // 9.96 M lines x 3 vectors 9.7-10.6 ms against 11.5-11.8; 1 M lines 1.05-1.17 ms against 1.09-1.13: two rounds, no steady state).
     // Everything else takes the three launches below.  (Diagnostic build: FIBERS_STREAM_UNFUSED=1 / FIBERS_STREAM_FUSED=1 force either.)
     const size_t fsmem = std::max(((size_t)FUSED_TILE * stride * 3 + FUSED_TILE + 8) * sizeof(float), (size_t)(FUSED_BLOCK / 16) * 4 * SCR_SLOT_FLOATS * sizeof(float));   // the pack's tile buffer; the trace loop parks four trips of points there
-    const bool fused_ok = !wide && !prm->interp && (prm->nvec == 1 || prm->nvec == 3) && fsmem <= 40 * 1024 &&
+    const bool fused_ok = !wide && !prm->interp && prm->nvec >= 1 && prm->nvec <= 3 && fsmem <= 40 * 1024 &&
                           nl < ((int64_t)1 << 26) && nl * (int64_t)(prm->len_max + 2) < ((int64_t)1 << 36) && b_excl >= ((size_t)fib::cdiv(nl, FUSED_BLOCK) + 1) * sizeof(unsigned long long);
     const bool fused = fused_ok && fib::ab_env("FIBERS_STREAM_UNFUSED") == nullptr && (nl >= ((int64_t)1 << 21) || fib::ab_env("FIBERS_STREAM_FUSED") != nullptr);
     if (fused) {
@@ -1662,15 +1663,16 @@ static int stream_run_impl(const fib_stream_params *prm, const float *field4, co
         ta.lines_cap = lines_cap; ta.points_cap = points_cap; ta.len_min = prm->len_min;
         if (hipMemsetAsync(ta.fstate, 0, ((size_t)fgrid + 1) * sizeof(unsigned long long), st) != hipSuccess)      // (+ the ticket counter behind the granules)
             return release(fib::fail(FIB_ERR_HIP, "hipMemsetAsync failed"));
-        if (fsmem > 48 * 1024) {
-            const void *fk = prm->nvec == 1 ? reinterpret_cast<const void *>(stream_trace_kernel<1, false, false, false, true>)
-                                            : reinterpret_cast<const void *>(stream_trace_kernel<3, false, false, false, true>);
-            if (hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsmem) != hipSuccess)
-                return release(fib::fail(FIB_ERR_HIP, "hipFuncSetAttribute failed"));
-        }
+        // [r6] one code path per vector count 1..3 (DTI e1 | e1 + e2 or two peaks | three peaks)
+        const void *fk = prm->nvec == 1 ? reinterpret_cast<const void *>(stream_trace_kernel<1, false, false, false, true>)
+                       : prm->nvec == 2 ? reinterpret_cast<const void *>(stream_trace_kernel<2, false, false, false, true>)
+                                        : reinterpret_cast<const void *>(stream_trace_kernel<3, false, false, false, true>);
+        if (fsmem > 48 * 1024 && hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsmem) != hipSuccess)
+            return release(fib::fail(FIB_ERR_HIP, "hipFuncSetAttribute failed"));
         fib::ProfScope prof("stream_trace", st);
-        if (prm->nvec == 1) hipLaunchKernelGGL((stream_trace_kernel<1, false, false, false, true>), dim3(fgrid), dim3(FUSED_BLOCK), fsmem, st, ta);
-        else                hipLaunchKernelGGL((stream_trace_kernel<3, false, false, false, true>), dim3(fgrid), dim3(FUSED_BLOCK), fsmem, st, ta);
+        if (prm->nvec == 1)      hipLaunchKernelGGL((stream_trace_kernel<1, false, false, false, true>), dim3(fgrid), dim3(FUSED_BLOCK), fsmem, st, ta);
+        else if (prm->nvec == 2) hipLaunchKernelGGL((stream_trace_kernel<2, false, false, false, true>), dim3(fgrid), dim3(FUSED_BLOCK), fsmem, st, ta);
+        else                     hipLaunchKernelGGL((stream_trace_kernel<3, false, false, false, true>), dim3(fgrid), dim3(FUSED_BLOCK), fsmem, st, ta);
     } else {
     {
         fib::ProfScope prof("stream_trace", st);

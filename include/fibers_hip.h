@@ -347,7 +347,13 @@ void fib_stream_job_destroy(fib_stream_job *job);
  * pipeline over voxel chunks (pinned staging ring: upload || kernels || download), and caches its plans and buffers
  * between calls; calls that share an entry are serialised, calls on different entries run concurrently.
  * fib_init(ndev, devs): devs[i] may repeat (two pipelines on one GPU); ndev == 0 selects every visible device (also
- * the default of FIB_DEVICE_ALL without fib_init).  fib_shutdown releases every cached plan, stream and buffer. */
+ * the default of FIB_DEVICE_ALL without fib_init).  fib_shutdown releases every cached plan, stream and buffer.
+ * What a worker KEEPS between calls (grow-only, so that the next call of the same size allocates nothing): its pinned staging ring and the
+ * ring's device mirror (3 x (rows in + rows out) x chunk x 4 bytes each: ~1.9 GB of host and of device memory after fib_gqi_rec on 270
+ * frames), the device buffers of fib_stream (orientation field, seeds, and the packed result: 1.5 GB after 129 M points) and the tracer's
+ * workspace (scratch for every line in flight).  A process that shares the GPU with other users of its memory calls fib_trim() when it
+ * is done with a batch: everything listed above goes back to the driver (plans are kept: small, and costly to rebuild), the next call
+ * re-allocates what it needs.  fib_trim waits for calls in flight; it returns FIB_OK. */
 #define FIB_DEVICE_ALL (-1)
 /* May be OR-ed into the mask_dtype of fib_dti_fit / fib_adc_fit / fib_gqi_rec / fib_dsi_rec: the caller's output arrays are zero already
  * (freshly allocated -- what the reference does itself: MRI(mask, n, Float32) -> zeros, mri.jl:251-255).  Voxels outside the mask
@@ -356,6 +362,7 @@ void fib_stream_job_destroy(fib_stream_job *job);
  * third of the bytes.  Without the flag every output voxel is written (outside the mask: 0). */
 #define FIB_MASK_OUTPUTS_ZEROED 0x100
 int fib_init(int ndev, const int *devs);
+int fib_trim(void);
 void fib_shutdown(void);
 
 /* dti_fit(dwi::MRI, mask::MRI)::DTI (dti.jl:221).  bval/bvec NULL or nvol<=0 reproduce the

@@ -20,6 +20,7 @@ const FIB_MASK_OUTPUTS_ZEROED = Cint(0x100)
 # fib_init the set is every visible GPU.  Results do not depend on the set.
 const FIB_DEVICE_ALL = Cint(-1)
 fib_init(devs::Vector{<:Integer}=Int[]) = fib_check(ccall((:fib_init, libfibers), Cint, (Cint, Ptr{Cint}), length(devs), Cint.(devs)))
+fib_trim() = ccall((:fib_trim, libfibers), Cint, ())          # buffers kept between calls go back to the driver (plans stay)
 fib_shutdown() = ccall((:fib_shutdown, libfibers), Cvoid, ())
 
 function fib_check(rc::Cint)

@@ -231,7 +231,7 @@ def test_two_ranks_with_device_kernels_match_one_rank_bit_for_bit():
     [p.start() for p in procs]
     res = [q.get(timeout=600) for _ in range(world)]
     [p.join(timeout=60) for p in procs]
-    assert all(r[1] == "ok" for r in res), res
+    assert all(r[1] == "ok" for r in res), "\n".join("rank %s: %s" % (r[0], r[1]) for r in sorted(res))
 
 
 def test_bench_rccl_branch_with_one_rank():

@@ -332,3 +332,29 @@ def test_errors_come_back_as_codes_not_exceptions(fj):
     finally:
         fj.shutdown()
     _same_gqi(fj.gqi_rec(dwi, mask), fj.gqi_rec(dwi, mask))      # still works afterwards
+
+
+def test_fib_trim_returns_the_kept_buffers_and_the_next_call_is_unaffected(fj):
+    """fib_trim (the host tier kept GBs of HBM between calls with no way to give them back): the pinned ring's device mirror,
+    fib_stream's device buffers and the tracer's workspace go back to the driver, plans stay; the next calls re-allocate and return the
+    same results (outputs allocated zero-filled by the caller, mri.jl:249-265)."""
+    import torch
+    from fibers_jl_amd import phantom
+    bval, bvec = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3)
+    dwi, _, _ = phantom.make_volume((16, 16, 12), bval, bvec, seed=3)
+    big = np.asfortranarray(np.tile(dwi, (3, 3, 3, 1)))
+    mask = np.ones(big.shape[:3], np.uint8)
+    g1 = fj.gqi_rec(fj.MRI(big, bval, bvec), fj.MRI(mask))
+    ov = np.asfortranarray(phantom.fibre_field(24, 24, 24).astype(np.float32))
+    sub = np.array([[0.1, -0.2, 0.3]], np.float32)
+    t1 = fj.stream(fj.MRI(ov), mask=fj.MRI(np.ones((24, 24, 24), np.uint8)), sublist=sub)
+    torch.cuda.synchronize()
+    held = torch.cuda.mem_get_info()[0]
+    fj.trim()
+    freed = torch.cuda.mem_get_info()[0] - held
+    assert freed > 100 << 20, freed                                            # the ring's device mirror alone is several hundred MB
+    fj.trim()                                                                  # (idempotent)
+    g2 = fj.gqi_rec(fj.MRI(big, bval, bvec), fj.MRI(mask))
+    t2 = fj.stream(fj.MRI(ov), mask=fj.MRI(np.ones((24, 24, 24), np.uint8)), sublist=sub)
+    assert np.array_equal(g1.odf.vol, g2.odf.vol) and all(np.array_equal(a.vol, b.vol, equal_nan=True) for a, b in zip(g1.qa, g2.qa))
+    assert np.array_equal(t1.npts, t2.npts) and np.array_equal(t1.xyz, t2.xyz)

@@ -531,6 +531,54 @@ def test_gqi_and_dsi_randomised_configurations(fj, orc, case, monkeypatch):
                    label="dsi case %d" % case)
 
 
+@pytest.mark.parametrize("kind", ["gqi", "dsi"])
+def test_normalisation_inside_the_post_kernel_matches_the_separate_launch(fj, kind):
+    """[r6] FIB_ODF_NORMALIZE runs inside odf_post_kernel (the last workgroup to arrive publishes the divisor, every workgroup divides
+    its share of qa).  Voxels on the redo list (NaN / Inf samples, candidate-list overflow) get their qa from one workgroup and have it
+    divided by another -- possibly on another XCD: bit-identical to `normalize=False` + fibd_qa_normalize_dev, over many volumes whose
+    poisoned voxels sit in different places; and the drain list of the exact-mean refinement at and beyond its capacity (a volume of
+    identical voxels: every voxel is a candidate for the maximum).  gqi.jl:164-168 / dsi.jl:263-267."""
+    import torch
+    from fibers_jl_amd import phantom
+    dev = torch.device("cuda", 0)
+    shape = (24, 20, 14)
+    nvox = shape[0] * shape[1] * shape[2]
+    bval, bvec = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3) if kind == "gqi" else phantom.scheme_dsi()
+    plan = fj.OdfPlan(kind, bval, bvec, fj.sphere_642)
+    base, _ = phantom.make_dwi_torch(shape, bval, bvec, seed=6, device=dev, noise_frac=0.05)
+    mask = torch.ones(nvox, dtype=torch.uint8, device=dev)
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    for trial in range(12):
+        d = base.clone()
+        npo = [0, 1, 7, 40][trial % 4]
+        if npo:
+            vox = torch.randint(0, nvox, (npo,), device=dev, generator=g)
+            frm = torch.randint(0, len(bval), (npo,), device=dev, generator=g)
+            d[frm, vox] = float("inf") if trial % 3 else float("nan")
+        if trial == 11:                                         # identical voxels: every mean is the maximum (list capacity 2048 < 6720 voxels)
+            d = base[:, :1].repeat(1, nvox).contiguous()
+        a = fj.odf_rec_device(plan, d, mask, normalize=True)
+        torch.cuda.synchronize()
+        a = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in a.items()}
+        b = fj.odf_rec_device(plan, d, mask, normalize=False)
+        fj.qa_normalize_device(b["qa"], b["odfmax"])
+        torch.cuda.synchronize()
+        nn = lambda t: t.nan_to_num(nan=-7.0, posinf=-8.0, neginf=-9.0)      # noqa: E731
+        assert torch.equal(nn(a["odfmax"]), nn(b["odfmax"])), (trial, a["odfmax"], b["odfmax"])
+        for k in range(3):
+            assert torch.equal(nn(a["qa"][k]), nn(b["qa"][k])), (trial, k)
+            assert torch.equal(nn(a["peak"][k]), nn(b["peak"][k])), (trial, k)
+        assert torch.equal(nn(a["odf"]), nn(b["odf"]))
+        if npo == 0 and trial != 11:
+            assert float(a["odfmax"][1]) == 0.0 and float(a["qa"][0].max()) > 0
+        if trial == 11:
+            ref = b["odf"][:, 0].cpu().numpy()
+            s = np.float32(0)
+            for x in ref:
+                s = np.float32(s + x)                          # mean(odf, dims=4): sequential float32 sum over the vertices, ./ n (gqi.jl:164)
+            assert float(a["odfmax"][0]) == float(np.float32(s / np.float32(len(ref))))
+
+
 def test_qa_normalize_with_device_scalar(fj):
     """fibd_qa_normalize_dev: the divisor comes from device memory (the all-reduced odfmax of the multi-GPU flow)"""
     import torch

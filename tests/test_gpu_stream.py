@@ -1,6 +1,8 @@
 """Parity: HIP streamline tractography (through the C ABI) vs the CPU oracle.  Reference: stream.jl:74-193,
 340-374, 501-541, 625-690, 730-790.  Both sides use IEEE single/double operations in the reference's order
 with no contraction, so lines are compared EXACTLY (counts, order and coordinates)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -124,16 +126,15 @@ def test_stream_pack_paths_agree(fj, orc, len_max, nvec):
     kw = dict(len_max=len_max, ang_thresh=60 if len_max == 3000 else 45)
     ref = orc.stream(ovs if nvec > 1 else ovs[0], sub, mask=mask, nthreads=4, **kw)
     res = []
-    for env in ({},):
-        for shift in range(4):
-            out = fj.stream_device(field, (n, n, n), seeds, subd, xyz_out=lambda npnt: torch.full((3 * npnt + 8,), -7.0, device="cuda")[shift:], **kw)
-            torch.cuda.synchronize()
-            assert np.array_equal(out["npts"].cpu().numpy(), ref["npts"]), (env, shift)
-            assert np.array_equal(out["seed_index"].cpu().numpy(), ref["seed_index"]), (env, shift)
-            assert np.array_equal(out["xyz"].cpu().numpy(), ref["xyz"]), (env, shift)
-            base = out["xyz"].untyped_storage()
-            full = torch.empty(0, dtype=torch.float32, device="cuda").set_(base)
-            assert float(full[:shift].sum()) == -7.0 * shift and bool((full[shift + out["xyz"].numel():] == -7.0).all()), "wrote outside the range"
+    for shift in range(4):
+        out = fj.stream_device(field, (n, n, n), seeds, subd, xyz_out=lambda npnt: torch.full((3 * npnt + 8,), -7.0, device="cuda")[shift:], **kw)
+        torch.cuda.synchronize()
+        assert np.array_equal(out["npts"].cpu().numpy(), ref["npts"]), shift
+        assert np.array_equal(out["seed_index"].cpu().numpy(), ref["seed_index"]), shift
+        assert np.array_equal(out["xyz"].cpu().numpy(), ref["xyz"]), shift
+        base = out["xyz"].untyped_storage()
+        full = torch.empty(0, dtype=torch.float32, device="cuda").set_(base)
+        assert float(full[:shift].sum()) == -7.0 * shift and bool((full[shift + out["xyz"].numel():] == -7.0).all()), "wrote outside the range"
 
 
 def _micro_case(n, seed):
@@ -418,6 +419,20 @@ def test_stream_angle_inputs_lcm_exact(fj, orc):
 
 
 # ---- fibd_stream_run: trace, scan and pack in one call into caller-kept buffers ---------------------------------------------------------
+def test_stream_fused_form_on_small_inputs_with_the_diagnostic_build():
+    """the fused trace + look-back + pack kernel (the product uses it from 2^21 lines on) forced on small inputs in a child process that
+    loads libfibers_hip_stamp.so (tools/stream_fused_check.py): nvec 1, 2, 3, a partial last workgroup, len_min drops, too-small buffers,
+    the enqueue form -- bit-identical to trace + scan + pack (stream.jl:625-690, 769-787)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "fibers.jl_amd", "libfibers_hip_stamp.so")):
+        pytest.skip("the diagnostic build is absent (make -C fibers.jl_amd/csrc stamp)")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("FIBERS_")}
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stream_fused_check.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "stream fused check: ok" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
 @pytest.mark.parametrize("nvec", [1, 2, 3])
 def test_stream_run_matches_trace_plus_pack(fj, nvec):
     """the one-call form returns exactly what fibd_stream_trace + fibd_stream_pack return: same lines, order, seed indices and
