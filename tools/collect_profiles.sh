@@ -3,7 +3,7 @@
 # counters in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc never together with tracing).
 # Output: gpurun_out/prof_<tag>/...; summarise with tools/summarise_profiles.py and copy into profiles/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r06}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -11,10 +11,10 @@ export TMPDIR=/tmp
 # 21 chunks), so that the kernel's average here is comparable with the hipEvent average in the JSON line
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/bench -o bench -- python3 bench.py --no-cpu-baseline --no-extra > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/benchfull -o benchfull -- python3 bench.py --no-cpu-baseline > $OUT/benchfull.json 2> $OUT/benchfull.err
-for what in gqi dti stream dsi; do
+for what in gqi dti stream dsi c5; do
   rocprofv3 --kernel-trace --stats -f csv -d $OUT/$what -o $what -- python3 tools/prof_step.py $what 5 > $OUT/$what.log 2>&1
 done
-for what in gqi dti dsi stream; do
+for what in gqi dti dsi stream c5; do
   rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/${what}_fetch -o fetch -- python3 tools/prof_step.py $what 2 > $OUT/${what}_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE -f csv -d $OUT/${what}_write -o write -- python3 tools/prof_step.py $what 2 > $OUT/${what}_write.log 2>&1
 done

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small driver for rocprofv3: runs N steps of one hot-path stage on resident synthetic data.
-usage: prof_step.py {gqi|dti|stream|dsi} [steps]"""
+usage: prof_step.py {gqi|dti|stream|dsi|c5} [steps]   (c5: BASELINE config 5's tracking -- 3 peaks of a DSI fit, ~10 M lines, the fused kernel)"""
 import os
 import sys
 
@@ -76,5 +76,19 @@ elif what == "stream":
     else:
         for _ in range(steps):
             fj.stream_device(field, SHAPE, seeds, sub)
+elif what == "c5":
+    import numpy as np
+    bval, bvec = phantom.scheme_dsi()
+    dwi, _ = phantom.make_dwi_torch(SHAPE, bval, bvec, 5, dev)
+    plan = fj.OdfPlan("dsi", bval, bvec, fj.sphere_642)
+    o5 = fj.odf_rec_device(plan, dwi, mask)
+    del dwi
+    bm = phantom.ball_mask_torch(SHAPE, dev)
+    field, mout = fj.stream_field_device(o5["peak"], f=o5["qa"], f_thresh=0.03, mask=bm)
+    seeds = torch.nonzero(mout).flatten()
+    sub = torch.from_numpy(fj.make_sublist(10, np.random.default_rng(5))).to(dev)
+    bufs = fj.StreamBuffers(dev)
+    for _ in range(steps + 1):
+        fj.stream_device_run(field, SHAPE, seeds, sub, buffers=bufs)
 torch.cuda.synchronize()
 print("done", what, steps)

@@ -20,7 +20,7 @@ def short(n):
 
 
 lines = []
-for what in ("bench", "benchfull", "gqi", "dti", "stream", "dsi"):
+for what in ("bench", "benchfull", "gqi", "dti", "stream", "dsi", "c5"):
     fs = glob.glob(os.path.join(src, what, "**", "*kernel_stats.csv"), recursive=True)
     if not fs:
         continue
@@ -44,11 +44,17 @@ def pmc(sub):
 
 
 traffic = {}
-for what in ("gqi", "dti", "dsi", "stream"):
+c5_bytes = None
+for what in ("gqi", "dti", "dsi", "stream", "c5"):
     fe, wr = pmc(what + "_fetch"), pmc(what + "_write")
     for k in sorted(set(fe) | set(wr)):
         f = fe.get(k, {}).get("FETCH_SIZE"); w = wr.get(k, {}).get("WRITE_SIZE")
         if f is None and w is None:
+            continue
+        if what == "c5":                                     # the fused tracer on 3 peaks x ~10 M lines: one launch = C5's tracking step
+            if k.startswith("stream_trace_kernel<3") and (f or 0) + (w or 0) > 1e6:
+                c5_bytes = (2.0 * (f or 0) + (w or 0)) * 1024.0
+                traffic["c5: " + k] = dict(FETCH_SIZE_KB=f, WRITE_SIZE_KB=w, hbm_bytes_per_launch=c5_bytes)
             continue
         if (f or 0) + (w or 0) < 1000 or not re.match(r"(odf_|fit_|stream_|dsi_|mask_|zero_|qa_|scan_)", k) or k in traffic:
             continue
@@ -83,7 +89,7 @@ for t in ("gqi_timeline.txt", "gqi_timeline_ball.txt"):
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 gem = [v for k, v in traffic.items() if k.startswith("odf_gemm3_kernel<10, 1, 8, false, true")] or [v for k, v in traffic.items() if k.startswith("odf_gemm")]
 if gem:   # what bench.py reports as roofline.traffic (per launch of the dominant kernel)
-    json.dump({"odf_gemm_bytes_per_launch": gem[0]["hbm_bytes_per_launch"], "source": "profiles/%s/traffic.json" % tag,
+    json.dump({"odf_gemm_bytes_per_launch": gem[0]["hbm_bytes_per_launch"], "stream_c5_bytes_per_step": c5_bytes, "source": "profiles/%s/traffic.json" % tag,
                "note": "FETCH_SIZE*1024*2 (gfx950 correction for wide coalesced reads) + WRITE_SIZE*1024, separate --pmc passes; algorithmic = 6.63e9 (DWI + mask in, ODF + peaks + qa out)",
                "kernels": traffic}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 open(os.path.join(dst, "summary.txt"), "w").write("\n".join(lines) + "\n")
