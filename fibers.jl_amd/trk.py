@@ -134,36 +134,55 @@ def str_add(tr: Tract, lines) -> Tract:
     return tr
 
 
-def _write_parallel(path, header: bytes, body, nthreads: int = 8, piece: int = 32 << 20):
-    """header + body to `path`: one thread copies a large buffer into the page cache at ~4 GB/s, so the body goes out as pieces through
-    os.pwrite from a few threads (the GIL is released inside the call); small bodies take the plain path"""
-    import os
-    from concurrent.futures import ThreadPoolExecutor
-    n = len(body)
-    if n < 2 * piece:
-        with open(path, "wb") as fh:
-            fh.write(header)
-            fh.write(body)
-        return
-    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-    try:
-        os.ftruncate(fd, len(header) + n)
-        os.pwrite(fd, header, 0)
+_STAGE = {}                      # device index -> two pinned staging buffers + a copy stream (kept: allocating pinned memory costs ~50 us per MB)
 
-        def put(o):
+
+def _download_and_write(path, header: bytes, body, piece: int = 32 << 20):
+    """header + a device tensor's bytes to `path`: the body comes down in pieces through two pinned staging buffers while the previous
+    piece goes to the file (a box writes its page cache at ~10 GB/s from one thread and no faster from eight; the download runs at ~50)"""
+    import os
+    import torch
+    dev = body.device
+    st = _STAGE.get(dev.index)
+    if st is None:
+        st = _STAGE[dev.index] = dict(buf=[torch.empty(piece, dtype=torch.uint8, pin_memory=True) for _ in range(2)], stream=torch.cuda.Stream(dev),
+                                      ev=[torch.cuda.Event() for _ in range(2)])
+    raw = body.view(torch.uint8).reshape(-1)
+    n = raw.numel()
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT, 0o644)
+    try:
+        os.pwrite(fd, header, 0)
+        st["stream"].wait_stream(torch.cuda.current_stream(dev))
+        offs = list(range(0, n, piece))
+
+        def issue(k):
+            o = offs[k]
+            with torch.cuda.stream(st["stream"]):
+                st["buf"][k & 1][: min(piece, n - o)].copy_(raw[o: o + piece], non_blocking=True)
+                st["ev"][k & 1].record(st["stream"])
+
+        def drain(k):
+            o = offs[k]
+            m = min(piece, n - o)
+            st["ev"][k & 1].synchronize()
+            view = memoryview(st["buf"][k & 1].numpy())[:m]
             done = 0
-            end = min(n, o + piece)
-            while o + done < end:
-                done += os.pwrite(fd, body[o + done:end], len(header) + o + done)
-        with ThreadPoolExecutor(nthreads) as ex:
-            list(ex.map(put, range(0, n, piece)))
+            while done < m:
+                done += os.pwrite(fd, view[done:], len(header) + o + done)
+        for k in range(len(offs)):
+            issue(k)
+            if k:
+                drain(k - 1)
+        if offs:
+            drain(len(offs) - 1)
+        os.ftruncate(fd, len(header) + n)                # (an existing longer file; the same length is a no-op)
     finally:
         os.close(fd)
 
 
 def stream_to_trk(outfile, field, shape, seeds, sublist, ref: MRI, stream=None, timings=None, **kw) -> dict:
-    """GPU path: trace, then let the pack kernel emit the .trk body directly (device tier: fibd_stream_pack_trk, trk.jl:471-482), one
-    download into pinned host memory and one write.  timings (optional dict): perf_counter stamps `device_done` (trace + pack finished)
+    """GPU path: trace, then let the pack kernel emit the .trk body directly (device tier: fibd_stream_pack_trk, trk.jl:471-482), downloaded
+    in pieces through pinned staging buffers while the previous piece is written.  timings (optional dict): perf_counter stamps `device_done` (trace + pack finished)
     and `file_done`."""
     import time
     import torch
@@ -185,11 +204,9 @@ def stream_to_trk(outfile, field, shape, seeds, sublist, ref: MRI, stream=None, 
         _sync(stream)                                   # the pack ran on `stream`: a copy only orders against the current one
         if timings is not None:
             timings["device_done"] = time.perf_counter()
-        host = torch.empty(body.shape, dtype=torch.float32, pin_memory=True)   # (torch's caching host allocator keeps it for the next call)
-        host.copy_(body)
+        _download_and_write(outfile, tract_header(ref, n_count=nl.value), body)
     finally:
         L.fib_stream_job_destroy(job)
-    _write_parallel(outfile, tract_header(ref, n_count=nl.value), memoryview(host.numpy()).cast("B"))
     if timings is not None:
         timings["file_done"] = time.perf_counter()
     return dict(nlines=nl.value, npoints=npnt.value)
