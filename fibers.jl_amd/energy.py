@@ -58,21 +58,34 @@ def rsmi_index_of(hip_device=0):
     raise RuntimeError("no rocm_smi board at PCI %04x:%02x:%02x (boards seen: %s)" % (want + (seen,)))
 
 
-def energy_joules(dev=0):
+def _resolve(dev):
+    """dev None: the rocm_smi board of torch's current device (rsmi_index_of); an int: that rsmi index"""
+    if dev is not None:
+        return dev
+    try:
+        import torch
+        return rsmi_index_of(torch.cuda.current_device()) if torch.cuda.is_available() else 0
+    except ImportError:
+        return 0
+
+
+def energy_joules(dev=None):
     """Accumulated board energy in Joules (monotonic), or None"""
     lib = _smi()
     if lib is None:
         return None
+    dev = _resolve(dev)
     c, res, ts = C.c_uint64(0), C.c_float(0), C.c_uint64(0)
     if lib.rsmi_dev_energy_count_get(dev, C.byref(c), C.byref(res), C.byref(ts)) != 0:
         return None
     return c.value * float(res.value) * 1e-6
 
 
-def power_watts(dev=0):
+def power_watts(dev=None):
     lib = _smi()
     if lib is None:
         return None
+    dev = _resolve(dev)
     p, ty = C.c_uint64(0), C.c_int(0)
     if lib.rsmi_dev_power_get(dev, C.byref(p), C.byref(ty)) != 0:
         return None
@@ -83,12 +96,13 @@ class _Freq(C.Structure):
     _fields_ = [("has_deep_sleep", C.c_bool), ("num_supported", C.c_uint32), ("current", C.c_uint32), ("frequency", C.c_uint64 * 33)]
 
 
-def sclk_mhz(dev=0):
+def sclk_mhz(dev=None):
     """The shader clock the SMU reports right now (sysfs pp_dpm_sclk's starred entry), or None.  NOT the in-kernel clock: see
     MI355X_MICROARCH.md 'DVFS give-back' (6) -- the contraction kernels' own clock comes from the diagnostic build's stamps."""
     lib = _smi()
     if lib is None:
         return None
+    dev = _resolve(dev)
     f = _Freq()
     try:
         if lib.rsmi_dev_gpu_clk_freq_get(dev, 0, C.byref(f)) != 0 or f.current >= 33:
@@ -98,9 +112,11 @@ def sclk_mhz(dev=0):
     return f.frequency[f.current] * 1e-6
 
 
-def measure(step, sync, seconds=2.0, batch=8, dev=0, sample_every=0.25):
+def measure(step, sync, seconds=2.0, batch=8, dev=None, sample_every=0.25):
     """Runs `step()` back to back for about `seconds` (after 0.5 s untimed), `sync()` after every `batch` calls.  Returns a dict:
-    steps, seconds, joules, watts, joules_per_step, ms_per_step, sclk_mhz_mean (SMU samples while running) -- or None without a counter."""
+    steps, seconds, joules, watts, joules_per_step, ms_per_step, sclk_mhz_mean (SMU samples while running) -- or None without a counter.
+    dev: a rocm_smi index; None = the board of torch's current device (rsmi ignores HIP_VISIBLE_DEVICES: rsmi_index_of matches PCI addresses)."""
+    dev = _resolve(dev)
     if energy_joules(dev) is None:
         return None
     t0 = time.perf_counter()
@@ -127,7 +143,8 @@ def measure(step, sync, seconds=2.0, batch=8, dev=0, sample_every=0.25):
                 ms_per_step=(t1 - t0) / n * 1e3, sclk_mhz_mean=sc / ns if ns else None)
 
 
-def idle_watts(seconds=1.5, dev=0):
+def idle_watts(seconds=1.5, dev=None):
+    dev = _resolve(dev)
     if energy_joules(dev) is None:
         return None
     time.sleep(0.3)

@@ -102,7 +102,7 @@ def gqi_variants(ctx, plan, dwi, out, step_ms):
     import torch
     import fibers_jl_amd as fj
     from fibers_jl_amd import dist as fd, phantom
-    args, dev, shape, L = ctx.args, ctx.dev, ctx.shape, ctx.L
+    args, dev, shape = ctx.args, ctx.dev, ctx.shape
     nx, ny, nz = shape
     nxy, nvox = nx * ny, nx * ny * nz
     res = {}
@@ -223,7 +223,7 @@ def dti_and_c4(ctx):
     npoints, nlines, t_st = int(cnt[0].item()), int(cnt[1].item()), t_st / nst
     tr_ms, tr_n = prof_get("stream_trace")
     pk_ms, pk_n = prof_get("stream_pack")
-    sc_ms, sc_n = prof_get("stream_scan")
+    sc_ms, _ = prof_get("stream_scan")
     ksum = (tr_ms + pk_ms + sc_ms) / max(tr_n, 1)
     alg = 25.0 * (npoints / world)                                       # 25 B per emitted point (nvec = 1), rank 0's share
     pmc = _kernel_traffic(tj, "stream_trace_kernel<1", "stream_pack_tile_kernel", "scan_block_kernel") if shape == (140, 140, 140) else None

@@ -30,8 +30,10 @@ for what in ("bench", "benchfull", "gqi", "dti", "stream", "dsi", "c5"):
         if LIB.search(r["Name"]):
             lines.append("  %-60s calls=%4d avg_us=%10.1f min_us=%10.1f" % (short(r["Name"])[:60], int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
 for bj, name in (("bench.json", "bench_under_rocprof.json"), ("benchfull.json", "bench_full_under_rocprof.json")):
-    if os.path.exists(os.path.join(src, bj)):
-        shutil.copy(os.path.join(src, bj), os.path.join(dst, name))
+    if os.path.exists(os.path.join(src, bj)):                 # (bench.py's stdout: the result line is the last one that starts with `{`)
+        res = [ln for ln in open(os.path.join(src, bj)).read().splitlines() if ln.startswith("{")]
+        if res:
+            open(os.path.join(dst, name), "w").write(res[-1] + "\n")
 
 
 def pmc(sub):
