@@ -368,7 +368,7 @@ def main():
 
     PRECOND_S = 0.15
 
-    def timed(fn, steps, warmup):
+    def timed(fn, steps, warmup, only=None):
         """W untimed steps, then K steps bracketed by barrier + synchronize; max over ranks.  Before the W warm-up steps the same step
         runs untimed for about PRECOND_S seconds (a step count derived from the first step's duration, identical on every rank): after
         the idle stretch that precedes every section (plan set-up, input generation) the chip needs ~50 ms of load to leave its idle
@@ -388,6 +388,7 @@ def main():
         for _ in range(warmup):
             fn()
         sync()
+        L.fib_profile_filter(only.encode() if only else None)   # (`only`: bracket just these kernels -- every event pair is two packets in the queue)
         L.fib_profile_enable(1)
         L.fib_profile_reset()
         t0 = time.perf_counter()
@@ -396,6 +397,7 @@ def main():
         sync()
         dt = time.perf_counter() - t0
         L.fib_profile_enable(0)
+        L.fib_profile_filter(None)
         if multi:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -426,9 +428,15 @@ def main():
         else:                                                              # slab + ONE all-reduce(MAX) of {odfmax, NaN flag} + qa ./= odfmax
             fd.odf_rec_sharded(plan, dwi, mask, out=out, counts=counts, always=force_pg)
 
-    dt = timed(gqi_step, args.steps, args.warmup)
+    dt = timed(gqi_step, args.steps, args.warmup, only="odf_gemm")      # the timed steps bracket the roofline's kernel only
     gemm_ms, gemm_n = prof_get("odf_gemm")
-    other_ms = sum(prof_get(k)[0] for k in ("odf_peaks", "odf_post", "mask_compact", "qa_normalize")) / max(gemm_n, 1)
+    # the step's other launches, from a few more steps with every kernel bracketed (outside the timed region)
+    L.fib_profile_enable(1); L.fib_profile_reset()
+    for _ in range(5):
+        gqi_step()
+    sync()
+    L.fib_profile_enable(0)
+    other_ms = sum(prof_get(k)[0] for k in ("odf_peaks", "odf_post", "mask_compact", "qa_normalize")) / 5.0
     value = nvox * args.steps / dt / 1e6
     step_ms = dt / args.steps * 1e3
 

@@ -53,6 +53,7 @@ _PROTOS = {
     "fib_version": (C.c_char_p, []),
     "fib_device_count": (i32, []),
     "fib_profile_enable": (i32, [i32]),
+    "fib_profile_filter": (i32, [C.c_char_p]),
     "fib_profile_reset": (i32, []),
     "fib_profile_get": (i32, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),
     "fib_dti_plan_create": (i32, [i32, vp, vp, i32, C.POINTER(vp)]),

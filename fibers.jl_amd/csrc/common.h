@@ -84,13 +84,15 @@ static inline const char *ab_env(const char *) { return nullptr; }
 
 // hipEvent bracket around a kernel launch when fib_profile_enable(1) is active (no-op otherwise)
 bool profiling_on();
+bool profile_wants(const char *name);                 // fib_profile_filter: only the named kernels are bracketed (every event is a packet in the queue)
+bool profile_events(hipEvent_t *a, hipEvent_t *b);   // a pair from the pool (events are reused: creating one costs more than recording it)
 void profile_push(const char *name, hipEvent_t a, hipEvent_t b);
 void profile_add_ms(const char *name, double ms);
 struct ProfScope {
     const char *name; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
     ProfScope(const char *n, hipStream_t s) : name(n), st(s) {
-        if (!profiling_on()) return;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        if (!profiling_on() || !profile_wants(n)) return;
+        if (!profile_events(&a, &b)) { a = b = nullptr; return; }
         (void)hipEventRecord(a, st);
     }
     ~ProfScope() {

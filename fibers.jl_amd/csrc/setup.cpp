@@ -283,19 +283,55 @@ int host_neighbours(const int32_t *faces, int nfaces, int nverts, std::vector<in
 // ------------------------------------------------------------------------------------------
 // per-kernel event timing
 // ------------------------------------------------------------------------------------------
-struct ProfEntry { std::string name; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; double ms = 0; int64_t count = 0; };
+struct ProfPair { hipEvent_t first, second; int dev; };
+struct ProfEntry { std::string name; std::vector<ProfPair> pending; double ms = 0; int64_t count = 0; };
 static std::mutex g_prof_mu;
 static std::vector<ProfEntry> g_prof;
 static bool g_prof_on = false;
+static std::vector<std::string> g_prof_filter;          // empty: every kernel
+static std::vector<std::pair<int, hipEvent_t>> g_prof_pool;   // (device, event) between uses: an event is recorded on streams of the device it was created on
 
 bool profiling_on() { return g_prof_on; }
 
-void profile_push(const char *name, hipEvent_t a, hipEvent_t b) {
+bool profile_wants(const char *name) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (auto &e : g_prof) if (e.name == name) { e.pending.emplace_back(a, b); return; }
+    if (g_prof_filter.empty()) return true;
+    for (auto &f : g_prof_filter) if (f == name) return true;
+    return false;
+}
+
+bool profile_events(hipEvent_t *a, hipEvent_t *b) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        int got = 0;
+        for (size_t i = g_prof_pool.size(); i-- > 0 && got < 2;)
+            if (g_prof_pool[i].first == dev) { ev[got++] = g_prof_pool[i].second; g_prof_pool.erase(g_prof_pool.begin() + (long)i); }
+    }
+    for (int i = 0; i < 2; i++)
+        if (!ev[i] && hipEventCreate(&ev[i]) != hipSuccess) {
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            for (int j = 0; j < 2; j++) if (ev[j]) g_prof_pool.emplace_back(dev, ev[j]);
+            return false;
+        }
+    *a = ev[0]; *b = ev[1];
+    return true;
+}
+static void profile_recycle(const ProfPair &pr) {         // (g_prof_mu held) back to the pool of the device the pair belongs to
+    g_prof_pool.emplace_back(pr.dev, pr.first);
+    g_prof_pool.emplace_back(pr.dev, pr.second);
+}
+
+void profile_push(const char *name, hipEvent_t a, hipEvent_t b) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);                                // (the scope that recorded the pair runs under the device it launches on)
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &e : g_prof) if (e.name == name) { e.pending.push_back(ProfPair{a, b, dev}); return; }
     g_prof.emplace_back();
     g_prof.back().name = name;
-    g_prof.back().pending.emplace_back(a, b);
+    g_prof.back().pending.push_back(ProfPair{a, b, dev});
 }
 
 // a host-side stage's duration (the host tier's gather / scatter stages), into the same table
@@ -311,10 +347,24 @@ void profile_add_ms(const char *name, double ms) {
 
 extern "C" int fib_profile_enable(int on) { fib::g_prof_on = on != 0; return FIB_OK; }
 
+// only the kernels named in the comma-separated list are bracketed (NULL or "": every kernel).  An event pair is two packets in the queue:
+// bench.py brackets the one kernel its roofline is about during the timed steps
+extern "C" int fib_profile_filter(const char *names) try {
+    std::lock_guard<std::mutex> lk(fib::g_prof_mu);
+    fib::g_prof_filter.clear();
+    if (!names) return FIB_OK;
+    std::string cur;
+    for (const char *c = names;; c++) {
+        if (*c == ',' || *c == '\0') { if (!cur.empty()) fib::g_prof_filter.push_back(cur); cur.clear(); if (*c == '\0') break; }
+        else if (*c != ' ') cur.push_back(*c);
+    }
+    return FIB_OK;
+} FIB_API_CATCH
+
 extern "C" int fib_profile_reset(void) try {
     std::lock_guard<std::mutex> lk(fib::g_prof_mu);
     for (auto &e : fib::g_prof) {
-        for (auto &pr : e.pending) { (void)hipEventSynchronize(pr.second); (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        for (auto &pr : e.pending) { (void)hipEventSynchronize(pr.second); fib::profile_recycle(pr); }
     }
     fib::g_prof.clear();
     return FIB_OK;
@@ -329,7 +379,7 @@ extern "C" int fib_profile_get(const char *kernel, double *total_ms, int64_t *co
         for (auto &pr : e.pending) {
             float ms = 0;
             if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { e.ms += ms; e.count++; }
-            (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+            fib::profile_recycle(pr);
         }
         e.pending.clear();
         *total_ms = e.ms; *count = e.count;

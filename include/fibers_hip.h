@@ -61,8 +61,11 @@ int fib_device_count(void);                 /* number of visible HIP devices (0 
 /* When enabled, every hot-path kernel launch is bracketed by a hipEvent pair recorded on the
  * stream it is launched on.  fib_profile_get synchronises the pending events of `kernel`
  * ("dti_fit", "odf_gemm", "odf_peaks", "qa_normalize", "stream_trace", "stream_pack", ...) and
- * returns the accumulated device time and launch count since the last fib_profile_reset. */
+ * returns the accumulated device time and launch count since the last fib_profile_reset.
+ * fib_profile_filter("odf_gemm,dti_fit"): only the named kernels are bracketed (NULL or "": all of them) -- an event pair is two packets in
+ * the queue, and a measurement of one kernel inside a timed region should not pay for the others' brackets. */
 int fib_profile_enable(int on);
+int fib_profile_filter(const char *names);
 int fib_profile_reset(void);
 int fib_profile_get(const char *kernel, double *total_ms, int64_t *count);
 
