@@ -133,23 +133,42 @@ def load_nifti(fname, headeronly=False, mmap=False):
             if os.path.getsize(fname) != off + int(np.prod(dim)) * dt.itemsize:
                 raise ValueError("%s, read a %s volume but did not reach end of file" % (fname, tuple(dim)))
             return hdr, np.memmap(fname, dtype=dt, mode="r", offset=off, shape=tuple(dim), order="F")
+    # one pass: the header, then the volume read straight into the array it stays in (the reference reads the whole file into a Julia array,
+    # mri.jl:1577-1672; round 5 read the file into a bytes object and copied it twice)
     with _open(fname, "rb") as fh:
-        raw = fh.read()
-    hdr = load_nifti_hdr(raw)
-    dims = hdr["dim"][1:]
-    last = max(i for i, v in enumerate(hdr["dim"]) if v != 0)
-    dim = [int(v) for v in hdr["dim"][1:last + 1]]
-    if hdr["datatype"] not in _NIFTI_DTYPES:
-        raise ValueError("Data type %d not supported" % hdr["datatype"])
-    dt = np.dtype(_NIFTI_DTYPES[hdr["datatype"]])
-    if headeronly:
-        return hdr, np.zeros([0] * len(dim), dt)
-    off = int(round(hdr["vox_offset"]))
-    n = int(np.prod(dim))
-    if len(raw) != off + n * dt.itemsize:
+        head = fh.read(352)
+        hdr = load_nifti_hdr(head)
+        last = max(i for i, v in enumerate(hdr["dim"]) if v != 0)
+        dim = [int(v) for v in hdr["dim"][1:last + 1]]
+        if hdr["datatype"] not in _NIFTI_DTYPES:
+            raise ValueError("Data type %d not supported" % hdr["datatype"])
+        dt = np.dtype(_NIFTI_DTYPES[hdr["datatype"]])
+        if headeronly:
+            return hdr, np.zeros([0] * len(dim), dt)
+        off = int(round(hdr["vox_offset"]))
+        n = int(np.prod(dim))
+        if off >= len(head):
+            skip = off - len(head)
+            if skip and len(fh.read(skip)) != skip:
+                raise ValueError("%s, read a %s volume but did not reach end of file" % (fname, tuple(dim)))
+            vol = np.empty(n, dtype=dt.newbyteorder(">" if hdr["do_bswap"] else "<"))
+            buf = memoryview(vol).cast("B")
+            got = 0
+            while got < len(buf):
+                k = fh.readinto(buf[got:])
+                if not k:
+                    break
+                got += k
+            complete = got == len(buf) and fh.read(1) == b""
+        else:                                                     # (a data offset inside the 352 bytes already read: not a file this writer makes)
+            raw = head + fh.read()
+            complete = len(raw) == off + n * dt.itemsize
+            vol = np.frombuffer(raw, dtype=dt.newbyteorder(">" if hdr["do_bswap"] else "<"), count=n if complete else 0, offset=off)
+    if not complete:
         raise ValueError("%s, read a %s volume but did not reach end of file" % (fname, tuple(dim)))
-    vol = np.frombuffer(raw, dtype=dt.newbyteorder(">" if hdr["do_bswap"] else "<"), count=n, offset=off)
-    vol = vol.astype(dt).reshape(dim, order="F")
+    if vol.dtype != dt or not vol.flags.writeable:
+        vol = vol.astype(dt)                                      # (byte-swapped files; the frombuffer fallback)
+    vol = vol.reshape(dim, order="F")
     if hdr["scl_slope"] != 0 and not (hdr["scl_inter"] == 0 and hdr["scl_slope"] == 1):
         vol = (vol * hdr["scl_slope"] + hdr["scl_inter"]).astype(dt)              # mri.jl:1664-1668
     return hdr, np.asfortranarray(vol)
