@@ -479,6 +479,8 @@ def main():
             else:
                 extra.update(r)
         except Exception as e:                                                       # noqa: BLE001
+            if multi:                                     # a leg with collectives: one rank skipping it would leave the others waiting -- fail the run
+                raise
             extra[name] = dict(error="%s: %s" % (type(e).__name__, e))
             sys.stderr.write("bench.py: leg %s failed: %s\n" % (name, e))
 
