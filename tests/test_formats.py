@@ -258,6 +258,8 @@ def test_gpu_trk_serialiser_matches_host(fj, tmp_path):
     tr = fj.Tract(xyz=res["xyz"].cpu().numpy(), npts=res["npts"].cpu().numpy(), volsize=(n, n, n), volres=ref.volres)
     f1, f2 = str(tmp_path / "host.trk"), str(tmp_path / "gpu.trk")
     fj.trk_write(tr, f1, ref)
+    with open(f2, "wb") as fh:                                    # an existing, longer file at the target: the writer must end it at its own length
+        fh.write(b"\xff" * (os.path.getsize(f1) + 4096))
     info = fj.stream_to_trk(f2, field, (n, n, n), seeds, sub, ref, len_min=4)
     assert info["nlines"] == tr.nstr and open(f1, "rb").read() == open(f2, "rb").read()
 

@@ -579,6 +579,46 @@ def test_normalisation_inside_the_post_kernel_matches_the_separate_launch(fj, ki
             assert float(a["odfmax"][0]) == float(np.float32(s / np.float32(len(ref))))
 
 
+def test_profile_filter_brackets_only_the_named_kernels(fj):
+    """fib_profile_filter("odf_gemm"): only that kernel's launches are bracketed by events (bench.py's timed steps); NULL: all again"""
+    import ctypes as C
+    import torch
+    from fibers_jl_amd import phantom
+    L = fj.lib()
+    dev = torch.device("cuda", 0)
+    bval, bvec = phantom.scheme_gqi(3, 20, (1000.0, 2000.0, 3000.0), 3)
+    plan = fj.OdfPlan("gqi", bval, bvec, fj.sphere_642)
+    d, _ = phantom.make_dwi_torch((16, 16, 8), bval, bvec, seed=6, device=dev)
+    mask = torch.ones(16 * 16 * 8, dtype=torch.uint8, device=dev)
+
+    def counts():
+        out = {}
+        for k in ("odf_gemm", "mask_compact", "odf_post"):
+            ms, n = C.c_double(0), C.c_int64(0)
+            L.fib_profile_get(k.encode(), C.byref(ms), C.byref(n))
+            out[k] = (n.value, ms.value)
+        return out
+    try:
+        L.fib_profile_filter(b"odf_gemm")
+        L.fib_profile_enable(1); L.fib_profile_reset()
+        for _ in range(3):
+            fj.odf_rec_device(plan, d, mask)
+        torch.cuda.synchronize()
+        c = counts()
+        assert c["odf_gemm"][0] == 3 and c["odf_gemm"][1] > 0 and c["mask_compact"][0] == 0 and c["odf_post"][0] == 0
+        L.fib_profile_filter(None)
+        L.fib_profile_reset()
+        for _ in range(2):
+            fj.odf_rec_device(plan, d, mask)
+        torch.cuda.synchronize()
+        c = counts()
+        assert c["odf_gemm"][0] == 2 and c["mask_compact"][0] == 2 and c["odf_post"][0] == 2
+    finally:
+        L.fib_profile_enable(0)
+        L.fib_profile_filter(None)
+        L.fib_profile_reset()
+
+
 def test_qa_normalize_with_device_scalar(fj):
     """fibd_qa_normalize_dev: the divisor comes from device memory (the all-reduced odfmax of the multi-GPU flow)"""
     import torch

@@ -9,7 +9,9 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 # the headline command alone (the extras launch the same kernels at other sizes: the host-tier call runs the contraction kernel on
 # 21 chunks), so that the kernel's average here is comparable with the hipEvent average in the JSON line
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/bench -o bench -- python3 bench.py --no-cpu-baseline --no-extra > $OUT/bench.json 2> $OUT/bench.err
+# (200 timed steps: the kernel's average over the whole run is then the steady state's, comparable with the line's hipEvent average -- the
+# preconditioning and warm-up steps in front of the timed region run while the chip still leaves its idle power state)
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/bench -o bench -- python3 bench.py --no-cpu-baseline --no-extra --steps 200 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/benchfull -o benchfull -- python3 bench.py --no-cpu-baseline > $OUT/benchfull.json 2> $OUT/benchfull.err
 for what in gqi dti stream dsi c5; do
   rocprofv3 --kernel-trace --stats -f csv -d $OUT/$what -o $what -- python3 tools/prof_step.py $what 5 > $OUT/$what.log 2>&1

@@ -25,7 +25,7 @@ for what in ("bench", "benchfull", "gqi", "dti", "stream", "dsi", "c5"):
     if not fs:
         continue
     shutil.copy(fs[0], os.path.join(dst, what + "_kernel_stats.csv"))
-    lines.append("== rocprofv3 --kernel-trace --stats -- python3 %s  (library kernels) ==" % ("bench.py --no-cpu-baseline --no-extra" if what == "bench" else "bench.py --no-cpu-baseline" if what == "benchfull" else "tools/prof_step.py %s 5" % what))
+    lines.append("== rocprofv3 --kernel-trace --stats -- python3 %s  (library kernels) ==" % ("bench.py --no-cpu-baseline --no-extra --steps 200 --warmup 5" if what == "bench" else "bench.py --no-cpu-baseline" if what == "benchfull" else "tools/prof_step.py %s 5" % what))
     for r in csv.DictReader(open(fs[0])):
         if LIB.search(r["Name"]):
             lines.append("  %-60s calls=%4d avg_us=%10.1f min_us=%10.1f" % (short(r["Name"])[:60], int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
