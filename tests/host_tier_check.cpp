@@ -237,6 +237,20 @@ int main() {
             zero_stream(a.data() + off, n);
             for (int i = 0; i < 128; i++) CHECK(a[i] == ((i >= off && i < off + n) ? 0.0f : 5.0f));
         }
+    // randomised sweep (fixed seeds): volume, range, rows, chunk, mask density, packing, flags
+    {
+        std::mt19937 rng(2024);
+        for (int t = 0; t < 40; t++) {
+            const int64_t nvox = 64 + rng() % 4000;
+            int64_t vbeg = rng() % (nvox / 2), vend = vbeg + 1 + rng() % (nvox - vbeg);
+            if (rng() % 3 == 0) { vbeg = 0; vend = nvox; }
+            const int rin = 1 + rng() % 5;
+            std::vector<int> out_rows(1 + rng() % 3);
+            for (auto &r : out_rows) r = 1 + rng() % 3;
+            const int64_t chunk = 32 * (1 + rng() % 12);
+            pipeline_case(nvox, vbeg, vend, rin, out_rows, chunk, (int)(rng() % 4), rng() % 2 != 0, rng() % 2 != 0, seed++, rng() % 2 != 0);
+        }
+    }
     printf("host_tier_check ok\n");
     return 0;
 }
