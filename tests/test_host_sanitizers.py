@@ -27,7 +27,11 @@ def _build(tmp_path, name, flags):
 def _run(exe):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
                TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
-    return subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    # a sanitizer runtime that cannot start on this kernel (address-space layout it does not know) says nothing about the code under test
+    if "unexpected memory mapping" in out.stderr or "Shadow memory range interleaves" in out.stderr:
+        pytest.skip("the sanitizer runtime cannot start here: " + out.stderr.strip().splitlines()[0][:200])
+    return out
 
 
 def test_host_tier_under_asan_ubsan(tmp_path):
